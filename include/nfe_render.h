@@ -1,0 +1,150 @@
+/*
+ * nfe_render.h — C ABI of libnfe_render.so: the MI355X (gfx950) volumetric-rendering hot path of
+ * NeRFFaceEditing (TriPlaneGenerator.synthesis()/sample(): ray sampling, plane statistics,
+ * tri-plane gather, dual MLP decoder, importance sampling, alpha compositing).
+ *
+ * Conventions (they mirror the reference's plugin convention in
+ * torch_utils/ops/bias_act.cpp:36-94 and upfirdn2d.cpp:20-96: validate -> launch on the caller's
+ * stream -> return, no host sync):
+ *   - extern "C", plain pointers and sizes; no torch / pybind types.
+ *   - every entry point returns 0 on success or a negative NFE_E* code; nfe_last_error() gives a
+ *     thread-local message (the Python shim raises RuntimeError, as TORCH_CHECK does in the
+ *     reference: bias_act.cpp:39-55).
+ *   - all data pointers are DEVICE pointers to fp32 unless stated; the caller allocates every
+ *     output and the workspace, the library never frees or retains caller memory.
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream.
+ *   - stateless and re-entrant.
+ *
+ * The reference has no native entry point for the renderer (its renderer is ~25 ATen ops,
+ * training/volumetric_rendering/renderer.py:301-363); each function below names the reference
+ * Python function(s) it replaces.
+ */
+#ifndef NFE_RENDER_H
+#define NFE_RENDER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFE_ABI_VERSION 1
+
+#define NFE_OK 0
+#define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */
+#define NFE_ELAUNCH (-2)     /* HIP launch / runtime error */
+#define NFE_EWORKSPACE (-3)  /* workspace too small */
+
+#define NFE_PLANE_CHANNELS 32   /* channels per plane (triplane.py:113-115) */
+#define NFE_NUM_PLANES 3
+#define NFE_RGB_CHANNELS 32     /* decoder_output_dim (triplane.py:49) */
+#define NFE_SEG_CHANNELS 15     /* decoder_seg_dim   (triplane.py:49) */
+#define NFE_MAX_SAMPLES 256     /* max depth_resolution and max depth_resolution_importance */
+/* floats in a packed decoder blob (see nfe_decoder_pack) */
+#define NFE_DECODER_PACKED_FLOATS (4 * 2048 + 64 + 64 + 32 + 32)
+
+typedef void* nfe_stream_t;
+
+int nfe_abi_version(void);
+const char* nfe_last_error(void);
+
+/* ---- a2: RaySampler.forward (training/volumetric_rendering/ray_sampler.py:24-62) -------------
+ * cam2world [N,16] row-major 4x4, intrinsics [N,9] row-major 3x3 (normalised by image size),
+ * -> origins [N,R*R,3], dirs [N,R*R,3]; pixel m = row*R + col. */
+int nfe_ray_sampler(const float* cam2world, const float* intrinsics, int n_views, int resolution,
+                    float* origins, float* dirs, nfe_stream_t stream);
+
+/* ---- a4: compute_mean_var (training/triplane.py:56-60) ---------------------------------------
+ * planes [N,C,H*W] (NCHW) -> mean [N,C], std [N,C] = sqrt(unbiased variance). */
+int nfe_plane_stats(const float* planes, int n, int c, int hw, float* mean, float* std,
+                    nfe_stream_t stream);
+
+/* ---- a4: normalize_plane / denormalize_plane as a per-channel affine (triplane.py:61-68) ------
+ * out[n,c,:] = in[n,c,:] * scale[n_s,c] + shift[n_s,c]; scale/shift are [N,C] or [1,C]
+ * (n_affine = N or 1).  normalize: scale=1/(std+1e-8), shift=-mean*scale (see nfe_make_affine). */
+int nfe_plane_affine(const float* in, const float* scale, const float* shift, int n, int c, int hw,
+                     int n_affine, float* out, nfe_stream_t stream);
+
+/* ---- a4 -> a5: the single-gather identity --------------------------------------
+ * From the statistics of the raw planes (mean,std [N,C]) and an optional override (new_mean,
+ * new_std [N_o,C] with N_o in {1,N}; NULL = no override, triplane.py:98-103) produce the four
+ * per-channel affines [N,C] that turn a bilinear sample s of the RAW plane (with in-bounds tap
+ * weight sum w) into a sample of the normalised plane (geo) and of the denormalised plane (app):
+ *     geo = s*geo_scale + w*geo_shift         app = s*app_scale + w*app_shift               */
+int nfe_make_affine(const float* mean, const float* std, const float* new_mean, const float* new_std,
+                    int n, int c, int n_override, float* geo_scale, float* geo_shift,
+                    float* app_scale, float* app_shift, nfe_stream_t stream);
+
+/* ---- layout: NCHW planes [N,96,H,W] -> gather layout [N,3,H,W,32] (one 128-byte texel per tap) */
+int nfe_plane_pack(const float* planes_nchw, int n, int h, int w, float* packed, nfe_stream_t stream);
+
+/* ---- a6: decoder weights -> MFMA operand layout ----------------------------------------------
+ * DisentangledOSGDecoder parameters (triplane.py:232-247), FullyConnectedLayer gains applied
+ * (networks_stylegan2.py:111-123: weight*lr_mul/sqrt(in), bias*lr_mul).  All device pointers:
+ * geo_w0[64,32] geo_b0[64] geo_w1[16,64] geo_b1[16] app_w0[64,32] app_b0[64] app_w1[32,64]
+ * app_b1[32] -> packed[NFE_DECODER_PACKED_FLOATS]. */
+int nfe_decoder_pack(const float* geo_w0, const float* geo_b0, const float* geo_w1, const float* geo_b1,
+                     const float* app_w0, const float* app_b0, const float* app_w1, const float* app_b1,
+                     float lr_mul, float* packed, nfe_stream_t stream);
+
+/* ---- a5..a12: DisentangledImportanceRenderer.forward (renderer.py:301-363) --------------------*/
+typedef struct nfe_render_args {
+    uint32_t struct_size;              /* = sizeof(nfe_render_args) */
+    /* planes, gather layout [Np,3,H,W,32]; planes_app may equal planes_geo (single gather) */
+    const float* planes_geo;           /* source of the geometry ("norm") feature set */
+    const float* planes_app;           /* source of the appearance ("denorm") feature set */
+    int32_t plane_h, plane_w;
+    int64_t plane_view_stride;         /* floats between views; 0 broadcasts one plane set */
+    /* optional per-(view,channel) affines [N,96] applied to sampled values (NULL = identity) */
+    const float* geo_scale; const float* geo_shift;
+    const float* app_scale; const float* app_shift;
+    const float* decoder_packed;       /* from nfe_decoder_pack */
+    /* rays: explicit origins/dirs [N,M,3], or (both NULL) generated from cam2world/intrinsics */
+    int32_t n_views, n_rays;           /* N, M */
+    const float* origins; const float* dirs;
+    const float* cam2world; const float* intrinsics;   /* [N,16], [N,9] */
+    int32_t resolution;                /* R with M == R*R (0 if unknown: no 2-D tiling) */
+    /* rendering_kwargs (train.py:288-313) */
+    int32_t depth_resolution;          /* D  >= 2 */
+    int32_t depth_resolution_importance; /* Di >= 0 */
+    float ray_start, ray_end;          /* scalar limits (ignored when per-ray limits given) */
+    const float* ray_start_per_ray;    /* [N,M] or NULL ('auto' branch, renderer.py:312-318) */
+    const float* ray_end_per_ray;
+    int32_t disparity_space_sampling;  /* renderer.py:174-181 */
+    float box_warp;
+    int32_t white_back;                /* ray_marcher.py:96-97 */
+    /* jitter: external buffers (parity mode) or Philox4x32-10 keyed by seed (NULL pointers) */
+    const float* u_coarse;             /* [N,M,D]   or NULL */
+    const float* u_fine;               /* [N*M,Di]  or NULL */
+    uint64_t seed;
+    /* outputs */
+    float* rgb;                        /* [N,M,32]  (or [N,32,M] if channels_first) */
+    float* seg;                        /* [N,M,15]  (or [N,15,M]) */
+    float* depth;                      /* [N,M] */
+    float* wsum;                       /* [N,M] */
+    int32_t channels_first;
+    float* tap_weights_coarse;         /* optional [N,M,D-1] (two-pass only) */
+    float* tap_depths_fine;            /* optional [N,M,Di] */
+    float* tap_depths_all;             /* optional [N,M,D+Di] sorted */
+    void* workspace; uint64_t workspace_bytes;
+} nfe_render_args;
+
+/* bytes of workspace nfe_render needs for these sizes */
+uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int depth_resolution,
+                                    int depth_resolution_importance);
+int nfe_render(const nfe_render_args* args, nfe_stream_t stream);
+
+/* ---- a15: renderer.run_model on caller-supplied points (triplane.py:140-157, renderer.py:259-287)
+ * coords [N,P,3] -> rgb [N,P,32], sigma [N,P], seg [N,P,15]. Plane/affine/decoder arguments as in
+ * nfe_render_args. */
+int nfe_point_query(const float* planes_geo, const float* planes_app, int plane_h, int plane_w,
+                    int64_t plane_view_stride, const float* geo_scale, const float* geo_shift,
+                    const float* app_scale, const float* app_shift, const float* decoder_packed,
+                    const float* coords, int n_views, int n_points, float box_warp,
+                    float* rgb, float* sigma, float* seg, nfe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFE_RENDER_H */

@@ -1,0 +1,86 @@
+"""ctypes binding of libnfe_render.so (include/nfe_render.h).  Fails loudly when the library is absent."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnfe_render.so")
+
+NFE_ABI_VERSION = 1
+NFE_MAX_SAMPLES = 256
+NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32
+
+FP = c_void_p      # device pointers travel as integers
+
+
+class RenderArgs(ctypes.Structure):
+    """Mirror of ``nfe_render_args`` (include/nfe_render.h) — keep field order identical."""
+    _fields_ = [
+        ("struct_size", c_uint32),
+        ("planes_geo", FP), ("planes_app", FP),
+        ("plane_h", c_int32), ("plane_w", c_int32),
+        ("plane_view_stride", c_int64),
+        ("geo_scale", FP), ("geo_shift", FP), ("app_scale", FP), ("app_shift", FP),
+        ("decoder_packed", FP),
+        ("n_views", c_int32), ("n_rays", c_int32),
+        ("origins", FP), ("dirs", FP), ("cam2world", FP), ("intrinsics", FP),
+        ("resolution", c_int32),
+        ("depth_resolution", c_int32), ("depth_resolution_importance", c_int32),
+        ("ray_start", c_float), ("ray_end", c_float),
+        ("ray_start_per_ray", FP), ("ray_end_per_ray", FP),
+        ("disparity_space_sampling", c_int32),
+        ("box_warp", c_float), ("white_back", c_int32),
+        ("u_coarse", FP), ("u_fine", FP), ("seed", c_uint64),
+        ("rgb", FP), ("seg", FP), ("depth", FP), ("wsum", FP),
+        ("channels_first", c_int32),
+        ("tap_weights_coarse", FP), ("tap_depths_fine", FP), ("tap_depths_all", FP),
+        ("workspace", FP), ("workspace_bytes", c_uint64),
+    ]
+
+
+_SIGNATURES = {
+    "nfe_abi_version": (c_int, []),
+    "nfe_last_error": (c_char_p, []),
+    "nfe_ray_sampler": (c_int, [FP, FP, c_int, c_int, FP, FP, c_void_p]),
+    "nfe_plane_stats": (c_int, [FP, c_int, c_int, c_int, FP, FP, c_void_p]),
+    "nfe_plane_affine": (c_int, [FP, FP, FP, c_int, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_make_affine": (c_int, [FP, FP, FP, FP, c_int, c_int, c_int, FP, FP, FP, FP, c_void_p]),
+    "nfe_plane_pack": (c_int, [FP, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_decoder_pack": (c_int, [FP] * 8 + [c_float, FP, c_void_p]),
+    "nfe_render_workspace_bytes": (c_uint64, [c_int, c_int, c_int, c_int]),
+    "nfe_render": (c_int, [POINTER(RenderArgs), c_void_p]),
+    "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, FP, c_int, c_int, c_float,
+                                FP, FP, FP, c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle; raises ImportError when the .so is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `make -C nerffaceediting_amd/csrc` "
+                "(or python -c 'import __graft_entry__ as g; g.build()'). There is no fallback path.")
+        lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        if lib.nfe_abi_version() != NFE_ABI_VERSION:
+            raise ImportError(f"libnfe_render.so ABI {lib.nfe_abi_version()} != expected {NFE_ABI_VERSION}")
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def check(rc, what=""):
+    """Turn a non-zero return code into RuntimeError (the reference's TORCH_CHECK behaviour,
+    torch_utils/ops/bias_act.cpp:39-55)."""
+    if rc != 0:
+        msg = load().nfe_last_error()
+        raise RuntimeError(f"{what or 'nfe'} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,235 @@
+// Memory-bound helper kernels around the render core (gfx950): ray sampler, plane statistics,
+// per-channel affine, NCHW -> gather-layout pack, decoder weight packing.
+#include "nfe_common.h"
+
+namespace nfe {
+
+// ---- a2: RaySampler.forward (ray_sampler.py:24-62) ------------------------------------------
+__global__ void ray_sampler_kernel(const float* __restrict__ cam2world, const float* __restrict__ intrinsics,
+                                   int N, int R, float* __restrict__ origins, float* __restrict__ dirs) {
+    const long long M = (long long)R * R, total = (long long)N * M;
+    const float inv = 1.0f / (float)R;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / M); const int m = (int)(i % M);
+        const int py = m / R, px = m % R;
+        const float* c = cam2world + n * 16; const float* K = intrinsics + n * 9;
+        const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+        const float xc = (float)px * inv + 0.5f * inv, yc = (float)py * inv + 0.5f * inv;   // :41
+        const float xl = (xc - cx + cy * sk / fy - sk * yc / fy) / fx;                      // :50
+        const float yl = (yc - cy) / fy;                                                    // :51
+        const float ox = c[3], oy = c[7], oz = c[11];
+        float dx = (c[0] * xl + c[1] * yl + c[2] + c[3]) - ox;                              // :55-57
+        float dy = (c[4] * xl + c[5] * yl + c[6] + c[7]) - oy;
+        float dz = (c[8] * xl + c[9] * yl + c[10] + c[11]) - oz;
+        const float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);                // F.normalize :59
+        origins[i * 3 + 0] = ox; origins[i * 3 + 1] = oy; origins[i * 3 + 2] = oz;
+        dirs[i * 3 + 0] = dx / nrm; dirs[i * 3 + 1] = dy / nrm; dirs[i * 3 + 2] = dz / nrm;
+    }
+}
+
+// ---- a4: compute_mean_var (triplane.py:56-60): one block per (n,c) row of HW elements -------
+__global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ planes, int hw,
+                                                          float* __restrict__ mean, float* __restrict__ stdv) {
+    __shared__ double sh[2][4];
+    const float* row = planes + (long long)blockIdx.x * hw;
+    double s = 0.0, ss = 0.0;
+    const int n4 = ((reinterpret_cast<uintptr_t>(row) & 15) == 0) ? hw / 4 : 0;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+        float4 v = reinterpret_cast<const float4*>(row)[i];
+        s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+        ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    for (int i = n4 * 4 + threadIdx.x; i < hw; i += 256) { double v = row[i]; s += v; ss += v * v; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off); ss += __shfl_xor(ss, off); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { sh[0][wave] = s; sh[1][wave] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        s = sh[0][0] + sh[0][1] + sh[0][2] + sh[0][3];
+        ss = sh[1][0] + sh[1][1] + sh[1][2] + sh[1][3];
+        const double mu = s / hw;
+        double var = (ss - s * mu) / (double)(hw - 1);       // unbiased (torch.var default)
+        if (var < 0.0) var = 0.0;
+        mean[blockIdx.x] = (float)mu;
+        stdv[blockIdx.x] = (float)sqrt(var);
+    }
+}
+
+// ---- a4: out = in*scale + shift per (n,c) row (normalize_plane / denormalize_plane) ----------
+__global__ __launch_bounds__(256) void plane_affine_kernel(const float* __restrict__ in, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, int c, int hw, int n_affine,
+                                                           float* __restrict__ out) {
+    const int row = blockIdx.x;                 // n*c + ch
+    const int n = row / c, ch = row % c;
+    const int ai = (n_affine == 1 ? 0 : n) * c + ch;
+    const float a = scale[ai], b = shift[ai];
+    const float* src = in + (long long)row * hw; float* dst = out + (long long)row * hw;
+    const bool al = ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) == 0;
+    const int n4 = al ? hw / 4 : 0;
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n4; i += gridDim.y * 256) {
+        float4 v = reinterpret_cast<const float4*>(src)[i];
+        v.x = fmaf(v.x, a, b); v.y = fmaf(v.y, a, b); v.z = fmaf(v.z, a, b); v.w = fmaf(v.w, a, b);
+        reinterpret_cast<float4*>(dst)[i] = v;
+    }
+    for (int i = n4 * 4 + blockIdx.y * 256 + threadIdx.x; i < hw; i += gridDim.y * 256) dst[i] = fmaf(src[i], a, b);
+}
+
+// ---- a4 -> a5 affines -----------------------------------------------------------
+__global__ void make_affine_kernel(const float* __restrict__ mean, const float* __restrict__ stdv,
+                                   const float* __restrict__ new_mean, const float* __restrict__ new_std,
+                                   int n, int c, int n_override, float* gs, float* gb, float* as, float* ab) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * c) return;
+    const float inv = 1.0f / (stdv[i] + 1e-8f);          // normalize_plane: (x - mean)/(std + 1e-8)
+    gs[i] = inv; gb[i] = -mean[i] * inv;
+    if (new_mean) {                                       // denormalize_plane(norm, new_mean, new_std)
+        const int o = (n_override == 1 ? 0 : i / c) * c + i % c;
+        const float sc = inv * new_std[o];
+        as[i] = sc; ab[i] = new_mean[o] - mean[i] * sc;
+    } else {
+        as[i] = 1.0f; ab[i] = 0.0f;
+    }
+}
+
+// ---- NCHW [N,96,H,W] -> [N,3,H,W,32]: LDS-tiled transpose, 32 channels x 64 pixels per block --
+__global__ __launch_bounds__(256) void plane_pack_kernel(const float* __restrict__ src, int hw, float* __restrict__ dst) {
+    __shared__ float tile[32][65];
+    const int np = blockIdx.y;                    // n*3 + plane
+    const int p0 = blockIdx.x * 64;
+    const float* s = src + (long long)np * 32 * hw;
+    float* d = dst + (long long)np * hw * 32;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;          // read: 64 pixels x 4 channels per pass
+#pragma unroll
+    for (int cc = 0; cc < 32; cc += 4) {
+        const int pix = p0 + tx;
+        tile[cc + ty][tx] = pix < hw ? s[(long long)(cc + ty) * hw + pix] : 0.0f;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 31, pr = threadIdx.x >> 5;            // write: 32 channels x 8 pixels per pass
+#pragma unroll
+    for (int pp = 0; pp < 64; pp += 8) {
+        const int pix = p0 + pp + pr;
+        if (pix < hw) d[(long long)pix * 32 + c] = tile[c][pp + pr];
+    }
+}
+
+// ---- decoder weights -> MFMA A-operand layout -----------------------------------
+// hidden unit held by (layer-0 M-block mb, accumulator register r, lane half h)
+__device__ __forceinline__ int hidden_unit(int mb, int r, int h) { return 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+__global__ void decoder_pack_kernel(const float* gw0, const float* gb0, const float* gw1, const float* gb1,
+                                    const float* aw0, const float* ab0, const float* aw1, const float* ab1,
+                                    float lr_mul, float* out) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= DEC_FLOATS) return;
+    const float g0 = lr_mul / sqrtf(32.0f), g1 = lr_mul / sqrtf(64.0f);   // weight_gain, networks_stylegan2.py:111
+    float v = 0.0f;
+    if (e < DEC_A_G1) {                       // layer-0 A fragments: [net][mb][ks4][lane][kk]
+        const float* w = e < DEC_A_A0 ? gw0 : aw0;
+        const int r_ = e % 2048;
+        const int mb = r_ / 1024, ks4 = (r_ % 1024) / 256, lane = (r_ % 256) / 4, kk = r_ % 4;
+        const int i = lane & 31, h = lane >> 5, ks = ks4 * 4 + kk;
+        v = w[(32 * mb + i) * 32 + (16 * h + ks)] * g0;
+    } else if (e < DEC_B_G0) {                // layer-1 A fragments: [net][ks4][lane][kk]
+        const bool geo = e < DEC_A_A1;
+        const int r_ = (e - DEC_A_G1) % 2048;
+        const int ks4 = r_ / 256, lane = (r_ % 256) / 4, kk = r_ % 4;
+        const int i = lane & 31, h = lane >> 5, ks = ks4 * 4 + kk;
+        const int u = hidden_unit(ks >> 4, ks & 15, h);
+        const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;    // output row i = register ri of lane half hi
+        if (geo) {
+            int idx = -1;                                             // sigma duplicated into both halves
+            if (ri == 0) idx = 0; else if (hi == 0 && ri <= 8) idx = ri; else if (hi == 1 && ri <= 7) idx = 8 + ri;
+            v = idx >= 0 ? gw1[idx * 64 + u] * g1 : 0.0f;
+        } else {
+            v = aw1[(16 * hi + ri) * 64 + u] * g1;
+        }
+    } else if (e < DEC_B_A0) {
+        v = gb0[e - DEC_B_G0] * lr_mul;
+    } else if (e < DEC_B_G1) {
+        v = ab0[e - DEC_B_A0] * lr_mul;
+    } else {
+        const bool geo = e < DEC_B_A1;
+        const int i = (e - DEC_B_G1) % 32;
+        const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;
+        if (geo) {
+            int idx = -1;
+            if (ri == 0) idx = 0; else if (hi == 0 && ri <= 8) idx = ri; else if (hi == 1 && ri <= 7) idx = 8 + ri;
+            v = idx >= 0 ? gb1[idx] * lr_mul : 0.0f;
+        } else {
+            v = ab1[16 * hi + ri] * lr_mul;
+        }
+    }
+    out[e] = v;
+}
+
+}  // namespace nfe
+
+using namespace nfe;
+
+extern "C" int nfe_ray_sampler(const float* cam2world, const float* intrinsics, int n_views, int resolution,
+                               float* origins, float* dirs, nfe_stream_t stream) {
+    NFE_REQUIRE(cam2world && intrinsics && origins && dirs, "nfe_ray_sampler: null pointer");
+    NFE_REQUIRE(n_views > 0 && resolution > 0 && resolution <= 16384, "nfe_ray_sampler: bad sizes N=%d R=%d", n_views, resolution);
+    const long long total = (long long)n_views * resolution * resolution;
+    long long blocks = (total + 255) / 256; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(ray_sampler_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       cam2world, intrinsics, n_views, resolution, origins, dirs);
+    NFE_CHECK_LAUNCH("ray_sampler_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_plane_stats(const float* planes, int n, int c, int hw, float* mean, float* std, nfe_stream_t stream) {
+    NFE_REQUIRE(planes && mean && std, "nfe_plane_stats: null pointer");
+    NFE_REQUIRE(n > 0 && c > 0 && hw > 1, "nfe_plane_stats: bad sizes n=%d c=%d hw=%d", n, c, hw);
+    hipLaunchKernelGGL(plane_stats_kernel, dim3((unsigned)(n * c)), dim3(256), 0, (hipStream_t)stream, planes, hw, mean, std);
+    NFE_CHECK_LAUNCH("plane_stats_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_plane_affine(const float* in, const float* scale, const float* shift, int n, int c, int hw,
+                                int n_affine, float* out, nfe_stream_t stream) {
+    NFE_REQUIRE(in && scale && shift && out, "nfe_plane_affine: null pointer");
+    NFE_REQUIRE(n > 0 && c > 0 && hw > 0, "nfe_plane_affine: bad sizes n=%d c=%d hw=%d", n, c, hw);
+    NFE_REQUIRE(n_affine == 1 || n_affine == n, "nfe_plane_affine: n_affine=%d must be 1 or n=%d", n_affine, n);
+    int gy = (hw / 4 + 1023) / 1024; if (gy < 1) gy = 1; if (gy > 64) gy = 64;
+    hipLaunchKernelGGL(plane_affine_kernel, dim3((unsigned)(n * c), (unsigned)gy), dim3(256), 0, (hipStream_t)stream,
+                       in, scale, shift, c, hw, n_affine, out);
+    NFE_CHECK_LAUNCH("plane_affine_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_make_affine(const float* mean, const float* std, const float* new_mean, const float* new_std,
+                               int n, int c, int n_override, float* geo_scale, float* geo_shift,
+                               float* app_scale, float* app_shift, nfe_stream_t stream) {
+    NFE_REQUIRE(mean && std && geo_scale && geo_shift && app_scale && app_shift, "nfe_make_affine: null pointer");
+    NFE_REQUIRE((new_mean != nullptr) == (new_std != nullptr), "nfe_make_affine: override mean/std must come in pairs");
+    NFE_REQUIRE(n > 0 && c > 0, "nfe_make_affine: bad sizes");
+    NFE_REQUIRE(!new_mean || n_override == 1 || n_override == n, "nfe_make_affine: n_override=%d must be 1 or n=%d", n_override, n);
+    hipLaunchKernelGGL(make_affine_kernel, dim3((unsigned)((n * c + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       mean, std, new_mean, new_std, n, c, n_override, geo_scale, geo_shift, app_scale, app_shift);
+    NFE_CHECK_LAUNCH("make_affine_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_plane_pack(const float* planes_nchw, int n, int h, int w, float* packed, nfe_stream_t stream) {
+    NFE_REQUIRE(planes_nchw && packed, "nfe_plane_pack: null pointer");
+    NFE_REQUIRE(n > 0 && h > 0 && w > 0, "nfe_plane_pack: bad sizes n=%d h=%d w=%d", n, h, w);
+    const int hw = h * w;
+    hipLaunchKernelGGL(plane_pack_kernel, dim3((unsigned)((hw + 63) / 64), (unsigned)(n * 3)), dim3(256), 0, (hipStream_t)stream,
+                       planes_nchw, hw, packed);
+    NFE_CHECK_LAUNCH("plane_pack_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_decoder_pack(const float* geo_w0, const float* geo_b0, const float* geo_w1, const float* geo_b1,
+                                const float* app_w0, const float* app_b0, const float* app_w1, const float* app_b1,
+                                float lr_mul, float* packed, nfe_stream_t stream) {
+    NFE_REQUIRE(geo_w0 && geo_b0 && geo_w1 && geo_b1 && app_w0 && app_b0 && app_w1 && app_b1 && packed,
+                "nfe_decoder_pack: null pointer");
+    hipLaunchKernelGGL(decoder_pack_kernel, dim3((DEC_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       geo_w0, geo_b0, geo_w1, geo_b1, app_w0, app_b0, app_w1, app_b1, lr_mul, packed);
+    NFE_CHECK_LAUNCH("decoder_pack_kernel");
+    return NFE_OK;
+}

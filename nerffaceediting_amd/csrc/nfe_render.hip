@@ -1,0 +1,778 @@
+// Fused tri-plane volume renderer for MI355X (gfx950): stratified depths -> tri-plane bilinear
+// gather -> dual MLP decoder (fp32 MFMA) -> mid-point alpha compositing, one kernel.
+//
+// Replaces DisentangledImportanceRenderer.forward (training/volumetric_rendering/renderer.py:301-363)
+// and everything it calls: sample_stratified (:169-192), sample_from_planes (:55-65),
+// DisentangledOSGDecoder.forward (training/triplane.py:249-270), SegMipRayMarcher2.run_forward
+// (ray_marcher.py:68-101), sample_importance/sample_pdf (renderer.py:194-253), unify_samples
+// (:288-300).  See DESIGN.md §4 for the lane mapping and the MFMA operand layouts.
+#include "nfe_common.h"
+
+namespace nfe {
+
+// ------------------------------------------------------------------------------------------
+// kernel parameters
+// ------------------------------------------------------------------------------------------
+enum DepthMode : int { DEPTH_STRATIFIED = 0, DEPTH_PER_RAY = 1, DEPTH_DISPARITY = 2, DEPTH_BUFFER = 3 };
+
+struct RenderK {
+    const float* planes_g; const float* planes_a; long long plane_view_stride;
+    int H, W;
+    const float* aff[4];          // geo_scale, geo_shift, app_scale, app_shift: [N,96] or null
+    const float* dec;
+    int N, M, R, tiled;
+    const float* origins; const float* dirs; const float* cam2world; const float* intrinsics;
+    int S;                         // samples marched per ray in this pass
+    int depth_mode;
+    float ray_start, ray_end;
+    const float* rs_ray; const float* re_ray;
+    const float* u; unsigned long long seed;
+    const float* depth_buf;        // DEPTH_BUFFER: [N*M, S]
+    float coord_scale;             // 2 / box_warp
+    int white_back;
+    float* rgb; float* seg; float* depth; float* wsum; int channels_first;
+    float* out_depths;             // optional [N*M, S]
+    float* out_weights;            // optional [N*M, S-1]
+    unsigned* depth_minmax;        // ordered-uint {min, max}
+};
+
+constexpr int LDS_AFF = DEC_FLOATS;             // per-wave affine region starts here
+constexpr int AFF_FLOATS = 4 * 96;
+constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * AFF_FLOATS) * 4;
+
+// Raw v_exp_f32 / v_log_f32 (1 ulp, no denormal-range fix-up code: results this small are far below
+// the 1e-3 parity budget).
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+
+__device__ __forceinline__ float softplus_f(float x) {
+    // torch Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x))
+    float r = fast_log(1.0f + fast_exp(x));
+    return x > 20.0f ? x : r;
+}
+
+// One bilinear tap group for one plane: accumulates 16 channels (this lane's half texel).
+template <bool DUAL, int TAPS_IN_FLIGHT>
+__device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const float* __restrict__ pa,
+                                             int H, int W, float u, float v, int hoff,
+                                             float (&sg)[16], float (&sa)[16], float& wsum) {
+    // F.grid_sample(bilinear, zeros, align_corners=False) — renderer.py:64; unnormalise as ATen does.
+    float ix = (u + 1.0f) * (0.5f * (float)W) - 0.5f;
+    float iy = (v + 1.0f) * (0.5f * (float)H) - 0.5f;
+    float x0f = floorf(ix), y0f = floorf(iy);
+    float dx = ix - x0f, dy = iy - y0f, ex = 1.0f - dx, ey = 1.0f - dy;
+    int x0 = (int)fminf(fmaxf(x0f, -2.0f), (float)(W + 1));
+    int y0 = (int)fminf(fmaxf(y0f, -2.0f), (float)(H + 1));
+    int x1 = x0 + 1, y1 = y0 + 1;
+    bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
+    bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
+    float w00 = (vx0 && vy0) ? ex * ey : 0.0f;
+    float w10 = (vx1 && vy0) ? dx * ey : 0.0f;
+    float w01 = (vx0 && vy1) ? ex * dy : 0.0f;
+    float w11 = (vx1 && vy1) ? dx * dy : 0.0f;
+    int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x1, 0), W - 1);
+    int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y1, 0), H - 1);
+    wsum = (w00 + w10) + (w01 + w11);
+    const int o00 = (yc0 * W + xc0) * 32 + hoff, o10 = (yc0 * W + xc1) * 32 + hoff;
+    const int o01 = (yc1 * W + xc0) * 32 + hoff, o11 = (yc1 * W + xc1) * 32 + hoff;
+    const int offs[4] = {o00, o10, o01, o11};
+    const float ws[4] = {w00, w10, w01, w11};
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { sg[c] = 0.0f; if (DUAL) sa[c] = 0.0f; }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const float4* tg = reinterpret_cast<const float4*>(pg + offs[t]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 a = tg[q];
+            sg[4 * q + 0] = fmaf(ws[t], a.x, sg[4 * q + 0]);
+            sg[4 * q + 1] = fmaf(ws[t], a.y, sg[4 * q + 1]);
+            sg[4 * q + 2] = fmaf(ws[t], a.z, sg[4 * q + 2]);
+            sg[4 * q + 3] = fmaf(ws[t], a.w, sg[4 * q + 3]);
+        }
+        if (DUAL) {
+            const float4* ta = reinterpret_cast<const float4*>(pa + offs[t]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 a = ta[q];
+                sa[4 * q + 0] = fmaf(ws[t], a.x, sa[4 * q + 0]);
+                sa[4 * q + 1] = fmaf(ws[t], a.y, sa[4 * q + 1]);
+                sa[4 * q + 2] = fmaf(ws[t], a.z, sa[4 * q + 2]);
+                sa[4 * q + 3] = fmaf(ws[t], a.w, sa[4 * q + 3]);
+            }
+        }
+        // Register discipline: at most TAPS_IN_FLIGHT taps' loads (4 float4 = 16 VGPRs each, x2 with
+        // two plane sets) are outstanding; the other wave on the SIMD covers the latency.
+        if (((t + 1) % TAPS_IN_FLIGHT) == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Evaluate the implicit model at one point per lane PAIR (lanes j and j+32 share a point; lane half
+// h holds channels [16h,16h+16) of every 32-vector).  Returns, for this lane:
+//   og[0] = sigma; og[1..] = seg channels (h=0: seg 0..7 in og[1..8]; h=1: seg 8..14 in og[1..7])
+//   oa[r] = rgb channel 16h + r   (after the sigmoid clamp, triplane.py:269)
+template <bool DUAL, bool SIGMA_ONLY>
+__device__ __forceinline__ void eval_point(const float* __restrict__ pg, const float* __restrict__ pa,
+                                           int H, int W, const float* __restrict__ lds,
+                                           const float* __restrict__ aff, float gx, float gy, float gz,
+                                           int lane, f32x16& og, f32x16& oa) {
+    const int h = lane >> 5;
+    const int hoff = h * 16;
+    float fn[16], fd[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) { fn[c] = 0.0f; fd[c] = 0.0f; }
+    const long long plane_elems = (long long)H * W * 32;
+    // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float u = (p == 2) ? gz : gx;
+        float v = (p == 0) ? gy : ((p == 1) ? gz : gx);
+        float sg[16], sa[16], wsum;
+        gather_plane<DUAL && !SIGMA_ONLY, (DUAL && !SIGMA_ONLY) ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, H, W, u, v, hoff, sg, sa, wsum);
+        const float4* gs = reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + hoff);
+        const float4* gb = reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + hoff);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 s = gs[q], b = gb[q];
+            fn[4 * q + 0] = fmaf(sg[4 * q + 0], s.x, fmaf(wsum, b.x, fn[4 * q + 0]));
+            fn[4 * q + 1] = fmaf(sg[4 * q + 1], s.y, fmaf(wsum, b.y, fn[4 * q + 1]));
+            fn[4 * q + 2] = fmaf(sg[4 * q + 2], s.z, fmaf(wsum, b.z, fn[4 * q + 2]));
+            fn[4 * q + 3] = fmaf(sg[4 * q + 3], s.w, fmaf(wsum, b.w, fn[4 * q + 3]));
+        }
+        if (!SIGMA_ONLY) {
+            const float4* as = reinterpret_cast<const float4*>(aff + 2 * 96 + p * 32 + hoff);
+            const float4* ab = reinterpret_cast<const float4*>(aff + 3 * 96 + p * 32 + hoff);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 s = as[q], b = ab[q];
+                fd[4 * q + 0] = fmaf(DUAL ? sa[4 * q + 0] : sg[4 * q + 0], s.x, fmaf(wsum, b.x, fd[4 * q + 0]));
+                fd[4 * q + 1] = fmaf(DUAL ? sa[4 * q + 1] : sg[4 * q + 1], s.y, fmaf(wsum, b.y, fd[4 * q + 1]));
+                fd[4 * q + 2] = fmaf(DUAL ? sa[4 * q + 2] : sg[4 * q + 2], s.z, fmaf(wsum, b.z, fd[4 * q + 2]));
+                fd[4 * q + 3] = fmaf(DUAL ? sa[4 * q + 3] : sg[4 * q + 3], s.w, fmaf(wsum, b.w, fd[4 * q + 3]));
+            }
+        }
+    }
+
+    // ---- decoder: FC 32->64, softplus, FC 64->{16|32}; weights are the MFMA A operand (LDS),
+    // the per-point vectors are the B operand and never leave registers. -------
+    // Register discipline: the machine scheduler would otherwise hoist every LDS weight read of both
+    // nets to the top (>150 VGPRs).  Each 4-k-step group prefetches the next group's A fragments and
+    // ends in a scheduling fence, so at most two groups of fragments are live.
+    auto mlp = [&](const float (&f)[16], int offA0, int offB0, int offA1, int offB1, f32x16& out) {
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 a0, a1;
+        const float4* b0 = reinterpret_cast<const float4*>(lds + offB0 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 x = b0[2 * q], y = b0[8 + 2 * q];
+            a0[4 * q + 0] = x.x; a0[4 * q + 1] = x.y; a0[4 * q + 2] = x.z; a0[4 * q + 3] = x.w;
+            a1[4 * q + 0] = y.x; a1[4 * q + 1] = y.y; a1[4 * q + 2] = y.z; a1[4 * q + 3] = y.w;
+        }
+        const float4* A0 = reinterpret_cast<const float4*>(lds + offA0) + lane;
+        float4 w0 = A0[0], w1 = A0[4 * 64];
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+            float4 n0 = w0, n1 = w1;
+            if (k4 < 3) { n0 = A0[(k4 + 1) * 64]; n1 = A0[(4 + k4 + 1) * 64]; }
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, f[4 * k4 + 0], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, f[4 * k4 + 0], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, f[4 * k4 + 1], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, f[4 * k4 + 1], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, f[4 * k4 + 2], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, f[4 * k4 + 2], a1, 0, 0, 0);
+            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, f[4 * k4 + 3], a0, 0, 0, 0);
+            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, f[4 * k4 + 3], a1, 0, 0, 0);
+            w0 = n0; w1 = n1;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a0[r] = softplus_f(a0[r]); a1[r] = softplus_f(a1[r]); }
+        const float4* b1 = reinterpret_cast<const float4*>(lds + offB1 + 4 * h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float4 x = b1[2 * q];
+            out[4 * q + 0] = x.x; out[4 * q + 1] = x.y; out[4 * q + 2] = x.z; out[4 * q + 3] = x.w;
+        }
+        const float4* A1 = reinterpret_cast<const float4*>(lds + offA1) + lane;
+        float4 w = A1[0];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k4 = 0; k4 < 8; ++k4) {
+            float4 nw = w;
+            if (k4 < 7) nw = A1[(k4 + 1) * 64];
+            const int kb = 4 * (k4 & 3);
+            if (k4 < 4) {
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a0[kb + 0], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a0[kb + 1], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a0[kb + 2], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a0[kb + 3], out, 0, 0, 0);
+            } else {
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a1[kb + 0], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a1[kb + 1], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a1[kb + 2], out, 0, 0, 0);
+                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a1[kb + 3], out, 0, 0, 0);
+            }
+            w = nw;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    mlp(fn, DEC_A_G0, DEC_B_G0, DEC_A_G1, DEC_B_G1, og);
+    if (!SIGMA_ONLY) {
+        mlp(fd, DEC_A_A0, DEC_B_A0, DEC_A_A1, DEC_B_A1, oa);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float s = __builtin_amdgcn_rcpf(1.0f + fast_exp(-oa[r]));
+            oa[r] = fmaf(s, 1.002f, -0.001f);      // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269
+        }
+    }
+}
+
+// Stage this wave's view affines into its LDS region, folding in the 1/3 of the mean over planes
+// (triplane.py:251-252).
+__device__ __forceinline__ void stage_affine(const float* const (&src)[4], int n, float* aff, int lane) {
+#pragma unroll
+    for (int arr = 0; arr < 4; ++arr) {
+        const float* p = src[arr];
+        const float dflt = (arr & 1) ? 0.0f : 1.0f;
+        for (int c = lane; c < 96; c += 64) {
+            float v = p ? p[(long long)n * 96 + c] : dflt;
+            aff[arr * 96 + c] = v * (1.0f / 3.0f);
+        }
+    }
+    __threadfence_block();
+}
+
+template <bool DUAL, bool SIGMA_ONLY>
+__global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < DEC_FLOATS / 4; i += 256)
+        reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(P.dec)[i];
+    // wave id in an SGPR: everything derived from it (ray block, view, plane base) stays scalar
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    float* aff = lds + LDS_AFF + wave * AFF_FLOATS;
+    __syncthreads();
+
+    const int S = P.S;
+    const int blocks_per_view = (P.M + 31) >> 5;
+    const long long total_rb = (long long)P.N * blocks_per_view;
+    const long long n_waves = (long long)gridDim.x * 4;
+    int cur_view = -1;
+    float tmin = INFINITY, tmax = -INFINITY;
+
+#pragma unroll 1
+    for (long long rb = (long long)blockIdx.x * 4 + wave; rb < total_rb; rb += n_waves) {
+        const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
+        if (n != cur_view) { stage_affine(P.aff, n, aff, lane); cur_view = n; }
+
+        // ---- ray for this lane pair -------------------------------------------------------
+        int m, px = 0, py = 0;
+        if (P.tiled) {   // 8x4 pixel tile per wave: neighbouring rays hit neighbouring texels
+            const int tiles_x = P.R >> 3;
+            px = (b % tiles_x) * 8 + (j & 7);
+            py = (b / tiles_x) * 4 + (j >> 3);
+            m = py * P.R + px;
+        } else {
+            m = b * 32 + j;
+            if (P.R > 0) { py = min(m, P.M - 1) / P.R; px = min(m, P.M - 1) % P.R; }
+        }
+        const bool valid = m < P.M;
+        m = min(m, P.M - 1);
+        const long long ray = (long long)n * P.M + m;
+        float ox, oy, oz, dx, dy, dz;
+        if (P.origins) {
+            const float* o = P.origins + ray * 3; const float* d = P.dirs + ray * 3;
+            ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
+        } else {
+            // RaySampler.forward, ray_sampler.py:35-61
+            const float* c = P.cam2world + n * 16; const float* K = P.intrinsics + n * 9;
+            const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+            const float inv = 1.0f / (float)P.R;
+            const float xc = (float)px * inv + 0.5f * inv, yc = (float)py * inv + 0.5f * inv;
+            const float xl = (xc - cx + cy * sk / fy - sk * yc / fy) / fx;
+            const float yl = (yc - cy) / fy;
+            ox = c[3]; oy = c[7]; oz = c[11];
+            float wx = c[0] * xl + c[1] * yl + c[2] + c[3];
+            float wy = c[4] * xl + c[5] * yl + c[6] + c[7];
+            float wz = c[8] * xl + c[9] * yl + c[10] + c[11];
+            dx = wx - ox; dy = wy - oy; dz = wz - oz;
+            float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+            dx /= nrm; dy /= nrm; dz /= nrm;
+        }
+        const float* pg = P.planes_g + (long long)n * P.plane_view_stride;
+        const float* pa = P.planes_a + (long long)n * P.plane_view_stride;
+
+        // ---- depth schedule (sample_stratified, renderer.py:169-192) -------------------------
+        float rs = P.ray_start, re = P.ray_end;
+        if (P.depth_mode == DEPTH_PER_RAY) { rs = P.rs_ray[ray]; re = P.re_ray[ray]; }
+        const float inv_dm1 = 1.0f / (float)(S - 1);
+        const float delta = (re - rs) / (float)(S - 1);
+
+        // ---- march state (SegMipRayMarcher2.run_forward, ray_marcher.py:68-101) --------------
+        float acc_rgb[16], acc_seg[8], prev_rgb[16], prev_seg[8];
+        float acc_d = 0.0f, acc_w = 0.0f, T = 1.0f, prev_t = 0.0f, prev_sig = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { acc_rgb[c] = 0.0f; prev_rgb[c] = 0.0f; }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { acc_seg[c] = 0.0f; prev_seg[c] = 0.0f; }
+        u32x4 rnd = {0, 0, 0, 0};
+
+#pragma unroll 1
+        for (int k = 0; k < S; ++k) {
+            float t;
+            if (P.depth_mode == DEPTH_BUFFER) {
+                t = P.depth_buf[ray * S + k];
+            } else {
+                float u;
+                if (P.u) {
+                    u = P.u[ray * S + k];
+                } else {
+                    if ((k & 3) == 0)
+                        rnd = philox4x32_10((unsigned)ray, (unsigned)(k >> 2), 0u, 0u,
+                                            (unsigned)P.seed, (unsigned)(P.seed >> 32));
+                    unsigned bits = (k & 3) == 0 ? rnd.x : (k & 3) == 1 ? rnd.y : (k & 3) == 2 ? rnd.z : rnd.w;
+                    u = u01(bits);
+                }
+                if (P.depth_mode == DEPTH_DISPARITY) {
+                    float s = (float)k * inv_dm1 + u * inv_dm1;
+                    t = 1.0f / (1.0f / rs * (1.0f - s) + 1.0f / re * s);
+                } else if (P.depth_mode == DEPTH_PER_RAY) {
+                    t = rs + ((float)k / (float)(S - 1)) * (re - rs) + u * delta;
+                } else {
+                    t = fmaf((float)k, delta, rs) + u * delta;
+                }
+            }
+            if (P.out_depths && valid && h == 0) P.out_depths[ray * S + k] = t;
+            tmin = fminf(tmin, t); tmax = fmaxf(tmax, t);
+
+            const float gx = P.coord_scale * fmaf(t, dx, ox);
+            const float gy = P.coord_scale * fmaf(t, dy, oy);
+            const float gz = P.coord_scale * fmaf(t, dz, oz);
+            f32x16 og, oa;
+            // Opaque zero: keeps the (loop-invariant) LDS weight reads inside the loop; hoisted, they
+            // would pin >200 VGPRs per lane and spill.
+            int opq;
+            asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
+            eval_point<DUAL, SIGMA_ONLY>(pg, pa, P.H, P.W, lds + opq, aff + opq, gx, gy, gz, lane, og, oa);
+
+            if (k > 0) {
+                const float dlt = t - prev_t;
+                const float dens = softplus_f((prev_sig + og[0]) * 0.5f - 1.0f);
+                const float alpha = 1.0f - fast_exp(-(dens * dlt));
+                const float w = alpha * T;
+                T = T * (1.0f - alpha + 1e-10f);
+                if (P.out_weights && valid && h == 0) P.out_weights[ray * (S - 1) + (k - 1)] = w;
+                if (!SIGMA_ONLY) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) acc_rgb[c] = fmaf(w, (prev_rgb[c] + oa[c]) * 0.5f, acc_rgb[c]);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c) acc_seg[c] = fmaf(w, (prev_seg[c] + og[1 + c]) * 0.5f, acc_seg[c]);
+                    acc_d = fmaf(w, (prev_t + t) * 0.5f, acc_d);
+                    acc_w += w;
+                }
+            }
+            prev_t = t; prev_sig = og[0];
+            if (!SIGMA_ONLY) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) prev_rgb[c] = oa[c];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) prev_seg[c] = og[1 + c];
+            }
+        }
+
+        // ---- outputs -------------------------------------------------------------------------
+        if (!SIGMA_ONLY && valid) {
+            const float wb = P.white_back ? (1.0f - acc_w) : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 16; ++c) acc_rgb[c] = (acc_rgb[c] + wb) * 2.0f - 1.0f;   // :96-99
+            if (P.channels_first) {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) P.rgb[((long long)n * 32 + 16 * h + c) * P.M + m] = acc_rgb[c];
+                const int nseg = h ? 7 : 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < nseg) P.seg[((long long)n * 15 + 8 * h + c) * P.M + m] = acc_seg[c];
+            } else {
+                float4* o = reinterpret_cast<float4*>(P.rgb + ray * 32 + 16 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    o[q] = make_float4(acc_rgb[4 * q], acc_rgb[4 * q + 1], acc_rgb[4 * q + 2], acc_rgb[4 * q + 3]);
+                const int nseg = h ? 7 : 8;
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (c < nseg) P.seg[ray * 15 + 8 * h + c] = acc_seg[c];
+            }
+            if (h == 0) {
+                P.depth[ray] = acc_d / acc_w;     // NaN when acc_w == 0; fixed by depth_clamp_kernel
+                P.wsum[ray] = acc_w;
+            }
+        }
+    }
+
+    // ---- whole-tensor depth bounds for the clamp (ray_marcher.py:94) -----------------------------
+    if (P.depth_minmax) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            tmin = fminf(tmin, __shfl_xor(tmin, off));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+        }
+        if (lane == 0 && tmin <= tmax) {
+            atomicMin(P.depth_minmax + 0, f2ord(tmin));
+            atomicMax(P.depth_minmax + 1, f2ord(tmax));
+        }
+    }
+}
+
+// nan_to_num(depth, inf) then clamp to the whole-tensor [min,max] of sampled depths (ray_marcher.py:93-94)
+__global__ void depth_clamp_kernel(float* depth, long long n, const unsigned* minmax) {
+    const float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        float d = depth[i];
+        if (d != d) d = INFINITY;
+        depth[i] = fminf(fmaxf(d, lo), hi);
+    }
+}
+
+__global__ void minmax_init_kernel(unsigned* minmax) {
+    minmax[0] = 0xFFFFFFFFu; minmax[1] = 0u;
+}
+
+// ------------------------------------------------------------------------------------------
+// Importance sampling + merge: one wave per ray, lanes over samples.
+// sample_importance / sample_pdf (renderer.py:194-253) and unify_samples (:288-300).
+// ------------------------------------------------------------------------------------------
+struct ImportanceK {
+    const float* t_coarse;   // [NR, D]
+    const float* w_coarse;   // [NR, D-1]
+    const float* u_fine;     // [NR, Di] or null
+    unsigned long long seed;
+    long long n_rays_total;
+    int D, Di;
+    float* t_all;            // [NR, D+Di] sorted ascending
+    float* tap_fine;         // optional [NR, Di] in draw order
+};
+
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        float o = __shfl_up(v, off);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int D = P.D, Di = P.Di;
+    const int stride = 3 * D + Di;                       // per-wave LDS floats
+    float* tc = lds + wave * stride;                     // [D] coarse depths
+    float* wq = tc + D;                                  // [D] weights, then smoothed weights
+    float* cdf = wq + D;                                 // [D] cdf knots (D-2 used)
+    float* tf = cdf + D;                                 // [Di] fine depths
+    const int B = D - 3;                                 // number of pdf bins (weights[:,1:-1])
+
+    for (long long ray = (long long)blockIdx.x * 4 + wave; ray < P.n_rays_total; ray += (long long)gridDim.x * 4) {
+        for (int i = lane; i < D; i += 64) tc[i] = P.t_coarse[ray * D + i];
+        for (int i = lane; i < D - 1; i += 64) wq[i] = P.w_coarse[ray * (D - 1) + i];
+        __threadfence_block();
+        // smoothed weights a_i, i=0..D-2 (max_pool1d(k2,s1,p1) then avg_pool1d(k2,s1), +0.01): :205-207
+        // only a[1..D-3] are used; q_i = a_{i+1} + 1e-5, i = 0..B-1 (:210, :228)
+        float qv[NFE_MAX_SAMPLES / 64];
+        float part = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+            const int i = c * 64 + lane;
+            float q = 0.0f;
+            if (i < B) {
+                const int a = i + 1;                     // a in [1, D-3]
+                const float w_m1 = wq[a - 1], w_0 = wq[a], w_p1 = wq[a + 1];
+                const float m0 = fmaxf(w_m1, w_0), m1 = fmaxf(w_0, w_p1);
+                q = ((m0 + m1) * 0.5f + 0.01f) + 1e-5f;
+            }
+            qv[c] = q;
+            part += q;
+        }
+        float total = part;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off);
+        // cdf knots: cdf[0] = 0, cdf[i+1] = cumsum(pdf)[i]  (:229-232)
+        float carry = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+            const int i = c * 64 + lane;
+            float pdf = qv[c] / total;
+            float sc = wave_incl_scan(pdf, lane) + carry;
+            if (i < B) cdf[i + 1] = sc;
+            carry = __shfl(sc, 63);
+        }
+        if (lane == 0) cdf[0] = 0.0f;
+        __threadfence_block();
+        // inverse-CDF sampling (:236-252)
+        for (int e = lane; e < Di; e += 64) {
+            float u;
+            if (P.u_fine) {
+                u = P.u_fine[ray * Di + e];
+            } else {
+                u32x4 r = philox4x32_10((unsigned)ray, (unsigned)(e >> 2), 1u, 0u,
+                                        (unsigned)P.seed, (unsigned)(P.seed >> 32));
+                unsigned bits = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+                u = u01(bits);
+            }
+            // searchsorted(cdf[0..B], u, right=True): number of knots <= u
+            int lo = 0, hi = B + 1;
+            while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+            const int below = max(lo - 1, 0), above = min(lo, B);
+            const float cb = cdf[below], ca = cdf[above];
+            const float bb = 0.5f * (tc[below] + tc[below + 1]);     // z_vals_mid (:209)
+            const float ba = 0.5f * (tc[above] + tc[above + 1]);
+            float den = ca - cb;
+            if (den < 1e-5f) den = 1.0f;
+            const float t = bb + (u - cb) / den * (ba - bb);
+            tf[e] = t;
+            if (P.tap_fine) P.tap_fine[ray * Di + e] = t;
+        }
+        __threadfence_block();
+        // merge by rank counting: stable, coarse before fine on ties
+        float* out = P.t_all + ray * (D + Di);
+        for (int e = lane; e < D + Di; e += 64) {
+            const bool is_f = e >= D;
+            const int idx = is_f ? e - D : e;
+            const float v = is_f ? tf[idx] : tc[idx];
+            int pos = 0;
+            for (int k = 0; k < D; ++k) {
+                const float o = tc[k];
+                pos += (o < v) || (o == v && (is_f || k < idx));
+            }
+            for (int k = 0; k < Di; ++k) {
+                const float o = tf[k];
+                pos += (o < v) || (o == v && is_f && k < idx);
+            }
+            out[pos] = v;
+        }
+        __threadfence_block();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// a15: point query (renderer.run_model), 32 points per wave step
+// ------------------------------------------------------------------------------------------
+struct PointK {
+    const float* planes_g; const float* planes_a; long long plane_view_stride; int H, W;
+    const float* aff[4]; const float* dec;
+    const float* coords; int N, Pn; float coord_scale;
+    float* rgb; float* sigma; float* seg;
+};
+
+template <bool DUAL>
+__global__ __launch_bounds__(256) void point_kernel(PointK P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < DEC_FLOATS / 4; i += 256)
+        reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(P.dec)[i];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    float* aff = lds + LDS_AFF + wave * AFF_FLOATS;
+    __syncthreads();
+    const int blocks_per_view = (P.Pn + 31) >> 5;
+    const long long total = (long long)P.N * blocks_per_view;
+    int cur_view = -1;
+    for (long long rb = (long long)blockIdx.x * 4 + wave; rb < total; rb += (long long)gridDim.x * 4) {
+        const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
+        if (n != cur_view) { stage_affine(P.aff, n, aff, lane); cur_view = n; }
+        int m = b * 32 + j;
+        const bool valid = m < P.Pn;
+        m = min(m, P.Pn - 1);
+        const long long pt = (long long)n * P.Pn + m;
+        const float* c = P.coords + pt * 3;
+        f32x16 og, oa;
+        eval_point<DUAL, false>(P.planes_g + (long long)n * P.plane_view_stride,
+                                P.planes_a + (long long)n * P.plane_view_stride, P.H, P.W, lds, aff,
+                                P.coord_scale * c[0], P.coord_scale * c[1], P.coord_scale * c[2], lane, og, oa);
+        if (valid) {
+            float4* o = reinterpret_cast<float4*>(P.rgb + pt * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = make_float4(oa[4 * q], oa[4 * q + 1], oa[4 * q + 2], oa[4 * q + 3]);
+            const int nseg = h ? 7 : 8;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                if (cc < nseg) P.seg[pt * 15 + 8 * h + cc] = og[1 + cc];
+            if (h == 0) P.sigma[pt] = og[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------
+static int num_cus() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
+            cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <typename K>
+static void allow_lds(K kernel, int bytes) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+
+static int launch_render(const RenderK& P, bool dual, bool sigma_only, hipStream_t st) {
+    const long long total_rb = (long long)P.N * ((P.M + 31) / 32);
+    long long blocks = (total_rb + 3) / 4;
+    const long long cap = (long long)num_cus() * 2;      // 2 blocks (8 waves) per CU, grid-stride beyond
+    if (blocks > cap) blocks = cap;
+    dim3 grid((unsigned)blocks), block(256);
+    if (sigma_only) {
+        if (dual) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, RENDER_LDS_BYTES, st, P);
+        else hipLaunchKernelGGL((render_kernel<false, true>), grid, block, RENDER_LDS_BYTES, st, P);
+    } else {
+        if (dual) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, RENDER_LDS_BYTES, st, P);
+        else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, RENDER_LDS_BYTES, st, P);
+    }
+    NFE_CHECK_LAUNCH("render_kernel");
+    return NFE_OK;
+}
+
+static uint64_t align256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
+
+}  // namespace nfe
+
+using namespace nfe;
+
+extern "C" uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int D, int Di) {
+    uint64_t nr = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0);
+    uint64_t b = 256;                                    // depth min/max words
+    if (Di > 0) {
+        b += align256(nr * (uint64_t)D * 4);             // coarse depths
+        b += align256(nr * (uint64_t)(D - 1) * 4);       // coarse weights
+        b += align256(nr * (uint64_t)(D + Di) * 4);      // merged depths
+    }
+    return b;
+}
+
+extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
+    NFE_REQUIRE(a != nullptr, "nfe_render: args is null");
+    NFE_REQUIRE(a->struct_size == sizeof(nfe_render_args), "nfe_render: struct_size %u != %zu (ABI mismatch)",
+                a->struct_size, sizeof(nfe_render_args));
+    NFE_REQUIRE(a->planes_geo && a->planes_app && a->decoder_packed, "nfe_render: planes/decoder pointers are null");
+    NFE_REQUIRE(a->plane_h > 0 && a->plane_w > 0 && a->plane_h <= 16384 && a->plane_w <= 16384, "nfe_render: bad plane size %dx%d", a->plane_h, a->plane_w);
+    NFE_REQUIRE(a->n_views > 0 && a->n_rays > 0, "nfe_render: n_views=%d n_rays=%d must be positive", a->n_views, a->n_rays);
+    const int D = a->depth_resolution, Di = a->depth_resolution_importance;
+    NFE_REQUIRE(D >= 2 && D <= NFE_MAX_SAMPLES, "nfe_render: depth_resolution=%d out of [2,%d]", D, NFE_MAX_SAMPLES);
+    NFE_REQUIRE(Di >= 0 && Di <= NFE_MAX_SAMPLES, "nfe_render: depth_resolution_importance=%d out of [0,%d]", Di, NFE_MAX_SAMPLES);
+    NFE_REQUIRE(Di == 0 || D >= 4, "nfe_render: importance sampling needs depth_resolution >= 4 (got %d)", D);
+    NFE_REQUIRE(Di == 0 || (long long)a->n_views * a->n_rays >= 2,
+                "nfe_render: importance sampling with a single ray is undefined in the reference (renderer.py:206 squeeze)");
+    NFE_REQUIRE((a->origins != nullptr) == (a->dirs != nullptr), "nfe_render: origins and dirs must both be given or both null");
+    if (!a->origins) {
+        NFE_REQUIRE(a->cam2world && a->intrinsics, "nfe_render: need origins/dirs or cam2world/intrinsics");
+        NFE_REQUIRE(a->resolution > 0 && (long long)a->resolution * a->resolution == a->n_rays,
+                    "nfe_render: resolution^2 (%d^2) != n_rays (%d)", a->resolution, a->n_rays);
+    }
+    NFE_REQUIRE((a->ray_start_per_ray != nullptr) == (a->ray_end_per_ray != nullptr), "nfe_render: per-ray limits must come in pairs");
+    NFE_REQUIRE(!(a->ray_start_per_ray && a->disparity_space_sampling), "nfe_render: disparity sampling with per-ray limits is not supported");
+    NFE_REQUIRE(a->box_warp > 0.0f, "nfe_render: box_warp must be positive");
+    NFE_REQUIRE(a->rgb && a->seg && a->depth && a->wsum, "nfe_render: output pointers are null");
+    NFE_REQUIRE(a->workspace != nullptr, "nfe_render: workspace is null");
+    const uint64_t need = nfe_render_workspace_bytes(a->n_views, a->n_rays, D, Di);
+    if (a->workspace_bytes < need) return fail(NFE_EWORKSPACE, "nfe_render: workspace %llu < %llu bytes",
+                                               (unsigned long long)a->workspace_bytes, (unsigned long long)need);
+    hipStream_t st = (hipStream_t)stream;
+    const uint64_t nr = (uint64_t)a->n_views * a->n_rays;
+    char* ws = (char*)a->workspace;
+    unsigned* minmax = (unsigned*)ws; ws += 256;
+
+    RenderK P{};
+    P.planes_g = a->planes_geo; P.planes_a = a->planes_app; P.plane_view_stride = a->plane_view_stride;
+    P.H = a->plane_h; P.W = a->plane_w;
+    P.aff[0] = a->geo_scale; P.aff[1] = a->geo_shift; P.aff[2] = a->app_scale; P.aff[3] = a->app_shift;
+    P.dec = a->decoder_packed;
+    P.N = a->n_views; P.M = a->n_rays;
+    P.R = (a->resolution > 0 && (long long)a->resolution * a->resolution == a->n_rays) ? a->resolution : 0;
+    P.tiled = (P.R > 0 && (P.R % 8) == 0) ? 1 : 0;
+    P.origins = a->origins; P.dirs = a->dirs; P.cam2world = a->cam2world; P.intrinsics = a->intrinsics;
+    P.ray_start = a->ray_start; P.ray_end = a->ray_end; P.rs_ray = a->ray_start_per_ray; P.re_ray = a->ray_end_per_ray;
+    P.coord_scale = 2.0f / a->box_warp;
+    P.white_back = a->white_back;
+    P.rgb = a->rgb; P.seg = a->seg; P.depth = a->depth; P.wsum = a->wsum; P.channels_first = a->channels_first;
+    P.seed = a->seed;
+    const int mode = a->ray_start_per_ray ? DEPTH_PER_RAY : (a->disparity_space_sampling ? DEPTH_DISPARITY : DEPTH_STRATIFIED);
+    const bool dual = a->planes_geo != a->planes_app;
+
+    hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, minmax);
+    NFE_CHECK_LAUNCH("minmax_init_kernel");
+
+    if (Di == 0) {
+        P.S = D; P.depth_mode = mode; P.u = a->u_coarse; P.depth_minmax = minmax;
+        P.out_depths = a->tap_depths_all;
+        int rc = launch_render(P, dual, false, st);
+        if (rc) return rc;
+    } else {
+        float* t_c = (float*)ws; ws += align256(nr * (uint64_t)D * 4);
+        float* w_c = (float*)ws; ws += align256(nr * (uint64_t)(D - 1) * 4);
+        float* t_all = (float*)ws;
+        // pass 1: coarse densities -> weights (only sigma is needed: geometry net, geometry planes)
+        RenderK C = P;
+        C.S = D; C.depth_mode = mode; C.u = a->u_coarse; C.depth_minmax = nullptr;
+        C.out_depths = t_c; C.out_weights = w_c;
+        int rc = launch_render(C, dual, true, st);
+        if (rc) return rc;
+        if (a->tap_weights_coarse) {
+            hipError_t e = hipMemcpyAsync(a->tap_weights_coarse, w_c, nr * (uint64_t)(D - 1) * 4, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return fail(NFE_ELAUNCH, "tap copy: %s", hipGetErrorString(e));
+        }
+        // pass 2: importance sampling + merge
+        ImportanceK I{};
+        I.t_coarse = t_c; I.w_coarse = w_c; I.u_fine = a->u_fine; I.seed = a->seed; I.n_rays_total = (long long)nr;
+        I.D = D; I.Di = Di; I.t_all = t_all; I.tap_fine = a->tap_depths_fine;
+        const int lds_bytes = 4 * (3 * D + Di) * 4;
+        long long blocks = ((long long)nr + 3) / 4;
+        if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
+        hipLaunchKernelGGL(importance_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, st, I);
+        NFE_CHECK_LAUNCH("importance_kernel");
+        // pass 3: march the merged samples
+        RenderK F = P;
+        F.S = D + Di; F.depth_mode = DEPTH_BUFFER; F.depth_buf = t_all; F.depth_minmax = minmax;
+        rc = launch_render(F, dual, false, st);
+        if (rc) return rc;
+        if (a->tap_depths_all) {
+            hipError_t e = hipMemcpyAsync(a->tap_depths_all, t_all, nr * (uint64_t)(D + Di) * 4, hipMemcpyDeviceToDevice, st);
+            if (e != hipSuccess) return fail(NFE_ELAUNCH, "tap copy: %s", hipGetErrorString(e));
+        }
+    }
+    long long cb = ((long long)nr + 255) / 256;
+    if (cb > 4096) cb = 4096;
+    hipLaunchKernelGGL(depth_clamp_kernel, dim3((unsigned)cb), dim3(256), 0, st, a->depth, (long long)nr, minmax);
+    NFE_CHECK_LAUNCH("depth_clamp_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app, int plane_h, int plane_w,
+                               int64_t plane_view_stride, const float* geo_scale, const float* geo_shift,
+                               const float* app_scale, const float* app_shift, const float* decoder_packed,
+                               const float* coords, int n_views, int n_points, float box_warp,
+                               float* rgb, float* sigma, float* seg, nfe_stream_t stream) {
+    NFE_REQUIRE(planes_geo && planes_app && decoder_packed && coords, "nfe_point_query: null input pointer");
+    NFE_REQUIRE(rgb && sigma && seg, "nfe_point_query: null output pointer");
+    NFE_REQUIRE(plane_h > 0 && plane_w > 0, "nfe_point_query: bad plane size");
+    NFE_REQUIRE(n_views > 0 && n_points >= 0, "nfe_point_query: bad sizes N=%d P=%d", n_views, n_points);
+    NFE_REQUIRE(box_warp > 0.0f, "nfe_point_query: box_warp must be positive");
+    if (n_points == 0) return NFE_OK;
+    PointK P{};
+    P.planes_g = planes_geo; P.planes_a = planes_app; P.plane_view_stride = plane_view_stride; P.H = plane_h; P.W = plane_w;
+    P.aff[0] = geo_scale; P.aff[1] = geo_shift; P.aff[2] = app_scale; P.aff[3] = app_shift;
+    P.dec = decoder_packed; P.coords = coords; P.N = n_views; P.Pn = n_points; P.coord_scale = 2.0f / box_warp;
+    P.rgb = rgb; P.sigma = sigma; P.seg = seg;
+    const long long total = (long long)n_views * ((n_points + 31) / 32);
+    long long blocks = (total + 3) / 4;
+    if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
+    hipStream_t st = (hipStream_t)stream;
+    if (planes_geo != planes_app) hipLaunchKernelGGL((point_kernel<true>), dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, st, P);
+    else hipLaunchKernelGGL((point_kernel<false>), dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, st, P);
+    NFE_CHECK_LAUNCH("point_kernel");
+    return NFE_OK;
+}

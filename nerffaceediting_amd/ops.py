@@ -1,0 +1,239 @@
+"""Tensor-level wrappers over the C ABI: validate, allocate outputs with torch, pass raw pointers and
+the current HIP stream.  PyTorch is plumbing here (memory + stream); all arithmetic is in the library."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+_workspaces = {}
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor, got {type(t)}")
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name}: tensor is on {t.device}; this path runs only on the GPU (no CPU fallback)")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    if shape is not None:
+        assert len(shape) == t.dim() and all(s is None or s == d for s, d in zip(shape, t.shape)), \
+            f"{name}: wrong shape {list(t.shape)}, expected {list(shape)}"      # misc.assert_shape convention
+    return t.contiguous()
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _workspace(device, nbytes):
+    key = (device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def ray_sampler(cam2world, intrinsics, resolution):
+    """RaySampler.forward (ray_sampler.py:24-62): [N,4,4],[N,3,3] -> origins, dirs [N,R*R,3]."""
+    lib = _lib.load()
+    cam2world = _dev(cam2world, "cam2world_matrix", (None, 4, 4))
+    N = cam2world.shape[0]
+    intrinsics = _dev(intrinsics, "intrinsics", (N, 3, 3))
+    R = int(resolution)
+    o = torch.empty(N, R * R, 3, device=cam2world.device)
+    d = torch.empty_like(o)
+    with torch.cuda.device(cam2world.device):
+        _lib.check(lib.nfe_ray_sampler(_ptr(cam2world), _ptr(intrinsics), N, R, _ptr(o), _ptr(d), _stream()), "nfe_ray_sampler")
+    return o, d
+
+
+def plane_stats(planes):
+    """compute_mean_var (triplane.py:56-60): [N,C,H,W] -> mean, std [N,C,1,1]."""
+    lib = _lib.load()
+    planes = _dev(planes, "planes", (None, None, None, None))
+    N, C, H, W = planes.shape
+    mean = torch.empty(N, C, 1, 1, device=planes.device)
+    std = torch.empty_like(mean)
+    with torch.cuda.device(planes.device):
+        _lib.check(lib.nfe_plane_stats(_ptr(planes), N, C, H * W, _ptr(mean), _ptr(std), _stream()), "nfe_plane_stats")
+    return mean, std
+
+
+def plane_affine(planes, scale, shift):
+    """out = planes*scale + shift with scale/shift [N|1,C,1,1] (normalize/denormalize_plane)."""
+    lib = _lib.load()
+    planes = _dev(planes, "planes", (None, None, None, None))
+    N, C, H, W = planes.shape
+    scale = _dev(scale, "scale").reshape(-1, C)
+    shift = _dev(shift, "shift").reshape(-1, C)
+    na = scale.shape[0]
+    assert shift.shape[0] == na and na in (1, N), "scale/shift must be [N,C,1,1] or [1,C,1,1]"
+    out = torch.empty_like(planes)
+    with torch.cuda.device(planes.device):
+        _lib.check(lib.nfe_plane_affine(_ptr(planes), _ptr(scale), _ptr(shift), N, C, H * W, na, _ptr(out), _stream()),
+                   "nfe_plane_affine")
+    return out
+
+
+def make_affine(mean, std, new_mean=None, new_std=None):
+    """Affines for the single-gather identity (include/nfe_render.h: nfe_make_affine). Returns 4x [N,C]."""
+    lib = _lib.load()
+    mean = _dev(mean, "mean")
+    N, C = mean.shape[0], mean.shape[1]
+    mean = mean.reshape(N, C)
+    std = _dev(std, "std").reshape(N, C)
+    no = 0
+    if new_mean is not None:
+        new_mean = _dev(new_mean, "planes_mean").reshape(-1, C)
+        new_std = _dev(new_std, "planes_var").reshape(-1, C)
+        no = new_mean.shape[0]
+        assert new_std.shape[0] == no and no in (1, N), "override statistics must be [N,C,1,1] or [1,C,1,1]"
+    outs = [torch.empty(N, C, device=mean.device) for _ in range(4)]
+    with torch.cuda.device(mean.device):
+        _lib.check(lib.nfe_make_affine(_ptr(mean), _ptr(std), _ptr(new_mean), _ptr(new_std), N, C, no,
+                                       *[_ptr(o) for o in outs], _stream()), "nfe_make_affine")
+    return outs
+
+
+def plane_pack(planes):
+    """[N,96,H,W] or [N,3,32,H,W] -> gather layout [N,3,H,W,32]."""
+    lib = _lib.load()
+    if planes.dim() == 5:
+        planes = planes.reshape(planes.shape[0], 96, planes.shape[-2], planes.shape[-1])
+    planes = _dev(planes, "planes", (None, 96, None, None))
+    N, _, H, W = planes.shape
+    out = torch.empty(N, 3, H, W, 32, device=planes.device)
+    with torch.cuda.device(planes.device):
+        _lib.check(lib.nfe_plane_pack(_ptr(planes), N, H, W, _ptr(out), _stream()), "nfe_plane_pack")
+    return out
+
+
+def decoder_pack(geo_w0, geo_b0, geo_w1, geo_b1, app_w0, app_b0, app_w1, app_b1, lr_mul=1.0):
+    lib = _lib.load()
+    ts = [_dev(geo_w0, "geo_net.0.weight", (64, 32)), _dev(geo_b0, "geo_net.0.bias", (64,)),
+          _dev(geo_w1, "geo_net.2.weight", (16, 64)), _dev(geo_b1, "geo_net.2.bias", (16,)),
+          _dev(app_w0, "app_net.0.weight", (64, 32)), _dev(app_b0, "app_net.0.bias", (64,)),
+          _dev(app_w1, "app_net.2.weight", (32, 64)), _dev(app_b1, "app_net.2.bias", (32,))]
+    out = torch.empty(_lib.NFE_DECODER_PACKED_FLOATS, device=ts[0].device)
+    with torch.cuda.device(out.device):
+        _lib.check(lib.nfe_decoder_pack(*[_ptr(t) for t in ts], float(lr_mul), _ptr(out), _stream()), "nfe_decoder_pack")
+    return out
+
+
+def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dirs=None, cam2world=None,
+           intrinsics=None, resolution=0, affines=None, u_coarse=None, u_fine=None, seed=0,
+           channels_first=False, taps=False, ray_limits=None):
+    """nfe_render.  planes_* are packed [Np,3,H,W,32] (Np == N or 1); affines = 4x [N,96] or None.
+
+    Returns (rgb, seg, depth, wsum[, taps]) with rgb [N,M,32] (or [N,32,M] if channels_first),
+    seg [N,M,15], depth [N,M,1], wsum [N,M,1] — the tuple DisentangledImportanceRenderer.forward
+    returns (renderer.py:363).
+    """
+    lib = _lib.load()
+    planes_geo = _dev(planes_geo, "planes_geo", (None, 3, None, None, 32))
+    planes_app = planes_geo if planes_app is planes_geo else _dev(planes_app, "planes_app", tuple(planes_geo.shape))
+    Np, _, H, W, _ = planes_geo.shape
+    dev = planes_geo.device
+    if origins is not None:
+        origins = _dev(origins, "ray_origins", (None, None, 3))
+        N, M = origins.shape[0], origins.shape[1]
+        dirs = _dev(dirs, "ray_directions", (N, M, 3))
+    else:
+        cam2world = _dev(cam2world, "cam2world_matrix", (None, 4, 4))
+        N = cam2world.shape[0]
+        intrinsics = _dev(intrinsics, "intrinsics", (N, 3, 3))
+        M = int(resolution) ** 2
+    assert Np in (1, N), f"planes batch {Np} must be 1 or equal the ray batch {N}"
+    D = int(options["depth_resolution"])
+    Di = int(options.get("depth_resolution_importance", 0) or 0)
+    if options.get("clamp_mode", "softplus") != "softplus":
+        raise AssertionError("MipRayMarcher only supports `clamp_mode`=`softplus`!")      # ray_marcher.py:78
+    if options.get("density_noise", 0):
+        raise RuntimeError("density_noise > 0 is not supported by the fused renderer")
+    a = _lib.RenderArgs()
+    a.struct_size = ctypes.sizeof(_lib.RenderArgs)
+    a.planes_geo, a.planes_app = planes_geo.data_ptr(), planes_app.data_ptr()
+    a.plane_h, a.plane_w = H, W
+    a.plane_view_stride = 0 if (Np == 1 and N > 1) else 3 * H * W * 32
+    keep = [planes_geo, planes_app, decoder_packed, origins, dirs, cam2world, intrinsics]
+    if affines is not None:
+        affines = [_dev(t, "affine", (N, 96)) for t in affines]
+        a.geo_scale, a.geo_shift, a.app_scale, a.app_shift = [t.data_ptr() for t in affines]
+        keep += affines
+    a.decoder_packed = _dev(decoder_packed, "decoder_packed", (_lib.NFE_DECODER_PACKED_FLOATS,)).data_ptr()
+    a.n_views, a.n_rays = N, M
+    if origins is not None:
+        a.origins, a.dirs = origins.data_ptr(), dirs.data_ptr()
+        r = int(round(M ** 0.5))
+        a.resolution = r if (resolution == 0 and r * r == M) else int(resolution)
+    else:
+        a.cam2world, a.intrinsics, a.resolution = cam2world.data_ptr(), intrinsics.data_ptr(), int(resolution)
+    a.depth_resolution, a.depth_resolution_importance = D, Di
+    if ray_limits is not None:
+        rs, re = (_dev(t, "ray_limits").reshape(N, M) for t in ray_limits)
+        a.ray_start_per_ray, a.ray_end_per_ray = rs.data_ptr(), re.data_ptr()
+        keep += [rs, re]
+    else:
+        a.ray_start, a.ray_end = float(options["ray_start"]), float(options["ray_end"])
+    a.disparity_space_sampling = int(bool(options.get("disparity_space_sampling", False)))
+    a.box_warp = float(options["box_warp"])
+    a.white_back = int(bool(options.get("white_back", False)))
+    if u_coarse is not None:
+        u_coarse = _dev(u_coarse, "u_coarse").reshape(N, M, D)
+        a.u_coarse = u_coarse.data_ptr()
+    if u_fine is not None and Di > 0:
+        u_fine = _dev(u_fine, "u_fine").reshape(N * M, Di)
+        a.u_fine = u_fine.data_ptr()
+    keep += [u_coarse, u_fine]
+    a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    rgb = torch.empty((N, 32, M) if channels_first else (N, M, 32), device=dev)
+    seg = torch.empty((N, 15, M) if channels_first else (N, M, 15), device=dev)
+    depth = torch.empty(N, M, 1, device=dev)
+    wsum = torch.empty(N, M, 1, device=dev)
+    a.rgb, a.seg, a.depth, a.wsum = rgb.data_ptr(), seg.data_ptr(), depth.data_ptr(), wsum.data_ptr()
+    a.channels_first = int(channels_first)
+    tap = {}
+    if taps:
+        tap["depths_all"] = torch.empty(N, M, D + Di, device=dev)
+        a.tap_depths_all = tap["depths_all"].data_ptr()
+        if Di > 0:
+            tap["weights_coarse"] = torch.empty(N, M, D - 1, device=dev)
+            tap["depths_fine"] = torch.empty(N, M, Di, device=dev)
+            a.tap_weights_coarse, a.tap_depths_fine = tap["weights_coarse"].data_ptr(), tap["depths_fine"].data_ptr()
+    need = lib.nfe_render_workspace_bytes(N, M, D, Di)
+    ws = _workspace(dev, need)
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    with torch.cuda.device(dev):
+        _lib.check(lib.nfe_render(ctypes.byref(a), _stream()), "nfe_render")
+    return (rgb, seg, depth, wsum, tap) if taps else (rgb, seg, depth, wsum)
+
+
+def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affines=None):
+    """nfe_point_query: coords [N,P,3] -> dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15])."""
+    lib = _lib.load()
+    planes_geo = _dev(planes_geo, "planes_geo", (None, 3, None, None, 32))
+    planes_app = planes_geo if planes_app is planes_geo else _dev(planes_app, "planes_app", tuple(planes_geo.shape))
+    coords = _dev(coords, "coordinates", (None, None, 3))
+    N, P = coords.shape[0], coords.shape[1]
+    Np, _, H, W, _ = planes_geo.shape
+    assert Np in (1, N)
+    dev = coords.device
+    aff = [None] * 4
+    if affines is not None:
+        aff = [_dev(t, "affine", (N, 96)) for t in affines]
+    decoder_packed = _dev(decoder_packed, "decoder_packed", (_lib.NFE_DECODER_PACKED_FLOATS,))
+    rgb = torch.empty(N, P, 32, device=dev)
+    sigma = torch.empty(N, P, 1, device=dev)
+    seg = torch.empty(N, P, 15, device=dev)
+    stride = 0 if (Np == 1 and N > 1) else 3 * H * W * 32
+    with torch.cuda.device(dev):
+        _lib.check(lib.nfe_point_query(_ptr(planes_geo), _ptr(planes_app), H, W, stride, *[_ptr(t) for t in aff],
+                                       _ptr(decoder_packed), _ptr(coords), N, P, float(box_warp),
+                                       _ptr(rgb), _ptr(sigma), _ptr(seg), _stream()), "nfe_point_query")
+    return {"rgb": rgb, "sigma": sigma, "seg": seg}

@@ -1,0 +1,219 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors captured from the
+reference and against the numpy oracle on the same seeded inputs.
+
+Tolerance: BASELINE.json north_star asks for <= 1e-3 max-abs in fp32 against the reference's
+PyTorch-CPU forward on identical inputs and jitter.
+"""
+import numpy as np
+import pytest
+
+from oracle import render_oracle as orc
+from tests._golden import RENDER_CASES, load, load_render_case, max_abs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3          # north_star parity bar
+TIGHT = 5e-5        # what fp32 with a different summation order actually achieves on these cases
+
+
+@pytest.fixture(scope="module")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def _t(x, dev):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).to(dev)
+
+
+def _dec(case_dec, dev, lr_mul=1.0):
+    from nerffaceediting_amd import ops
+    names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
+             "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+    return ops.decoder_pack(*[_t(case_dec[k], dev) for k in names], lr_mul=lr_mul)
+
+
+def _run_case(case, dev, mode, from_camera=False, channels_first=False):
+    """mode 'single': raw planes + affines (single-gather identity); 'dual': separate norm/denorm planes."""
+    from nerffaceediting_amd import ops
+    planes = _t(case["planes"], dev)
+    N = planes.shape[0]
+    opts = dict(case["options"])
+    Ni = opts["depth_resolution_importance"]
+    mean, std = ops.plane_stats(planes)
+    new_mean = new_std = None
+    if case["swap"]:
+        new_mean, new_std = mean.flip(0).contiguous(), std.flip(0).contiguous()
+    if mode == "single":
+        packed = ops.plane_pack(planes)
+        aff = ops.make_affine(mean, std, new_mean, new_std)
+        pg = pa = packed
+    else:
+        gs, gb, as_, ab = ops.make_affine(mean, std, new_mean, new_std)
+        norm = ops.plane_affine(planes, gs.reshape(N, 96, 1, 1), gb.reshape(N, 96, 1, 1))
+        denorm = ops.plane_affine(planes, as_.reshape(N, 96, 1, 1), ab.reshape(N, 96, 1, 1))
+        pg, pa, aff = ops.plane_pack(norm), ops.plane_pack(denorm), None
+    dec = _dec(case["dec"], dev)
+    kw = dict(affines=aff, u_coarse=_t(case["u_coarse"], dev), u_fine=_t(case["u_fine"], dev) if Ni > 0 else None,
+              taps=True, channels_first=channels_first)
+    c2w, K = _t(case["cam2world"], dev), _t(case["intrinsics"], dev)
+    if opts["ray_start"] == "auto":
+        o, d = orc.ray_sampler(case["cam2world"], case["intrinsics"], case["R"])
+        rs, re = orc.get_ray_limits_box(o, d, opts["box_warp"])
+        ok = re > rs
+        rs = np.where(ok, rs, rs[ok].min()); re = np.where(ok, re, rs[ok].max())
+        kw["ray_limits"] = (_t(rs, dev), _t(re, dev))
+    if from_camera:
+        out = ops.render(pg, pa, dec, opts, cam2world=c2w, intrinsics=K, resolution=case["R"], **kw)
+    else:
+        o, d = ops.ray_sampler(c2w, K, case["R"])
+        out = ops.render(pg, pa, dec, opts, origins=o, dirs=d, **kw)
+    return [x.cpu().numpy() if hasattr(x, "cpu") else {k: v.cpu().numpy() for k, v in x.items()} for x in out]
+
+
+@pytest.mark.parametrize("mode", ["single", "dual"])
+@pytest.mark.parametrize("tag", RENDER_CASES)
+def test_render_vs_reference_golden(tag, mode, dev):
+    case = load_render_case(tag)
+    rgb, seg, depth, wsum, tap = _run_case(case, dev, mode)
+    got = dict(rgb=rgb, seg=seg, depth=depth, wsum=wsum)
+    errs = {k: max_abs(got[k], case["out"][k]) for k in got}
+    print(tag, mode, errs)
+    for k, e in errs.items():
+        assert e <= TOL, (k, e)
+        assert e <= TIGHT or k == "depth", (k, e)
+    if case["options"]["depth_resolution_importance"] > 0:
+        N, M = case["u_coarse"].shape[:2]
+        assert max_abs(tap["weights_coarse"].reshape(-1), case["tap"]["weights_coarse"].reshape(-1)) <= 1e-4
+        assert max_abs(tap["depths_fine"].reshape(-1), case["tap"]["depths_fine"].reshape(-1)) <= 1e-3
+        assert (np.diff(tap["depths_all"], axis=-1) >= 0).all(), "merged depths must be sorted"
+
+
+@pytest.mark.parametrize("tag", ["single_r16_d48", "two_r8_d8_i8"])
+def test_render_from_camera_and_channels_first(tag, dev):
+    """Rays generated in-kernel from cam2world/intrinsics (synthesis() path) + planar output layout."""
+    case = load_render_case(tag)
+    rgb, seg, depth, wsum, _ = _run_case(case, dev, "single", from_camera=True, channels_first=True)
+    assert max_abs(rgb.transpose(0, 2, 1), case["out"]["rgb"]) <= TIGHT
+    assert max_abs(seg.transpose(0, 2, 1), case["out"]["seg"]) <= TIGHT
+    assert max_abs(depth, case["out"]["depth"]) <= TOL
+    assert max_abs(wsum, case["out"]["wsum"]) <= TIGHT
+
+
+def test_ray_sampler(dev):
+    from nerffaceediting_amd import ops
+    z = load("ray_sampler")
+    for tag in ("a", "b", "orbit"):
+        o, d = ops.ray_sampler(_t(z[tag + ".cam2world"], dev), _t(z[tag + ".intrinsics"], dev), int(z[tag + ".R"]))
+        assert max_abs(o.cpu().numpy(), z[tag + ".origins"]) <= 1e-6
+        assert max_abs(d.cpu().numpy(), z[tag + ".dirs"]) <= 1e-6
+
+
+def test_plane_stats_and_affine(dev):
+    from nerffaceediting_amd import ops
+    z = load("plane_stats")
+    planes = _t(z["planes"], dev)
+    N = planes.shape[0]
+    mean, std = ops.plane_stats(planes)
+    assert max_abs(mean.cpu().numpy(), z["mean"]) <= 1e-6
+    assert max_abs(std.cpu().numpy(), z["std"]) <= 1e-6
+    gs, gb, _, _ = ops.make_affine(mean, std)
+    norm = ops.plane_affine(planes, gs.reshape(N, 96, 1, 1), gb.reshape(N, 96, 1, 1))
+    assert max_abs(norm.cpu().numpy(), z["norm"]) <= 2e-5
+    _, _, as_, ab = ops.make_affine(mean, std, _t(z["ext_mean"], dev), _t(z["ext_std"], dev))
+    den = ops.plane_affine(planes, as_.reshape(N, 96, 1, 1), ab.reshape(N, 96, 1, 1))
+    assert max_abs(den.cpu().numpy(), z["denorm_tensor"]) <= 5e-5
+    # (int,int) special case (triplane.py:100-101): statistics of batch entries 1 and 2
+    _, _, as_, ab = ops.make_affine(mean, std, mean[1:2].contiguous(), std[2:3].contiguous())
+    den = ops.plane_affine(planes, as_.reshape(N, 96, 1, 1), ab.reshape(N, 96, 1, 1))
+    assert max_abs(den.cpu().numpy(), z["denorm_int_1_2"]) <= 5e-5
+
+
+def test_plane_pack_layout(dev):
+    from nerffaceediting_amd import ops
+    rng = np.random.RandomState(0)
+    x = rng.randn(2, 96, 5, 7).astype(np.float32)
+    got = ops.plane_pack(_t(x, dev)).cpu().numpy()
+    want = x.reshape(2, 3, 32, 5, 7).transpose(0, 1, 3, 4, 2)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("mode", ["single", "dual"])
+def test_point_query(mode, dev):
+    from nerffaceediting_amd import ops
+    z = load("point_query")
+    dec = {k[4:]: z[k] for k in z.files if k.startswith("dec.")}
+    planes = _t(z["planes"], dev)
+    N = planes.shape[0]
+    mean, std = ops.plane_stats(planes)
+    aff = ops.make_affine(mean, std)
+    if mode == "single":
+        p = ops.plane_pack(planes)
+        out = ops.point_query(p, p, _dec(dec, dev), _t(z["coords"], dev), 1.0, affines=aff)
+    else:
+        norm = ops.plane_affine(planes, aff[0].reshape(N, 96, 1, 1), aff[1].reshape(N, 96, 1, 1))
+        out = ops.point_query(ops.plane_pack(norm), ops.plane_pack(planes), _dec(dec, dev), _t(z["coords"], dev), 1.0)
+    for k in ("rgb", "sigma", "seg"):
+        assert max_abs(out[k].cpu().numpy(), z["out." + k]) <= TIGHT, k
+
+
+def test_philox_jitter_matches_oracle_generator(dev):
+    """Production mode (in-kernel Philox) == injected mode fed with the oracle's Philox stream."""
+    case = load_render_case("two_r8_d8_i8")
+    N, M, D = case["u_coarse"].shape
+    Ni = case["options"]["depth_resolution_importance"]
+    seed = 0x1234ABCD5678
+    inj = dict(case)
+    inj["u_coarse"] = orc.philox_uniform(N * M, D, seed, 0).reshape(N, M, D)
+    inj["u_fine"] = orc.philox_uniform(N * M, Ni, seed, 1)
+    a = _run_case(inj, dev, "single")
+    from nerffaceediting_amd import ops
+    import torch
+    planes = _t(case["planes"], dev)
+    mean, std = ops.plane_stats(planes)
+    packed = ops.plane_pack(planes)
+    o, d = ops.ray_sampler(_t(case["cam2world"], dev), _t(case["intrinsics"], dev), case["R"])
+    b = ops.render(packed, packed, _dec(case["dec"], dev), case["options"], origins=o, dirs=d,
+                   affines=ops.make_affine(mean, std), seed=seed, taps=True)
+    assert np.array_equal(a[4]["depths_all"], b[4]["depths_all"].cpu().numpy())
+    for x, y in zip(a[:4], b[:4]):
+        assert np.array_equal(x, y.cpu().numpy())
+
+
+def test_larger_render_vs_oracle(dev):
+    """64x64 rays, 48+48 samples (BASELINE config 1's render shape), 64^2 planes: HIP vs the numpy oracle."""
+    rng = np.random.RandomState(123)
+    N, R, H, D, Ni = 2, 64, 64, 48, 48
+    planes = (rng.randn(N, 96, H, H) * np.exp(rng.randn(1, 96, 1, 1) * 0.5) + rng.randn(1, 96, 1, 1)).astype(np.float32)
+    dec = orc.random_decoder(5, bias_scale=0.2)
+    c2w = np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2 - 0.2, [0, 0, 0.2], 2.7) for y in (0.4, -0.4)], 0)
+    K = np.tile(orc.fov_to_intrinsics(18.837)[None], (N, 1, 1))
+    opts = dict(orc.FFHQ_OPTIONS, depth_resolution=D, depth_resolution_importance=Ni)
+    u_c = rng.rand(N, R * R, D).astype(np.float32)
+    u_f = rng.rand(N * R * R, Ni).astype(np.float32)
+    norm, denorm, _, _ = orc.synthesis_planes(planes)
+    o, d = orc.ray_sampler(c2w, K, R)
+    want = orc.render_chunked(norm, denorm, dec, o, d, opts, u_c, u_f, chunk=1024)
+    case = dict(planes=planes, cam2world=c2w, intrinsics=K, R=R, swap=False, u_coarse=u_c, u_fine=u_f,
+                options=opts, dec=dec)
+    got = _run_case(case, dev, "single", from_camera=True)
+    for k, g, w in zip(("rgb", "seg", "depth", "wsum"), got[:4], want):
+        e = max_abs(g, w)
+        print(k, e)
+        assert e <= TOL, (k, e)
+
+
+def test_errors_raise(dev):
+    from nerffaceediting_amd import ops
+    import torch
+    case = load_render_case("single_r8_d8")
+    planes = _t(case["planes"], dev)
+    packed = ops.plane_pack(planes)
+    dec = _dec(case["dec"], dev)
+    o, d = ops.ray_sampler(_t(case["cam2world"], dev), _t(case["intrinsics"], dev), case["R"])
+    bad = dict(case["options"], depth_resolution=1)
+    with pytest.raises(RuntimeError):
+        ops.render(packed, packed, dec, bad, origins=o, dirs=d)
+    with pytest.raises(RuntimeError):                      # CPU tensors are refused: no fallback path
+        ops.plane_stats(torch.zeros(1, 96, 4, 4))
