@@ -41,8 +41,13 @@ extern "C" {
 #define NFE_RGB_CHANNELS 32     /* decoder_output_dim (triplane.py:49) */
 #define NFE_SEG_CHANNELS 15     /* decoder_seg_dim   (triplane.py:49) */
 #define NFE_MAX_SAMPLES 256     /* max depth_resolution and max depth_resolution_importance */
-/* floats in a packed decoder blob (see nfe_decoder_pack) */
-#define NFE_DECODER_PACKED_FLOATS (4 * 2048 + 64 + 64 + 32 + 32)
+/* 4-byte words in a packed decoder blob (see nfe_decoder_pack): fp32 MFMA fragments + biases,
+ * followed by the split-bf16 (hi,lo) MFMA fragments */
+#define NFE_DECODER_PACKED_FLOATS (4 * 2048 + 64 + 64 + 32 + 32 + 8192)
+/* nfe_render_args.decoder_math */
+#define NFE_MATH_BF16X3 0   /* default: operands split into bf16 hi+lo, 3 bf16 MFMAs per product
+                               (~2^-16 relative per product, fp32 accumulate) */
+#define NFE_MATH_FP32 1     /* exact fp32 MFMA (v_mfma_f32_32x32x2_f32), ~5x more matrix-pipe time */
 
 typedef void* nfe_stream_t;
 
@@ -100,6 +105,7 @@ typedef struct nfe_render_args {
     const float* geo_scale; const float* geo_shift;
     const float* app_scale; const float* app_shift;
     const float* decoder_packed;       /* from nfe_decoder_pack */
+    int32_t decoder_math;              /* NFE_MATH_* */
     /* rays: explicit origins/dirs [N,M,3], or (both NULL) generated from cam2world/intrinsics */
     int32_t n_views, n_rays;           /* N, M */
     const float* origins; const float* dirs;
@@ -141,7 +147,7 @@ int nfe_render(const nfe_render_args* args, nfe_stream_t stream);
 int nfe_point_query(const float* planes_geo, const float* planes_app, int plane_h, int plane_w,
                     int64_t plane_view_stride, const float* geo_scale, const float* geo_shift,
                     const float* app_scale, const float* app_shift, const float* decoder_packed,
-                    const float* coords, int n_views, int n_points, float box_warp,
+                    int decoder_math, const float* coords, int n_views, int n_points, float box_warp,
                     float* rgb, float* sigma, float* seg, nfe_stream_t stream);
 
 #ifdef __cplusplus

@@ -8,7 +8,8 @@ LIB_PATH = os.path.join(_HERE, "libnfe_render.so")
 
 NFE_ABI_VERSION = 1
 NFE_MAX_SAMPLES = 256
-NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32
+NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
+NFE_MATH_BF16X3, NFE_MATH_FP32 = 0, 1
 
 FP = c_void_p      # device pointers travel as integers
 
@@ -21,7 +22,7 @@ class RenderArgs(ctypes.Structure):
         ("plane_h", c_int32), ("plane_w", c_int32),
         ("plane_view_stride", c_int64),
         ("geo_scale", FP), ("geo_shift", FP), ("app_scale", FP), ("app_shift", FP),
-        ("decoder_packed", FP),
+        ("decoder_packed", FP), ("decoder_math", c_int32),
         ("n_views", c_int32), ("n_rays", c_int32),
         ("origins", FP), ("dirs", FP), ("cam2world", FP), ("intrinsics", FP),
         ("resolution", c_int32),
@@ -49,7 +50,7 @@ _SIGNATURES = {
     "nfe_decoder_pack": (c_int, [FP] * 8 + [c_float, FP, c_void_p]),
     "nfe_render_workspace_bytes": (c_uint64, [c_int, c_int, c_int, c_int]),
     "nfe_render": (c_int, [POINTER(RenderArgs), c_void_p]),
-    "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, FP, c_int, c_int, c_float,
+    "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
                                 FP, FP, FP, c_void_p]),
 }
 

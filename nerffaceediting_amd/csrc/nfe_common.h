@@ -35,8 +35,15 @@ constexpr int DEC_B_G0 = 8192;   // [64] hidden-unit order
 constexpr int DEC_B_A0 = 8256;   // [64]
 constexpr int DEC_B_G1 = 8320;   // [32] MFMA row order
 constexpr int DEC_B_A1 = 8352;   // [32] MFMA row order
-constexpr int DEC_FLOATS = NFE_DECODER_PACKED_FLOATS;
-static_assert(DEC_FLOATS == 8384, "decoder blob size");
+constexpr int DEC_FLOATS = 8384;  // fp32 fragments + biases (also the LDS footprint of either math mode)
+// Split-bf16 fragments: 32 fragments x 64 lanes x 4 words (8 bf16).  Fragment index:
+//   layer 0: ((net*2 + mb)*2 + ks)*2 + part        net 0=geo 1=app, ks 0..1, part 0=hi 1=lo
+//   layer 1: 16 + (net*4 + ks)*2 + part            ks 0..3
+constexpr int DEC_BF16 = DEC_FLOATS;
+constexpr int DEC_BF16_WORDS = 32 * 64 * 4;
+constexpr int DEC_TOTAL = DEC_FLOATS + DEC_BF16_WORDS;
+static_assert(DEC_TOTAL == NFE_DECODER_PACKED_FLOATS, "decoder blob size");
+constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 // order-preserving float <-> uint map for atomicMin/atomicMax on depths
 __device__ __forceinline__ unsigned f2ord(float f) {

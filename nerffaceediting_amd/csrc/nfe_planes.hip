@@ -114,52 +114,81 @@ __global__ __launch_bounds__(256) void plane_pack_kernel(const float* __restrict
     }
 }
 
-// ---- decoder weights -> MFMA A-operand layout -----------------------------------
+// ---- decoder weights -> MFMA A-operand layouts ----------------------------------
 // hidden unit held by (layer-0 M-block mb, accumulator register r, lane half h)
 __device__ __forceinline__ int hidden_unit(int mb, int r, int h) { return 32 * mb + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-__global__ void decoder_pack_kernel(const float* gw0, const float* gb0, const float* gw1, const float* gb1,
-                                    const float* aw0, const float* ab0, const float* aw1, const float* ab1,
-                                    float lr_mul, float* out) {
+// MFMA output row i of the geometry head -> geo_net.2 output index (0 = sigma, 1..15 = seg), -1 = unused.
+// Row i is register ri of lane half hi; sigma is duplicated into both halves.
+__device__ __forceinline__ int geo_row_to_out(int i) {
+    const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;
+    if (ri == 0) return 0;
+    if (hi == 0 && ri <= 8) return ri;
+    if (hi == 1 && ri <= 7) return 8 + ri;
+    return -1;
+}
+__device__ __forceinline__ int app_row_to_out(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+
+// The hidden activation is evaluated as log2(1 + 2^y) (v_exp_f32/v_log_f32 are base 2): log2(e) is
+// folded into layer 0, ln(2) into layer 1; the appearance head additionally carries log2(e) for its
+// sigmoid, which cancels the ln(2).  All foldings are exact algebra on softplus/sigmoid.
+struct DecSrc { const float *gw0, *gb0, *gw1, *gb1, *aw0, *ab0, *aw1, *ab1; float lr_mul; };
+
+__device__ __forceinline__ float dec_w0(const DecSrc& S, int net, int unit, int ch) {
+    return (net ? S.aw0 : S.gw0)[unit * 32 + ch] * (S.lr_mul / sqrtf(32.0f)) * LOG2E;   // weight_gain, networks_stylegan2.py:111
+}
+__device__ __forceinline__ float dec_w1(const DecSrc& S, int net, int row, int unit) {
+    const float g1 = S.lr_mul / sqrtf(64.0f);
+    if (net == 0) { const int o = geo_row_to_out(row); return o >= 0 ? S.gw1[o * 64 + unit] * g1 * LN2 : 0.0f; }
+    return S.aw1[app_row_to_out(row) * 64 + unit] * g1;       // * LN2 * LOG2E == 1
+}
+__device__ __forceinline__ unsigned bf16_rne_bits(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ void decoder_pack_kernel(DecSrc S, float* out) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= DEC_FLOATS) return;
-    const float g0 = lr_mul / sqrtf(32.0f), g1 = lr_mul / sqrtf(64.0f);   // weight_gain, networks_stylegan2.py:111
+    if (e >= DEC_TOTAL) return;
     float v = 0.0f;
-    if (e < DEC_A_G1) {                       // layer-0 A fragments: [net][mb][ks4][lane][kk]
-        const float* w = e < DEC_A_A0 ? gw0 : aw0;
-        const int r_ = e % 2048;
+    if (e < DEC_A_G1) {                       // fp32 layer-0 A fragments: [net][mb][ks4][lane][kk]
+        const int net = e / 2048, r_ = e % 2048;
         const int mb = r_ / 1024, ks4 = (r_ % 1024) / 256, lane = (r_ % 256) / 4, kk = r_ % 4;
-        const int i = lane & 31, h = lane >> 5, ks = ks4 * 4 + kk;
-        v = w[(32 * mb + i) * 32 + (16 * h + ks)] * g0;
-    } else if (e < DEC_B_G0) {                // layer-1 A fragments: [net][ks4][lane][kk]
-        const bool geo = e < DEC_A_A1;
-        const int r_ = (e - DEC_A_G1) % 2048;
-        const int ks4 = r_ / 256, lane = (r_ % 256) / 4, kk = r_ % 4;
-        const int i = lane & 31, h = lane >> 5, ks = ks4 * 4 + kk;
-        const int u = hidden_unit(ks >> 4, ks & 15, h);
-        const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;    // output row i = register ri of lane half hi
-        if (geo) {
-            int idx = -1;                                             // sigma duplicated into both halves
-            if (ri == 0) idx = 0; else if (hi == 0 && ri <= 8) idx = ri; else if (hi == 1 && ri <= 7) idx = 8 + ri;
-            v = idx >= 0 ? gw1[idx * 64 + u] * g1 : 0.0f;
-        } else {
-            v = aw1[(16 * hi + ri) * 64 + u] * g1;
-        }
+        v = dec_w0(S, net, 32 * mb + (lane & 31), 16 * (lane >> 5) + ks4 * 4 + kk);
+    } else if (e < DEC_B_G0) {                // fp32 layer-1 A fragments: [net][ks4][lane][kk]
+        const int net = (e - DEC_A_G1) / 2048, r_ = (e - DEC_A_G1) % 2048;
+        const int ks4 = r_ / 256, lane = (r_ % 256) / 4, kk = r_ % 4, ks = ks4 * 4 + kk;
+        v = dec_w1(S, net, lane & 31, hidden_unit(ks >> 4, ks & 15, lane >> 5));
     } else if (e < DEC_B_A0) {
-        v = gb0[e - DEC_B_G0] * lr_mul;
+        v = S.gb0[e - DEC_B_G0] * S.lr_mul * LOG2E;
     } else if (e < DEC_B_G1) {
-        v = ab0[e - DEC_B_A0] * lr_mul;
-    } else {
-        const bool geo = e < DEC_B_A1;
-        const int i = (e - DEC_B_G1) % 32;
-        const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;
-        if (geo) {
-            int idx = -1;
-            if (ri == 0) idx = 0; else if (hi == 0 && ri <= 8) idx = ri; else if (hi == 1 && ri <= 7) idx = 8 + ri;
-            v = idx >= 0 ? gb1[idx] * lr_mul : 0.0f;
-        } else {
-            v = ab1[16 * hi + ri] * lr_mul;
+        v = S.ab0[e - DEC_B_A0] * S.lr_mul * LOG2E;
+    } else if (e < DEC_B_A1) {
+        const int o = geo_row_to_out(e - DEC_B_G1);
+        v = o >= 0 ? S.gb1[o] * S.lr_mul : 0.0f;
+    } else if (e < DEC_FLOATS) {
+        v = S.ab1[app_row_to_out(e - DEC_B_A1)] * S.lr_mul * LOG2E;
+    } else {                                  // split-bf16 fragments: [frag][lane][word], 2 bf16 per word
+        const int x = e - DEC_BF16;
+        const int frag = x / 256, lane = (x % 256) / 4, word = x % 4;
+        const int i = lane & 31, h = lane >> 5, part = frag & 1;
+        unsigned bits[2];
+        for (int t = 0; t < 2; ++t) {
+            const int el = 2 * word + t;      // element of the 8-vector: k = 8h + el within the k-step
+            float w;
+            if (frag < 16) {
+                const int net = frag >> 3, mb = (frag >> 2) & 1, ks = (frag >> 1) & 1;
+                w = dec_w0(S, net, 32 * mb + i, 16 * h + 8 * ks + el);
+            } else {
+                const int f = frag - 16, net = f >> 3, ks = (f >> 1) & 3;
+                w = dec_w1(S, net, i, hidden_unit(ks >> 1, 8 * (ks & 1) + el, h));
+            }
+            const unsigned hi = bf16_rne_bits(w);
+            bits[t] = part == 0 ? hi : bf16_rne_bits(w - __uint_as_float(hi << 16));
         }
+        out[e] = __uint_as_float((bits[0] & 0xffffu) | (bits[1] << 16));
+        return;
     }
     out[e] = v;
 }
@@ -228,8 +257,8 @@ extern "C" int nfe_decoder_pack(const float* geo_w0, const float* geo_b0, const 
                                 float lr_mul, float* packed, nfe_stream_t stream) {
     NFE_REQUIRE(geo_w0 && geo_b0 && geo_w1 && geo_b1 && app_w0 && app_b0 && app_w1 && app_b1 && packed,
                 "nfe_decoder_pack: null pointer");
-    hipLaunchKernelGGL(decoder_pack_kernel, dim3((DEC_FLOATS + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       geo_w0, geo_b0, geo_w1, geo_b1, app_w0, app_b0, app_w1, app_b1, lr_mul, packed);
+    DecSrc S{geo_w0, geo_b0, geo_w1, geo_b1, app_w0, app_b0, app_w1, app_b1, lr_mul};
+    hipLaunchKernelGGL(decoder_pack_kernel, dim3((DEC_TOTAL + 255) / 256), dim3(256), 0, (hipStream_t)stream, S, packed);
     NFE_CHECK_LAUNCH("decoder_pack_kernel");
     return NFE_OK;
 }

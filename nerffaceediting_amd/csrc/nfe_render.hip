@@ -40,22 +40,44 @@ constexpr int LDS_AFF = DEC_FLOATS;             // per-wave affine region starts
 constexpr int AFF_FLOATS = 4 * 96;
 constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * AFF_FLOATS) * 4;
 
-// Raw v_exp_f32 / v_log_f32 (1 ulp, no denormal-range fix-up code: results this small are far below
-// the 1e-3 parity budget).
-__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
-__device__ __forceinline__ float fast_log(float x) { return __builtin_amdgcn_logf(x) * 0.6931471805599453f; }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+union Frag { bf16x8 v; uint4 q; unsigned u[4]; };
 
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
+
+// Raw v_exp_f32 / v_log_f32 (base 2, 1 ulp, no denormal-range fix-up code: the differences are far
+// below the 1e-3 parity budget).
+__device__ __forceinline__ float exp2_fast(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float log2_fast(float x) { return __builtin_amdgcn_logf(x); }
+
+// torch Softplus(beta=1, threshold=20) in natural units (used by the ray marcher, ray_marcher.py:76)
 __device__ __forceinline__ float softplus_f(float x) {
-    // torch Softplus(beta=1, threshold=20): x > 20 ? x : log1p(exp(x))
-    float r = fast_log(1.0f + fast_exp(x));
+    float r = log2_fast(1.0f + exp2_fast(x * LOG2E)) * LN2;
     return x > 20.0f ? x : r;
 }
+// The same function on y = x*log2(e), returning softplus(x)/ln(2): the scale factors live in the packed
+// decoder weights (nfe_decoder_pack).  threshold 20 -> 20*log2(e).
+__device__ __forceinline__ float softplus_log2(float y) {
+    float r = log2_fast(1.0f + exp2_fast(y));
+    return y > 20.0f * LOG2E ? y : r;
+}
 
-// One bilinear tap group for one plane: accumulates 16 channels (this lane's half texel).
+// fp32 -> (hi, lo) bf16 pairs: hi = top 16 bits (truncation), lo = bf16(x - hi); x - hi - lo <= 2^-17 |x|.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    bf16x2 p = {(__bf16)(a - __uint_as_float(ua & 0xffff0000u)), (__bf16)(b - __uint_as_float(ub & 0xffff0000u))};
+    lo = *reinterpret_cast<unsigned*>(&p);
+}
+
+// One plane's bilinear taps: accumulates this lane's 16 channels (half a 128-byte texel) as 8 float2.
 template <bool DUAL, int TAPS_IN_FLIGHT>
 __device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const float* __restrict__ pa,
                                              int H, int W, float u, float v, int hoff,
-                                             float (&sg)[16], float (&sa)[16], float& wsum) {
+                                             f32x2 (&sg)[8], f32x2 (&sa)[8], float& wsum) {
     // F.grid_sample(bilinear, zeros, align_corners=False) — renderer.py:64; unnormalise as ATen does.
     float ix = (u + 1.0f) * (0.5f * (float)W) - 0.5f;
     float iy = (v + 1.0f) * (0.5f * (float)H) - 0.5f;
@@ -73,32 +95,28 @@ __device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const
     int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x1, 0), W - 1);
     int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y1, 0), H - 1);
     wsum = (w00 + w10) + (w01 + w11);
-    const int o00 = (yc0 * W + xc0) * 32 + hoff, o10 = (yc0 * W + xc1) * 32 + hoff;
-    const int o01 = (yc1 * W + xc0) * 32 + hoff, o11 = (yc1 * W + xc1) * 32 + hoff;
-    const int offs[4] = {o00, o10, o01, o11};
+    const int offs[4] = {(yc0 * W + xc0) * 32 + hoff, (yc0 * W + xc1) * 32 + hoff,
+                         (yc1 * W + xc0) * 32 + hoff, (yc1 * W + xc1) * 32 + hoff};
     const float ws[4] = {w00, w10, w01, w11};
 #pragma unroll
-    for (int c = 0; c < 16; ++c) { sg[c] = 0.0f; if (DUAL) sa[c] = 0.0f; }
+    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); if (DUAL) sa[c] = splat(0.0f); }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
+        const f32x2 w2 = splat(ws[t]);
         const float4* tg = reinterpret_cast<const float4*>(pg + offs[t]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 a = tg[q];
-            sg[4 * q + 0] = fmaf(ws[t], a.x, sg[4 * q + 0]);
-            sg[4 * q + 1] = fmaf(ws[t], a.y, sg[4 * q + 1]);
-            sg[4 * q + 2] = fmaf(ws[t], a.z, sg[4 * q + 2]);
-            sg[4 * q + 3] = fmaf(ws[t], a.w, sg[4 * q + 3]);
+            sg[2 * q + 0] = pk_fma(w2, f32x2{a.x, a.y}, sg[2 * q + 0]);
+            sg[2 * q + 1] = pk_fma(w2, f32x2{a.z, a.w}, sg[2 * q + 1]);
         }
         if (DUAL) {
             const float4* ta = reinterpret_cast<const float4*>(pa + offs[t]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 a = ta[q];
-                sa[4 * q + 0] = fmaf(ws[t], a.x, sa[4 * q + 0]);
-                sa[4 * q + 1] = fmaf(ws[t], a.y, sa[4 * q + 1]);
-                sa[4 * q + 2] = fmaf(ws[t], a.z, sa[4 * q + 2]);
-                sa[4 * q + 3] = fmaf(ws[t], a.w, sa[4 * q + 3]);
+                sa[2 * q + 0] = pk_fma(w2, f32x2{a.x, a.y}, sa[2 * q + 0]);
+                sa[2 * q + 1] = pk_fma(w2, f32x2{a.z, a.w}, sa[2 * q + 1]);
             }
         }
         // Register discipline: at most TAPS_IN_FLIGHT taps' loads (4 float4 = 16 VGPRs each, x2 with
@@ -107,37 +125,158 @@ __device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const
     }
 }
 
+// ---- decoder, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) ---------------------------------------------
+// FC 32->64, softplus, FC 64->32 rows; weights are the A operand (LDS), the per-point vectors are the
+// B operand and never leave registers.  Register discipline: the machine scheduler
+// would otherwise hoist every LDS weight read of both nets to the top (>150 VGPRs); each group of
+// k-steps prefetches the next group's A fragments and ends in a scheduling fence.
+__device__ __forceinline__ void mlp_fp32(const float* __restrict__ lds, const f32x2 (&f)[8], int net, int lane, f32x16& out) {
+    const int h = lane >> 5;
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 a0, a1;
+    const float4* b0 = reinterpret_cast<const float4*>(lds + (net ? DEC_B_A0 : DEC_B_G0) + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 x = b0[2 * q], y = b0[8 + 2 * q];
+        a0[4 * q + 0] = x.x; a0[4 * q + 1] = x.y; a0[4 * q + 2] = x.z; a0[4 * q + 3] = x.w;
+        a1[4 * q + 0] = y.x; a1[4 * q + 1] = y.y; a1[4 * q + 2] = y.z; a1[4 * q + 3] = y.w;
+    }
+    const float4* A0 = reinterpret_cast<const float4*>(lds + (net ? DEC_A_A0 : DEC_A_G0)) + lane;
+    float4 w0 = A0[0], w1 = A0[4 * 64];
+#pragma unroll
+    for (int k4 = 0; k4 < 4; ++k4) {
+        float4 n0 = w0, n1 = w1;
+        if (k4 < 3) { n0 = A0[(k4 + 1) * 64]; n1 = A0[(4 + k4 + 1) * 64]; }
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, f[2 * k4][0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, f[2 * k4][0], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, f[2 * k4][1], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, f[2 * k4][1], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, f[2 * k4 + 1][0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, f[2 * k4 + 1][0], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, f[2 * k4 + 1][1], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, f[2 * k4 + 1][1], a1, 0, 0, 0);
+        w0 = n0; w1 = n1;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = softplus_log2(a0[r]); a1[r] = softplus_log2(a1[r]); }
+    const float4* b1 = reinterpret_cast<const float4*>(lds + (net ? DEC_B_A1 : DEC_B_G1) + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 x = b1[2 * q];
+        out[4 * q + 0] = x.x; out[4 * q + 1] = x.y; out[4 * q + 2] = x.z; out[4 * q + 3] = x.w;
+    }
+    const float4* A1 = reinterpret_cast<const float4*>(lds + (net ? DEC_A_A1 : DEC_A_G1)) + lane;
+    float4 w = A1[0];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k4 = 0; k4 < 8; ++k4) {
+        float4 nw = w;
+        if (k4 < 7) nw = A1[(k4 + 1) * 64];
+        const int kb = 4 * (k4 & 3);
+        if (k4 < 4) {
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a0[kb + 0], out, 0, 0, 0);
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a0[kb + 1], out, 0, 0, 0);
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a0[kb + 2], out, 0, 0, 0);
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a0[kb + 3], out, 0, 0, 0);
+        } else {
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a1[kb + 0], out, 0, 0, 0);
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a1[kb + 1], out, 0, 0, 0);
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a1[kb + 2], out, 0, 0, 0);
+            out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a1[kb + 3], out, 0, 0, 0);
+        }
+        w = nw;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// ---- decoder, split-bf16 MFMA (v_mfma_f32_32x32x16_bf16, 3 per product: hi*hi + hi*lo + lo*hi) ------
+// LDS holds the bf16 fragment image at word 0 (DEC_BF16 area of the blob) and the fp32 biases at
+// DEC_B_*.  Fragment f of lane l is the uint4 at (f*64 + l).
+#define NFE_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).v, (B).v, (C), 0, 0, 0)
+__device__ __forceinline__ void mlp_bf16(const float* __restrict__ lds, const f32x2 (&f)[8], int net, int lane, f32x16& out) {
+    const int h = lane >> 5;
+    const uint4* F = reinterpret_cast<const uint4*>(lds) + lane;
+    __builtin_amdgcn_sched_barrier(0);
+    Frag fh[2], fl[2];                       // B operand of k-step s: channels 16h + 8s + (0..7)
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) split_pair(f[4 * s + w][0], f[4 * s + w][1], fh[s].u[w], fl[s].u[w]);
+    f32x16 a0, a1;
+    const float4* b0 = reinterpret_cast<const float4*>(lds + (net ? DEC_B_A0 : DEC_B_G0) + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 x = b0[2 * q], y = b0[8 + 2 * q];
+        a0[4 * q + 0] = x.x; a0[4 * q + 1] = x.y; a0[4 * q + 2] = x.z; a0[4 * q + 3] = x.w;
+        a1[4 * q + 0] = y.x; a1[4 * q + 1] = y.y; a1[4 * q + 2] = y.z; a1[4 * q + 3] = y.w;
+    }
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        Frag h0, l0, h1, l1;
+        h0.q = F[(((net * 2 + 0) * 2 + s) * 2 + 0) * 64]; l0.q = F[(((net * 2 + 0) * 2 + s) * 2 + 1) * 64];
+        h1.q = F[(((net * 2 + 1) * 2 + s) * 2 + 0) * 64]; l1.q = F[(((net * 2 + 1) * 2 + s) * 2 + 1) * 64];
+        a0 = NFE_MFMA_BF16(h0, fh[s], a0); a1 = NFE_MFMA_BF16(h1, fh[s], a1);
+        a0 = NFE_MFMA_BF16(h0, fl[s], a0); a1 = NFE_MFMA_BF16(h1, fl[s], a1);
+        a0 = NFE_MFMA_BF16(l0, fh[s], a0); a1 = NFE_MFMA_BF16(l1, fh[s], a1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a0[r] = softplus_log2(a0[r]); a1[r] = softplus_log2(a1[r]); }
+    const float4* b1 = reinterpret_cast<const float4*>(lds + (net ? DEC_B_A1 : DEC_B_G1) + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 x = b1[2 * q];
+        out[4 * q + 0] = x.x; out[4 * q + 1] = x.y; out[4 * q + 2] = x.z; out[4 * q + 3] = x.w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {            // k-step s: hidden registers 8(s&1)..+7 of M-block s>>1
+        Frag hh, hl, wh, wl;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const int r = 8 * (s & 1) + 2 * w;
+            if (s < 2) split_pair(a0[r], a0[r + 1], hh.u[w], hl.u[w]);
+            else split_pair(a1[r], a1[r + 1], hh.u[w], hl.u[w]);
+        }
+        wh.q = F[(16 + (net * 4 + s) * 2 + 0) * 64]; wl.q = F[(16 + (net * 4 + s) * 2 + 1) * 64];
+        out = NFE_MFMA_BF16(wh, hh, out);
+        out = NFE_MFMA_BF16(wh, hl, out);
+        out = NFE_MFMA_BF16(wl, hh, out);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // Evaluate the implicit model at one point per lane PAIR (lanes j and j+32 share a point; lane half
 // h holds channels [16h,16h+16) of every 32-vector).  Returns, for this lane:
 //   og[0] = sigma; og[1..] = seg channels (h=0: seg 0..7 in og[1..8]; h=1: seg 8..14 in og[1..7])
 //   oa[r] = rgb channel 16h + r   (after the sigmoid clamp, triplane.py:269)
-template <bool DUAL, bool SIGMA_ONLY>
+template <bool DUAL, bool SIGMA_ONLY, int MATH>
 __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const float* __restrict__ pa,
                                            int H, int W, const float* __restrict__ lds,
                                            const float* __restrict__ aff, float gx, float gy, float gz,
                                            int lane, f32x16& og, f32x16& oa) {
-    const int h = lane >> 5;
-    const int hoff = h * 16;
-    float fn[16], fd[16];
+    const int hoff = (lane >> 5) * 16;
+    f32x2 fn[8], fd[8];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) { fn[c] = 0.0f; fd[c] = 0.0f; }
+    for (int c = 0; c < 8; ++c) { fn[c] = splat(0.0f); fd[c] = splat(0.0f); }
     const long long plane_elems = (long long)H * W * 32;
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         float u = (p == 2) ? gz : gx;
         float v = (p == 0) ? gy : ((p == 1) ? gz : gx);
-        float sg[16], sa[16], wsum;
+        f32x2 sg[8], sa[8];
+        float wsum;
         gather_plane<DUAL && !SIGMA_ONLY, (DUAL && !SIGMA_ONLY) ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, H, W, u, v, hoff, sg, sa, wsum);
+        const f32x2 w2 = splat(wsum);
         const float4* gs = reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + hoff);
         const float4* gb = reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + hoff);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             float4 s = gs[q], b = gb[q];
-            fn[4 * q + 0] = fmaf(sg[4 * q + 0], s.x, fmaf(wsum, b.x, fn[4 * q + 0]));
-            fn[4 * q + 1] = fmaf(sg[4 * q + 1], s.y, fmaf(wsum, b.y, fn[4 * q + 1]));
-            fn[4 * q + 2] = fmaf(sg[4 * q + 2], s.z, fmaf(wsum, b.z, fn[4 * q + 2]));
-            fn[4 * q + 3] = fmaf(sg[4 * q + 3], s.w, fmaf(wsum, b.w, fn[4 * q + 3]));
+            fn[2 * q + 0] = pk_fma(sg[2 * q + 0], f32x2{s.x, s.y}, pk_fma(w2, f32x2{b.x, b.y}, fn[2 * q + 0]));
+            fn[2 * q + 1] = pk_fma(sg[2 * q + 1], f32x2{s.z, s.w}, pk_fma(w2, f32x2{b.z, b.w}, fn[2 * q + 1]));
         }
         if (!SIGMA_ONLY) {
             const float4* as = reinterpret_cast<const float4*>(aff + 2 * 96 + p * 32 + hoff);
@@ -145,86 +284,29 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 s = as[q], b = ab[q];
-                fd[4 * q + 0] = fmaf(DUAL ? sa[4 * q + 0] : sg[4 * q + 0], s.x, fmaf(wsum, b.x, fd[4 * q + 0]));
-                fd[4 * q + 1] = fmaf(DUAL ? sa[4 * q + 1] : sg[4 * q + 1], s.y, fmaf(wsum, b.y, fd[4 * q + 1]));
-                fd[4 * q + 2] = fmaf(DUAL ? sa[4 * q + 2] : sg[4 * q + 2], s.z, fmaf(wsum, b.z, fd[4 * q + 2]));
-                fd[4 * q + 3] = fmaf(DUAL ? sa[4 * q + 3] : sg[4 * q + 3], s.w, fmaf(wsum, b.w, fd[4 * q + 3]));
+                fd[2 * q + 0] = pk_fma(DUAL ? sa[2 * q + 0] : sg[2 * q + 0], f32x2{s.x, s.y}, pk_fma(w2, f32x2{b.x, b.y}, fd[2 * q + 0]));
+                fd[2 * q + 1] = pk_fma(DUAL ? sa[2 * q + 1] : sg[2 * q + 1], f32x2{s.z, s.w}, pk_fma(w2, f32x2{b.z, b.w}, fd[2 * q + 1]));
             }
         }
     }
-
-    // ---- decoder: FC 32->64, softplus, FC 64->{16|32}; weights are the MFMA A operand (LDS),
-    // the per-point vectors are the B operand and never leave registers. -------
-    // Register discipline: the machine scheduler would otherwise hoist every LDS weight read of both
-    // nets to the top (>150 VGPRs).  Each 4-k-step group prefetches the next group's A fragments and
-    // ends in a scheduling fence, so at most two groups of fragments are live.
-    auto mlp = [&](const float (&f)[16], int offA0, int offB0, int offA1, int offB1, f32x16& out) {
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 a0, a1;
-        const float4* b0 = reinterpret_cast<const float4*>(lds + offB0 + 4 * h);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 x = b0[2 * q], y = b0[8 + 2 * q];
-            a0[4 * q + 0] = x.x; a0[4 * q + 1] = x.y; a0[4 * q + 2] = x.z; a0[4 * q + 3] = x.w;
-            a1[4 * q + 0] = y.x; a1[4 * q + 1] = y.y; a1[4 * q + 2] = y.z; a1[4 * q + 3] = y.w;
-        }
-        const float4* A0 = reinterpret_cast<const float4*>(lds + offA0) + lane;
-        float4 w0 = A0[0], w1 = A0[4 * 64];
-#pragma unroll
-        for (int k4 = 0; k4 < 4; ++k4) {
-            float4 n0 = w0, n1 = w1;
-            if (k4 < 3) { n0 = A0[(k4 + 1) * 64]; n1 = A0[(4 + k4 + 1) * 64]; }
-            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.x, f[4 * k4 + 0], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.x, f[4 * k4 + 0], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.y, f[4 * k4 + 1], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.y, f[4 * k4 + 1], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.z, f[4 * k4 + 2], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.z, f[4 * k4 + 2], a1, 0, 0, 0);
-            a0 = __builtin_amdgcn_mfma_f32_32x32x2f32(w0.w, f[4 * k4 + 3], a0, 0, 0, 0);
-            a1 = __builtin_amdgcn_mfma_f32_32x32x2f32(w1.w, f[4 * k4 + 3], a1, 0, 0, 0);
-            w0 = n0; w1 = n1;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { a0[r] = softplus_f(a0[r]); a1[r] = softplus_f(a1[r]); }
-        const float4* b1 = reinterpret_cast<const float4*>(lds + offB1 + 4 * h);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 x = b1[2 * q];
-            out[4 * q + 0] = x.x; out[4 * q + 1] = x.y; out[4 * q + 2] = x.z; out[4 * q + 3] = x.w;
-        }
-        const float4* A1 = reinterpret_cast<const float4*>(lds + offA1) + lane;
-        float4 w = A1[0];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int k4 = 0; k4 < 8; ++k4) {
-            float4 nw = w;
-            if (k4 < 7) nw = A1[(k4 + 1) * 64];
-            const int kb = 4 * (k4 & 3);
-            if (k4 < 4) {
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a0[kb + 0], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a0[kb + 1], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a0[kb + 2], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a0[kb + 3], out, 0, 0, 0);
-            } else {
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.x, a1[kb + 0], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.y, a1[kb + 1], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.z, a1[kb + 2], out, 0, 0, 0);
-                out = __builtin_amdgcn_mfma_f32_32x32x2f32(w.w, a1[kb + 3], out, 0, 0, 0);
-            }
-            w = nw;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    mlp(fn, DEC_A_G0, DEC_B_G0, DEC_A_G1, DEC_B_G1, og);
+    if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og); else mlp_bf16(lds, fn, 0, lane, og);
     if (!SIGMA_ONLY) {
-        mlp(fd, DEC_A_A0, DEC_B_A0, DEC_A_A1, DEC_B_A1, oa);
+        if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa); else mlp_bf16(lds, fd, 1, lane, oa);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float s = __builtin_amdgcn_rcpf(1.0f + fast_exp(-oa[r]));
+        for (int r = 0; r < 16; ++r) {       // oa carries log2(e): sigmoid(x) = 1/(1 + 2^-(x log2 e))
+            float s = __builtin_amdgcn_rcpf(1.0f + exp2_fast(-oa[r]));
             oa[r] = fmaf(s, 1.002f, -0.001f);      // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269
         }
     }
+}
+
+// Copy the decoder image for this math mode into LDS words [0, DEC_FLOATS): fragments then biases.
+template <int MATH>
+__device__ __forceinline__ void stage_decoder(const float* __restrict__ dec, float* lds) {
+    const float4* frag = reinterpret_cast<const float4*>(dec + (MATH == NFE_MATH_FP32 ? 0 : DEC_BF16));
+    for (int i = threadIdx.x; i < DEC_B_G0 / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = frag[i];
+    const float4* bias = reinterpret_cast<const float4*>(dec + DEC_B_G0);
+    for (int i = threadIdx.x; i < (DEC_FLOATS - DEC_B_G0) / 4; i += 256) reinterpret_cast<float4*>(lds + DEC_B_G0)[i] = bias[i];
 }
 
 // Stage this wave's view affines into its LDS region, folding in the 1/3 of the mean over planes
@@ -242,11 +324,10 @@ __device__ __forceinline__ void stage_affine(const float* const (&src)[4], int n
     __threadfence_block();
 }
 
-template <bool DUAL, bool SIGMA_ONLY>
+template <bool DUAL, bool SIGMA_ONLY, int MATH>
 __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    for (int i = threadIdx.x; i < DEC_FLOATS / 4; i += 256)
-        reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(P.dec)[i];
+    stage_decoder<MATH>(P.dec, lds);
     // wave id in an SGPR: everything derived from it (ray block, view, plane base) stays scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -309,12 +390,12 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
         const float delta = (re - rs) / (float)(S - 1);
 
         // ---- march state (SegMipRayMarcher2.run_forward, ray_marcher.py:68-101) --------------
-        float acc_rgb[16], acc_seg[8], prev_rgb[16], prev_seg[8];
+        f32x2 acc_rgb[8], acc_seg[4], prev_rgb[8], prev_seg[4];
         float acc_d = 0.0f, acc_w = 0.0f, T = 1.0f, prev_t = 0.0f, prev_sig = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { acc_rgb[c] = 0.0f; prev_rgb[c] = 0.0f; }
+        for (int c = 0; c < 8; ++c) { acc_rgb[c] = splat(0.0f); prev_rgb[c] = splat(0.0f); }
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { acc_seg[c] = 0.0f; prev_seg[c] = 0.0f; }
+        for (int c = 0; c < 4; ++c) { acc_seg[c] = splat(0.0f); prev_seg[c] = splat(0.0f); }
         u32x4 rnd = {0, 0, 0, 0};
 
 #pragma unroll 1
@@ -353,20 +434,23 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             // would pin >200 VGPRs per lane and spill.
             int opq;
             asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
-            eval_point<DUAL, SIGMA_ONLY>(pg, pa, P.H, P.W, lds + opq, aff + opq, gx, gy, gz, lane, og, oa);
+            eval_point<DUAL, SIGMA_ONLY, MATH>(pg, pa, P.H, P.W, lds + opq, aff + opq, gx, gy, gz, lane, og, oa);
 
             if (k > 0) {
                 const float dlt = t - prev_t;
                 const float dens = softplus_f((prev_sig + og[0]) * 0.5f - 1.0f);
-                const float alpha = 1.0f - fast_exp(-(dens * dlt));
+                const float alpha = 1.0f - exp2_fast(-(dens * dlt) * LOG2E);
                 const float w = alpha * T;
                 T = T * (1.0f - alpha + 1e-10f);
                 if (P.out_weights && valid && h == 0) P.out_weights[ray * (S - 1) + (k - 1)] = w;
                 if (!SIGMA_ONLY) {
+                    const f32x2 wh = splat(w * 0.5f);      // w * (a + b)/2 == (w/2) * (a + b), exactly
 #pragma unroll
-                    for (int c = 0; c < 16; ++c) acc_rgb[c] = fmaf(w, (prev_rgb[c] + oa[c]) * 0.5f, acc_rgb[c]);
+                    for (int c = 0; c < 8; ++c)
+                        acc_rgb[c] = pk_fma(wh, prev_rgb[c] + f32x2{oa[2 * c], oa[2 * c + 1]}, acc_rgb[c]);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c) acc_seg[c] = fmaf(w, (prev_seg[c] + og[1 + c]) * 0.5f, acc_seg[c]);
+                    for (int c = 0; c < 4; ++c)
+                        acc_seg[c] = pk_fma(wh, prev_seg[c] + f32x2{og[1 + 2 * c], og[2 + 2 * c]}, acc_seg[c]);
                     acc_d = fmaf(w, (prev_t + t) * 0.5f, acc_d);
                     acc_w += w;
                 }
@@ -374,33 +458,38 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             prev_t = t; prev_sig = og[0];
             if (!SIGMA_ONLY) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) prev_rgb[c] = oa[c];
+                for (int c = 0; c < 8; ++c) prev_rgb[c] = f32x2{oa[2 * c], oa[2 * c + 1]};
 #pragma unroll
-                for (int c = 0; c < 8; ++c) prev_seg[c] = og[1 + c];
+                for (int c = 0; c < 4; ++c) prev_seg[c] = f32x2{og[1 + 2 * c], og[2 + 2 * c]};
             }
         }
 
         // ---- outputs -------------------------------------------------------------------------
         if (!SIGMA_ONLY && valid) {
             const float wb = P.white_back ? (1.0f - acc_w) : 0.0f;
+            float rgbv[16], segv[8];
 #pragma unroll
-            for (int c = 0; c < 16; ++c) acc_rgb[c] = (acc_rgb[c] + wb) * 2.0f - 1.0f;   // :96-99
+            for (int c = 0; c < 8; ++c) {                                                  // :96-99
+                rgbv[2 * c] = (acc_rgb[c][0] + wb) * 2.0f - 1.0f;
+                rgbv[2 * c + 1] = (acc_rgb[c][1] + wb) * 2.0f - 1.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { segv[2 * c] = acc_seg[c][0]; segv[2 * c + 1] = acc_seg[c][1]; }
+            const int nseg = h ? 7 : 8;
             if (P.channels_first) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) P.rgb[((long long)n * 32 + 16 * h + c) * P.M + m] = acc_rgb[c];
-                const int nseg = h ? 7 : 8;
+                for (int c = 0; c < 16; ++c) P.rgb[((long long)n * 32 + 16 * h + c) * P.M + m] = rgbv[c];
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    if (c < nseg) P.seg[((long long)n * 15 + 8 * h + c) * P.M + m] = acc_seg[c];
+                    if (c < nseg) P.seg[((long long)n * 15 + 8 * h + c) * P.M + m] = segv[c];
             } else {
                 float4* o = reinterpret_cast<float4*>(P.rgb + ray * 32 + 16 * h);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
-                    o[q] = make_float4(acc_rgb[4 * q], acc_rgb[4 * q + 1], acc_rgb[4 * q + 2], acc_rgb[4 * q + 3]);
-                const int nseg = h ? 7 : 8;
+                    o[q] = make_float4(rgbv[4 * q], rgbv[4 * q + 1], rgbv[4 * q + 2], rgbv[4 * q + 3]);
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    if (c < nseg) P.seg[ray * 15 + 8 * h + c] = acc_seg[c];
+                    if (c < nseg) P.seg[ray * 15 + 8 * h + c] = segv[c];
             }
             if (h == 0) {
                 P.depth[ray] = acc_d / acc_w;     // NaN when acc_w == 0; fixed by depth_clamp_kernel
@@ -564,11 +653,10 @@ struct PointK {
     float* rgb; float* sigma; float* seg;
 };
 
-template <bool DUAL>
-__global__ __launch_bounds__(256) void point_kernel(PointK P) {
+template <bool DUAL, int MATH>
+__global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    for (int i = threadIdx.x; i < DEC_FLOATS / 4; i += 256)
-        reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(P.dec)[i];
+    stage_decoder<MATH>(P.dec, lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     float* aff = lds + LDS_AFF + wave * AFF_FLOATS;
@@ -585,7 +673,7 @@ __global__ __launch_bounds__(256) void point_kernel(PointK P) {
         const long long pt = (long long)n * P.Pn + m;
         const float* c = P.coords + pt * 3;
         f32x16 og, oa;
-        eval_point<DUAL, false>(P.planes_g + (long long)n * P.plane_view_stride,
+        eval_point<DUAL, false, MATH>(P.planes_g + (long long)n * P.plane_view_stride,
                                 P.planes_a + (long long)n * P.plane_view_stride, P.H, P.W, lds, aff,
                                 P.coord_scale * c[0], P.coord_scale * c[1], P.coord_scale * c[2], lane, og, oa);
         if (valid) {
@@ -620,18 +708,24 @@ static void allow_lds(K kernel, int bytes) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 
-static int launch_render(const RenderK& P, bool dual, bool sigma_only, hipStream_t st) {
+template <bool DUAL, bool SIGMA_ONLY>
+static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_t st) {
+    if (math == NFE_MATH_FP32)
+        hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+    else
+        hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+}
+
+static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math, hipStream_t st) {
     const long long total_rb = (long long)P.N * ((P.M + 31) / 32);
     long long blocks = (total_rb + 3) / 4;
     const long long cap = (long long)num_cus() * 2;      // 2 blocks (8 waves) per CU, grid-stride beyond
     if (blocks > cap) blocks = cap;
-    dim3 grid((unsigned)blocks), block(256);
+    dim3 grid((unsigned)blocks);
     if (sigma_only) {
-        if (dual) hipLaunchKernelGGL((render_kernel<true, true>), grid, block, RENDER_LDS_BYTES, st, P);
-        else hipLaunchKernelGGL((render_kernel<false, true>), grid, block, RENDER_LDS_BYTES, st, P);
+        if (dual) launch_render_math<true, true>(P, math, grid, st); else launch_render_math<false, true>(P, math, grid, st);
     } else {
-        if (dual) hipLaunchKernelGGL((render_kernel<true, false>), grid, block, RENDER_LDS_BYTES, st, P);
-        else hipLaunchKernelGGL((render_kernel<false, false>), grid, block, RENDER_LDS_BYTES, st, P);
+        if (dual) launch_render_math<true, false>(P, math, grid, st); else launch_render_math<false, false>(P, math, grid, st);
     }
     NFE_CHECK_LAUNCH("render_kernel");
     return NFE_OK;
@@ -676,6 +770,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     NFE_REQUIRE((a->ray_start_per_ray != nullptr) == (a->ray_end_per_ray != nullptr), "nfe_render: per-ray limits must come in pairs");
     NFE_REQUIRE(!(a->ray_start_per_ray && a->disparity_space_sampling), "nfe_render: disparity sampling with per-ray limits is not supported");
     NFE_REQUIRE(a->box_warp > 0.0f, "nfe_render: box_warp must be positive");
+    NFE_REQUIRE(a->decoder_math == NFE_MATH_BF16X3 || a->decoder_math == NFE_MATH_FP32, "nfe_render: unknown decoder_math %d", a->decoder_math);
     NFE_REQUIRE(a->rgb && a->seg && a->depth && a->wsum, "nfe_render: output pointers are null");
     NFE_REQUIRE(a->workspace != nullptr, "nfe_render: workspace is null");
     const uint64_t need = nfe_render_workspace_bytes(a->n_views, a->n_rays, D, Di);
@@ -702,6 +797,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.seed = a->seed;
     const int mode = a->ray_start_per_ray ? DEPTH_PER_RAY : (a->disparity_space_sampling ? DEPTH_DISPARITY : DEPTH_STRATIFIED);
     const bool dual = a->planes_geo != a->planes_app;
+    const int math = a->decoder_math;
 
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, minmax);
     NFE_CHECK_LAUNCH("minmax_init_kernel");
@@ -709,7 +805,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     if (Di == 0) {
         P.S = D; P.depth_mode = mode; P.u = a->u_coarse; P.depth_minmax = minmax;
         P.out_depths = a->tap_depths_all;
-        int rc = launch_render(P, dual, false, st);
+        int rc = launch_render(P, dual, false, math, st);
         if (rc) return rc;
     } else {
         float* t_c = (float*)ws; ws += align256(nr * (uint64_t)D * 4);
@@ -719,7 +815,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         RenderK C = P;
         C.S = D; C.depth_mode = mode; C.u = a->u_coarse; C.depth_minmax = nullptr;
         C.out_depths = t_c; C.out_weights = w_c;
-        int rc = launch_render(C, dual, true, st);
+        int rc = launch_render(C, dual, true, math, st);
         if (rc) return rc;
         if (a->tap_weights_coarse) {
             hipError_t e = hipMemcpyAsync(a->tap_weights_coarse, w_c, nr * (uint64_t)(D - 1) * 4, hipMemcpyDeviceToDevice, st);
@@ -737,7 +833,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         // pass 3: march the merged samples
         RenderK F = P;
         F.S = D + Di; F.depth_mode = DEPTH_BUFFER; F.depth_buf = t_all; F.depth_minmax = minmax;
-        rc = launch_render(F, dual, false, st);
+        rc = launch_render(F, dual, false, math, st);
         if (rc) return rc;
         if (a->tap_depths_all) {
             hipError_t e = hipMemcpyAsync(a->tap_depths_all, t_all, nr * (uint64_t)(D + Di) * 4, hipMemcpyDeviceToDevice, st);
@@ -754,13 +850,14 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
 extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app, int plane_h, int plane_w,
                                int64_t plane_view_stride, const float* geo_scale, const float* geo_shift,
                                const float* app_scale, const float* app_shift, const float* decoder_packed,
-                               const float* coords, int n_views, int n_points, float box_warp,
+                               int decoder_math, const float* coords, int n_views, int n_points, float box_warp,
                                float* rgb, float* sigma, float* seg, nfe_stream_t stream) {
     NFE_REQUIRE(planes_geo && planes_app && decoder_packed && coords, "nfe_point_query: null input pointer");
     NFE_REQUIRE(rgb && sigma && seg, "nfe_point_query: null output pointer");
     NFE_REQUIRE(plane_h > 0 && plane_w > 0, "nfe_point_query: bad plane size");
     NFE_REQUIRE(n_views > 0 && n_points >= 0, "nfe_point_query: bad sizes N=%d P=%d", n_views, n_points);
     NFE_REQUIRE(box_warp > 0.0f, "nfe_point_query: box_warp must be positive");
+    NFE_REQUIRE(decoder_math == NFE_MATH_BF16X3 || decoder_math == NFE_MATH_FP32, "nfe_point_query: unknown decoder_math %d", decoder_math);
     if (n_points == 0) return NFE_OK;
     PointK P{};
     P.planes_g = planes_geo; P.planes_a = planes_app; P.plane_view_stride = plane_view_stride; P.H = plane_h; P.W = plane_w;
@@ -771,8 +868,15 @@ extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app,
     long long blocks = (total + 3) / 4;
     if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
     hipStream_t st = (hipStream_t)stream;
-    if (planes_geo != planes_app) hipLaunchKernelGGL((point_kernel<true>), dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, st, P);
-    else hipLaunchKernelGGL((point_kernel<false>), dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, st, P);
+    const bool dual = planes_geo != planes_app;
+    dim3 grid((unsigned)blocks), block(256);
+    if (decoder_math == NFE_MATH_FP32) {
+        if (dual) hipLaunchKernelGGL((point_kernel<true, NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);
+        else hipLaunchKernelGGL((point_kernel<false, NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);
+    } else {
+        if (dual) hipLaunchKernelGGL((point_kernel<true, NFE_MATH_BF16X3>), grid, block, RENDER_LDS_BYTES, st, P);
+        else hipLaunchKernelGGL((point_kernel<false, NFE_MATH_BF16X3>), grid, block, RENDER_LDS_BYTES, st, P);
+    }
     NFE_CHECK_LAUNCH("point_kernel");
     return NFE_OK;
 }

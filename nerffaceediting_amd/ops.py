@@ -30,6 +30,15 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
 
+def _math_mode(mode):
+    """None/'bf16x3' -> split-bf16 MFMA decoder (default); 'fp32' -> exact fp32 MFMA."""
+    if mode in (None, "bf16x3", _lib.NFE_MATH_BF16X3):
+        return _lib.NFE_MATH_BF16X3
+    if mode in ("fp32", _lib.NFE_MATH_FP32):
+        return _lib.NFE_MATH_FP32
+    raise ValueError(f"unknown decoder_math {mode!r}")
+
+
 def _workspace(device, nbytes):
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(key)
@@ -128,7 +137,7 @@ def decoder_pack(geo_w0, geo_b0, geo_w1, geo_b1, app_w0, app_b0, app_w1, app_b1,
 
 def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dirs=None, cam2world=None,
            intrinsics=None, resolution=0, affines=None, u_coarse=None, u_fine=None, seed=0,
-           channels_first=False, taps=False, ray_limits=None):
+           channels_first=False, taps=False, ray_limits=None, decoder_math=None):
     """nfe_render.  planes_* are packed [Np,3,H,W,32] (Np == N or 1); affines = 4x [N,96] or None.
 
     Returns (rgb, seg, depth, wsum[, taps]) with rgb [N,M,32] (or [N,32,M] if channels_first),
@@ -167,6 +176,7 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
         a.geo_scale, a.geo_shift, a.app_scale, a.app_shift = [t.data_ptr() for t in affines]
         keep += affines
     a.decoder_packed = _dev(decoder_packed, "decoder_packed", (_lib.NFE_DECODER_PACKED_FLOATS,)).data_ptr()
+    a.decoder_math = _math_mode(decoder_math)
     a.n_views, a.n_rays = N, M
     if origins is not None:
         a.origins, a.dirs = origins.data_ptr(), dirs.data_ptr()
@@ -214,7 +224,7 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
     return (rgb, seg, depth, wsum, tap) if taps else (rgb, seg, depth, wsum)
 
 
-def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affines=None):
+def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affines=None, decoder_math=None):
     """nfe_point_query: coords [N,P,3] -> dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15])."""
     lib = _lib.load()
     planes_geo = _dev(planes_geo, "planes_geo", (None, 3, None, None, 32))
@@ -234,6 +244,6 @@ def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affine
     stride = 0 if (Np == 1 and N > 1) else 3 * H * W * 32
     with torch.cuda.device(dev):
         _lib.check(lib.nfe_point_query(_ptr(planes_geo), _ptr(planes_app), H, W, stride, *[_ptr(t) for t in aff],
-                                       _ptr(decoder_packed), _ptr(coords), N, P, float(box_warp),
+                                       _ptr(decoder_packed), _math_mode(decoder_math), _ptr(coords), N, P, float(box_warp),
                                        _ptr(rgb), _ptr(sigma), _ptr(seg), _stream()), "nfe_point_query")
     return {"rgb": rgb, "sigma": sigma, "seg": seg}

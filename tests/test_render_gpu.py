@@ -12,7 +12,9 @@ from tests._golden import RENDER_CASES, load, load_render_case, max_abs
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3          # north_star parity bar
-TIGHT = 5e-5        # what fp32 with a different summation order actually achieves on these cases
+# what the two decoder math modes actually achieve on these cases (summation order differs from ATen)
+TIGHT = {"fp32": 5e-5, "bf16x3": 3e-4}
+MATHS = ["bf16x3", "fp32"]
 
 
 @pytest.fixture(scope="module")
@@ -34,7 +36,7 @@ def _dec(case_dec, dev, lr_mul=1.0):
     return ops.decoder_pack(*[_t(case_dec[k], dev) for k in names], lr_mul=lr_mul)
 
 
-def _run_case(case, dev, mode, from_camera=False, channels_first=False):
+def _run_case(case, dev, mode, from_camera=False, channels_first=False, math=None):
     """mode 'single': raw planes + affines (single-gather identity); 'dual': separate norm/denorm planes."""
     from nerffaceediting_amd import ops
     planes = _t(case["planes"], dev)
@@ -56,7 +58,7 @@ def _run_case(case, dev, mode, from_camera=False, channels_first=False):
         pg, pa, aff = ops.plane_pack(norm), ops.plane_pack(denorm), None
     dec = _dec(case["dec"], dev)
     kw = dict(affines=aff, u_coarse=_t(case["u_coarse"], dev), u_fine=_t(case["u_fine"], dev) if Ni > 0 else None,
-              taps=True, channels_first=channels_first)
+              taps=True, channels_first=channels_first, decoder_math=math)
     c2w, K = _t(case["cam2world"], dev), _t(case["intrinsics"], dev)
     if opts["ray_start"] == "auto":
         o, d = orc.ray_sampler(case["cam2world"], case["intrinsics"], case["R"])
@@ -72,17 +74,18 @@ def _run_case(case, dev, mode, from_camera=False, channels_first=False):
     return [x.cpu().numpy() if hasattr(x, "cpu") else {k: v.cpu().numpy() for k, v in x.items()} for x in out]
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("mode", ["single", "dual"])
 @pytest.mark.parametrize("tag", RENDER_CASES)
-def test_render_vs_reference_golden(tag, mode, dev):
+def test_render_vs_reference_golden(tag, mode, math, dev):
     case = load_render_case(tag)
-    rgb, seg, depth, wsum, tap = _run_case(case, dev, mode)
+    rgb, seg, depth, wsum, tap = _run_case(case, dev, mode, math=math)
     got = dict(rgb=rgb, seg=seg, depth=depth, wsum=wsum)
     errs = {k: max_abs(got[k], case["out"][k]) for k in got}
-    print(tag, mode, errs)
+    print(tag, mode, math, errs)
     for k, e in errs.items():
         assert e <= TOL, (k, e)
-        assert e <= TIGHT or k == "depth", (k, e)
+        assert e <= TIGHT[math] or k == "depth", (k, e)
     if case["options"]["depth_resolution_importance"] > 0:
         N, M = case["u_coarse"].shape[:2]
         assert max_abs(tap["weights_coarse"].reshape(-1), case["tap"]["weights_coarse"].reshape(-1)) <= 1e-4
@@ -95,10 +98,10 @@ def test_render_from_camera_and_channels_first(tag, dev):
     """Rays generated in-kernel from cam2world/intrinsics (synthesis() path) + planar output layout."""
     case = load_render_case(tag)
     rgb, seg, depth, wsum, _ = _run_case(case, dev, "single", from_camera=True, channels_first=True)
-    assert max_abs(rgb.transpose(0, 2, 1), case["out"]["rgb"]) <= TIGHT
-    assert max_abs(seg.transpose(0, 2, 1), case["out"]["seg"]) <= TIGHT
+    assert max_abs(rgb.transpose(0, 2, 1), case["out"]["rgb"]) <= TIGHT["bf16x3"]
+    assert max_abs(seg.transpose(0, 2, 1), case["out"]["seg"]) <= TIGHT["bf16x3"]
     assert max_abs(depth, case["out"]["depth"]) <= TOL
-    assert max_abs(wsum, case["out"]["wsum"]) <= TIGHT
+    assert max_abs(wsum, case["out"]["wsum"]) <= TIGHT["bf16x3"]
 
 
 def test_ray_sampler(dev):
@@ -139,8 +142,9 @@ def test_plane_pack_layout(dev):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("math", MATHS)
 @pytest.mark.parametrize("mode", ["single", "dual"])
-def test_point_query(mode, dev):
+def test_point_query(mode, math, dev):
     from nerffaceediting_amd import ops
     z = load("point_query")
     dec = {k[4:]: z[k] for k in z.files if k.startswith("dec.")}
@@ -150,12 +154,15 @@ def test_point_query(mode, dev):
     aff = ops.make_affine(mean, std)
     if mode == "single":
         p = ops.plane_pack(planes)
-        out = ops.point_query(p, p, _dec(dec, dev), _t(z["coords"], dev), 1.0, affines=aff)
+        out = ops.point_query(p, p, _dec(dec, dev), _t(z["coords"], dev), 1.0, affines=aff, decoder_math=math)
     else:
         norm = ops.plane_affine(planes, aff[0].reshape(N, 96, 1, 1), aff[1].reshape(N, 96, 1, 1))
-        out = ops.point_query(ops.plane_pack(norm), ops.plane_pack(planes), _dec(dec, dev), _t(z["coords"], dev), 1.0)
+        out = ops.point_query(ops.plane_pack(norm), ops.plane_pack(planes), _dec(dec, dev), _t(z["coords"], dev), 1.0,
+                              decoder_math=math)
     for k in ("rgb", "sigma", "seg"):
-        assert max_abs(out[k].cpu().numpy(), z["out." + k]) <= TIGHT, k
+        e = max_abs(out[k].cpu().numpy(), z["out." + k])
+        print(mode, math, k, e)
+        assert e <= TIGHT[math], k
 
 
 def test_philox_jitter_matches_oracle_generator(dev):
@@ -181,7 +188,8 @@ def test_philox_jitter_matches_oracle_generator(dev):
         assert np.array_equal(x, y.cpu().numpy())
 
 
-def test_larger_render_vs_oracle(dev):
+@pytest.mark.parametrize("math", MATHS)
+def test_larger_render_vs_oracle(math, dev):
     """64x64 rays, 48+48 samples (BASELINE config 1's render shape), 64^2 planes: HIP vs the numpy oracle."""
     rng = np.random.RandomState(123)
     N, R, H, D, Ni = 2, 64, 64, 48, 48
@@ -197,10 +205,10 @@ def test_larger_render_vs_oracle(dev):
     want = orc.render_chunked(norm, denorm, dec, o, d, opts, u_c, u_f, chunk=1024)
     case = dict(planes=planes, cam2world=c2w, intrinsics=K, R=R, swap=False, u_coarse=u_c, u_fine=u_f,
                 options=opts, dec=dec)
-    got = _run_case(case, dev, "single", from_camera=True)
+    got = _run_case(case, dev, "single", from_camera=True, math=math)
     for k, g, w in zip(("rgb", "seg", "depth", "wsum"), got[:4], want):
         e = max_abs(g, w)
-        print(k, e)
+        print(math, k, e)
         assert e <= TOL, (k, e)
 
 
