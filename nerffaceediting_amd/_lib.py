@@ -4,7 +4,8 @@ import os
 from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnfe_render.so")
+# NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
+LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
 NFE_ABI_VERSION = 1
 NFE_MAX_SAMPLES = 256

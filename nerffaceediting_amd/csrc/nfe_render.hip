@@ -106,7 +106,11 @@ __device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const
         const float4* tg = reinterpret_cast<const float4*>(pg + offs[t]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+#ifdef NFE_ABLATE_GATHER   // timing experiment only (tools/ablate.sh): no plane loads
+            float4 a = make_float4(ws[t], u, v, (float)q);
+#else
             float4 a = tg[q];
+#endif
             sg[2 * q + 0] = pk_fma(w2, f32x2{a.x, a.y}, sg[2 * q + 0]);
             sg[2 * q + 1] = pk_fma(w2, f32x2{a.z, a.w}, sg[2 * q + 1]);
         }
@@ -289,6 +293,11 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
             }
         }
     }
+#ifdef NFE_ABLATE_MLP      // timing experiment only (tools/ablate.sh): no decoder
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { og[r] = fn[r >> 1][r & 1]; oa[r] = fd[r >> 1][r & 1]; }
+    return;
+#endif
     if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og); else mlp_bf16(lds, fn, 0, lane, og);
     if (!SIGMA_ONLY) {
         if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa); else mlp_bf16(lds, fd, 1, lane, oa);

@@ -1,0 +1,77 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nfe_render.h declares; the ctypes
+mirror of nfe_render_args matches the C struct; host-side argument handling works without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "nfe_render.h")
+
+
+def _declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nfe_[a-z_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nerffaceediting_amd import _lib
+    lib = _lib.load()
+    declared = _declared_functions()
+    assert len(declared) >= 11
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/nfe_render.h but not exported"
+    assert sorted(_lib.exported_symbols()) == declared, "ctypes signature table out of sync with the header"
+    assert lib.nfe_abi_version() == _lib.NFE_ABI_VERSION
+
+
+def test_render_args_struct_matches_header(tmp_path):
+    """Compile a probe against the real header and compare sizeof/offsetof with the ctypes mirror."""
+    from nerffaceediting_amd import _lib
+    fields = [f[0] for f in _lib.RenderArgs._fields_]
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"nfe_render.h\"\nint main(){\n"
+    prog += 'printf("%zu\\n", sizeof(nfe_render_args));\n'
+    for f in fields:
+        prog += f'printf("{f} %zu\\n", offsetof(nfe_render_args, {f}));\n'
+    prog += 'printf("%d %d %d\\n", NFE_DECODER_PACKED_FLOATS, NFE_MAX_SAMPLES, NFE_ABI_VERSION);return 0;}\n'
+    c = tmp_path / "probe.c"
+    c.write_text(prog)
+    exe = tmp_path / "probe"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    assert int(out[0]) == ctypes.sizeof(_lib.RenderArgs)
+    for line, f in zip(out[1:], fields):
+        name, off = line.split()
+        assert name == f and int(off) == getattr(_lib.RenderArgs, f).offset, (line, f)
+    consts = [int(x) for x in out[1 + len(fields)].split()]
+    assert consts == [_lib.NFE_DECODER_PACKED_FLOATS, _lib.NFE_MAX_SAMPLES, _lib.NFE_ABI_VERSION]
+
+
+def test_workspace_query_and_argument_errors_without_gpu():
+    from nerffaceediting_amd import _lib
+    lib = _lib.load()
+    assert lib.nfe_render_workspace_bytes(4, 512 * 512, 64, 0) == 256
+    two_pass = lib.nfe_render_workspace_bytes(1, 128 * 128, 96, 96)
+    assert two_pass >= 128 * 128 * (96 + 95 + 192) * 4
+    # validation happens before any launch: a null args pointer / bad struct size is refused
+    assert lib.nfe_render(None, None) == -1
+    assert b"args is null" in lib.nfe_last_error()
+    a = _lib.RenderArgs()
+    a.struct_size = 8
+    assert lib.nfe_render(ctypes.byref(a), None) == -1
+    assert b"struct_size" in lib.nfe_last_error()
+    assert lib.nfe_ray_sampler(None, None, 1, 8, None, None, None) == -1
+    with pytest.raises(RuntimeError):
+        _lib.check(-1, "nfe_ray_sampler")
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from nerffaceediting_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.plane_pack(torch.zeros(1, 96, 4, 4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.ray_sampler(torch.eye(4)[None], torch.eye(3)[None], 8)
