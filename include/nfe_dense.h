@@ -1,0 +1,103 @@
+/*
+ * nfe_dense.h — C ABI of the dense (MFMA) half of the hot path in libnfe_render.so: StyleGAN2 mapping
+ * network, modulated convolutions, ToRGB / skip-upsampling and the super-resolution pre-resize.
+ * Same conventions as nfe_render.h (device fp32 pointers, caller allocates, async on `stream`,
+ * 0 / negative error code + nfe_last_error()).
+ *
+ * Activations between layers are NHWC fp32 ([N,H,W,C]); the reference's NCHW tensors exist only at
+ * the module boundary (nfe_nchw_to_nhwc / nfe_nhwc_to_nchw).  Convolutions run on
+ * v_mfma_f32_32x32x16_bf16 with fp32 operands split into bf16 hi+lo (3 MFMAs per product, fp32
+ * accumulate: NFE_CONV_BF16X3) or rounded to bf16 (1 MFMA: NFE_CONV_BF16, the throughput mode of
+ * BASELINE config 3).
+ *
+ * The reference's native entry points on this path are the two plugins
+ *   bias_act(x, b, xref, yref, dy, grad, dim, act, alpha, gain, clamp)    torch_utils/ops/bias_act.cpp:36
+ *   upfirdn2d(x, f, upx, upy, downx, downy, padx0.., flip, gain)         torch_utils/ops/upfirdn2d.cpp:20
+ * plus cuDNN conv2d / conv_transpose2d (torch_utils/ops/conv2d_gradfix.py:127-129).  Here their forward
+ * semantics are fused into the convolution kernels' epilogues; each function names what it replaces.
+ */
+#ifndef NFE_DENSE_H
+#define NFE_DENSE_H
+
+#include "nfe_render.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NFE_CONV_BF16X3 0
+#define NFE_CONV_BF16 1
+
+/* conv modes */
+#define NFE_CONV_3X3 0        /* SynthesisLayer up=1: 3x3, pad 1 (networks_stylegan2.py:311-330) */
+#define NFE_CONV_3X3_UP2 1    /* SynthesisLayer up=2: conv_transpose2d stride 2 + 4x4 FIR (conv2d_resample.py:114-128) */
+#define NFE_CONV_1X1 2        /* ToRGBLayer: 1x1, no demodulation (networks_stylegan2.py:353-357) */
+
+/* ---- layouts -------------------------------------------------------------------------------- */
+int nfe_nchw_to_nhwc(const float* in, int n, int c, int h, int w, float* out, nfe_stream_t stream);
+int nfe_nhwc_to_nchw(const float* in, int n, int c, int h, int w, float* out, nfe_stream_t stream);
+/* NHWC image [N,H,W,96] -> tri-plane gather layout [N,3,H,W,32] (what nfe_render reads) */
+int nfe_nhwc_to_planes(const float* in, int n, int h, int w, float* out, nfe_stream_t stream);
+/* compute_mean_var (triplane.py:56-60) on an NHWC tensor: [N,H*W,C] -> mean,std [N,C].
+ * scratch: n*c*16 bytes of device memory (fp64 partial sums). */
+int nfe_plane_stats_nhwc(const float* x, int n, int hw, int c, float* mean, float* std, void* scratch,
+                         nfe_stream_t stream);
+
+/* ---- FullyConnectedLayer.forward (networks_stylegan2.py:114-127) ------------------------------
+ * y[n,o] = act( (sum_i x[n,i] * w[o,i]) * weight_gain + b[o] * bias_gain ) with act = linear or
+ * lrelu(0.2)*sqrt(2) (bias_act.py:23-33).  b may be NULL.  y_stride lets the caller write into a
+ * wider row (the concat of MappingNetwork.forward, :244). */
+int nfe_fully_connected(const float* x, const float* w, const float* b, int n, int in_features, int out_features,
+                        float weight_gain, float bias_gain, int lrelu, float* y, int y_stride, nfe_stream_t stream);
+
+/* normalize_2nd_moment (networks_stylegan2.py:24-26): y = x * rsqrt(mean(x^2, dim=1) + 1e-8) */
+int nfe_normalize_2nd_moment(const float* x, int n, int features, float* y, int y_stride, nfe_stream_t stream);
+
+/* MappingNetwork tail (networks_stylegan2.py:257-267): broadcast w[n,:] to num_ws rows and lerp the first
+ * `cutoff` rows toward w_avg: ws[n,k,:] = k < cutoff ? w_avg + psi*(w - w_avg) : w.  w_avg may be NULL
+ * when psi == 1. */
+int nfe_broadcast_truncate(const float* w, const float* w_avg, int n, int w_dim, int num_ws, float psi, int cutoff,
+                           float* ws, nfe_stream_t stream);
+
+/* ---- modulated convolution (modulated_conv2d, networks_stylegan2.py:34-91) --------------------- */
+/* weight [Cout,Cin,k,k] fp32 -> MFMA fragment image (bf16 hi/lo) + per-(o,i) squared norms.
+ * packed must hold nfe_conv_packed_words(cout,cin,k) 4-byte words; wsq is [Cout,Cin]. */
+uint64_t nfe_conv_packed_words(int cout, int cin, int k);
+int nfe_conv_pack(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream);
+
+/* demodulation coefficients: dcoef[n,o] = rsqrt(sum_i styles[n,i]^2 * wsq[o,i] + 1e-8)  (:64-65) */
+int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int cout, float* dcoef, nfe_stream_t stream);
+
+typedef struct nfe_conv_args {
+    uint32_t struct_size;
+    int32_t mode;                 /* NFE_CONV_3X3 / _3X3_UP2 / _1X1 */
+    int32_t math;                 /* NFE_CONV_BF16X3 / NFE_CONV_BF16 */
+    const float* x;               /* [N,H,W,Cin] */
+    const float* styles;          /* [N,Cin] (ToRGB: already times weight_gain) */
+    const float* packed;          /* from nfe_conv_pack */
+    const float* dcoef;           /* [N,Cout] or NULL (no demodulation) */
+    const float* noise;           /* [Ho,Wo] noise_const (or [N,Ho,Wo] per-sample noise) or NULL */
+    int64_t noise_n_stride;       /* floats between samples of `noise`; 0 = shared noise_const */
+    float noise_strength;
+    const float* bias;            /* [Cout] */
+    int32_t n, h, w, cin, cout;   /* input size; output is h x w (modes 0,2) or 2h x 2w (mode 1) */
+    int32_t lrelu;                /* 1: lrelu(0.2); 0: linear */
+    float act_gain;               /* def_gain*gain (sqrt(2) for lrelu layers) */
+    float clamp;                  /* conv_clamp*gain, < 0 = none */
+    const float* skip;            /* mode 2 only: previous-resolution image [N,H/2,W/2,Cout] to be
+                                     upsample2d()'d (upfirdn2d.py:315-350) and added, or NULL */
+    int32_t out_planes;           /* mode 2 only: 1 = write [N,3,H,W,32] instead of [N,H,W,Cout] */
+    float* out;
+    float* scratch;               /* mode 1: [N,2H+1,2W+1,Cout] transposed-conv result before the FIR */
+} nfe_conv_args;
+int nfe_modulated_conv(const nfe_conv_args* args, nfe_stream_t stream);
+
+/* ---- F.interpolate(mode='bilinear', align_corners=False, antialias=...) (superresolution.py:283-286)
+ * NHWC [N,H,W,C] -> [N,OH,OW,C] */
+int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int ow, int antialias, float* out,
+                        nfe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NFE_DENSE_H */

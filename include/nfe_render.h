@@ -60,6 +60,14 @@ const char* nfe_last_error(void);
 int nfe_ray_sampler(const float* cam2world, const float* intrinsics, int n_views, int resolution,
                     float* origins, float* dirs, nfe_stream_t stream);
 
+/* ---- a12 ('auto' ray limits): math_utils.get_ray_limits_box (math_utils.py:46-98) followed by the
+ * invalid-ray fix-up of renderer.py:312-318: rays that miss the [-L/2,L/2]^3 box get
+ * start = min(valid starts), end = max(valid STARTS) (sic, as the reference does); if no ray hits the box
+ * the (-1,-2) sentinels are left in place.  origins/dirs [n_rays,3] -> ray_start/ray_end [n_rays].
+ * scratch: 8 bytes of device memory. */
+int nfe_ray_limits_box(const float* origins, const float* dirs, int64_t n_rays, float box_side_length,
+                       float* ray_start, float* ray_end, void* scratch, nfe_stream_t stream);
+
 /* ---- a4: compute_mean_var (training/triplane.py:56-60) ---------------------------------------
  * planes [N,C,H*W] (NCHW) -> mean [N,C], std [N,C] = sqrt(unbiased variance). */
 int nfe_plane_stats(const float* planes, int n, int c, int hw, float* mean, float* std,

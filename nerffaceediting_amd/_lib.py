@@ -40,10 +40,26 @@ class RenderArgs(ctypes.Structure):
     ]
 
 
+class ConvArgs(ctypes.Structure):
+    """Mirror of ``nfe_conv_args`` (include/nfe_dense.h)."""
+    _fields_ = [
+        ("struct_size", c_uint32), ("mode", c_int32), ("math", c_int32),
+        ("x", FP), ("styles", FP), ("packed", FP), ("dcoef", FP), ("noise", FP), ("noise_n_stride", c_int64), ("noise_strength", c_float),
+        ("bias", FP),
+        ("n", c_int32), ("h", c_int32), ("w", c_int32), ("cin", c_int32), ("cout", c_int32),
+        ("lrelu", c_int32), ("act_gain", c_float), ("clamp", c_float),
+        ("skip", FP), ("out_planes", c_int32), ("out", FP), ("scratch", FP),
+    ]
+
+
+NFE_CONV_BF16X3, NFE_CONV_BF16 = 0, 1
+NFE_CONV_3X3, NFE_CONV_3X3_UP2, NFE_CONV_1X1 = 0, 1, 2
+
 _SIGNATURES = {
     "nfe_abi_version": (c_int, []),
     "nfe_last_error": (c_char_p, []),
     "nfe_ray_sampler": (c_int, [FP, FP, c_int, c_int, FP, FP, c_void_p]),
+    "nfe_ray_limits_box": (c_int, [FP, FP, c_int64, c_float, FP, FP, FP, c_void_p]),
     "nfe_plane_stats": (c_int, [FP, c_int, c_int, c_int, FP, FP, c_void_p]),
     "nfe_plane_affine": (c_int, [FP, FP, FP, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_make_affine": (c_int, [FP, FP, FP, FP, c_int, c_int, c_int, FP, FP, FP, FP, c_void_p]),
@@ -51,6 +67,19 @@ _SIGNATURES = {
     "nfe_decoder_pack": (c_int, [FP] * 8 + [c_float, FP, c_void_p]),
     "nfe_render_workspace_bytes": (c_uint64, [c_int, c_int, c_int, c_int]),
     "nfe_render": (c_int, [POINTER(RenderArgs), c_void_p]),
+    # include/nfe_dense.h
+    "nfe_nchw_to_nhwc": (c_int, [FP, c_int, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_nhwc_to_nchw": (c_int, [FP, c_int, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_nhwc_to_planes": (c_int, [FP, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_plane_stats_nhwc": (c_int, [FP, c_int, c_int, c_int, FP, FP, FP, c_void_p]),
+    "nfe_fully_connected": (c_int, [FP, FP, FP, c_int, c_int, c_int, c_float, c_float, c_int, FP, c_int, c_void_p]),
+    "nfe_normalize_2nd_moment": (c_int, [FP, c_int, c_int, FP, c_int, c_void_p]),
+    "nfe_broadcast_truncate": (c_int, [FP, FP, c_int, c_int, c_int, c_float, c_int, FP, c_void_p]),
+    "nfe_conv_packed_words": (c_uint64, [c_int, c_int, c_int]),
+    "nfe_conv_pack": (c_int, [FP, c_int, c_int, c_int, FP, FP, c_void_p]),
+    "nfe_conv_demod": (c_int, [FP, FP, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_modulated_conv": (c_int, [POINTER(ConvArgs), c_void_p]),
+    "nfe_resize_bilinear": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
                                 FP, FP, FP, c_void_p]),
 }

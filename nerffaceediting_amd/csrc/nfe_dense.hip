@@ -1,0 +1,578 @@
+// Dense half of the hot path for MI355X (gfx950): StyleGAN2 mapping network, modulated convolutions as
+// implicit GEMMs on v_mfma_f32_32x32x16_bf16 (fp32 operands split into bf16 hi+lo, or rounded to bf16),
+// ToRGB with fused skip upsampling, the up-conv FIR epilogue and the SR pre-resize.  See include/nfe_dense.h
+// and DESIGN.md §5.  Replaces, on this path, modulated_conv2d (training/networks_stylegan2.py:34-91),
+// conv2d_resample (torch_utils/ops/conv2d_resample.py:48-143), upfirdn2d (upfirdn2d.py:120-350) and
+// bias_act (bias_act.py:54-125).
+#include "nfe_common.h"
+#include "nfe_dense.h"
+
+namespace nfe {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+union Frag8 { bf16x8 v; uint4 q; unsigned u[4]; };
+
+__device__ __forceinline__ unsigned bf16_rne(float v) {
+    bf16x2 p = {(__bf16)v, (__bf16)0.0f};
+    return *reinterpret_cast<unsigned*>(&p) & 0xffffu;
+}
+// (a,b) -> packed bf16 pair: hi word and lo word.  TERMS==3: hi = truncated top 16 bits, lo = bf16(x - hi).
+// TERMS==1: hi = round-to-nearest-even bf16, lo unused.
+template <int TERMS>
+__device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned& lo) {
+    if (TERMS == 3) {
+        const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+        hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+        bf16x2 p = {(__bf16)(a - __uint_as_float(ua & 0xffff0000u)), (__bf16)(b - __uint_as_float(ub & 0xffff0000u))};
+        lo = *reinterpret_cast<unsigned*>(&p);
+    } else {
+        bf16x2 p = {(__bf16)a, (__bf16)b};
+        hi = *reinterpret_cast<unsigned*>(&p);
+        lo = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// layouts
+// ------------------------------------------------------------------------------------------------
+// [N,C,HW] <-> [N,HW,C] through a 32x32 LDS tile
+template <bool TO_NHWC>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int c, int hw, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const int n = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (long long)n * c * hw;
+    float* dst = out + (long long)n * c * hw;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        if (TO_NHWC) { const int cc = c0 + r, pp = p0 + tx; tile[r][tx] = (cc < c && pp < hw) ? src[(long long)cc * hw + pp] : 0.0f; }
+        else { const int pp = p0 + r, cc = c0 + tx; tile[r][tx] = (cc < c && pp < hw) ? src[(long long)pp * c + cc] : 0.0f; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        if (TO_NHWC) { const int pp = p0 + r, cc = c0 + tx; if (cc < c && pp < hw) dst[(long long)pp * c + cc] = tile[tx][r]; }
+        else { const int cc = c0 + r, pp = p0 + tx; if (cc < c && pp < hw) dst[(long long)cc * hw + pp] = tile[tx][r]; }
+    }
+}
+
+__global__ void nhwc_to_planes_kernel(const float4* __restrict__ in, long long n_pix, int hw, float4* __restrict__ out) {
+    // in [N,HW,96] -> out [N,3,HW,32]; one thread per float4 (24 per pixel)
+    const long long total = n_pix * 24;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const long long pix = i / 24; const int q = (int)(i % 24);
+        const long long n = pix / hw, p = pix % hw;
+        out[((n * 3 + q / 8) * hw + p) * 8 + (q % 8)] = in[i];
+    }
+}
+
+// per-(n,c) mean / unbiased std over HW of an NHWC tensor (compute_mean_var, triplane.py:56-60).
+// grid (C/64, N, SPLIT): fp64 partial sums via atomics into scratch, finalised by stats_finish_kernel.
+__global__ __launch_bounds__(256) void stats_nhwc_kernel(const float* __restrict__ x, int hw, int c, double* __restrict__ sums) {
+    const int n = blockIdx.y, ch = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const int rows_per = (hw + gridDim.z - 1) / gridDim.z;
+    const int r0 = blockIdx.z * rows_per, r1 = min(hw, r0 + rows_per);
+    double s = 0.0, ss = 0.0;
+    if (ch < c)
+        for (int r = r0 + sub; r < r1; r += 4) { const double v = x[((long long)n * hw + r) * c + ch]; s += v; ss += v * v; }
+    __shared__ double sh[2][4][64];
+    sh[0][sub][threadIdx.x & 63] = s; sh[1][sub][threadIdx.x & 63] = ss;
+    __syncthreads();
+    if (sub == 0 && ch < c) {
+        const int l = threadIdx.x;
+        atomicAdd(&sums[((long long)n * c + ch) * 2 + 0], sh[0][0][l] + sh[0][1][l] + sh[0][2][l] + sh[0][3][l]);
+        atomicAdd(&sums[((long long)n * c + ch) * 2 + 1], sh[1][0][l] + sh[1][1][l] + sh[1][2][l] + sh[1][3][l]);
+    }
+}
+__global__ void stats_finish_kernel(const double* __restrict__ sums, int total, int hw, float* mean, float* stdv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double s = sums[2 * i], ss = sums[2 * i + 1], mu = s / hw;
+    double var = (ss - s * mu) / (double)(hw - 1);
+    mean[i] = (float)mu; stdv[i] = (float)sqrt(var > 0.0 ? var : 0.0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// small dense ops of the mapping network / style affines
+// ------------------------------------------------------------------------------------------------
+// one wave per output element; FullyConnectedLayer.forward (networks_stylegan2.py:114-127)
+__global__ __launch_bounds__(256) void fc_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b,
+                                                 int n, int fin, int fout, float wg, float bg, int lrelu, float* __restrict__ y, int ys) {
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long long)n * fout) return;
+    const int row = (int)(wid / fout), o = (int)(wid % fout);
+    const float* xr = x + (long long)row * fin; const float* wr = w + (long long)o * fin;
+    float acc = 0.0f;
+    for (int i = lane; i < fin; i += 64) acc = fmaf(xr[i], wr[i], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) {
+        float v = acc * wg + (b ? b[o] * bg : 0.0f);
+        if (lrelu) v = (v < 0.0f ? v * 0.2f : v) * 1.4142135623730951f;     // bias_act 'lrelu': alpha 0.2, gain sqrt(2)
+        y[(long long)row * ys + o] = v;
+    }
+}
+
+__global__ __launch_bounds__(64) void norm2_kernel(const float* __restrict__ x, int f, float* __restrict__ y, int ys) {
+    const int row = blockIdx.x, lane = threadIdx.x;
+    float s = 0.0f;
+    for (int i = lane; i < f; i += 64) { const float v = x[(long long)row * f + i]; s = fmaf(v, v, s); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float r = rsqrtf(s / (float)f + 1e-8f);
+    for (int i = lane; i < f; i += 64) y[(long long)row * ys + i] = x[(long long)row * f + i] * r;
+}
+
+__global__ void broadcast_truncate_kernel(const float* __restrict__ w, const float* __restrict__ w_avg, int n, int d, int num_ws,
+                                          float psi, int cutoff, float* __restrict__ ws) {
+    const long long total = (long long)n * num_ws * d;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(i % d); const int k = (int)((i / d) % num_ws); const long long row = i / ((long long)d * num_ws);
+        float v = w[row * d + j];
+        if (k < cutoff && psi != 1.0f) { const float a = w_avg[j]; v = a + psi * (v - a); }   // torch.lerp(w_avg, x, psi)
+        ws[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq, int n, int cin, int cout,
+                                                    float* __restrict__ dcoef) {
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long long)n * cout) return;
+    const int row = (int)(wid / cout), o = (int)(wid % cout);
+    float acc = 0.0f;
+    for (int i = lane; i < cin; i += 64) { const float s = styles[(long long)row * cin + i]; acc = fmaf(s * s, wsq[(long long)o * cin + i], acc); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) dcoef[wid] = rsqrtf(acc + 1e-8f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// weights -> MFMA A-fragment image: [Cout/32][Cin/16][taps][part][lane 64][4 words]; word w of lane l
+// holds elements e = 2w, 2w+1 of the 8-vector: out channel 32*mb + (l&31), in channel 16g + 8(l>>5) + e.
+// ------------------------------------------------------------------------------------------------
+__global__ void conv_pack_kernel(const float* __restrict__ weight, int cout, int cin, int taps, float* __restrict__ packed, float* __restrict__ wsq) {
+    const int G = (cin + 15) / 16, MB = (cout + 31) / 32;
+    const long long total = (long long)MB * G * taps * 2 * 256;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int word = (int)(i & 3), lane = (int)((i >> 2) & 63), part = (int)((i >> 8) & 1);
+        long long r = i >> 9;
+        const int t = (int)(r % taps); r /= taps;
+        const int g = (int)(r % G); const int mb = (int)(r / G);
+        const int o = 32 * mb + (lane & 31), h = lane >> 5;
+        unsigned bits[2];
+        for (int k = 0; k < 2; ++k) {
+            const int ch = 16 * g + 8 * h + 2 * word + k;
+            const float v = (o < cout && ch < cin) ? weight[((long long)o * cin + ch) * taps + t] : 0.0f;
+            const unsigned hi = bf16_rne(v);
+            bits[k] = part == 0 ? hi : bf16_rne(v - __uint_as_float(hi << 16));
+        }
+        packed[i] = __uint_as_float(bits[0] | (bits[1] << 16));
+    }
+    const long long nw = (long long)cout * cin;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (long long)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int t = 0; t < taps; ++t) { const float v = weight[i * taps + t]; s = fmaf(v, v, s); }
+        wsq[i] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// modulated convolution as implicit GEMM.  Workgroup = 4 waves = one 32-channel M-block x a 16x16 pixel
+// tile of one sample; wave w owns tile rows 4w..4w+3 as two 32-pixel N-blocks.  Per 16-channel K-group
+// the block stages (a) the weight fragments of its M-block (taps x hi/lo x 1 KiB, straight copy) and
+// (b) the input patch with halo, multiplied by the styles and split to bf16 hi/lo, laid out
+// [part][row][channel-half][col][8 bf16] so a lane's 16-byte B fragment read is conflict-free.
+// ------------------------------------------------------------------------------------------------
+struct ConvK {
+    const float* x; const float* styles; const uint4* packed; const float* dcoef; const float* noise; long long noise_n_stride; float noise_strength;
+    const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp; const float* skip; int out_planes;
+    float* out; float* scratch;
+};
+
+constexpr int PATCH = 18;                                         // 16 + halo
+constexpr int PATCH_PART_BYTES = PATCH * 2 * PATCH * 16;          // one of hi / lo
+
+__device__ __forceinline__ float epilogue_act(float v, int lrelu, float gain, float clamp) {
+    if (lrelu) v = v < 0.0f ? v * 0.2f : v;
+    v *= gain;
+    if (clamp >= 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
+    return v;
+}
+
+// upsample2d (upfirdn2d.py:315-350: zero-insert x2, pad (2,1), [1,3,3,1]/8*2 per axis) evaluated at (y,x)
+__device__ __forceinline__ float4 skip_up2(const float* __restrict__ skip, int n, int hs, int ws, int c, int y, int x, int o) {
+    const int ya = (y & 1) ? (y >> 1) : (y >> 1) - 1, yb = ya + 1;
+    const int xa = (x & 1) ? (x >> 1) : (x >> 1) - 1, xb = xa + 1;
+    const float wya = (y & 1) ? 0.75f : 0.25f, wyb = 1.0f - wya, wxa = (x & 1) ? 0.75f : 0.25f, wxb = 1.0f - wxa;
+    float4 r = make_float4(0, 0, 0, 0);
+    const int ys[2] = {ya, yb}, xs[2] = {xa, xb};
+    const float wy[2] = {wya, wyb}, wx[2] = {wxa, wxb};
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            if (ys[a] < 0 || ys[a] >= hs || xs[b] < 0 || xs[b] >= ws) continue;
+            const float* p = skip + (((long long)n * hs + ys[a]) * ws + xs[b]) * c + o;
+            const float wgt = wy[a] * wx[b];
+            r.x = fmaf(wgt, p[0], r.x);
+            if (o + 1 < c) r.y = fmaf(wgt, p[1], r.y);
+            if (o + 2 < c) r.z = fmaf(wgt, p[2], r.z);
+            if (o + 3 < c) r.w = fmaf(wgt, p[3], r.w);
+        }
+    return r;
+}
+
+template <int MODE, int TERMS>
+__global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
+    constexpr int TAPS = MODE == NFE_CONV_1X1 ? 1 : 9;
+    constexpr int HALO = MODE == NFE_CONV_1X1 ? 0 : 1;
+    constexpr int PUSED = MODE == NFE_CONV_3X3 ? 18 : (MODE == NFE_CONV_3X3_UP2 ? 17 : 16);
+    constexpr int NACC = MODE == NFE_CONV_3X3_UP2 ? 4 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[TAPS * 2 * 1024 + 2 * PATCH_PART_BYTES];
+    uint4* ldsA = reinterpret_cast<uint4*>(lds);
+    unsigned char* ldsP = lds + TAPS * 2 * 1024;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 31, h = lane >> 5;
+    // tile grid: output pixels (modes 0,2) or the (H+1)x(W+1) extended input grid (mode 1)
+    const int gh = MODE == NFE_CONV_3X3_UP2 ? P.H + 1 : P.H, gw = MODE == NFE_CONV_3X3_UP2 ? P.W + 1 : P.W;
+    const int tiles_x = (gw + 15) >> 4;
+    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const int mb = blockIdx.y, n = blockIdx.z;
+    const int G = (P.Cin + 15) >> 4;          // a ragged last K-group is zero-filled (Cin % 4 == 0)
+
+    f32x16 acc[NACC][2];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.0f;
+
+    const int q = tid & 3;                                    // staging: this thread's 4-channel quarter
+    for (int g = 0; g < G; ++g) {
+        __syncthreads();
+        // (a) weight fragments of this M-block / K-group: TAPS*2 KiB, contiguous in the packed image
+        const uint4* src = P.packed + ((long long)mb * G + g) * (TAPS * 2 * 64);
+        for (int i = tid; i < TAPS * 2 * 64; i += 256) ldsA[i] = src[i];
+        // (b) input patch * styles -> bf16 hi/lo
+        const bool ch_ok = 16 * g + 4 * q < P.Cin;
+        const float4 s4 = ch_ok ? *reinterpret_cast<const float4*>(P.styles + (long long)n * P.Cin + 16 * g + 4 * q) : make_float4(0, 0, 0, 0);
+        for (int idx = tid; idx < PUSED * PUSED * 4; idx += 256) {
+            const int pix = idx >> 2, py = pix / PUSED, px = pix % PUSED;
+            const int y = ty0 - HALO + py, x = tx0 - HALO + px;
+            float4 v = make_float4(0, 0, 0, 0);
+            if (ch_ok && y >= 0 && y < P.H && x >= 0 && x < P.W)
+                v = *reinterpret_cast<const float4*>(P.x + (((long long)n * P.H + y) * P.W + x) * P.Cin + 16 * g + 4 * q);
+            v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
+            unsigned h0, l0, h1, l1;
+            split2<TERMS>(v.x, v.y, h0, l0);
+            split2<TERMS>(v.z, v.w, h1, l1);
+            const int off = ((py * 2 + (q >> 1)) * PATCH + px) * 16 + (q & 1) * 8;
+            *reinterpret_cast<uint2*>(ldsP + off) = make_uint2(h0, h1);
+            if (TERMS == 3) *reinterpret_cast<uint2*>(ldsP + PATCH_PART_BYTES + off) = make_uint2(l0, l1);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TAPS; ++t) {
+            const int kh = t / 3, kw = t % 3;
+            Frag8 ah, al;
+            ah.q = ldsA[(t * 2 + 0) * 64 + lane];
+            if (TERMS == 3) al.q = ldsA[(t * 2 + 1) * 64 + lane];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const int ly = 4 * wave + 2 * nb + (j >> 4), lx = j & 15;
+                int py, px, a = 0;
+                if (MODE == NFE_CONV_3X3) { py = ly + kh; px = lx + kw; }
+                else if (MODE == NFE_CONV_3X3_UP2) { py = ly + 1 - (kh >> 1); px = lx + 1 - (kw >> 1); a = (kh & 1) * 2 + (kw & 1); }
+                else { py = ly; px = lx; }
+                const int off = ((py * 2 + h) * PATCH + px) * 16;
+                Frag8 bh, bl;
+                bh.q = *reinterpret_cast<const uint4*>(ldsP + off);
+                acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[a][nb], 0, 0, 0);
+                if (TERMS == 3) {
+                    bl.q = *reinterpret_cast<const uint4*>(ldsP + PATCH_PART_BYTES + off);
+                    acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[a][nb], 0, 0, 0);
+                    acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[a][nb], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of its pixel ----
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int ly = 4 * wave + 2 * nb + (j >> 4), lx = j & 15;
+        const int y = ty0 + ly, x = tx0 + lx;
+        if (MODE == NFE_CONV_3X3_UP2) {
+            if (y > P.H || x > P.W) continue;
+            const int TH = 2 * P.H + 1, TW = 2 * P.W + 1;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int Y = 2 * y + (a >> 1), X = 2 * x + (a & 1);
+                if (Y >= TH || X >= TW) continue;
+                float* dst = P.scratch + (((long long)n * TH + Y) * TW + X) * P.Cout + 32 * mb + 4 * h;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    if (32 * mb + 8 * qq + 4 * h < P.Cout)       // Cout % 4 == 0 on up-conv layers (checked on host)
+                        *reinterpret_cast<float4*>(dst + 8 * qq) = make_float4(acc[a][nb][4 * qq], acc[a][nb][4 * qq + 1],
+                                                                                acc[a][nb][4 * qq + 2], acc[a][nb][4 * qq + 3]);
+            }
+        } else {
+            if (y >= P.H || x >= P.W) continue;
+            const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int o0 = 32 * mb + 8 * qq + 4 * h;
+                if (o0 >= P.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = o0 + i;
+                    float t = acc[0][nb][4 * qq + i];
+                    if (o < P.Cout) {
+                        if (P.dcoef) t *= P.dcoef[(long long)n * P.Cout + o];
+                        t = epilogue_act(t + nz + P.bias[o], P.lrelu, P.act_gain, P.clamp);
+                    }
+                    v[i] = t;
+                }
+                if (MODE == NFE_CONV_1X1 && P.skip) {
+                    const float4 s = skip_up2(P.skip, n, P.H >> 1, P.W >> 1, P.Cout, y, x, o0);
+                    v[0] += s.x; v[1] += s.y; v[2] += s.z; v[3] += s.w;
+                }
+                float* dst;
+                if (MODE == NFE_CONV_1X1 && P.out_planes)
+                    dst = P.out + ((((long long)n * 3 + mb) * P.H + y) * P.W + x) * 32 + 8 * qq + 4 * h;
+                else
+                    dst = P.out + (((long long)n * P.H + y) * P.W + x) * P.Cout + o0;
+                if (o0 + 3 < P.Cout && (P.Cout & 3) == 0) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (o0 + i < P.Cout) dst[i] = v[i];
+                }
+            }
+        }
+    }
+}
+
+// FIR + epilogue of the up-conv: out[Y][X] = act(dcoef * sum_ab F[a]F[b] T[Y+a-1][X+b-1] + noise + bias),
+// F = [1,3,3,1]/4 per axis (setup_filter/64 * gain 4; conv2d_resample.py:127, upfirdn2d.py:169-207)
+__global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
+    const int OH = 2 * P.H, OW = 2 * P.W, TH = OH + 1, TW = OW + 1, C4 = P.Cout >> 2;
+    const long long total = (long long)P.N * OH * OW * C4;
+    const float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4); long long r = i / C4;
+        const int X = (int)(r % OW); r /= OW;
+        const int Y = (int)(r % OH); const int n = (int)(r / OH);
+        float4 s = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int ty = Y + a - 1;
+            if (ty < 0 || ty >= TH) continue;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int tx = X + b - 1;
+                if (tx < 0 || tx >= TW) continue;
+                const float4 t = *reinterpret_cast<const float4*>(P.scratch + (((long long)n * TH + ty) * TW + tx) * P.Cout + 4 * c4);
+                const float wgt = F[a] * F[b];
+                s.x = fmaf(wgt, t.x, s.x); s.y = fmaf(wgt, t.y, s.y); s.z = fmaf(wgt, t.z, s.z); s.w = fmaf(wgt, t.w, s.w);
+            }
+        }
+        const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
+        const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + 4 * c4) : make_float4(1, 1, 1, 1);
+        const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
+        float4 o;
+        o.x = epilogue_act(s.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+        o.y = epilogue_act(s.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+        o.z = epilogue_act(s.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+        o.w = epilogue_act(s.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+        *reinterpret_cast<float4*>(P.out + (((long long)n * OH + Y) * OW + X) * P.Cout + 4 * c4) = o;
+    }
+}
+
+// F.interpolate(bilinear, align_corners=False, antialias) — ATen's separable triangle filter
+// (UpSampleKernel.cpp compute_indices_weights_aa) evaluated as one 2-D gather per output pixel.
+struct AxisW { int lo, n; float scale, support, inv; };
+__device__ __forceinline__ AxisW axis_setup(int i, int in, int out, int aa) {
+    AxisW a;
+    a.scale = (float)in / (float)out;
+    if (aa) {
+        a.support = a.scale >= 1.0f ? a.scale : 1.0f;
+        a.inv = a.scale >= 1.0f ? 1.0f / a.scale : 1.0f;
+        const float center = a.scale * ((float)i + 0.5f);
+        a.lo = max((int)(center - a.support + 0.5f), 0);
+        a.n = min((int)(center + a.support + 0.5f), in) - a.lo;
+    } else {
+        float src = a.scale * ((float)i + 0.5f) - 0.5f;
+        if (src < 0.0f) src = 0.0f;
+        a.lo = min((int)src, in - 1);
+        a.n = (a.lo + 1 < in) ? 2 : 1;
+        a.support = src - (float)a.lo;                 // lambda1 (weight of lo+1)
+        a.inv = 0.0f;
+    }
+    return a;
+}
+__device__ __forceinline__ float axis_weight(const AxisW& a, int k, int i, int aa) {
+    if (!aa) return k == 0 ? 1.0f - a.support : a.support;
+    const float center = a.scale * ((float)i + 0.5f);
+    const float xx = ((float)(k + a.lo) - center + 0.5f) * a.inv;
+    return fmaxf(0.0f, 1.0f - fabsf(xx));
+}
+__global__ void resize_kernel(const float* __restrict__ in, int N, int H, int W, int C, int OH, int OW, int aa, float* __restrict__ out) {
+    const long long total = (long long)N * OH * OW * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); long long r = i / C;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH); const int n = (int)(r / OH);
+        const AxisW ay = axis_setup(oy, H, OH, aa), ax = axis_setup(ox, W, OW, aa);
+        float sy = 0.0f, sx = 0.0f;
+        for (int k = 0; k < ay.n; ++k) sy += axis_weight(ay, k, oy, aa);
+        for (int k = 0; k < ax.n; ++k) sx += axis_weight(ax, k, ox, aa);
+        // ATen resizes horizontally first, then vertically (separable passes): keep that order of products
+        float acc = 0.0f;
+        for (int ky = 0; ky < ay.n; ++ky) {
+            float rowv = 0.0f;
+            for (int kx = 0; kx < ax.n; ++kx)
+                rowv = fmaf(axis_weight(ax, kx, ox, aa) / (aa ? sx : 1.0f), in[(((long long)n * H + ay.lo + ky) * W + ax.lo + kx) * C + c], rowv);
+            acc = fmaf(axis_weight(ay, ky, oy, aa) / (aa ? sy : 1.0f), rowv, acc);
+        }
+        out[i] = acc;
+    }
+}
+
+static unsigned grid1d(long long total, int per_block, long long cap = 1 << 16) {
+    long long b = (total + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (unsigned)b;
+}
+
+}  // namespace nfe
+
+using namespace nfe;
+
+extern "C" int nfe_nchw_to_nhwc(const float* in, int n, int c, int h, int w, float* out, nfe_stream_t stream) {
+    NFE_REQUIRE(in && out && n > 0 && c > 0 && h > 0 && w > 0, "nfe_nchw_to_nhwc: bad arguments");
+    const int hw = h * w;
+    hipLaunchKernelGGL((transpose_kernel<true>), dim3((hw + 31) / 32, (c + 31) / 32, n), dim3(256), 0, (hipStream_t)stream, in, c, hw, out);
+    NFE_CHECK_LAUNCH("transpose_kernel");
+    return NFE_OK;
+}
+extern "C" int nfe_nhwc_to_nchw(const float* in, int n, int c, int h, int w, float* out, nfe_stream_t stream) {
+    NFE_REQUIRE(in && out && n > 0 && c > 0 && h > 0 && w > 0, "nfe_nhwc_to_nchw: bad arguments");
+    const int hw = h * w;
+    hipLaunchKernelGGL((transpose_kernel<false>), dim3((hw + 31) / 32, (c + 31) / 32, n), dim3(256), 0, (hipStream_t)stream, in, c, hw, out);
+    NFE_CHECK_LAUNCH("transpose_kernel");
+    return NFE_OK;
+}
+extern "C" int nfe_nhwc_to_planes(const float* in, int n, int h, int w, float* out, nfe_stream_t stream) {
+    NFE_REQUIRE(in && out && n > 0 && h > 0 && w > 0, "nfe_nhwc_to_planes: bad arguments");
+    const long long npix = (long long)n * h * w;
+    hipLaunchKernelGGL(nhwc_to_planes_kernel, dim3(grid1d(npix * 24, 256, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(in), npix, h * w, reinterpret_cast<float4*>(out));
+    NFE_CHECK_LAUNCH("nhwc_to_planes_kernel");
+    return NFE_OK;
+}
+extern "C" int nfe_plane_stats_nhwc(const float* x, int n, int hw, int c, float* mean, float* std, void* scratch, nfe_stream_t stream) {
+    NFE_REQUIRE(x && mean && std && scratch && n > 0 && hw > 1 && c > 0, "nfe_plane_stats_nhwc: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    double* sums = (double*)scratch;
+    if (hipMemsetAsync(sums, 0, (size_t)n * c * 2 * sizeof(double), st) != hipSuccess) return fail(NFE_ELAUNCH, "memset failed");
+    int split = hw / 256; if (split < 1) split = 1; if (split > 64) split = 64;
+    hipLaunchKernelGGL(stats_nhwc_kernel, dim3((c + 63) / 64, n, split), dim3(256), 0, st, x, hw, c, sums);
+    hipLaunchKernelGGL(stats_finish_kernel, dim3((n * c + 255) / 256), dim3(256), 0, st, sums, n * c, hw, mean, std);
+    NFE_CHECK_LAUNCH("stats_nhwc kernels");
+    return NFE_OK;
+}
+
+extern "C" int nfe_fully_connected(const float* x, const float* w, const float* b, int n, int in_features, int out_features,
+                                   float weight_gain, float bias_gain, int lrelu, float* y, int y_stride, nfe_stream_t stream) {
+    NFE_REQUIRE(x && w && y && n > 0 && in_features > 0 && out_features > 0 && y_stride >= out_features, "nfe_fully_connected: bad arguments");
+    const long long waves = (long long)n * out_features;
+    hipLaunchKernelGGL(fc_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, w, b, n, in_features, out_features,
+                       weight_gain, bias_gain, lrelu, y, y_stride);
+    NFE_CHECK_LAUNCH("fc_kernel");
+    return NFE_OK;
+}
+extern "C" int nfe_normalize_2nd_moment(const float* x, int n, int features, float* y, int y_stride, nfe_stream_t stream) {
+    NFE_REQUIRE(x && y && n > 0 && features > 0 && y_stride >= features, "nfe_normalize_2nd_moment: bad arguments");
+    hipLaunchKernelGGL(norm2_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, x, features, y, y_stride);
+    NFE_CHECK_LAUNCH("norm2_kernel");
+    return NFE_OK;
+}
+extern "C" int nfe_broadcast_truncate(const float* w, const float* w_avg, int n, int w_dim, int num_ws, float psi, int cutoff,
+                                      float* ws, nfe_stream_t stream) {
+    NFE_REQUIRE(w && ws && n > 0 && w_dim > 0 && num_ws > 0, "nfe_broadcast_truncate: bad arguments");
+    NFE_REQUIRE(psi == 1.0f || w_avg, "nfe_broadcast_truncate: truncation_psi != 1 needs w_avg");
+    hipLaunchKernelGGL(broadcast_truncate_kernel, dim3(grid1d((long long)n * num_ws * w_dim, 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       w, w_avg, n, w_dim, num_ws, psi, cutoff, ws);
+    NFE_CHECK_LAUNCH("broadcast_truncate_kernel");
+    return NFE_OK;
+}
+
+extern "C" uint64_t nfe_conv_packed_words(int cout, int cin, int k) {
+    if (cout <= 0 || cin <= 0 || cin % 4 != 0 || (k != 1 && k != 3)) return 0;
+    return (uint64_t)((cout + 31) / 32) * ((cin + 15) / 16) * (k * k) * 2 * 256;
+}
+extern "C" int nfe_conv_pack(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream) {
+    NFE_REQUIRE(weight && packed && wsq, "nfe_conv_pack: null pointer");
+    NFE_REQUIRE(cout > 0 && cin > 0 && cin % 4 == 0 && (k == 1 || k == 3), "nfe_conv_pack: need cin %% 4 == 0 and k in {1,3} (cout=%d cin=%d k=%d)", cout, cin, k);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(grid1d((long long)nfe_conv_packed_words(cout, cin, k), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       weight, cout, cin, k * k, packed, wsq);
+    NFE_CHECK_LAUNCH("conv_pack_kernel");
+    return NFE_OK;
+}
+extern "C" int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int cout, float* dcoef, nfe_stream_t stream) {
+    NFE_REQUIRE(styles && wsq && dcoef && n > 0 && cin > 0 && cout > 0, "nfe_conv_demod: bad arguments");
+    const long long waves = (long long)n * cout;
+    hipLaunchKernelGGL(demod_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, styles, wsq, n, cin, cout, dcoef);
+    NFE_CHECK_LAUNCH("demod_kernel");
+    return NFE_OK;
+}
+
+template <int MODE>
+static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
+    if (math == NFE_CONV_BF16) hipLaunchKernelGGL((conv_kernel<MODE, 1>), grid, dim3(256), 0, st, P);
+    else hipLaunchKernelGGL((conv_kernel<MODE, 3>), grid, dim3(256), 0, st, P);
+}
+
+extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
+    NFE_REQUIRE(a != nullptr, "nfe_modulated_conv: args is null");
+    NFE_REQUIRE(a->struct_size == sizeof(nfe_conv_args), "nfe_modulated_conv: struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(nfe_conv_args));
+    NFE_REQUIRE(a->mode >= 0 && a->mode <= 2, "nfe_modulated_conv: unknown mode %d", a->mode);
+    NFE_REQUIRE(a->math == NFE_CONV_BF16X3 || a->math == NFE_CONV_BF16, "nfe_modulated_conv: unknown math %d", a->math);
+    NFE_REQUIRE(a->x && a->styles && a->packed && a->bias && a->out, "nfe_modulated_conv: null pointer");
+    NFE_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->cin > 0 && a->cout > 0 && a->cin % 4 == 0, "nfe_modulated_conv: bad sizes n=%d h=%d w=%d cin=%d cout=%d", a->n, a->h, a->w, a->cin, a->cout);
+    NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || (a->scratch && a->cout % 4 == 0), "nfe_modulated_conv: up-conv needs scratch and cout %% 4 == 0");
+    NFE_REQUIRE(!a->skip || (a->mode == NFE_CONV_1X1 && a->h % 2 == 0 && a->w % 2 == 0), "nfe_modulated_conv: skip needs mode 1x1 and even size");
+    NFE_REQUIRE(!a->out_planes || (a->mode == NFE_CONV_1X1 && a->cout == 96), "nfe_modulated_conv: out_planes needs mode 1x1 and cout 96");
+    ConvK P{};
+    P.x = a->x; P.styles = a->styles; P.packed = reinterpret_cast<const uint4*>(a->packed); P.dcoef = a->dcoef; P.noise = a->noise; P.noise_n_stride = a->noise_n_stride;
+    P.noise_strength = a->noise_strength; P.bias = a->bias; P.N = a->n; P.H = a->h; P.W = a->w; P.Cin = a->cin; P.Cout = a->cout;
+    P.lrelu = a->lrelu; P.act_gain = a->act_gain; P.clamp = a->clamp; P.skip = a->skip; P.out_planes = a->out_planes; P.out = a->out; P.scratch = a->scratch;
+    hipStream_t st = (hipStream_t)stream;
+    const int up = a->mode == NFE_CONV_3X3_UP2;
+    const int gh = a->h + up, gw = a->w + up;
+    dim3 grid(((gh + 15) / 16) * ((gw + 15) / 16), (a->cout + 31) / 32, a->n);
+    if (a->mode == NFE_CONV_3X3) launch_conv<NFE_CONV_3X3>(P, a->math, grid, st);
+    else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, a->math, grid, st);
+    else {
+        launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st);
+        const long long total = (long long)a->n * 4 * a->h * a->w * (a->cout / 4);
+        hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
+    }
+    NFE_CHECK_LAUNCH("conv kernels");
+    return NFE_OK;
+}
+
+extern "C" int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int ow, int antialias, float* out, nfe_stream_t stream) {
+    NFE_REQUIRE(in && out && n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0, "nfe_resize_bilinear: bad arguments");
+    hipLaunchKernelGGL(resize_kernel, dim3(grid1d((long long)n * oh * ow * c, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream,
+                       in, n, h, w, c, oh, ow, antialias, out);
+    NFE_CHECK_LAUNCH("resize_kernel");
+    return NFE_OK;
+}

@@ -27,6 +27,39 @@ __global__ void ray_sampler_kernel(const float* __restrict__ cam2world, const fl
     }
 }
 
+// ---- 'auto' ray limits: math_utils.get_ray_limits_box (math_utils.py:46-98) ----------------------
+__global__ void ray_limits_kernel(const float* __restrict__ origins, const float* __restrict__ dirs, long long n,
+                                  float half, float* __restrict__ rs, float* __restrict__ re, unsigned* minmax) {
+    float lo = INFINITY, hi = -INFINITY;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+        const float ox = origins[i * 3], oy = origins[i * 3 + 1], oz = origins[i * 3 + 2];
+        const float ix = 1.0f / dirs[i * 3], iy = 1.0f / dirs[i * 3 + 1], iz = 1.0f / dirs[i * 3 + 2];
+        bool valid = true;
+        float tmin = ((ix < 0 ? half : -half) - ox) * ix, tmax = ((ix < 0 ? -half : half) - ox) * ix;
+        const float tymin = ((iy < 0 ? half : -half) - oy) * iy, tymax = ((iy < 0 ? -half : half) - oy) * iy;
+        if (tmin > tymax || tymin > tmax) valid = false;
+        tmin = fmaxf(tmin, tymin); tmax = fminf(tmax, tymax);          // torch.max/min propagate like fmax here
+        const float tzmin = ((iz < 0 ? half : -half) - oz) * iz, tzmax = ((iz < 0 ? -half : half) - oz) * iz;
+        if (tmin > tzmax || tzmin > tmax) valid = false;
+        tmin = fmaxf(tmin, tzmin); tmax = fminf(tmax, tzmax);
+        if (!valid) { tmin = -1.0f; tmax = -2.0f; }
+        rs[i] = tmin; re[i] = tmax;
+        if (tmax > tmin) { lo = fminf(lo, tmin); hi = fmaxf(hi, tmin); }  // is_ray_valid = ray_end > ray_start
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+    if ((threadIdx.x & 63) == 0 && lo <= hi) { atomicMin(minmax, f2ord(lo)); atomicMax(minmax + 1, f2ord(hi)); }
+}
+
+__global__ void ray_limits_fix_kernel(long long n, float* __restrict__ rs, float* __restrict__ re, const unsigned* minmax) {
+    if (minmax[0] == 0xFFFFFFFFu && minmax[1] == 0u) return;          // torch.any(is_ray_valid) is False
+    const float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
+        if (!(re[i] > rs[i])) { rs[i] = lo; re[i] = hi; }
+}
+
+__global__ void limits_init_kernel(unsigned* minmax) { minmax[0] = 0xFFFFFFFFu; minmax[1] = 0u; }
+
 // ---- a4: compute_mean_var (triplane.py:56-60): one block per (n,c) row of HW elements -------
 __global__ __launch_bounds__(256) void plane_stats_kernel(const float* __restrict__ planes, int hw,
                                                           float* __restrict__ mean, float* __restrict__ stdv) {
@@ -206,6 +239,21 @@ extern "C" int nfe_ray_sampler(const float* cam2world, const float* intrinsics, 
     hipLaunchKernelGGL(ray_sampler_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                        cam2world, intrinsics, n_views, resolution, origins, dirs);
     NFE_CHECK_LAUNCH("ray_sampler_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_ray_limits_box(const float* origins, const float* dirs, int64_t n_rays, float box_side_length,
+                                  float* ray_start, float* ray_end, void* scratch, nfe_stream_t stream) {
+    NFE_REQUIRE(origins && dirs && ray_start && ray_end && scratch, "nfe_ray_limits_box: null pointer");
+    NFE_REQUIRE(n_rays > 0 && box_side_length > 0.0f, "nfe_ray_limits_box: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    long long blocks = (n_rays + 255) / 256; if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(limits_init_kernel, dim3(1), dim3(1), 0, st, (unsigned*)scratch);
+    hipLaunchKernelGGL(ray_limits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, origins, dirs, (long long)n_rays,
+                       box_side_length * 0.5f, ray_start, ray_end, (unsigned*)scratch);
+    hipLaunchKernelGGL(ray_limits_fix_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (long long)n_rays, ray_start, ray_end,
+                       (const unsigned*)scratch);
+    NFE_CHECK_LAUNCH("ray_limits kernels");
     return NFE_OK;
 }
 

@@ -1,0 +1,181 @@
+"""Tensor-level wrappers over include/nfe_dense.h (mapping network, modulated convs, resize, layouts).
+Activations are NHWC fp32 between layers."""
+import ctypes
+
+import torch
+
+from . import _lib
+from .ops import _dev, _ptr, _stream
+
+MATH = {None: _lib.NFE_CONV_BF16X3, "bf16x3": _lib.NFE_CONV_BF16X3, "bf16": _lib.NFE_CONV_BF16,
+        _lib.NFE_CONV_BF16X3: _lib.NFE_CONV_BF16X3, _lib.NFE_CONV_BF16: _lib.NFE_CONV_BF16}
+
+
+def _call(dev, rc_fn, what):
+    with torch.cuda.device(dev):
+        _lib.check(rc_fn(), what)
+
+
+def nchw_to_nhwc(x):
+    lib = _lib.load()
+    x = _dev(x, "x", (None, None, None, None))
+    N, C, H, W = x.shape
+    out = torch.empty(N, H, W, C, device=x.device)
+    _call(x.device, lambda: lib.nfe_nchw_to_nhwc(_ptr(x), N, C, H, W, _ptr(out), _stream()), "nfe_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x):
+    lib = _lib.load()
+    x = _dev(x, "x", (None, None, None, None))
+    N, H, W, C = x.shape
+    out = torch.empty(N, C, H, W, device=x.device)
+    _call(x.device, lambda: lib.nfe_nhwc_to_nchw(_ptr(x), N, C, H, W, _ptr(out), _stream()), "nfe_nhwc_to_nchw")
+    return out
+
+
+def nhwc_to_planes(x):
+    """[N,H,W,96] -> tri-plane gather layout [N,3,H,W,32]."""
+    lib = _lib.load()
+    x = _dev(x, "planes", (None, None, None, 96))
+    N, H, W, _ = x.shape
+    out = torch.empty(N, 3, H, W, 32, device=x.device)
+    _call(x.device, lambda: lib.nfe_nhwc_to_planes(_ptr(x), N, H, W, _ptr(out), _stream()), "nfe_nhwc_to_planes")
+    return out
+
+
+def plane_stats_nhwc(x):
+    """compute_mean_var on NHWC [N,H,W,C] -> mean, std [N,C,1,1]."""
+    lib = _lib.load()
+    x = _dev(x, "planes", (None, None, None, None))
+    N, H, W, C = x.shape
+    mean = torch.empty(N, C, 1, 1, device=x.device)
+    std = torch.empty_like(mean)
+    scratch = torch.empty(N * C * 2, dtype=torch.float64, device=x.device)
+    _call(x.device, lambda: lib.nfe_plane_stats_nhwc(_ptr(x), N, H * W, C, _ptr(mean), _ptr(std), _ptr(scratch), _stream()),
+          "nfe_plane_stats_nhwc")
+    return mean, std
+
+
+def fully_connected(x, weight, bias, weight_gain, bias_gain=1.0, lrelu=False, out=None, out_offset=0):
+    """FullyConnectedLayer.forward; `out` (a [N,S] buffer) + out_offset write into a wider row (concat)."""
+    lib = _lib.load()
+    x = _dev(x, "x", (None, None))
+    N, fin = x.shape
+    weight = _dev(weight, "weight", (None, fin))
+    fout = weight.shape[0]
+    if bias is not None:
+        bias = _dev(bias, "bias", (fout,))
+    if out is None:
+        out = torch.empty(N, fout, device=x.device)
+        view, stride = out, fout
+    else:
+        stride = out.shape[1]
+        view = out[:, out_offset:]
+    _call(x.device, lambda: lib.nfe_fully_connected(_ptr(x), _ptr(weight), _ptr(bias), N, fin, fout, float(weight_gain),
+                                                    float(bias_gain), int(bool(lrelu)),
+                                                    ctypes.c_void_p(view.data_ptr()), stride, _stream()), "nfe_fully_connected")
+    return out
+
+
+def normalize_2nd_moment(x, out=None, out_offset=0):
+    lib = _lib.load()
+    x = _dev(x, "x", (None, None))
+    N, f = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+        view, stride = out, f
+    else:
+        stride = out.shape[1]
+        view = out[:, out_offset:]
+    _call(x.device, lambda: lib.nfe_normalize_2nd_moment(_ptr(x), N, f, ctypes.c_void_p(view.data_ptr()), stride, _stream()),
+          "nfe_normalize_2nd_moment")
+    return out
+
+
+def broadcast_truncate(w, w_avg, num_ws, psi=1.0, cutoff=None):
+    lib = _lib.load()
+    w = _dev(w, "w", (None, None))
+    N, D = w.shape
+    if w_avg is not None:
+        w_avg = _dev(w_avg, "w_avg", (D,))
+    cutoff = num_ws if cutoff is None else int(cutoff)
+    ws = torch.empty(N, num_ws, D, device=w.device)
+    _call(w.device, lambda: lib.nfe_broadcast_truncate(_ptr(w), _ptr(w_avg), N, D, num_ws, float(psi), cutoff, _ptr(ws), _stream()),
+          "nfe_broadcast_truncate")
+    return ws
+
+
+def conv_pack(weight):
+    """[Cout,Cin,k,k] -> (packed MFMA fragment image, wsq [Cout,Cin])."""
+    lib = _lib.load()
+    weight = _dev(weight, "weight", (None, None, None, None))
+    cout, cin, k, _ = weight.shape
+    words = lib.nfe_conv_packed_words(cout, cin, k)
+    if words == 0:
+        raise RuntimeError(f"conv_pack: unsupported weight shape {list(weight.shape)}")
+    packed = torch.empty(words, device=weight.device)
+    wsq = torch.empty(cout, cin, device=weight.device)
+    _call(weight.device, lambda: lib.nfe_conv_pack(_ptr(weight), cout, cin, k, _ptr(packed), _ptr(wsq), _stream()), "nfe_conv_pack")
+    return packed, wsq
+
+
+def conv_demod(styles, wsq):
+    lib = _lib.load()
+    styles = _dev(styles, "styles", (None, None))
+    N, cin = styles.shape
+    wsq = _dev(wsq, "wsq", (None, cin))
+    cout = wsq.shape[0]
+    d = torch.empty(N, cout, device=styles.device)
+    _call(styles.device, lambda: lib.nfe_conv_demod(_ptr(styles), _ptr(wsq), N, cin, cout, _ptr(d), _stream()), "nfe_conv_demod")
+    return d
+
+
+def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, noise_strength=0.0, lrelu=True,
+                   act_gain=1.0, clamp=None, skip=None, out_planes=False, math=None):
+    """nfe_modulated_conv.  x [N,H,W,Cin] NHWC -> [N,Ho,Wo,Cout] (or [N,3,Ho,Wo,32] if out_planes)."""
+    lib = _lib.load()
+    x = _dev(x, "x", (None, None, None, None))
+    N, H, W, cin = x.shape
+    styles = _dev(styles, "styles", (N, cin))
+    a = _lib.ConvArgs()
+    a.struct_size = ctypes.sizeof(_lib.ConvArgs)
+    a.mode, a.math = int(mode), MATH[math]
+    a.x, a.styles, a.packed = x.data_ptr(), styles.data_ptr(), _dev(packed, "packed").data_ptr()
+    keep = [x, styles, packed]
+    if dcoef is not None:
+        dcoef = _dev(dcoef, "dcoef", (N, cout)); a.dcoef = dcoef.data_ptr()
+    up = 2 if mode == _lib.NFE_CONV_3X3_UP2 else 1
+    Ho, Wo = H * up, W * up
+    if noise is not None:
+        noise = _dev(noise, "noise")
+        assert tuple(noise.shape[-2:]) == (Ho, Wo) and noise.numel() in (Ho * Wo, N * Ho * Wo), "noise must be [Ho,Wo] or [N,1,Ho,Wo]"
+        a.noise, a.noise_strength = noise.data_ptr(), float(noise_strength)
+        a.noise_n_stride = Ho * Wo if noise.numel() == N * Ho * Wo and N > 1 else 0
+    bias = _dev(bias, "bias", (cout,)); a.bias = bias.data_ptr()
+    a.n, a.h, a.w, a.cin, a.cout = N, H, W, cin, cout
+    a.lrelu, a.act_gain = int(bool(lrelu)), float(act_gain)
+    a.clamp = -1.0 if clamp is None else float(clamp)
+    if skip is not None:
+        skip = _dev(skip, "skip", (N, H // 2, W // 2, cout)); a.skip = skip.data_ptr()
+    a.out_planes = int(bool(out_planes))
+    out = torch.empty((N, 3, Ho, Wo, 32) if out_planes else (N, Ho, Wo, cout), device=x.device)
+    a.out = out.data_ptr()
+    scratch = None
+    if up == 2:
+        scratch = torch.empty(N * (2 * H + 1) * (2 * W + 1) * cout, device=x.device)
+        a.scratch = scratch.data_ptr()
+    keep += [dcoef, noise, bias, skip, scratch]
+    _call(x.device, lambda: lib.nfe_modulated_conv(ctypes.byref(a), _stream()), "nfe_modulated_conv")
+    return out
+
+
+def resize_bilinear(x, oh, ow, antialias=True):
+    """F.interpolate(mode='bilinear', align_corners=False, antialias=...) on NHWC."""
+    lib = _lib.load()
+    x = _dev(x, "x", (None, None, None, None))
+    N, H, W, C = x.shape
+    out = torch.empty(N, oh, ow, C, device=x.device)
+    _call(x.device, lambda: lib.nfe_resize_bilinear(_ptr(x), N, H, W, C, int(oh), int(ow), int(bool(antialias)), _ptr(out), _stream()),
+          "nfe_resize_bilinear")
+    return out

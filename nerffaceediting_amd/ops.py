@@ -62,6 +62,21 @@ def ray_sampler(cam2world, intrinsics, resolution):
     return o, d
 
 
+def ray_limits_box(origins, dirs, box_side_length):
+    """get_ray_limits_box + the invalid-ray fix-up of renderer.py:312-318 -> (ray_start, ray_end) [N,M,1]."""
+    lib = _lib.load()
+    origins = _dev(origins, "ray_origins", (None, None, 3))
+    dirs = _dev(dirs, "ray_directions", tuple(origins.shape))
+    N, M = origins.shape[:2]
+    rs = torch.empty(N, M, 1, device=origins.device)
+    re = torch.empty_like(rs)
+    scratch = torch.empty(2, dtype=torch.int32, device=origins.device)
+    with torch.cuda.device(origins.device):
+        _lib.check(lib.nfe_ray_limits_box(_ptr(origins), _ptr(dirs), N * M, float(box_side_length), _ptr(rs), _ptr(re),
+                                          _ptr(scratch), _stream()), "nfe_ray_limits_box")
+    return rs, re
+
+
 def plane_stats(planes):
     """compute_mean_var (triplane.py:56-60): [N,C,H,W] -> mean, std [N,C,1,1]."""
     lib = _lib.load()

@@ -1,0 +1,174 @@
+"""TriPlaneGenerator with the reference's interface (training/triplane.py:19-162) on the MI355X-native
+kernels: mapping -> StyleGAN2 backbone (MFMA convs, NHWC) -> plane statistics -> fused volume render
+-> super-resolution.  Drop-in for the callers listed in SURVEY.md §8(b1): same constructor, same
+`mapping / synthesis / sample / sample_mixed / forward` signatures and output dict, same parameter
+names (App. B), `rendering_kwargs` read at call time.
+"""
+import importlib
+
+import torch
+
+from .. import dense_ops, ops
+from .networks_stylegan2 import FullyConnectedLayer, Generator as StyleGAN2Backbone
+from .volumetric_rendering.ray_sampler import RaySampler
+from .volumetric_rendering.renderer import DisentangledImportanceRenderer
+
+
+def _construct_class_by_name(class_name, **kwargs):
+    """dnnlib.util.construct_class_by_name (dnnlib/util.py:303) for 'training.superresolution.X' names."""
+    mod, _, cls = class_name.rpartition(".")
+    if mod.startswith("training."):
+        mod = __package__.rsplit(".training", 1)[0] + "." + mod
+    return getattr(importlib.import_module(mod), cls)(**kwargs)
+
+
+class DisentangledOSGDecoder(torch.nn.Module):
+    """training/triplane.py:232-270: geometry net (norm features -> sigma + 15 seg) and appearance net
+    (denorm features -> 32 rgb).  The fused renderer reads the parameters through `packed()`; evaluation
+    happens inside the render / point-query kernels."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        assert n_features == 32 and options["decoder_output_dim"] == 32 and options["decoder_seg_dim"] == 15
+        self.hidden_dim = 64
+        lr = options["decoder_lr_mul"]
+        self.lr_mul = lr
+        self.geo_net = torch.nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr), torch.nn.Softplus(),
+                                           FullyConnectedLayer(self.hidden_dim, 1 + options["decoder_seg_dim"], lr_multiplier=lr))
+        self.app_net = torch.nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr), torch.nn.Softplus(),
+                                           FullyConnectedLayer(self.hidden_dim, options["decoder_output_dim"], lr_multiplier=lr))
+
+    def _params(self):
+        return [self.geo_net[0].weight, self.geo_net[0].bias, self.geo_net[2].weight, self.geo_net[2].bias,
+                self.app_net[0].weight, self.app_net[0].bias, self.app_net[2].weight, self.app_net[2].bias]
+
+    def packed(self):
+        ps = self._params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_packed_key", None) != key:
+            self._packed = ops.decoder_pack(*[p.detach() for p in ps], lr_mul=self.lr_mul)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, sampled_norm_features, sampled_denorm_features, ray_directions):
+        raise NotImplementedError("the decoder is evaluated inside the fused kernels: use renderer.run_model(...) "
+                                  "or TriPlaneGenerator.sample(...)")
+
+
+class TriPlaneGenerator(torch.nn.Module):
+    def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={},
+                 rendering_kwargs={}, sr_kwargs={}, disable_disentangle=False, disable_alignment=False, **synthesis_kwargs):
+        super().__init__()
+        if disable_disentangle or disable_alignment:
+            raise NotImplementedError("the disable_disentangle / disable_alignment ablations (triplane.py:48-51,93) are not built")
+        self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
+        self.img_resolution, self.img_channels = img_resolution, img_channels
+        self.disable_disentangle, self.disable_alignment = False, False
+        self.init_args, self.init_kwargs = (), dict(                      # what persistence.persistent_class records
+            z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels,
+            sr_num_fp16_res=sr_num_fp16_res, mapping_kwargs=mapping_kwargs, rendering_kwargs=rendering_kwargs,
+            sr_kwargs=sr_kwargs, **synthesis_kwargs)
+        self.renderer = DisentangledImportanceRenderer()
+        self.ray_sampler = RaySampler()
+        self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3,
+                                          mapping_kwargs=mapping_kwargs, **synthesis_kwargs)
+        self.superresolution = _construct_class_by_name(class_name=rendering_kwargs["superresolution_module"], channels=32,
+                                                        img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res,
+                                                        sr_antialias=rendering_kwargs["sr_antialias"], **sr_kwargs)
+        self.decoder = DisentangledOSGDecoder(32, {"decoder_lr_mul": rendering_kwargs.get("decoder_lr_mul", 1),
+                                                   "decoder_output_dim": 32, "decoder_seg_dim": 15})
+        self.neural_rendering_resolution = 64
+        self.rendering_kwargs = rendering_kwargs
+        self._last_planes = None
+
+    # ---- plane statistics (triplane.py:56-68), NCHW in / out as the reference's helpers ------------
+    def compute_mean_var(self, planes):
+        return ops.plane_stats(planes)
+
+    def normalize_plane(self, planes):
+        mean, var = ops.plane_stats(planes)
+        gs, gb, _, _ = ops.make_affine(mean, var)
+        N, C = planes.shape[:2]
+        return ops.plane_affine(planes, gs.reshape(N, C, 1, 1), gb.reshape(N, C, 1, 1)), mean, var
+
+    def denormalize_plane(self, planes, mean, var):
+        return ops.plane_affine(planes, var, mean)
+
+    def mapping(self, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False):
+        if self.rendering_kwargs["c_gen_conditioning_zero"]:
+            c = torch.zeros_like(c)
+        return self.backbone.mapping(z, c * self.rendering_kwargs.get("c_scale", 0), truncation_psi=truncation_psi,
+                                     truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+
+    def _planes(self, ws, synthesis_kwargs):
+        """backbone -> (tri-plane gather layout [N,3,H,W,32], mean, std [N,96,1,1])."""
+        packed = self.backbone.synthesis.forward_nhwc(ws, out_planes=True, **synthesis_kwargs)
+        N, _, H, W, _ = packed.shape
+        mean, std = dense_ops.plane_stats_nhwc(packed.view(N * 3, H, W, 32))      # channel p*32+c <-> row (n*3+p), col c
+        return packed, mean.reshape(N, 96, 1, 1), std.reshape(N, 96, 1, 1)
+
+    def synthesis(self, ws, c, neural_rendering_resolution=None, update_emas=False, cache_backbone=False,
+                  use_cached_backbone=False, planes_mean=None, planes_var=None, **synthesis_kwargs):
+        cam2world_matrix = c[:, :16].reshape(-1, 4, 4).to(torch.float32)
+        intrinsics = c[:, 16:25].reshape(-1, 3, 3).to(torch.float32)
+        if neural_rendering_resolution is None:
+            neural_rendering_resolution = self.neural_rendering_resolution
+        else:
+            self.neural_rendering_resolution = neural_rendering_resolution
+        N = cam2world_matrix.shape[0]
+        R = neural_rendering_resolution
+
+        if use_cached_backbone and self._last_planes is not None:
+            packed, mean, var = self._last_planes
+        else:
+            packed, mean, var = self._planes(ws, synthesis_kwargs)
+        if cache_backbone:
+            self._last_planes = (packed, mean, var)
+
+        # normalisation + optional appearance override as per-channel affines on the sampled values
+        # (single-gather identity; triplane.py:93-103 incl. the (int,int) special case)
+        new_mean = new_var = None
+        if planes_mean is not None and planes_var is not None:
+            if type(planes_mean) == int and type(planes_var) == int:
+                new_mean, new_var = mean[planes_mean][None].contiguous(), var[planes_var][None].contiguous()
+            else:
+                new_mean, new_var = planes_mean, planes_var
+        affines = ops.make_affine(mean, var, new_mean, new_var)
+
+        feature_samples, seg_samples, depth_samples, _ = self.renderer.render_raw_planes(
+            packed, affines, self.decoder, cam2world_matrix, intrinsics, R, self.rendering_kwargs, channels_first=False)
+
+        # [N,M,32] is already NHWC for the SR head; the reference's NCHW images are produced for the output dict
+        feat_nhwc = feature_samples.view(N, R, R, 32)
+        rgb_nhwc = feat_nhwc[..., :3].contiguous()
+        sr_kwargs = {k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"}
+        sr_nhwc = self.superresolution.forward_nhwc(rgb_nhwc, feat_nhwc, ws,
+                                                    noise_mode=self.rendering_kwargs["superresolution_noise_mode"], **sr_kwargs)
+        return {
+            "image": dense_ops.nhwc_to_nchw(sr_nhwc),
+            "image_seg": dense_ops.nhwc_to_nchw(seg_samples.view(N, R, R, 15)),
+            "image_raw": dense_ops.nhwc_to_nchw(rgb_nhwc),
+            "image_depth": depth_samples.permute(0, 2, 1).reshape(N, 1, R, R),
+            "plane_mean": mean,
+            "plane_var": var,
+        }
+
+    def _sample_planes(self, ws, coordinates, synthesis_kwargs):
+        packed, mean, var = self._planes(ws, synthesis_kwargs)
+        return ops.point_query(packed, packed, self.decoder.packed(), coordinates.to(torch.float32),
+                               self.rendering_kwargs["box_warp"], affines=ops.make_affine(mean, var),
+                               decoder_math=self.renderer.decoder_math)
+
+    def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self._sample_planes(ws, coordinates, synthesis_kwargs)
+
+    def sample_mixed(self, coordinates, directions, ws, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
+        return self._sample_planes(ws, coordinates, synthesis_kwargs)
+
+    def forward(self, z, c, truncation_psi=1, truncation_cutoff=None, neural_rendering_resolution=None, update_emas=False,
+                cache_backbone=False, use_cached_backbone=False, planes_mean=None, planes_var=None, **synthesis_kwargs):
+        ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)
+        return self.synthesis(ws, c, update_emas=update_emas, neural_rendering_resolution=neural_rendering_resolution,
+                              cache_backbone=cache_backbone, use_cached_backbone=use_cached_backbone, planes_mean=planes_mean,
+                              planes_var=planes_var, **synthesis_kwargs)

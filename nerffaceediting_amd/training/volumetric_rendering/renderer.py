@@ -1,0 +1,95 @@
+"""DisentangledImportanceRenderer with the reference's interface
+(training/volumetric_rendering/renderer.py:255-363): one call into the fused HIP renderer instead of
+~25 ATen ops with materialised [N,3,M*D,32] intermediates.
+
+Jitter: the reference draws torch.rand_like / torch.rand from the global RNG (renderer.py:190,237).
+Here the kernel runs Philox4x32-10 keyed by a seed drawn from torch's CPU generator (so
+torch.manual_seed still makes calls reproducible); parity tests inject the uniforms through
+`inject_jitter` (or the optional rendering_options keys 'jitter_coarse' / 'jitter_fine').
+"""
+import torch
+
+from ... import ops
+
+
+def generate_planes():
+    """Plane axes as in renderer.py:23-37 (kept for API compatibility; the projection p0=(x,y),
+    p1=(x,z), p2=(z,x) these axes define is built into the kernel)."""
+    return torch.tensor([[[1, 0, 0], [0, 1, 0], [0, 0, 1]],
+                         [[1, 0, 0], [0, 0, 1], [0, 1, 0]],
+                         [[0, 0, 1], [1, 0, 0], [0, 1, 0]]], dtype=torch.float32)
+
+
+class DisentangledImportanceRenderer(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.plane_axes = generate_planes()
+        self._jitter = None
+        self.keep_taps = False
+        self.last_taps = None
+        self.decoder_math = None          # None -> split-bf16 MFMA; 'fp32' -> exact fp32 MFMA
+
+    # -- parity hook ---------------------------------------------------------------------------------
+    def inject_jitter(self, u_coarse, u_fine=None):
+        """Use these uniforms ([N,M,D], [N*M,Di]) for the next forward() instead of Philox."""
+        self._jitter = (u_coarse, u_fine)
+
+    def _take_jitter(self, options):
+        j, self._jitter = self._jitter, None
+        if j is None and "jitter_coarse" in options:
+            j = (options["jitter_coarse"], options.get("jitter_fine"))
+        return j if j is not None else (None, None)
+
+    @staticmethod
+    def _seed():
+        return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
+
+    @staticmethod
+    def _pack_pair(norm_planes, denorm_planes):
+        pg = ops.plane_pack(norm_planes)
+        same = (norm_planes is denorm_planes) or (norm_planes.data_ptr() == denorm_planes.data_ptr()
+                                                 and norm_planes.shape == denorm_planes.shape)
+        return pg, (pg if same else ops.plane_pack(denorm_planes))
+
+    # -- reference interface -------------------------------------------------------------------------
+    def forward(self, norm_planes, denorm_planes, decoder, ray_origins, ray_directions, rendering_options):
+        """norm_planes/denorm_planes [N,3,32,H,W]; ray_origins/ray_directions [N,M,3] ->
+        (rgb [N,M,32], seg [N,M,15], depth [N,M,1], weights.sum(2) [N,M,1])   (renderer.py:363)."""
+        pg, pa = self._pack_pair(norm_planes, denorm_planes)
+        limits = None
+        if rendering_options["ray_start"] == rendering_options["ray_end"] == "auto":      # renderer.py:312
+            limits = ops.ray_limits_box(ray_origins, ray_directions, rendering_options["box_warp"])
+        u_c, u_f = self._take_jitter(rendering_options)
+        out = ops.render(pg, pa, decoder.packed(), rendering_options, origins=ray_origins, dirs=ray_directions,
+                         u_coarse=u_c, u_fine=u_f, seed=self._seed(), ray_limits=limits, taps=self.keep_taps,
+                         decoder_math=self.decoder_math)
+        if self.keep_taps:
+            self.last_taps = out[4]
+        return out[0], out[1], out[2], out[3]
+
+    def render_raw_planes(self, packed_planes, affines, decoder, cam2world, intrinsics, resolution, rendering_options,
+                          channels_first=True):
+        """synthesis() fast path: raw backbone planes gathered once (single-gather identity),
+        rays generated in-kernel, image-layout outputs.  Returns (rgb [N,32,M], seg [N,15,M], depth, wsum)."""
+        if rendering_options["ray_start"] == rendering_options["ray_end"] == "auto":
+            o, d = ops.ray_sampler(cam2world, intrinsics, resolution)
+            limits = ops.ray_limits_box(o, d, rendering_options["box_warp"])
+        else:
+            limits = None
+        u_c, u_f = self._take_jitter(rendering_options)
+        out = ops.render(packed_planes, packed_planes, decoder.packed(), rendering_options, cam2world=cam2world,
+                         intrinsics=intrinsics, resolution=resolution, affines=affines, u_coarse=u_c, u_fine=u_f,
+                         seed=self._seed(), ray_limits=limits, channels_first=channels_first, taps=self.keep_taps,
+                         decoder_math=self.decoder_math)
+        if self.keep_taps:
+            self.last_taps = out[4]
+        return out[0], out[1], out[2], out[3]
+
+    def run_model(self, norm_planes, denorm_planes, decoder, sample_coordinates, sample_directions, options):
+        """renderer.py:259-287: dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15]) at arbitrary points.
+        sample_directions is unused, as in every decoder of the reference (triplane.py:249)."""
+        if options.get("density_noise", 0) > 0:
+            raise RuntimeError("density_noise > 0 is not supported")
+        pg, pa = self._pack_pair(norm_planes, denorm_planes)
+        return ops.point_query(pg, pa, decoder.packed(), sample_coordinates, options["box_warp"],
+                               decoder_math=self.decoder_math)

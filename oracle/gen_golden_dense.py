@@ -1,0 +1,158 @@
+"""Golden vectors for the dense half of the path, produced by running the REFERENCE modules on CPU
+(build container only: needs /root/reference).  Parameters are drawn from seeded numpy generators
+(oracle.dense_params) so fixtures only store seeds, small inputs and outputs.  The torch-CPU oracle
+(oracle/dense_oracle.py) is checked against every output before anything is written.
+
+    python oracle/gen_golden_dense.py
+"""
+import os
+import sys
+
+import numpy as np
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from training import networks_stylegan2 as ref_sg2  # noqa: E402
+from training.superresolution import SuperresolutionHybrid8XDC  # noqa: E402
+
+from oracle import dense_oracle as dor  # noqa: E402
+from oracle.dense_params import layer_params, mapping_params, sr_params, synthesis_params  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+torch.set_grad_enabled(False)
+
+
+def check(name, a, b, tol):
+    err = float((a.double() - b.double()).abs().max())
+    print(f"    oracle vs reference  {name:22s} max-abs {err:.3e}  (|ref| max {float(b.abs().max()):.3g})")
+    assert err <= tol, (name, err)
+
+
+def load(module, params):
+    sd = module.state_dict()
+    for k, v in params.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+        sd[k] = v.clone()
+    module.load_state_dict(sd)
+    return module.eval()
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+
+
+def gen_mapping():
+    z_dim, c_dim, w_dim, num_ws = 64, 25, 64, 6
+    p = mapping_params(11, z_dim, c_dim, w_dim, num_layers=2)
+    m = load(ref_sg2.MappingNetwork(z_dim, c_dim, w_dim, num_ws, num_layers=2), p)
+    rng = np.random.RandomState(12)
+    z, c = t(rng.randn(3, z_dim)), t(rng.randn(3, c_dim))
+    out = {}
+    for tag, (psi, cut) in dict(a=(1.0, None), b=(0.7, None), c=(0.5, 4)).items():
+        ref = m(z, c, truncation_psi=psi, truncation_cutoff=cut)
+        mine = dor.mapping(p, z, c, num_ws, 2, psi, cut)
+        check("mapping." + tag, mine, ref, 1e-5)
+        out["ws." + tag] = ref.numpy()
+    np.savez_compressed(os.path.join(OUT, "dense_mapping.npz"), z=z.numpy(), c=c.numpy(), seed=11, z_dim=z_dim, c_dim=c_dim,
+                        w_dim=w_dim, num_ws=num_ws, **out)
+    print("  wrote dense_mapping.npz")
+
+
+def gen_layers():
+    rng = np.random.RandomState(21)
+    w_dim = 64
+    data = {}
+    # SynthesisLayer up=1 with clamp, up=2, ToRGB
+    cases = dict(conv_up1=dict(cin=32, cout=48, res=16, up=1, clamp=1.5, gain=1.0),
+                 conv_up1_g=dict(cin=16, cout=32, res=12, up=1, clamp=None, gain=0.5),
+                 conv_up2=dict(cin=32, cout=32, res=16, up=2, clamp=None, gain=1.0),
+                 conv_up2_odd=dict(cin=16, cout=64, res=10, up=2, clamp=4.0, gain=1.0))
+    for i, (tag, cfg) in enumerate(cases.items()):
+        p = layer_params(100 + i, cfg["cin"], cfg["cout"], w_dim, cfg["res"], k=3)
+        m = load(ref_sg2.SynthesisLayer(cfg["cin"], cfg["cout"], w_dim, cfg["res"], up=cfg["up"], conv_clamp=cfg["clamp"]), p)
+        rin = cfg["res"] // cfg["up"]
+        x, w = t(rng.randn(2, cfg["cin"], rin, rin)), t(rng.randn(2, w_dim))
+        ref = m(x, w, noise_mode="const", gain=cfg["gain"])
+        mine = dor.synthesis_layer(p, x, w, up=cfg["up"], conv_clamp=cfg["clamp"], gain=cfg["gain"])
+        check(tag, mine, ref, 2e-5)
+        data.update({f"{tag}.x": x.numpy(), f"{tag}.w": w.numpy(), f"{tag}.out": ref.numpy(),
+                     f"{tag}.cfg": np.array([100 + i, cfg["cin"], cfg["cout"], cfg["res"], cfg["up"],
+                                             -1 if cfg["clamp"] is None else cfg["clamp"], cfg["gain"]], dtype=np.float64)})
+    for i, (tag, cfg) in enumerate(dict(torgb96=dict(cin=32, cout=96, res=16, clamp=None),
+                                        torgb3=dict(cin=48, cout=3, res=12, clamp=0.8)).items()):
+        p = layer_params(200 + i, cfg["cin"], cfg["cout"], w_dim, cfg["res"], k=1, torgb=True)
+        m = load(ref_sg2.ToRGBLayer(cfg["cin"], cfg["cout"], w_dim, conv_clamp=cfg["clamp"]), p)
+        x, w = t(rng.randn(2, cfg["cin"], cfg["res"], cfg["res"])), t(rng.randn(2, w_dim))
+        ref = m(x, w)
+        mine = dor.torgb_layer(p, x, w, conv_clamp=cfg["clamp"])
+        check(tag, mine, ref, 2e-5)
+        data.update({f"{tag}.x": x.numpy(), f"{tag}.w": w.numpy(), f"{tag}.out": ref.numpy(),
+                     f"{tag}.cfg": np.array([200 + i, cfg["cin"], cfg["cout"], cfg["res"], 1,
+                                             -1 if cfg["clamp"] is None else cfg["clamp"], 1.0], dtype=np.float64)})
+    # upsample2d
+    from torch_utils.ops import upfirdn2d
+    img = t(rng.randn(2, 5, 6, 6))
+    ref = upfirdn2d.upsample2d(img, upfirdn2d.setup_filter([1, 3, 3, 1]))
+    check("upsample2d", dor.upsample2d(img), ref, 1e-6)
+    data.update({"upsample2d.x": img.numpy(), "upsample2d.out": ref.numpy()})
+    # antialiased / plain bilinear resize (superresolution.py:283-286)
+    for tag, (hin, hout, aa) in dict(down_aa=(40, 16, True), up_aa=(12, 32, True), down_noaa=(40, 16, False), odd_aa=(50, 16, True)).items():
+        x = t(rng.randn(1, 4, hin, hin))
+        ref = torch.nn.functional.interpolate(x, size=(hout, hout), mode="bilinear", align_corners=False, antialias=aa)
+        check("resize." + tag, dor.resize_bilinear(x, hout, hout, aa), ref, 2e-6)
+        data.update({f"resize.{tag}.x": x.numpy(), f"resize.{tag}.out": ref.numpy(), f"resize.{tag}.aa": int(aa)})
+    np.savez_compressed(os.path.join(OUT, "dense_layers.npz"), w_dim=w_dim, **data)
+    print("  wrote dense_layers.npz")
+
+
+def gen_synthesis():
+    """Reduced backbone: img_resolution 32, channels min(256//res, 32), 96 output channels, w_dim 64."""
+    w_dim, res, cb, cm = 64, 32, 256, 32
+    net = ref_sg2.SynthesisNetwork(w_dim, res, 96, channel_base=cb, channel_max=cm, num_fp16_res=0, conv_clamp=None,
+                                   fused_modconv_default="inference_only")
+    p = synthesis_params(31, w_dim, res, 96, cb, cm)
+    load(net, p)
+    rng = np.random.RandomState(32)
+    ws = t(rng.randn(2, net.num_ws, w_dim))
+    ref = net(ws, noise_mode="const")
+    mine = dor.synthesis_network(p, ws, net.block_resolutions)
+    check("synthesis(32px)", mine, ref, 5e-5)
+    np.savez_compressed(os.path.join(OUT, "dense_synthesis.npz"), ws=ws.numpy(), out=ref.numpy(), seed=31, w_dim=w_dim, res=res,
+                        channel_base=cb, channel_max=cm, num_ws=net.num_ws)
+    print("  wrote dense_synthesis.npz")
+
+
+def gen_sr():
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=4, sr_antialias=True,
+                                   channel_base=32768, channel_max=512, fused_modconv_default="inference_only")
+    p = sr_params(41)
+    load(sr, p)
+    rng = np.random.RandomState(42)
+    data = {}
+    for tag, r in dict(r64=64, r128=128).items():
+        x = t(rng.randn(1, 32, r, r) * 0.5)
+        ws = t(rng.randn(1, 14, 512))
+        ref = sr(x[:, :3].contiguous(), x, ws, noise_mode="none")
+        mine = dor.superresolution_8xdc(p, x[:, :3].contiguous(), x, ws)
+        check("sr." + tag, mine, ref, 2e-4)
+        data.update({f"{tag}.x": x.numpy(), f"{tag}.ws": ws.numpy(), f"{tag}.out_s4": ref[:, :, ::4, ::4].numpy(),
+                     f"{tag}.out_mean": float(ref.mean()), f"{tag}.out_abs_mean": float(ref.abs().mean())})
+    np.savez_compressed(os.path.join(OUT, "dense_sr.npz"), seed=41, **data)
+    print("  wrote dense_sr.npz")
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    gen_mapping()
+    gen_layers()
+    gen_synthesis()
+    gen_sr()
+    for f in sorted(os.listdir(OUT)):
+        if f.startswith("dense_"):
+            print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -8,13 +8,15 @@ import subprocess
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(ROOT, "include", "nfe_render.h")
+HEADERS = [os.path.join(ROOT, "include", h) for h in ("nfe_render.h", "nfe_dense.h")]
 
 
 def _declared_functions():
-    src = open(HEADER).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(nfe_[a-z_]+)\s*\(", src)))
+    names = set()
+    for h in HEADERS:
+        src = re.sub(r"/\*.*?\*/", "", open(h).read(), flags=re.S)
+        names |= set(re.findall(r"\b(nfe_[a-z_0-9]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_library_exports_every_declared_symbol():
@@ -23,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     declared = _declared_functions()
     assert len(declared) >= 11
     for name in declared:
-        assert hasattr(lib, name), f"{name} declared in include/nfe_render.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     assert sorted(_lib.exported_symbols()) == declared, "ctypes signature table out of sync with the header"
     assert lib.nfe_abi_version() == _lib.NFE_ABI_VERSION
 
@@ -48,6 +50,25 @@ def test_render_args_struct_matches_header(tmp_path):
         assert name == f and int(off) == getattr(_lib.RenderArgs, f).offset, (line, f)
     consts = [int(x) for x in out[1 + len(fields)].split()]
     assert consts == [_lib.NFE_DECODER_PACKED_FLOATS, _lib.NFE_MAX_SAMPLES, _lib.NFE_ABI_VERSION]
+
+
+def test_conv_args_struct_matches_header(tmp_path):
+    from nerffaceediting_amd import _lib
+    fields = [f[0] for f in _lib.ConvArgs._fields_]
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"nfe_dense.h\"\nint main(){\n"
+    prog += 'printf("%zu\\n", sizeof(nfe_conv_args));\n'
+    for f in fields:
+        prog += f'printf("{f} %zu\\n", offsetof(nfe_conv_args, {f}));\n'
+    prog += "return 0;}\n"
+    c = tmp_path / "probe2.c"
+    c.write_text(prog)
+    exe = tmp_path / "probe2"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    assert int(out[0]) == ctypes.sizeof(_lib.ConvArgs)
+    for line, f in zip(out[1:], fields):
+        name, off = line.split()
+        assert name == f and int(off) == getattr(_lib.ConvArgs, f).offset, (line, f)
 
 
 def test_workspace_query_and_argument_errors_without_gpu():

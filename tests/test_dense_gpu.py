@@ -1,0 +1,143 @@
+"""GPU parity of the dense half (mapping, modulated convs, ToRGB+skip, resize, backbone, SR head) through
+the C ABI, against the golden vectors captured from the reference and the torch-CPU oracle.
+
+Tolerances: 1e-3 max-abs is the north_star bar for the whole path in fp32-grade math ('bf16x3': fp32
+operands split into bf16 hi+lo, fp32 accumulate).  The plain-bf16 throughput mode ('bf16', BASELINE
+config 3) is held to a relative bound stated at each test.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import dense_oracle as dor
+from oracle.dense_params import mapping_params, sr_params, synthesis_params
+from tests._golden import load
+from tests.test_dense_oracle_golden import LAYERS, layer_case
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def t(a, dev=None):
+    x = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return x.to(dev) if dev is not None else x
+
+
+def maxerr(a, b):
+    return float((a.detach().cpu().double() - torch.as_tensor(b).double()).abs().max())
+
+
+def load_module(m, params, dev):
+    sd = m.state_dict()
+    for k, v in params.items():
+        assert k in sd and tuple(sd[k].shape) == tuple(v.shape), k
+        sd[k] = v.clone()
+    m.load_state_dict(sd)
+    return m.to(dev).eval()
+
+
+def test_layout_roundtrip_and_stats(dev):
+    from nerffaceediting_amd import dense_ops, ops
+    rng = np.random.RandomState(0)
+    x = t(rng.randn(2, 96, 9, 7) * 2 + 0.3, dev)
+    y = dense_ops.nchw_to_nhwc(x)
+    assert torch.equal(y, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(dense_ops.nhwc_to_nchw(y), x)
+    assert torch.equal(dense_ops.nhwc_to_planes(y), ops.plane_pack(x))
+    m0, s0 = ops.plane_stats(x)
+    m1, s1 = dense_ops.plane_stats_nhwc(y)
+    assert maxerr(m1, m0.cpu()) <= 1e-6 and maxerr(s1, s0.cpu()) <= 1e-6
+
+
+def test_mapping_network(dev):
+    from nerffaceediting_amd.training.networks_stylegan2 import MappingNetwork
+    z = load("dense_mapping")
+    p = mapping_params(int(z["seed"]), int(z["z_dim"]), int(z["c_dim"]), int(z["w_dim"]))
+    m = load_module(MappingNetwork(int(z["z_dim"]), int(z["c_dim"]), int(z["w_dim"]), int(z["num_ws"]), num_layers=2), p, dev)
+    for tag, (psi, cut) in dict(a=(1.0, None), b=(0.7, None), c=(0.5, 4)).items():
+        ws = m(t(z["z"], dev), t(z["c"], dev), truncation_psi=psi, truncation_cutoff=cut)
+        assert maxerr(ws, z["ws." + tag]) <= 2e-5, tag
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("tag", LAYERS)
+def test_modulated_conv_layers(tag, math, dev):
+    from nerffaceediting_amd import dense_ops
+    from nerffaceediting_amd.training.networks_stylegan2 import SynthesisLayer, ToRGBLayer
+    z = load("dense_layers")
+    cfg, p = layer_case(z, tag)
+    w_dim = int(z["w_dim"])
+    x, w = dense_ops.nchw_to_nhwc(t(z[tag + ".x"], dev)), t(z[tag + ".w"], dev)
+    if cfg["torgb"]:
+        m = load_module(ToRGBLayer(cfg["cin"], cfg["cout"], w_dim, conv_clamp=cfg["clamp"]), p, dev)
+        y = m.forward_nhwc(x, w, conv_math=math)
+    else:
+        m = load_module(SynthesisLayer(cfg["cin"], cfg["cout"], w_dim, cfg["res"], up=cfg["up"], conv_clamp=cfg["clamp"]), p, dev)
+        y = m.forward_nhwc(x, w, noise_mode="const", gain=cfg["gain"], conv_math=math)
+    ref = z[tag + ".out"]
+    e = maxerr(dense_ops.nhwc_to_nchw(y), ref)
+    print(tag, math, e, float(np.abs(ref).max()))
+    # bf16x3: fp32-grade.  bf16: 8-bit mantissa operands, K up to 432 terms -> ~1e-2 of the output scale
+    assert e <= (1e-4 if math == "bf16x3" else 3e-2 * float(np.abs(ref).max()))
+
+
+def test_torgb_skip_matches_upsample2d(dev):
+    """img = upsample2d(img) + torgb(x)  (networks_stylegan2.py:450-457), fused in the ToRGB epilogue."""
+    from nerffaceediting_amd import dense_ops
+    from nerffaceediting_amd.training.networks_stylegan2 import ToRGBLayer
+    z = load("dense_layers")
+    cfg, p = layer_case(z, "torgb96")
+    m = load_module(ToRGBLayer(cfg["cin"], cfg["cout"], int(z["w_dim"])), p, dev)
+    rng = np.random.RandomState(3)
+    prev = t(rng.randn(2, 96, cfg["res"] // 2, cfg["res"] // 2))
+    x, w = t(z["torgb96.x"]), t(z["torgb96.w"])
+    want = dor.upsample2d(prev) + dor.torgb_layer(p, x, w)
+    got = m.forward_nhwc(dense_ops.nchw_to_nhwc(x.to(dev)), w.to(dev), skip=dense_ops.nchw_to_nhwc(prev.to(dev)))
+    assert maxerr(dense_ops.nhwc_to_nchw(got), want) <= 1e-4
+    planes = m.forward_nhwc(dense_ops.nchw_to_nhwc(x.to(dev)), w.to(dev), skip=dense_ops.nchw_to_nhwc(prev.to(dev)), out_planes=True)
+    assert torch.equal(planes, dense_ops.nhwc_to_planes(got))
+
+
+def test_resize_bilinear(dev):
+    from nerffaceediting_amd import dense_ops
+    z = load("dense_layers")
+    for tag in ("down_aa", "up_aa", "down_noaa", "odd_aa"):
+        out = z[f"resize.{tag}.out"]
+        y = dense_ops.resize_bilinear(dense_ops.nchw_to_nhwc(t(z[f"resize.{tag}.x"], dev)), out.shape[2], out.shape[3],
+                                      bool(int(z[f"resize.{tag}.aa"])))
+        assert maxerr(dense_ops.nhwc_to_nchw(y), out) <= 2e-6, tag
+
+
+def test_reduced_synthesis_network(dev):
+    from nerffaceediting_amd.training.networks_stylegan2 import SynthesisNetwork
+    z = load("dense_synthesis")
+    p = synthesis_params(int(z["seed"]), int(z["w_dim"]), int(z["res"]), 96, int(z["channel_base"]), int(z["channel_max"]))
+    net = load_module(SynthesisNetwork(int(z["w_dim"]), int(z["res"]), 96, channel_base=int(z["channel_base"]),
+                                       channel_max=int(z["channel_max"]), num_fp16_res=0, conv_clamp=None), p, dev)
+    out = net(t(z["ws"], dev), noise_mode="const")
+    e = maxerr(out, z["out"])
+    print("synthesis 32px", e)
+    assert e <= TOL
+    planes = net.forward_nhwc(t(z["ws"], dev), out_planes=True, noise_mode="const")
+    from nerffaceediting_amd import ops
+    assert torch.equal(planes, ops.plane_pack(out))
+
+
+@pytest.mark.parametrize("tag", ["r64", "r128"])
+def test_superresolution_8xdc(tag, dev):
+    from nerffaceediting_amd.training.superresolution import SuperresolutionHybrid8XDC
+    z = load("dense_sr")
+    sr = load_module(SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=4, sr_antialias=True), sr_params(int(z["seed"])), dev)
+    x = t(z[tag + ".x"], dev)
+    y = sr(x[:, :3].contiguous(), x, t(z[tag + ".ws"], dev), noise_mode="none")
+    assert y.shape == (1, 3, 512, 512)
+    e = maxerr(y[:, :, ::4, ::4], z[tag + ".out_s4"])
+    print("sr", tag, e)
+    assert e <= TOL
+    assert abs(float(y.mean()) - float(z[tag + ".out_mean"])) <= 1e-4
