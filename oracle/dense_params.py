@@ -59,3 +59,24 @@ def sr_params(seed):
     p = block_params(seed, 32, 256, 512, 256, 3, prefix="block0.")
     p.update(block_params(seed + 100, 256, 128, 512, 512, 3, prefix="block1."))
     return p
+
+
+def generator_params(seed, channel_base=4096, channel_max=32, z_dim=512, c_dim=25, w_dim=512):
+    """Whole TriPlaneGenerator state (SURVEY.md App. B names) for a REDUCED backbone width (channel_base /
+    channel_max) — the SR head and the decoder are always full size."""
+    p = {}
+    for k, v in mapping_params(seed, z_dim, c_dim, w_dim).items():
+        p["backbone.mapping." + k] = v
+    for k, v in synthesis_params(seed + 1, w_dim, 256, 96, channel_base, channel_max).items():
+        p["backbone.synthesis." + k] = v
+    for k, v in sr_params(seed + 2).items():
+        p["superresolution." + k] = v
+    r = np.random.RandomState(seed + 3)
+    for net, out in (("geo_net", 16), ("app_net", 32)):
+        p[f"decoder.{net}.0.weight"] = _t(r.randn(64, 32)); p[f"decoder.{net}.0.bias"] = _t(r.randn(64) * 0.2)
+        p[f"decoder.{net}.2.weight"] = _t(r.randn(out, 64)); p[f"decoder.{net}.2.bias"] = _t(r.randn(out) * 0.2)
+    # tone the backbone's output scale down so densities/colours are not saturated with random weights
+    for k in list(p):
+        if k.startswith("backbone.synthesis.") and k.endswith("torgb.weight"):
+            p[k] = p[k] * 0.3
+    return p

@@ -147,12 +147,69 @@ def gen_sr():
     print("  wrote dense_sr.npz")
 
 
+E2E_KW = dict(
+    rendering_kwargs=dict(superresolution_module="training.superresolution.SuperresolutionHybrid8XDC", sr_antialias=True,
+                          c_gen_conditioning_zero=False, c_scale=1, superresolution_noise_mode="none", depth_resolution=12,
+                          depth_resolution_importance=12, ray_start=2.25, ray_end=3.3, box_warp=1,
+                          disparity_space_sampling=False, clamp_mode="softplus", decoder_lr_mul=1),
+    channel_base=4096, channel_max=32)
+
+
+def gen_e2e():
+    """Whole TriPlaneGenerator forward (mapping -> backbone -> normalise -> render -> SR) on a reduced-width
+    backbone, 32^2 neural render, 12+12 samples, injected jitter, plus an appearance-swapped second call
+    and a sample_mixed() point query."""
+    import math
+    from camera_utils import FOV_to_intrinsics, LookAtPoseSampler
+    from training.triplane import TriPlaneGenerator
+    from oracle import e2e_oracle
+    from oracle.dense_params import generator_params
+    from oracle.gen_golden import InjectRand
+    rk = dict(E2E_KW["rendering_kwargs"])
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default="inference_only"),
+                          channel_base=E2E_KW["channel_base"], channel_max=E2E_KW["channel_max"],
+                          fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+    p = generator_params(51, E2E_KW["channel_base"], E2E_KW["channel_max"])
+    load(G, p)
+    rng = np.random.RandomState(52)
+    N, R, D, Di = 2, 32, 12, 12
+    z = t(rng.randn(N, 512))
+    c2w = torch.cat([LookAtPoseSampler.sample(math.pi / 2 + y, math.pi / 2 - 0.2, torch.tensor([0, 0, 0.2]), radius=2.7) for y in (0.4, -0.3)], 0)
+    c = torch.cat([c2w.reshape(N, 16), FOV_to_intrinsics(18.837).reshape(1, 9).repeat(N, 1)], 1)
+    u_c = rng.rand(N, R * R, D).astype(np.float32)
+    u_f = rng.rand(N * R * R, Di).astype(np.float32)
+    ws = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=14)
+    check("e2e.mapping", e2e_oracle.mapping(p, z, c, rk, 0.7, 14), ws, 1e-4)
+    data = dict(z=z.numpy(), c=c.numpy(), ws=ws.numpy(), u_coarse=u_c, u_fine=u_f, seed=51, R=R)
+    for tag, kw in dict(plain={}, swap=dict(planes_mean=1, planes_var=0)).items():
+        with InjectRand([u_c, u_f]):
+            ref = G.synthesis(ws, c, neural_rendering_resolution=R, noise_mode="const", **kw)
+        mine = e2e_oracle.synthesis(p, ws, c, rk, R, u_c, u_f, noise_mode="const", **kw)
+        for k in ("image", "image_seg", "image_raw", "image_depth", "plane_mean", "plane_var"):
+            check(f"e2e.{tag}.{k}", torch.from_numpy(np.ascontiguousarray(mine[k])), ref[k], 3e-4)
+        data.update({f"{tag}.image_s4": ref["image"][:, :, ::4, ::4].numpy(), f"{tag}.image_mean": float(ref["image"].mean()),
+                     f"{tag}.image_seg": ref["image_seg"].numpy(), f"{tag}.image_raw": ref["image_raw"].numpy(),
+                     f"{tag}.image_depth": ref["image_depth"].numpy(), f"{tag}.plane_mean": ref["plane_mean"].numpy(),
+                     f"{tag}.plane_var": ref["plane_var"].numpy()})
+    coords = t((rng.rand(N, 300, 3) - 0.5) * 1.1)
+    ref = G.sample_mixed(coords, None, ws, noise_mode="const")
+    mine = e2e_oracle.sample_mixed(p, coords.numpy(), ws, rk)
+    for k in ("rgb", "sigma", "seg"):
+        check("e2e.sample." + k, torch.from_numpy(mine[k]), ref[k], 3e-4)
+        data["sample." + k] = ref[k].numpy()
+    data["sample.coords"] = coords.numpy()
+    np.savez_compressed(os.path.join(OUT, "dense_e2e.npz"), **data)
+    print("  wrote dense_e2e.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     gen_mapping()
     gen_layers()
     gen_synthesis()
     gen_sr()
+    gen_e2e()
     for f in sorted(os.listdir(OUT)):
         if f.startswith("dense_"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

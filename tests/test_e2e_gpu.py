@@ -1,0 +1,92 @@
+"""GPU: the whole TriPlaneGenerator path (mapping -> backbone -> plane statistics -> fused render -> SR)
+through the reference's own call signatures, against golden vectors captured from the reference
+TriPlaneGenerator (reduced backbone width; full-size SR head and decoder).  Bar: <= 1e-3 max-abs
+(BASELINE.json north_star) with identical latents, poses and jitter."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.dense_params import generator_params
+from tests._golden import load
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+RENDERING_KWARGS = dict(superresolution_module="training.superresolution.SuperresolutionHybrid8XDC", sr_antialias=True,
+                        c_gen_conditioning_zero=False, c_scale=1, superresolution_noise_mode="none", depth_resolution=12,
+                        depth_resolution_importance=12, ray_start=2.25, ray_end=3.3, box_warp=1,
+                        disparity_space_sampling=False, clamp_mode="softplus", decoder_lr_mul=1)
+
+
+@pytest.fixture(scope="module")
+def setup():
+    from nerffaceediting_amd.training.triplane import TriPlaneGenerator
+    assert torch.cuda.is_available()
+    dev = torch.device("cuda:0")
+    z = load("dense_e2e")
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2),
+                          rendering_kwargs=dict(RENDERING_KWARGS),
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default="inference_only"),
+                          channel_base=4096, channel_max=32, fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+    sd = G.state_dict()
+    for k, v in generator_params(int(z["seed"]), 4096, 32).items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        sd[k] = v
+    G.load_state_dict(sd)
+    return G.to(dev).eval().requires_grad_(False), z, dev
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def err(a, b):
+    return float((a.detach().cpu().double() - torch.from_numpy(np.asarray(b)).double()).abs().max())
+
+
+def test_mapping(setup):
+    G, z, dev = setup
+    ws = G.mapping(t(z["z"], dev), t(z["c"], dev), truncation_psi=0.7, truncation_cutoff=14)
+    assert err(ws, z["ws"]) <= 1e-4
+
+
+@pytest.mark.parametrize("tag", ["plain", "swap"])
+def test_synthesis(setup, tag):
+    G, z, dev = setup
+    R = int(z["R"])
+    kw = dict(planes_mean=1, planes_var=0) if tag == "swap" else {}        # (int,int) override, triplane.py:100-101
+    G.renderer.inject_jitter(t(z["u_coarse"], dev), t(z["u_fine"], dev))
+    out = G.synthesis(t(z["ws"], dev), t(z["c"], dev), neural_rendering_resolution=R, noise_mode="const", **kw)
+    assert G.neural_rendering_resolution == R                                  # stored on self, triplane.py:78-81
+    assert out["image"].shape == (2, 3, 512, 512) and out["image_seg"].shape == (2, 15, R, R)
+    assert out["image_raw"].shape == (2, 3, R, R) and out["image_depth"].shape == (2, 1, R, R)
+    errs = {"image": err(out["image"][:, :, ::4, ::4], z[tag + ".image_s4"])}
+    for k in ("image_seg", "image_raw", "image_depth", "plane_mean", "plane_var"):
+        errs[k] = err(out[k], z[f"{tag}.{k}"])
+    print(tag, errs)
+    for k, e in errs.items():
+        assert e <= TOL, (k, e)
+    assert abs(float(out["image"].mean()) - float(z[tag + ".image_mean"])) <= 1e-4
+
+
+def test_forward_and_cached_backbone(setup):
+    G, z, dev = setup
+    R = int(z["R"])
+    uc, uf = t(z["u_coarse"], dev), t(z["u_fine"], dev)
+    G.renderer.inject_jitter(uc, uf)
+    a = G(t(z["z"], dev), t(z["c"], dev), truncation_psi=0.7, truncation_cutoff=14, neural_rendering_resolution=R,
+          noise_mode="const", cache_backbone=True)
+    assert err(a["image_raw"], z["plain.image_raw"]) <= TOL
+    G.renderer.inject_jitter(uc, uf)
+    b = G.synthesis(torch.zeros_like(t(z["ws"], dev)), t(z["c"], dev), use_cached_backbone=True, noise_mode="const")
+    # the planes came from the cache, not from the zero ws (the SR head still sees ws, so compare the raw render)
+    for k in ("image_raw", "image_seg", "image_depth", "plane_mean"):
+        assert torch.equal(a[k], b[k]), k
+    G._last_planes = None
+
+
+def test_sample_mixed(setup):
+    G, z, dev = setup
+    out = G.sample_mixed(t(z["sample.coords"], dev), None, t(z["ws"], dev), noise_mode="const")
+    for k in ("rgb", "sigma", "seg"):
+        assert err(out[k], z["sample." + k]) <= TOL, k
