@@ -27,6 +27,19 @@ sys.path.insert(0, ROOT)
 VIEWS_PER_GPU, R, D, PLANE = 4, 512, 64, 256
 BYTES_PER_RAY_S1 = D * 1 * 1536 + 196        # S=1 (single-gather identity) -> 98 500 B/ray
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # written by tools/pmc.sh (rocprofv3 --pmc passes)
+
+
+def measured_traffic():
+    """HBM bytes per render_kernel launch from the committed rocprofv3 PMC passes of this same command
+    (tools/pmc.sh): FETCH_SIZE*1024*2 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE*1024.  PMC counters
+    cannot be collected from inside the timed process, so the figure comes from the profile file."""
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            d = json.load(f)
+        return float(d["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def synth_inputs(torch, dev, seed):
@@ -146,11 +159,12 @@ def main():
                        "views_per_step": n_total, "views_per_s": n_total * args.steps / dt,
                        "rays_per_view": M, "depth_samples": D, "parallelism": f"views-dp{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
                          "kernel": "nfe::render_kernel<false,false>", "kernel_ms": kern_ms,
                          "algorithmic_bytes_per_launch": launch_bytes,
-                         "note": "logical gather bytes (S=1: 98500 B/ray); planes are L2/Infinity-Cache resident, "
-                                 "see DESIGN.md §6"},
+                         "note": "achieved = logical gather bytes (S=1: 98500 B/ray) / kernel time; traffic = HBM bytes per "
+                                 "launch from profiles/r01_pmc_traffic.json (planes stay L2/Infinity-Cache resident, so "
+                                 "traffic << algorithmic bytes); the kernel is TA/VALU-bound, see DESIGN.md §6"},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(planes_np, dec_np, c2w, K, opts, seed)

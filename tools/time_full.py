@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Stage timings of the full path (BASELINE config 3 shape): TriPlaneGenerator.synthesis at full width,
+N views, R^2 neural render x (D + Di) samples, SR to 512^2.  Usage: tools/time_full.py [N] [R] [D] [Di] [math]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from nerffaceediting_amd.training.triplane import TriPlaneGenerator
+
+N, R, D, Di = (int(a) for a in (sys.argv[1:5] + ["4", "128", "48", "48"][len(sys.argv) - 1:])[:4])
+math = sys.argv[5] if len(sys.argv) > 5 else "bf16x3"
+rk = dict(superresolution_module="training.superresolution.SuperresolutionHybrid8XDC", sr_antialias=True, c_gen_conditioning_zero=False,
+          c_scale=1, superresolution_noise_mode="none", depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3,
+          box_warp=1, disparity_space_sampling=False, clamp_mode="softplus", decoder_lr_mul=1)
+torch.manual_seed(0)
+G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+                      sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default="inference_only"), channel_base=32768,
+                      channel_max=512, fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+dev = torch.device("cuda:0")
+G = G.to(dev).eval().requires_grad_(False)
+G.backbone.synthesis.conv_math = math
+G.superresolution.conv_math = math
+from oracle import render_oracle as orc
+import numpy as np, math as m
+c2w = np.concatenate([orc.lookat_pose(m.pi / 2 + 0.1 * i, m.pi / 2 - 0.2, [0, 0, 0.2], 2.7) for i in range(N)], 0)
+c = torch.from_numpy(orc.make_c(c2w, orc.fov_to_intrinsics(18.837))).to(dev)
+z = torch.randn(N, 512, device=dev)
+
+
+def timed(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3, out
+
+
+t_map, ws = timed(lambda: G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=14))
+t_bb, planes = timed(lambda: G.backbone.synthesis.forward_nhwc(ws, out_planes=True, noise_mode="const"))
+t_all, out = timed(lambda: G.synthesis(ws, c, neural_rendering_resolution=R, noise_mode="const"))
+feat = torch.randn(N, 128, 128, 32, device=dev)
+t_sr, _ = timed(lambda: G.superresolution.forward_nhwc(feat[..., :3].contiguous(), feat, ws, noise_mode="none"))
+print(f"N={N} R={R} D={D}+{Di} math={math}: mapping {t_map:.2f} ms, backbone {t_bb:.2f} ms, SR {t_sr:.2f} ms, synthesis total {t_all:.2f} ms "
+      f"-> {N / t_all * 1e3:.1f} views/s; backbone {46.55 * 2 * N / t_bb:.1f} TFLOP/s, SR {98.0 * 2 * N / t_sr:.1f} TFLOP/s (algorithmic)")
+print("finite:", bool(torch.isfinite(out["image"]).all()), out["image"].shape)
