@@ -91,6 +91,9 @@ def load():
     """Load (once) and return the ctypes handle; raises ImportError when the .so is missing."""
     global _lib
     if _lib is None:
+        # torch must be imported first: it carries its own HIP runtime (same SONAME as /opt/rocm's); loading
+        # our .so before it would bind the kernels to a second runtime instance that never sees torch's device.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `make -C nerffaceediting_amd/csrc` "
