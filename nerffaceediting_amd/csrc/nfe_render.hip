@@ -36,9 +36,12 @@ struct RenderK {
     unsigned* depth_minmax;        // ordered-uint {min, max}
 };
 
-constexpr int LDS_AFF = DEC_FLOATS;             // per-wave affine region starts here
+// LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then AFF_FLOATS of view
+// affines per wave.
+constexpr int LDS_AFF = DEC_FLOATS;
 constexpr int AFF_FLOATS = 4 * 96;
-constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * AFF_FLOATS) * 4;
+constexpr int WAVE_LDS_FLOATS = AFF_FLOATS;
+constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * WAVE_LDS_FLOATS) * 4;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -73,41 +76,48 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = *reinterpret_cast<unsigned*>(&p);
 }
 
-// One plane's bilinear taps: accumulates this lane's 16 channels (half a 128-byte texel) as 8 float2.
+// Bilinear tap geometry of one sample on one plane: F.grid_sample(bilinear, zeros, align_corners=False),
+// renderer.py:64, unnormalised as ATen's CPU kernel does.  Clamped coordinates are always addressable;
+// out-of-range taps carry weight 0.
+struct Taps { int xc0, xc1, yc0, yc1; float w[4]; float wsum; };
+
+__device__ __forceinline__ Taps tap_geometry(int H, int W, float u, float v) {
+    Taps t;
+    const float ix = (u + 1.0f) * (0.5f * (float)W) - 0.5f;
+    const float iy = (v + 1.0f) * (0.5f * (float)H) - 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float dx = ix - x0f, dy = iy - y0f, ex = 1.0f - dx, ey = 1.0f - dy;
+    const int x0 = (int)fminf(fmaxf(x0f, -2.0f), (float)(W + 1));
+    const int y0 = (int)fminf(fmaxf(y0f, -2.0f), (float)(H + 1));
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
+    t.w[0] = (vx0 && vy0) ? ex * ey : 0.0f;
+    t.w[1] = (vx1 && vy0) ? dx * ey : 0.0f;
+    t.w[2] = (vx0 && vy1) ? ex * dy : 0.0f;
+    t.w[3] = (vx1 && vy1) ? dx * dy : 0.0f;
+    t.xc0 = min(max(x0, 0), W - 1); t.xc1 = min(max(x1, 0), W - 1);
+    t.yc0 = min(max(y0, 0), H - 1); t.yc1 = min(max(y1, 0), H - 1);
+    t.wsum = (t.w[0] + t.w[1]) + (t.w[2] + t.w[3]);
+    return t;
+}
+
+// Direct gather: this lane's 16 channels (half a 128-byte texel) of the 4 taps straight from global memory.
 template <bool DUAL, int TAPS_IN_FLIGHT>
-__device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const float* __restrict__ pa,
-                                             int H, int W, float u, float v, int hoff,
-                                             f32x2 (&sg)[8], f32x2 (&sa)[8], float& wsum) {
-    // F.grid_sample(bilinear, zeros, align_corners=False) — renderer.py:64; unnormalise as ATen does.
-    float ix = (u + 1.0f) * (0.5f * (float)W) - 0.5f;
-    float iy = (v + 1.0f) * (0.5f * (float)H) - 0.5f;
-    float x0f = floorf(ix), y0f = floorf(iy);
-    float dx = ix - x0f, dy = iy - y0f, ex = 1.0f - dx, ey = 1.0f - dy;
-    int x0 = (int)fminf(fmaxf(x0f, -2.0f), (float)(W + 1));
-    int y0 = (int)fminf(fmaxf(y0f, -2.0f), (float)(H + 1));
-    int x1 = x0 + 1, y1 = y0 + 1;
-    bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
-    bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
-    float w00 = (vx0 && vy0) ? ex * ey : 0.0f;
-    float w10 = (vx1 && vy0) ? dx * ey : 0.0f;
-    float w01 = (vx0 && vy1) ? ex * dy : 0.0f;
-    float w11 = (vx1 && vy1) ? dx * dy : 0.0f;
-    int xc0 = min(max(x0, 0), W - 1), xc1 = min(max(x1, 0), W - 1);
-    int yc0 = min(max(y0, 0), H - 1), yc1 = min(max(y1, 0), H - 1);
-    wsum = (w00 + w10) + (w01 + w11);
-    const int offs[4] = {(yc0 * W + xc0) * 32 + hoff, (yc0 * W + xc1) * 32 + hoff,
-                         (yc1 * W + xc0) * 32 + hoff, (yc1 * W + xc1) * 32 + hoff};
-    const float ws[4] = {w00, w10, w01, w11};
+__device__ __forceinline__ void fetch_direct(const float* __restrict__ pg, const float* __restrict__ pa, int W, const Taps& t,
+                                             int hoff, f32x2 (&sg)[8], f32x2 (&sa)[8]) {
+    const int offs[4] = {(t.yc0 * W + t.xc0) * 32 + hoff, (t.yc0 * W + t.xc1) * 32 + hoff,
+                         (t.yc1 * W + t.xc0) * 32 + hoff, (t.yc1 * W + t.xc1) * 32 + hoff};
 #pragma unroll
     for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); if (DUAL) sa[c] = splat(0.0f); }
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const f32x2 w2 = splat(ws[t]);
-        const float4* tg = reinterpret_cast<const float4*>(pg + offs[t]);
+    for (int k = 0; k < 4; ++k) {
+        const f32x2 w2 = splat(t.w[k]);
+        const float4* tg = reinterpret_cast<const float4*>(pg + offs[k]);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
 #ifdef NFE_ABLATE_GATHER   // timing experiment only (tools/ablate.sh): no plane loads
-            float4 a = make_float4(ws[t], u, v, (float)q);
+            float4 a = make_float4(t.w[k], t.wsum, (float)k, (float)q);
 #else
             float4 a = tg[q];
 #endif
@@ -115,7 +125,7 @@ __device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const
             sg[2 * q + 1] = pk_fma(w2, f32x2{a.z, a.w}, sg[2 * q + 1]);
         }
         if (DUAL) {
-            const float4* ta = reinterpret_cast<const float4*>(pa + offs[t]);
+            const float4* ta = reinterpret_cast<const float4*>(pa + offs[k]);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 float4 a = ta[q];
@@ -125,9 +135,14 @@ __device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const
         }
         // Register discipline: at most TAPS_IN_FLIGHT taps' loads (4 float4 = 16 VGPRs each, x2 with
         // two plane sets) are outstanding; the other wave on the SIMD covers the latency.
-        if (((t + 1) % TAPS_IN_FLIGHT) == 0) __builtin_amdgcn_sched_barrier(0);
+        if (((k + 1) % TAPS_IN_FLIGHT) == 0) __builtin_amdgcn_sched_barrier(0);
     }
 }
+
+// Launder a value through an empty asm: the optimiser can no longer prove it loop-invariant, so addresses
+// and constants derived from it are recomputed at the point of use (a few VALU ops) instead of being hoisted
+// to the kernel prologue and spilled to scratch (which is what happens at 256 VGPRs otherwise).
+__device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
 
 // ---- decoder, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) ---------------------------------------------
 // FC 32->64, softplus, FC 64->32 rows; weights are the A operand (LDS), the per-point vectors are the
@@ -135,6 +150,7 @@ __device__ __forceinline__ void gather_plane(const float* __restrict__ pg, const
 // would otherwise hoist every LDS weight read of both nets to the top (>150 VGPRs); each group of
 // k-steps prefetches the next group's A fragments and ends in a scheduling fence.
 __device__ __forceinline__ void mlp_fp32(const float* __restrict__ lds, const f32x2 (&f)[8], int net, int lane, f32x16& out) {
+    lane = launder(lane);
     const int h = lane >> 5;
     __builtin_amdgcn_sched_barrier(0);
     f32x16 a0, a1;
@@ -199,6 +215,7 @@ __device__ __forceinline__ void mlp_fp32(const float* __restrict__ lds, const f3
 // DEC_B_*.  Fragment f of lane l is the uint4 at (f*64 + l).
 #define NFE_MFMA_BF16(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16((A).v, (B).v, (C), 0, 0, 0)
 __device__ __forceinline__ void mlp_bf16(const float* __restrict__ lds, const f32x2 (&f)[8], int net, int lane, f32x16& out) {
+    lane = launder(lane);
     const int h = lane >> 5;
     const uint4* F = reinterpret_cast<const uint4*>(lds) + lane;
     __builtin_amdgcn_sched_barrier(0);
@@ -258,9 +275,9 @@ __device__ __forceinline__ void mlp_bf16(const float* __restrict__ lds, const f3
 template <bool DUAL, bool SIGMA_ONLY, int MATH>
 __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const float* __restrict__ pa,
                                            int H, int W, const float* __restrict__ lds,
-                                           const float* __restrict__ aff, float gx, float gy, float gz,
+                                           const float* __restrict__ aff,
+                                           float gx, float gy, float gz,
                                            int lane, f32x16& og, f32x16& oa) {
-    const int hoff = (lane >> 5) * 16;
     f32x2 fn[8], fd[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) { fn[c] = splat(0.0f); fd[c] = splat(0.0f); }
@@ -271,9 +288,11 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
         float u = (p == 2) ? gz : gx;
         float v = (p == 0) ? gy : ((p == 1) ? gz : gx);
         f32x2 sg[8], sa[8];
-        float wsum;
-        gather_plane<DUAL && !SIGMA_ONLY, (DUAL && !SIGMA_ONLY) ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, H, W, u, v, hoff, sg, sa, wsum);
-        const f32x2 w2 = splat(wsum);
+        const int hoff = (launder(lane) >> 5) * 16;
+        const Taps tp = tap_geometry(H, W, u, v);
+        constexpr bool TWO_SETS = DUAL && !SIGMA_ONLY;
+        fetch_direct<TWO_SETS, TWO_SETS ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, W, tp, hoff, sg, sa);
+        const f32x2 w2 = splat(tp.wsum);
         const float4* gs = reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + hoff);
         const float4* gb = reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + hoff);
 #pragma unroll
@@ -340,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     // wave id in an SGPR: everything derived from it (ray block, view, plane base) stays scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    float* aff = lds + LDS_AFF + wave * AFF_FLOATS;
+    float* aff = lds + LDS_AFF + wave * WAVE_LDS_FLOATS;
     __syncthreads();
 
     const int S = P.S;
@@ -668,7 +687,7 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
     stage_decoder<MATH>(P.dec, lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    float* aff = lds + LDS_AFF + wave * AFF_FLOATS;
+    float* aff = lds + LDS_AFF + wave * WAVE_LDS_FLOATS;
     __syncthreads();
     const int blocks_per_view = (P.Pn + 31) >> 5;
     const long long total = (long long)P.N * blocks_per_view;
