@@ -1,0 +1,91 @@
+"""Batch-of-views drivers: the counterparts of the reference's inference scripts for the path this package
+accelerates.  gen_samples.py:160-183 renders 3 fixed yaws per seed, gen_videos.py:122-147 an
+orbit of `w_frames` cameras — both sequentially, batch 1, on one GPU.  Here views are rendered in batches and
+sharded over the ranks of a torch.distributed job (views are independent; one all-gather of frames).
+
+File output (PNG / mp4 / mrc / ply) is out of scope; these return tensors.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import camera_utils, sharding
+
+FFHQ_INTRINSICS = [[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]]           # gen_videos.py:132
+
+
+def seed_to_z(seed, z_dim=512, device="cuda"):
+    """gen_samples.py:162 / gen_videos.py:84: z = RandomState(seed).randn(1, z_dim)."""
+    return torch.from_numpy(np.random.RandomState(seed).randn(1, z_dim)).to(device=device, dtype=torch.float32)
+
+
+def sample_cameras(device, cam_pivot=(0, 0, 0.2), cam_radius=2.7, fov_deg=18.837):
+    """The three poses gen_samples.py:165-171 renders per seed -> c [3,25]."""
+    intr = camera_utils.FOV_to_intrinsics(fov_deg, device=device)
+    cs = []
+    for yaw, pitch in [(0.4, -0.2), (0.0, -0.2), (-0.4, -0.2)]:
+        c2w = camera_utils.LookAtPoseSampler.sample(np.pi / 2 + yaw, np.pi / 2 + pitch, torch.tensor(cam_pivot, device=device),
+                                                    radius=cam_radius, device=device)
+        cs.append(torch.cat([c2w.reshape(-1, 16), intr.reshape(-1, 9)], 1))
+    return torch.cat(cs, 0)
+
+
+def orbit_cameras(num_frames, device, lookat=(0, 0, 0.2), radius=2.7, pitch_range=0.25, yaw_range=0.35):
+    """gen_videos.py:126-133 camera path (including its 3.14 constants) -> c [num_frames,25]."""
+    intr = torch.tensor(FFHQ_INTRINSICS, device=device)
+    cs = []
+    for f in range(num_frames):
+        c2w = camera_utils.LookAtPoseSampler.sample(3.14 / 2 + yaw_range * np.sin(2 * 3.14 * f / num_frames),
+                                                    3.14 / 2 - 0.05 + pitch_range * np.cos(2 * 3.14 * f / num_frames),
+                                                    torch.tensor(lookat, device=device), radius=radius, device=device)
+        cs.append(torch.cat([c2w.reshape(-1, 16), intr.reshape(-1, 9)], 1))
+    return torch.cat(cs, 0)
+
+
+def to_uint8(img):
+    """gen_samples.py:177: (img.permute(0,2,3,1) * 127.5 + 128).clamp(0,255).uint8."""
+    return (img.permute(0, 2, 3, 1) * 127.5 + 128).clamp(0, 255).to(torch.uint8)
+
+
+@torch.no_grad()
+def render_views(G, ws, c, batch=4, gather=True, **synthesis_kwargs):
+    """Render V independent (ws[v], c[v]) pairs -> frames [V,3,H,W] (fp32, in view order on every rank).
+
+    ws [V,num_ws,w_dim] (or [1,...] broadcast: one identity, many cameras, as utils.render_video does),
+    c [V,25].  Under torch.distributed each rank renders a contiguous block of views
+    (sharding.shard_range) and frames are all-gathered once; without it everything runs locally."""
+    V = c.shape[0]
+    if ws.shape[0] == 1 and V > 1:
+        ws = ws.expand(V, -1, -1)
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    a, b = sharding.shard_range(V, rank, world)
+    frames = []
+    for i in range(a, b, batch):
+        j = min(b, i + batch)
+        frames.append(G.synthesis(ws[i:j].contiguous(), c[i:j].contiguous(), **synthesis_kwargs)["image"])
+    local = torch.cat(frames, 0) if frames else c.new_zeros((0, 3, G.img_resolution, G.img_resolution))
+    return sharding.all_gather_frames(local, V) if (gather and world > 1) else local
+
+
+@torch.no_grad()
+def extract_density(G, ws, shape_res=128, max_batch=1 << 20, cube_length=None, **synthesis_kwargs):
+    """gen_samples.py:79-101,186-205 shape extraction: sigma on a shape_res^3 grid -> [R,R,R].
+    The tri-planes are synthesised ONCE and reused for every chunk (the reference re-runs the backbone per chunk)."""
+    from . import ops
+    L = cube_length if cube_length is not None else G.rendering_kwargs["box_warp"]
+    R = shape_res
+    lin = torch.arange(R, device=ws.device, dtype=torch.float32)
+    idx = torch.arange(R ** 3, device=ws.device)
+    voxel = L / (R - 1)                                                       # create_samples, gen_samples.py:79-101
+    pts = torch.stack([(idx % R).float(), ((idx // R) % R).float(), ((idx // R) // R % R).float()], 1) * voxel - L / 2
+    packed, mean, var = G._planes(ws, synthesis_kwargs)
+    aff = ops.make_affine(mean, var)
+    out = torch.empty(R ** 3, device=ws.device)
+    for s in range(0, R ** 3, max_batch):
+        e = min(R ** 3, s + max_batch)
+        out[s:e] = ops.point_query(packed, packed, G.decoder.packed(), pts[None, s:e].contiguous(), G.rendering_kwargs["box_warp"],
+                                   affines=aff)["sigma"].reshape(-1)
+    del lin
+    return out.reshape(R, R, R)
