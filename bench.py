@@ -166,7 +166,7 @@ def main():
                                  "launch from profiles/r01_pmc_traffic.json (planes stay L2/Infinity-Cache resident, so "
                                  "traffic << algorithmic bytes); the kernel is TA/VALU-bound, see DESIGN.md §6"},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (host cores are shared by all ranks)
             out["cpu_baseline"] = cpu_baseline(planes_np, dec_np, c2w, K, opts, seed)
         print(json.dumps(out))
     if world > 1:
