@@ -155,9 +155,9 @@ __device__ __forceinline__ int hidden_unit(int mb, int r, int h) { return 32 * m
 // Row i is register ri of lane half hi; sigma is duplicated into both halves.
 __device__ __forceinline__ int geo_row_to_out(int i) {
     const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;
-    if (ri == 0) return 0;
-    if (hi == 0 && ri <= 8) return ri;
-    if (hi == 1 && ri <= 7) return 8 + ri;
+    if (ri == 0) return 0;                          // sigma in register 0 of both halves
+    if (hi == 0 && ri >= 2 && ri <= 9) return ri - 1;       // seg 0..7 in registers 2..9 (even start: packed pairs)
+    if (hi == 1 && ri >= 2 && ri <= 8) return ri + 7;       // seg 8..14 in registers 2..8
     return -1;
 }
 __device__ __forceinline__ int app_row_to_out(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }

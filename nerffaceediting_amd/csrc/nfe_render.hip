@@ -68,6 +68,17 @@ __device__ __forceinline__ float softplus_log2(float y) {
     return y > 20.0f * LOG2E ? y : r;
 }
 
+// softplus_log2 over a whole accumulator; the "+1" runs as packed adds (v_pk_add_f32), two values per issue
+__device__ __forceinline__ void softplus_log2_x16(f32x16& a) {
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const f32x2 e = f32x2{exp2_fast(a[r]), exp2_fast(a[r + 1])} + splat(1.0f);
+        const float r0 = log2_fast(e[0]), r1 = log2_fast(e[1]);
+        a[r] = a[r] > 20.0f * LOG2E ? a[r] : r0;
+        a[r + 1] = a[r + 1] > 20.0f * LOG2E ? a[r + 1] : r1;
+    }
+}
+
 // fp32 -> (hi, lo) bf16 pairs: hi = top 16 bits (truncation), lo = bf16(x - hi); x - hi - lo <= 2^-17 |x|.
 __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
     const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
@@ -178,8 +189,7 @@ __device__ __forceinline__ void mlp_fp32(const float* __restrict__ lds, const f3
         w0 = n0; w1 = n1;
         __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = softplus_log2(a0[r]); a1[r] = softplus_log2(a1[r]); }
+    softplus_log2_x16(a0); softplus_log2_x16(a1);
     const float4* b1 = reinterpret_cast<const float4*>(lds + (net ? DEC_B_A1 : DEC_B_G1) + 4 * h);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -242,8 +252,7 @@ __device__ __forceinline__ void mlp_bf16(const float* __restrict__ lds, const f3
         a0 = NFE_MFMA_BF16(l0, fh[s], a0); a1 = NFE_MFMA_BF16(l1, fh[s], a1);
         __builtin_amdgcn_sched_barrier(0);
     }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = softplus_log2(a0[r]); a1[r] = softplus_log2(a1[r]); }
+    softplus_log2_x16(a0); softplus_log2_x16(a1);
     const float4* b1 = reinterpret_cast<const float4*>(lds + (net ? DEC_B_A1 : DEC_B_G1) + 4 * h);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -270,7 +279,8 @@ __device__ __forceinline__ void mlp_bf16(const float* __restrict__ lds, const f3
 
 // Evaluate the implicit model at one point per lane PAIR (lanes j and j+32 share a point; lane half
 // h holds channels [16h,16h+16) of every 32-vector).  Returns, for this lane:
-//   og[0] = sigma; og[1..] = seg channels (h=0: seg 0..7 in og[1..8]; h=1: seg 8..14 in og[1..7])
+//   og[0] = sigma; og[2..] = seg channels (h=0: seg 0..7 in og[2..9]; h=1: seg 8..14 in og[2..8]); og[1] unused
+//   (seg starts on an even register so packed-fp32 pairs need no realigning moves)
 //   oa[r] = rgb channel 16h + r   (after the sigmoid clamp, triplane.py:269)
 template <bool DUAL, bool SIGMA_ONLY, int MATH>
 __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const float* __restrict__ pa,
@@ -321,9 +331,10 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
     if (!SIGMA_ONLY) {
         if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa); else mlp_bf16(lds, fd, 1, lane, oa);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {       // oa carries log2(e): sigmoid(x) = 1/(1 + 2^-(x log2 e))
-            float s = __builtin_amdgcn_rcpf(1.0f + exp2_fast(-oa[r]));
-            oa[r] = fmaf(s, 1.002f, -0.001f);      // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269
+        for (int r = 0; r < 16; r += 2) {    // oa carries log2(e): sigmoid(x) = 1/(1 + 2^-(x log2 e))
+            const f32x2 d = f32x2{exp2_fast(-oa[r]), exp2_fast(-oa[r + 1])} + splat(1.0f);
+            const f32x2 sg = pk_fma(f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])}, splat(1.002f), splat(-0.001f));
+            oa[r] = sg[0]; oa[r + 1] = sg[1];    // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269
         }
     }
 }
@@ -478,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                         acc_rgb[c] = pk_fma(wh, prev_rgb[c] + f32x2{oa[2 * c], oa[2 * c + 1]}, acc_rgb[c]);
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        acc_seg[c] = pk_fma(wh, prev_seg[c] + f32x2{og[1 + 2 * c], og[2 + 2 * c]}, acc_seg[c]);
+                        acc_seg[c] = pk_fma(wh, prev_seg[c] + f32x2{og[2 + 2 * c], og[3 + 2 * c]}, acc_seg[c]);
                     acc_d = fmaf(w, (prev_t + t) * 0.5f, acc_d);
                     acc_w += w;
                 }
@@ -488,7 +499,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) prev_rgb[c] = f32x2{oa[2 * c], oa[2 * c + 1]};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) prev_seg[c] = f32x2{og[1 + 2 * c], og[2 + 2 * c]};
+                for (int c = 0; c < 4; ++c) prev_seg[c] = f32x2{og[2 + 2 * c], og[3 + 2 * c]};
             }
         }
 
@@ -711,7 +722,7 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
             const int nseg = h ? 7 : 8;
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc)
-                if (cc < nseg) P.seg[pt * 15 + 8 * h + cc] = og[1 + cc];
+                if (cc < nseg) P.seg[pt * 15 + 8 * h + cc] = og[2 + cc];
             if (h == 0) P.sigma[pt] = og[0];
         }
     }
