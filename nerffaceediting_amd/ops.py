@@ -256,6 +256,8 @@ def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affine
     rgb = torch.empty(N, P, 32, device=dev)
     sigma = torch.empty(N, P, 1, device=dev)
     seg = torch.empty(N, P, 15, device=dev)
+    if P == 0:                                   # empty query: nothing to launch (zero-size tensors have no storage)
+        return {"rgb": rgb, "sigma": sigma, "seg": seg}
     stride = 0 if (Np == 1 and N > 1) else 3 * H * W * 32
     with torch.cuda.device(dev):
         _lib.check(lib.nfe_point_query(_ptr(planes_geo), _ptr(planes_app), H, W, stride, *[_ptr(t) for t in aff],

@@ -1,0 +1,102 @@
+"""GPU edge cases of the render path against the oracle: ragged ray counts, broadcast planes, rectangular
+planes, minimum / maximum sample counts, rays that miss the volume, empty point queries."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import c_oracle
+from oracle import render_oracle as orc
+from tests._golden import max_abs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+NAMES = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
+         "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+
+
+def run_both(dev, planes_norm, planes_den, dec, o, d, opts, u_c, u_f=None):
+    """HIP (dual-plane entry, explicit rays) vs the C oracle on identical inputs."""
+    from nerffaceediting_amd import ops
+    want = c_oracle.render(planes_norm, planes_den, dec, o, d, opts, u_c, u_f)
+    decp = ops.decoder_pack(*[t(dec[k], dev) for k in NAMES])
+    pg, pa = ops.plane_pack(t(planes_norm, dev)), ops.plane_pack(t(planes_den, dev))
+    got = ops.render(pg, pa, decp, opts, origins=t(o, dev), dirs=t(d, dev), u_coarse=t(u_c, dev),
+                     u_fine=None if u_f is None else t(u_f, dev))
+    return [g.cpu().numpy() for g in got], want
+
+
+def rays(rng, N, M, miss=False):
+    o = np.tile(np.array([0.0, 0.0, 2.7], np.float32), (N, M, 1)) + rng.randn(N, M, 3).astype(np.float32) * 0.02
+    tgt = rng.uniform(-0.45, 0.45, (N, M, 3)).astype(np.float32) + (5.0 if miss else 0.0)
+    d = tgt - o
+    return o, (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+
+
+@pytest.mark.parametrize("N,M,Np,H,W,D,Di", [
+    (1, 25, 1, 16, 16, 8, 0),        # ragged: 25 rays in one 32-ray block
+    (3, 70, 1, 16, 16, 6, 6),        # three views sharing ONE plane set (broadcast), ragged blocks, two-pass
+    (2, 33, 2, 12, 20, 5, 4),        # rectangular planes (H != W), minimum two-pass D
+    (1, 40, 1, 8, 8, 2, 0),          # minimum depth_resolution
+    (1, 32, 1, 8, 8, 256, 0),        # maximum depth_resolution
+    (1, 32, 1, 8, 8, 130, 126),      # long two-pass lists
+])
+def test_shapes(N, M, Np, H, W, D, Di, dev):
+    rng = np.random.RandomState(N * 1000 + M)
+    pn = rng.randn(Np, 3, 32, H, W).astype(np.float32)
+    pd = (rng.randn(Np, 3, 32, H, W) * 0.7 + 0.2).astype(np.float32)
+    dec = orc.random_decoder(M, bias_scale=0.2)
+    o, d = rays(rng, N, M)
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1)
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, Di).astype(np.float32) if Di else None
+    got, want = run_both(dev, pn, pd, dec, o, d, opts, u_c, u_f)
+    for k, g, w in zip(("rgb", "seg", "depth", "wsum"), got, want):
+        assert g.shape == w.shape
+        assert max_abs(g, w) <= TOL, k
+
+
+def test_all_rays_miss_the_volume(dev):
+    """Every sample falls outside the planes: features are zero, weights come from the biases only; the depth
+    clamp and nan_to_num (ray_marcher.py:93-94) must give finite numbers equal to the oracle's."""
+    rng = np.random.RandomState(5)
+    N, M, D = 1, 48, 10
+    pn = rng.randn(1, 3, 32, 8, 8).astype(np.float32)
+    dec = orc.random_decoder(3, bias_scale=0.0)
+    dec["geo_net.2.bias"][0] = -40.0                      # sigma -> softplus(-41) ~ 1e-18: weights underflow to 0
+    o, d = rays(rng, N, M, miss=True)
+    opts = dict(depth_resolution=D, depth_resolution_importance=0, ray_start=2.25, ray_end=3.3, box_warp=1)
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    got, want = run_both(dev, pn, pn, dec, o, d, opts, u_c)
+    assert np.isfinite(got[2]).all()
+    assert max_abs(got[2], want[2]) <= TOL and max_abs(got[3], want[3]) <= 1e-6
+    assert max_abs(got[0], want[0]) <= TOL
+
+
+def test_empty_point_query_and_bad_arguments(dev):
+    from nerffaceediting_amd import ops
+    rng = np.random.RandomState(1)
+    p = ops.plane_pack(t(rng.randn(1, 96, 8, 8), dev))
+    dec = orc.random_decoder(1)
+    decp = ops.decoder_pack(*[t(dec[k], dev) for k in NAMES])
+    out = ops.point_query(p, p, decp, torch.zeros(1, 0, 3, device=dev), 1.0)
+    assert out["rgb"].shape == (1, 0, 32) and out["sigma"].shape == (1, 0, 1)
+    o, d = rays(rng, 1, 8)
+    with pytest.raises(RuntimeError, match="importance sampling needs depth_resolution >= 4"):
+        ops.render(p, p, decp, dict(depth_resolution=3, depth_resolution_importance=2, ray_start=2.25, ray_end=3.3, box_warp=1),
+                   origins=t(o, dev), dirs=t(d, dev))
+    with pytest.raises(RuntimeError, match="out of"):
+        ops.render(p, p, decp, dict(depth_resolution=257, depth_resolution_importance=0, ray_start=2.25, ray_end=3.3, box_warp=1),
+                   origins=t(o, dev), dirs=t(d, dev))
+    with pytest.raises(AssertionError):
+        ops.render(p, p, decp, dict(depth_resolution=8, depth_resolution_importance=0, ray_start=2.25, ray_end=3.3, box_warp=1,
+                                    clamp_mode="relu"), origins=t(o, dev), dirs=t(d, dev))
