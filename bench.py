@@ -70,7 +70,7 @@ def cpu_baseline(planes_np, dec_np, c2w, K, opts, seed):
     u = orc.philox_uniform(R * R, D, seed, 0)[None]
     threads = c_oracle.max_threads()
     t0 = time.perf_counter()
-    c_oracle.render(norm, denorm, dec_np, o, d, opts, u)
+    c_oracle.render(norm, denorm, dec_np, o, d, opts, u, threads=0)
     dt = time.perf_counter() - t0
     return {"value": R * R / dt, "unit": "rays/s", "cores": threads, "kind": "port",
             "sample": f"1 of the {VIEWS_PER_GPU} views: {R * R} rays x {D} samples, oracle/render_oracle.c "

@@ -44,9 +44,12 @@ def max_threads():
 
 
 def render(norm_planes, denorm_planes, dec, origins, dirs, options, u_coarse, u_fine=None, ray_limits=None,
-           taps=False, threads=0):
-    """Same contract as oracle.render_oracle.render (scalar or per-ray limits; not the 'auto' keyword)."""
+           taps=False, threads=None):
+    """Same contract as oracle.render_oracle.render (scalar or per-ray limits; not the 'auto' keyword).
+    threads: None = min(host cores, 16) (checker use); 0 = every core OpenMP offers (bench cpu_baseline)."""
     lib = load()
+    if threads is None:
+        threads = min(os.cpu_count() or 1, 16)
     norm_planes, denorm_planes, origins, dirs = map(_f, (norm_planes, denorm_planes, origins, dirs))
     Np, _, _, H, W = norm_planes.shape
     N, M, _ = origins.shape
