@@ -8,6 +8,8 @@
 // (:288-300).  See DESIGN.md §4 for the lane mapping and the MFMA operand layouts.
 #include "nfe_common.h"
 
+#include <cstdlib>
+
 namespace nfe {
 
 // ------------------------------------------------------------------------------------------
@@ -34,14 +36,22 @@ struct RenderK {
     float* out_depths;             // optional [N*M, S]
     float* out_weights;            // optional [N*M, S-1]
     unsigned* depth_minmax;        // ordered-uint {min, max}
+    int no_patch;                  // debugging: disable LDS patch staging
 };
 
-// LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then AFF_FLOATS of view
-// affines per wave.
+// LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's waves, then one private region per wave.
+// Render kernel (8 waves, one block per CU): view affines | plane patch of the current depth step (§4.4) |
+// the previous sample's decoder outputs (mid-point rule), 157 KiB in all.  Point kernel (4 waves): affines only.
 constexpr int LDS_AFF = DEC_FLOATS;
 constexpr int AFF_FLOATS = 4 * 96;
-constexpr int WAVE_LDS_FLOATS = AFF_FLOATS;
-constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * WAVE_LDS_FLOATS) * 4;
+constexpr int PATCH_DIM = 8;                                  // 8 x 8 texels x 128 B = 8 KiB
+constexpr int PATCH_FLOATS = PATCH_DIM * PATCH_DIM * 32;
+constexpr int PREV_FLOATS = 6 * 4 * 64;                       // 6 float4 per lane: 16 rgb + 8 seg
+constexpr int RENDER_WAVES = 8;
+constexpr int WAVE_LDS_FLOATS = AFF_FLOATS + PATCH_FLOATS + PREV_FLOATS;
+constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + RENDER_WAVES * WAVE_LDS_FLOATS) * 4;
+constexpr int POINT_LDS_BYTES = (DEC_FLOATS + 4 * AFF_FLOATS) * 4;
+static_assert(RENDER_LDS_BYTES <= 160 * 1024, "render kernel LDS must fit one CU");
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -154,6 +164,92 @@ __device__ __forceinline__ void fetch_direct(const float* __restrict__ pg, const
 // and constants derived from it are recomputed at the point of use (a few VALU ops) instead of being hoisted
 // to the kernel prologue and spilled to scratch (which is what happens at 256 VGPRs otherwise).
 __device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ long long launder(long long v) { asm volatile("" : "+v"(v)); return v; }
+
+// ---- LDS patch staging ------------------------------------------------------------
+// The 32 samples a wave evaluates in one depth step are spatial neighbours (8x4 pixel tile, same depth
+// index), so their 128 taps on a plane fall on a few dozen distinct texels.  Instead of every lane pulling
+// its own 64 bytes per tap through the texture addresser (the measured bottleneck: ~30 cycles per
+// dwordx4 wave-instruction), the wave loads the bounding window of its taps ONCE with full-line loads
+// (8 lanes per 128-byte texel) into LDS in chunk-major order [16-byte chunk][texel], from which the taps
+// are read conflict-free (lanes on distinct texels hit consecutive 16-byte slots; equal texels broadcast).
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int pk16(int x, int y) { return (x & 0xffff) | (y << 16); }
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_pk_reduce_i16(int v) {
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {       // lanes j and j+32 hold equal values: 5 steps suffice
+        const int o = __shfl_xor(v, off);
+        const s16x2 a = *reinterpret_cast<const s16x2*>(&v), b = *reinterpret_cast<const s16x2*>(&o);
+        const s16x2 r = IS_MIN ? __builtin_elementwise_min(a, b) : __builtin_elementwise_max(a, b);
+        v = *reinterpret_cast<const int*>(&r);
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
+// Fills sg[] (this lane's 16 channels of the bilinear sample) through the LDS patch.  The bounding box of the
+// wave's taps is covered by 8x8-texel windows (one in the dense regime: 512^2 rays over 256^2 planes give a
+// ~5x7 box; sparse sampling takes several passes); each tap is taken from the window that contains it.
+__device__ __forceinline__ void fetch_patch(const float* __restrict__ pg, int W, const Taps& t, float* __restrict__ patch,
+                                            int lane, f32x2 (&sg)[8]) {
+    const int lo = wave_pk_reduce_i16<true>(pk16(t.xc0, t.yc0));
+    const int hi = wave_pk_reduce_i16<false>(pk16(t.xc1, t.yc1));
+    const int xmin = (short)(lo & 0xffff), ymin = lo >> 16, xmax = (short)(hi & 0xffff), ymax = hi >> 16;
+#pragma unroll
+    for (int c8 = 0; c8 < 8; ++c8) sg[c8] = splat(0.0f);
+    for (int wy = ymin; wy <= ymax; wy += PATCH_DIM) {
+        for (int wx = xmin; wx <= xmax; wx += PATCH_DIM) {
+            const int rows = min(PATCH_DIM, ymax - wy + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // cooperative load: lane -> (chunk c = lane>>3, texel column g = lane&7): the 8 lanes one ds_write_b128
+            // pass services write 8 consecutive 16-byte slots; a wave instruction covers 8 whole 128-byte texels.
+            {
+                const int ll = launder(lane);
+                const int c = ll >> 3, g = ll & 7;
+                const int col = (min(wx + g, W - 1)) * 32 + 4 * c;
+                float4* dst = reinterpret_cast<float4*>(patch) + c * 64 + g;
+                const int nrow = rows <= 4 ? 4 : 8;              // wave-uniform: 4 or 8 row loads
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    if (half * 4 < nrow) {
+                        float4 v[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int row = wy + min(half * 4 + i, rows - 1);
+                            v[i] = *reinterpret_cast<const float4*>(pg + (unsigned)(row * W * 32 + col));
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) dst[(half * 4 + i) * 8] = v[i];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // the stores have landed (s_waitcnt)
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            __builtin_amdgcn_sched_barrier(0);
+            // taps from LDS: chunk (4h + q) of texel index ty*8 + tx; taps outside this window contribute 0
+            const int h4 = (launder(lane) >> 5) * 4;
+            const float4* pl = reinterpret_cast<const float4*>(patch) + h4 * 64;
+            const int xs[4] = {t.xc0, t.xc1, t.xc0, t.xc1}, ys[4] = {t.yc0, t.yc0, t.yc1, t.yc1};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int tx = xs[k] - wx, ty = ys[k] - wy;
+                const bool in = (unsigned)tx < (unsigned)PATCH_DIM && (unsigned)ty < (unsigned)PATCH_DIM;
+                const f32x2 w2 = splat(in ? t.w[k] : 0.0f);
+                const int ti = in ? ty * 8 + tx : 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 a = pl[q * 64 + ti];
+                    sg[2 * q + 0] = pk_fma(w2, f32x2{a.x, a.y}, sg[2 * q + 0]);
+                    sg[2 * q + 1] = pk_fma(w2, f32x2{a.z, a.w}, sg[2 * q + 1]);
+                }
+                if (k & 1) __builtin_amdgcn_sched_barrier(0);       // two taps (8 x 16 B) of LDS reads in flight
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");  // reads retire before the next window's writes
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
 
 // ---- decoder, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) ---------------------------------------------
 // FC 32->64, softplus, FC 64->32 rows; weights are the A operand (LDS), the per-point vectors are the
@@ -282,10 +378,10 @@ __device__ __forceinline__ void mlp_bf16(const float* __restrict__ lds, const f3
 //   og[0] = sigma; og[2..] = seg channels (h=0: seg 0..7 in og[2..9]; h=1: seg 8..14 in og[2..8]); og[1] unused
 //   (seg starts on an even register so packed-fp32 pairs need no realigning moves)
 //   oa[r] = rgb channel 16h + r   (after the sigmoid clamp, triplane.py:269)
-template <bool DUAL, bool SIGMA_ONLY, int MATH>
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool USE_PATCH>
 __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const float* __restrict__ pa,
                                            int H, int W, const float* __restrict__ lds,
-                                           const float* __restrict__ aff,
+                                           const float* __restrict__ aff, float* __restrict__ patch,
                                            float gx, float gy, float gz,
                                            int lane, f32x16& og, f32x16& oa) {
     f32x2 fn[8], fd[8];
@@ -301,7 +397,11 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
         const int hoff = (launder(lane) >> 5) * 16;
         const Taps tp = tap_geometry(H, W, u, v);
         constexpr bool TWO_SETS = DUAL && !SIGMA_ONLY;
-        fetch_direct<TWO_SETS, TWO_SETS ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, W, tp, hoff, sg, sa);
+        if (!TWO_SETS && USE_PATCH) fetch_patch(pg + p * plane_elems, W, tp, patch, lane, sg);
+        else fetch_direct<TWO_SETS, TWO_SETS ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, W, tp, hoff, sg, sa);
+        // The affine coefficients are read only now: hoisted above the patch phase (whose fences pin LDS reads)
+        // they would sit in 64 VGPRs for its whole duration.
+        __builtin_amdgcn_sched_barrier(0);
         const f32x2 w2 = splat(tp.wsum);
         const float4* gs = reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + hoff);
         const float4* gb = reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + hoff);
@@ -343,14 +443,15 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
 template <int MATH>
 __device__ __forceinline__ void stage_decoder(const float* __restrict__ dec, float* lds) {
     const float4* frag = reinterpret_cast<const float4*>(dec + (MATH == NFE_MATH_FP32 ? 0 : DEC_BF16));
-    for (int i = threadIdx.x; i < DEC_B_G0 / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = frag[i];
+    for (int i = threadIdx.x; i < DEC_B_G0 / 4; i += blockDim.x) reinterpret_cast<float4*>(lds)[i] = frag[i];
     const float4* bias = reinterpret_cast<const float4*>(dec + DEC_B_G0);
-    for (int i = threadIdx.x; i < (DEC_FLOATS - DEC_B_G0) / 4; i += 256) reinterpret_cast<float4*>(lds + DEC_B_G0)[i] = bias[i];
+    for (int i = threadIdx.x; i < (DEC_FLOATS - DEC_B_G0) / 4; i += blockDim.x) reinterpret_cast<float4*>(lds + DEC_B_G0)[i] = bias[i];
 }
 
 // Stage this wave's view affines into its LDS region, folding in the 1/3 of the mean over planes
 // (triplane.py:251-252).
 __device__ __forceinline__ void stage_affine(const float* const (&src)[4], int n, float* aff, int lane) {
+    lane = launder(lane);          // runs once per view: keep its addresses out of the kernel prologue
 #pragma unroll
     for (int arr = 0; arr < 4; ++arr) {
         const float* p = src[arr];
@@ -364,24 +465,26 @@ __device__ __forceinline__ void stage_affine(const float* const (&src)[4], int n
 }
 
 template <bool DUAL, bool SIGMA_ONLY, int MATH>
-__global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
+__global__ __launch_bounds__(64 * RENDER_WAVES, 2) void render_kernel(RenderK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_decoder<MATH>(P.dec, lds);
     // wave id in an SGPR: everything derived from it (ray block, view, plane base) stays scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     float* aff = lds + LDS_AFF + wave * WAVE_LDS_FLOATS;
+    float* patch = aff + AFF_FLOATS;      // (the window reduction packs coordinates in 16 bits: planes up to 16384^2, checked on host)
+    float4* const prev_base = reinterpret_cast<float4*>(aff + AFF_FLOATS + PATCH_FLOATS);  // [6][64 lanes] float4
     __syncthreads();
 
     const int S = P.S;
     const int blocks_per_view = (P.M + 31) >> 5;
     const long long total_rb = (long long)P.N * blocks_per_view;
-    const long long n_waves = (long long)gridDim.x * 4;
+    const long long n_waves = (long long)gridDim.x * RENDER_WAVES;
     int cur_view = -1;
     float tmin = INFINITY, tmax = -INFINITY;
 
 #pragma unroll 1
-    for (long long rb = (long long)blockIdx.x * 4 + wave; rb < total_rb; rb += n_waves) {
+    for (long long rb = (long long)blockIdx.x * RENDER_WAVES + wave; rb < total_rb; rb += n_waves) {
         const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
         if (n != cur_view) { stage_affine(P.aff, n, aff, lane); cur_view = n; }
 
@@ -399,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
         const bool valid = m < P.M;
         m = min(m, P.M - 1);
         const long long ray = (long long)n * P.M + m;
+        const long long ray_ = ray; const int m_ = m;
         float ox, oy, oz, dx, dy, dz;
         if (P.origins) {
             const float* o = P.origins + ray * 3; const float* d = P.dirs + ray * 3;
@@ -429,23 +533,25 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
         const float delta = (re - rs) / (float)(S - 1);
 
         // ---- march state (SegMipRayMarcher2.run_forward, ray_marcher.py:68-101) --------------
-        f32x2 acc_rgb[8], acc_seg[4], prev_rgb[8], prev_seg[4];
+        // The previous sample's rgb/seg (needed by the mid-point rule) live in LDS, not in 24 VGPRs: written at
+        // the end of a step, read back at the march of the next one.
+        f32x2 acc_rgb[8], acc_seg[4];
         float acc_d = 0.0f, acc_w = 0.0f, T = 1.0f, prev_t = 0.0f, prev_sig = 0.0f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { acc_rgb[c] = splat(0.0f); prev_rgb[c] = splat(0.0f); }
+        for (int c = 0; c < 8; ++c) acc_rgb[c] = splat(0.0f);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { acc_seg[c] = splat(0.0f); prev_seg[c] = splat(0.0f); }
+        for (int c = 0; c < 4; ++c) acc_seg[c] = splat(0.0f);
         u32x4 rnd = {0, 0, 0, 0};
 
 #pragma unroll 1
         for (int k = 0; k < S; ++k) {
             float t;
             if (P.depth_mode == DEPTH_BUFFER) {
-                t = P.depth_buf[ray * S + k];
+                t = P.depth_buf[launder(ray) * S + k];
             } else {
                 float u;
                 if (P.u) {
-                    u = P.u[ray * S + k];
+                    u = P.u[launder(ray) * S + k];
                 } else {
                     if ((k & 3) == 0)
                         rnd = philox4x32_10((unsigned)ray, (unsigned)(k >> 2), 0u, 0u,
@@ -462,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                     t = fmaf((float)k, delta, rs) + u * delta;
                 }
             }
-            if (P.out_depths && valid && h == 0) P.out_depths[ray * S + k] = t;
+            if (P.out_depths && valid && (launder(lane) >> 5) == 0) P.out_depths[launder(ray) * S + k] = t;
             tmin = fminf(tmin, t); tmax = fmaxf(tmax, t);
 
             const float gx = P.coord_scale * fmaf(t, dx, ox);
@@ -473,7 +579,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             // would pin >200 VGPRs per lane and spill.
             int opq;
             asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
-            eval_point<DUAL, SIGMA_ONLY, MATH>(pg, pa, P.H, P.W, lds + opq, aff + opq, gx, gy, gz, lane, og, oa);
+            eval_point<DUAL, SIGMA_ONLY, MATH, true>(pg, pa, P.H, P.W, lds + opq, aff + opq, patch, gx, gy, gz, lane, og, oa);
 
             if (k > 0) {
                 const float dlt = t - prev_t;
@@ -481,30 +587,42 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                 const float alpha = 1.0f - exp2_fast(-(dens * dlt) * LOG2E);
                 const float w = alpha * T;
                 T = T * (1.0f - alpha + 1e-10f);
-                if (P.out_weights && valid && h == 0) P.out_weights[ray * (S - 1) + (k - 1)] = w;
+                if (P.out_weights && valid && (launder(lane) >> 5) == 0) P.out_weights[launder(ray) * (S - 1) + (k - 1)] = w;
                 if (!SIGMA_ONLY) {
+                    const float4* prev = prev_base + launder(lane);
                     const f32x2 wh = splat(w * 0.5f);      // w * (a + b)/2 == (w/2) * (a + b), exactly
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        acc_rgb[c] = pk_fma(wh, prev_rgb[c] + f32x2{oa[2 * c], oa[2 * c + 1]}, acc_rgb[c]);
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 pv = prev[q * 64];
+                        acc_rgb[2 * q] = pk_fma(wh, f32x2{pv.x, pv.y} + f32x2{oa[4 * q], oa[4 * q + 1]}, acc_rgb[2 * q]);
+                        acc_rgb[2 * q + 1] = pk_fma(wh, f32x2{pv.z, pv.w} + f32x2{oa[4 * q + 2], oa[4 * q + 3]}, acc_rgb[2 * q + 1]);
+                    }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc_seg[c] = pk_fma(wh, prev_seg[c] + f32x2{og[2 + 2 * c], og[3 + 2 * c]}, acc_seg[c]);
+                    for (int q = 0; q < 2; ++q) {
+                        const float4 pv = prev[(4 + q) * 64];
+                        acc_seg[2 * q] = pk_fma(wh, f32x2{pv.x, pv.y} + f32x2{og[2 + 4 * q], og[3 + 4 * q]}, acc_seg[2 * q]);
+                        acc_seg[2 * q + 1] = pk_fma(wh, f32x2{pv.z, pv.w} + f32x2{og[4 + 4 * q], og[5 + 4 * q]}, acc_seg[2 * q + 1]);
+                    }
                     acc_d = fmaf(w, (prev_t + t) * 0.5f, acc_d);
                     acc_w += w;
                 }
             }
             prev_t = t; prev_sig = og[0];
             if (!SIGMA_ONLY) {
+                float4* prev = prev_base + launder(lane);
 #pragma unroll
-                for (int c = 0; c < 8; ++c) prev_rgb[c] = f32x2{oa[2 * c], oa[2 * c + 1]};
+                for (int q = 0; q < 4; ++q) prev[q * 64] = make_float4(oa[4 * q], oa[4 * q + 1], oa[4 * q + 2], oa[4 * q + 3]);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) prev_seg[c] = f32x2{og[2 + 2 * c], og[3 + 2 * c]};
+                for (int q = 0; q < 2; ++q) prev[(4 + q) * 64] = make_float4(og[2 + 4 * q], og[3 + 4 * q], og[4 + 4 * q], og[5 + 4 * q]);
             }
         }
 
         // ---- outputs -------------------------------------------------------------------------
         if (!SIGMA_ONLY && valid) {
+            // ray / lane / pixel index laundered: output addresses are formed here, not hoisted above the
+            // depth loop where they would be held (or spilled) for its whole duration
+            const long long ray = launder(ray_), n_ll = launder((long long)n);
+            const int h = launder(lane) >> 5, m = launder(m_);
             const float wb = P.white_back ? (1.0f - acc_w) : 0.0f;
             float rgbv[16], segv[8];
 #pragma unroll
@@ -517,10 +635,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             const int nseg = h ? 7 : 8;
             if (P.channels_first) {
 #pragma unroll
-                for (int c = 0; c < 16; ++c) P.rgb[((long long)n * 32 + 16 * h + c) * P.M + m] = rgbv[c];
+                for (int c = 0; c < 16; ++c) P.rgb[(n_ll * 32 + 16 * h + c) * P.M + m] = rgbv[c];
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    if (c < nseg) P.seg[((long long)n * 15 + 8 * h + c) * P.M + m] = segv[c];
+                    if (c < nseg) P.seg[(n_ll * 15 + 8 * h + c) * P.M + m] = segv[c];
             } else {
                 float4* o = reinterpret_cast<float4*>(P.rgb + ray * 32 + 16 * h);
 #pragma unroll
@@ -698,7 +816,7 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
     stage_decoder<MATH>(P.dec, lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
-    float* aff = lds + LDS_AFF + wave * WAVE_LDS_FLOATS;
+    float* aff = lds + LDS_AFF + wave * AFF_FLOATS;
     __syncthreads();
     const int blocks_per_view = (P.Pn + 31) >> 5;
     const long long total = (long long)P.N * blocks_per_view;
@@ -712,8 +830,8 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
         const long long pt = (long long)n * P.Pn + m;
         const float* c = P.coords + pt * 3;
         f32x16 og, oa;
-        eval_point<DUAL, false, MATH>(P.planes_g + (long long)n * P.plane_view_stride,
-                                P.planes_a + (long long)n * P.plane_view_stride, P.H, P.W, lds, aff,
+        eval_point<DUAL, false, MATH, false>(P.planes_g + (long long)n * P.plane_view_stride,
+                                P.planes_a + (long long)n * P.plane_view_stride, P.H, P.W, lds, aff, nullptr,
                                 P.coord_scale * c[0], P.coord_scale * c[1], P.coord_scale * c[2], lane, og, oa);
         if (valid) {
             float4* o = reinterpret_cast<float4*>(P.rgb + pt * 32 + 16 * h);
@@ -749,16 +867,20 @@ static void allow_lds(K kernel, int bytes) {
 
 template <bool DUAL, bool SIGMA_ONLY>
 static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_t st) {
-    if (math == NFE_MATH_FP32)
-        hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
-    else
-        hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+    // > 64 KiB of dynamic LDS has to be enabled per kernel (idempotent, cheap)
+    if (math == NFE_MATH_FP32) {
+        allow_lds(render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>, RENDER_LDS_BYTES);
+        hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(64 * RENDER_WAVES), RENDER_LDS_BYTES, st, P);
+    } else {
+        allow_lds(render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>, RENDER_LDS_BYTES);
+        hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(64 * RENDER_WAVES), RENDER_LDS_BYTES, st, P);
+    }
 }
 
 static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math, hipStream_t st) {
     const long long total_rb = (long long)P.N * ((P.M + 31) / 32);
-    long long blocks = (total_rb + 3) / 4;
-    const long long cap = (long long)num_cus() * 2;      // 2 blocks (8 waves) per CU, grid-stride beyond
+    long long blocks = (total_rb + RENDER_WAVES - 1) / RENDER_WAVES;
+    const long long cap = (long long)num_cus();            // one 8-wave block per CU (157 KiB of LDS), grid-stride beyond
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks);
     if (sigma_only) {
@@ -837,6 +959,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     const int mode = a->ray_start_per_ray ? DEPTH_PER_RAY : (a->disparity_space_sampling ? DEPTH_DISPARITY : DEPTH_STRATIFIED);
     const bool dual = a->planes_geo != a->planes_app;
     const int math = a->decoder_math;
+    P.no_patch = getenv("NFE_NO_PATCH") != nullptr;
 
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, minmax);
     NFE_CHECK_LAUNCH("minmax_init_kernel");
@@ -910,11 +1033,11 @@ extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app,
     const bool dual = planes_geo != planes_app;
     dim3 grid((unsigned)blocks), block(256);
     if (decoder_math == NFE_MATH_FP32) {
-        if (dual) hipLaunchKernelGGL((point_kernel<true, NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);
-        else hipLaunchKernelGGL((point_kernel<false, NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);
+        if (dual) hipLaunchKernelGGL((point_kernel<true, NFE_MATH_FP32>), grid, block, POINT_LDS_BYTES, st, P);
+        else hipLaunchKernelGGL((point_kernel<false, NFE_MATH_FP32>), grid, block, POINT_LDS_BYTES, st, P);
     } else {
-        if (dual) hipLaunchKernelGGL((point_kernel<true, NFE_MATH_BF16X3>), grid, block, RENDER_LDS_BYTES, st, P);
-        else hipLaunchKernelGGL((point_kernel<false, NFE_MATH_BF16X3>), grid, block, RENDER_LDS_BYTES, st, P);
+        if (dual) hipLaunchKernelGGL((point_kernel<true, NFE_MATH_BF16X3>), grid, block, POINT_LDS_BYTES, st, P);
+        else hipLaunchKernelGGL((point_kernel<false, NFE_MATH_BF16X3>), grid, block, POINT_LDS_BYTES, st, P);
     }
     NFE_CHECK_LAUNCH("point_kernel");
     return NFE_OK;
