@@ -132,6 +132,8 @@ typedef struct nfe_render_args {
     const float* u_coarse;             /* [N,M,D]   or NULL */
     const float* u_fine;               /* [N*M,Di]  or NULL */
     uint64_t seed;
+    const uint64_t* seed_device;       /* optional: read the Philox key from device memory instead (lets a
+                                          captured hipGraph draw new jitter per replay); NULL = use `seed` */
     /* outputs */
     float* rgb;                        /* [N,M,32]  (or [N,32,M] if channels_first) */
     float* seg;                        /* [N,M,15]  (or [N,15,M]) */

@@ -32,7 +32,7 @@ class RenderArgs(ctypes.Structure):
         ("ray_start_per_ray", FP), ("ray_end_per_ray", FP),
         ("disparity_space_sampling", c_int32),
         ("box_warp", c_float), ("white_back", c_int32),
-        ("u_coarse", FP), ("u_fine", FP), ("seed", c_uint64),
+        ("u_coarse", FP), ("u_fine", FP), ("seed", c_uint64), ("seed_device", FP),
         ("rgb", FP), ("seg", FP), ("depth", FP), ("wsum", FP),
         ("channels_first", c_int32),
         ("tap_weights_coarse", FP), ("tap_depths_fine", FP), ("tap_depths_all", FP),

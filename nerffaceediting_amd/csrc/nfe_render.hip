@@ -26,7 +26,7 @@ struct RenderK {
     int depth_mode;
     float ray_start, ray_end;
     const float* rs_ray; const float* re_ray;
-    const float* u; unsigned long long seed;
+    const float* u; unsigned long long seed; const unsigned long long* seed_dev;
     const float* depth_buf;        // DEPTH_BUFFER: [N*M, S]
     float coord_scale;             // 2 / box_warp
     int white_back;
@@ -374,6 +374,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     __syncthreads();
 
     const int S = P.S;
+    const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
     const int blocks_per_view = (P.M + 31) >> 5;
     const long long total_rb = (long long)P.N * blocks_per_view;
     const long long n_waves = (long long)gridDim.x * 4;
@@ -449,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                 } else {
                     if ((k & 3) == 0)
                         rnd = philox4x32_10((unsigned)ray, (unsigned)(k >> 2), 0u, 0u,
-                                            (unsigned)P.seed, (unsigned)(P.seed >> 32));
+                                            (unsigned)seed, (unsigned)(seed >> 32));
                     unsigned bits = (k & 3) == 0 ? rnd.x : (k & 3) == 1 ? rnd.y : (k & 3) == 2 ? rnd.z : rnd.w;
                     u = u01(bits);
                 }
@@ -573,7 +574,7 @@ struct ImportanceK {
     const float* t_coarse;   // [NR, D]
     const float* w_coarse;   // [NR, D-1]
     const float* u_fine;     // [NR, Di] or null
-    unsigned long long seed;
+    unsigned long long seed; const unsigned long long* seed_dev;
     long long n_rays_total;
     int D, Di;
     float* t_all;            // [NR, D+Di] sorted ascending
@@ -642,8 +643,9 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
             if (P.u_fine) {
                 u = P.u_fine[ray * Di + e];
             } else {
+                const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
                 u32x4 r = philox4x32_10((unsigned)ray, (unsigned)(e >> 2), 1u, 0u,
-                                        (unsigned)P.seed, (unsigned)(P.seed >> 32));
+                                        (unsigned)seed, (unsigned)(seed >> 32));
                 unsigned bits = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
                 u = u01(bits);
             }
@@ -833,7 +835,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.coord_scale = 2.0f / a->box_warp;
     P.white_back = a->white_back;
     P.rgb = a->rgb; P.seg = a->seg; P.depth = a->depth; P.wsum = a->wsum; P.channels_first = a->channels_first;
-    P.seed = a->seed;
+    P.seed = a->seed; P.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device);
     const int mode = a->ray_start_per_ray ? DEPTH_PER_RAY : (a->disparity_space_sampling ? DEPTH_DISPARITY : DEPTH_STRATIFIED);
     const bool dual = a->planes_geo != a->planes_app;
     const int math = a->decoder_math;
@@ -862,7 +864,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         }
         // pass 2: importance sampling + merge
         ImportanceK I{};
-        I.t_coarse = t_c; I.w_coarse = w_c; I.u_fine = a->u_fine; I.seed = a->seed; I.n_rays_total = (long long)nr;
+        I.t_coarse = t_c; I.w_coarse = w_c; I.u_fine = a->u_fine; I.seed = a->seed; I.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device); I.n_rays_total = (long long)nr;
         I.D = D; I.Di = Di; I.t_all = t_all; I.tap_fine = a->tap_depths_fine;
         const int lds_bytes = 4 * (3 * D + Di) * 4;
         long long blocks = ((long long)nr + 3) / 4;

@@ -40,6 +40,8 @@ def _math_mode(mode):
 
 
 def _workspace(device, nbytes):
+    if torch.cuda.is_current_stream_capturing():          # graph capture: memory must come from the graph's pool
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(key)
     if ws is None or ws.numel() < nbytes:
@@ -216,7 +218,12 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
         u_fine = _dev(u_fine, "u_fine").reshape(N * M, Di)
         a.u_fine = u_fine.data_ptr()
     keep += [u_coarse, u_fine]
-    a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    if isinstance(seed, torch.Tensor):           # device-resident key (int64 [1]): graph-replay friendly
+        assert seed.dtype == torch.int64 and seed.numel() == 1 and seed.device == dev
+        a.seed_device = seed.data_ptr()
+        keep.append(seed)
+    else:
+        a.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
     rgb = torch.empty((N, 32, M) if channels_first else (N, M, 32), device=dev)
     seg = torch.empty((N, 15, M) if channels_first else (N, M, 15), device=dev)
     depth = torch.empty(N, M, 1, device=dev)

@@ -28,6 +28,7 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         self.keep_taps = False
         self.last_taps = None
         self.decoder_math = None          # None -> split-bf16 MFMA; 'fp32' -> exact fp32 MFMA
+        self.seed_tensor = None
 
     # -- parity hook ---------------------------------------------------------------------------------
     def inject_jitter(self, u_coarse, u_fine=None):
@@ -40,8 +41,11 @@ class DisentangledImportanceRenderer(torch.nn.Module):
             j = (options["jitter_coarse"], options.get("jitter_fine"))
         return j if j is not None else (None, None)
 
-    @staticmethod
-    def _seed():
+    def _seed(self):
+        """Philox key of this call: a host integer drawn from torch's CPU generator, or — when `seed_tensor`
+        (device int64 [1]) is set, e.g. by graphs.GraphedSynthesis — a device-resident key the kernels read."""
+        if self.seed_tensor is not None:
+            return self.seed_tensor
         return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
     @staticmethod

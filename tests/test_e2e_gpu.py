@@ -112,3 +112,29 @@ def test_render_views_and_density_grid(setup):
     want = G.sample_mixed(torch.tensor([[[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]]], device=dev), None, ws, noise_mode="const")["sigma"]
     assert abs(float(sig[0, 0, 0]) - float(want[0, 0, 0])) <= 1e-5 and abs(float(sig[-1, -1, -1]) - float(want[0, 1, 0])) <= 1e-5
     del b
+
+
+def test_graphed_synthesis_matches_eager(setup):
+    """hipGraph replay == eager synthesis (same Philox key), and new inputs take effect on replay."""
+    from nerffaceediting_amd.graphs import GraphedSynthesis
+    G, z, dev = setup
+    ws, c = t(z["ws"], dev), t(z["c"], dev)
+    g = GraphedSynthesis(G, batch=2, neural_rendering_resolution=32, noise_mode="const")
+    seed = 777
+    out = {k: v.clone() for k, v in g(ws, c, seed=seed).items()}
+    G.renderer.seed_tensor = torch.tensor([seed], dtype=torch.int64, device=dev)
+    try:
+        eager = G.synthesis(ws, c, neural_rendering_resolution=32, noise_mode="const")
+    finally:
+        G.renderer.seed_tensor = None
+    for k in ("image", "image_raw", "image_seg", "image_depth"):
+        assert torch.equal(out[k], eager[k]), k
+    out2 = {k: v.clone() for k, v in g(ws.flip(0), c.flip(0), seed=seed).items()}        # new inputs take effect
+    G.renderer.seed_tensor = torch.tensor([seed], dtype=torch.int64, device=dev)
+    try:
+        eager2 = G.synthesis(ws.flip(0).contiguous(), c.flip(0).contiguous(), neural_rendering_resolution=32, noise_mode="const")
+    finally:
+        G.renderer.seed_tensor = None
+    assert torch.equal(out2["image"], eager2["image"]) and not torch.equal(out2["image"], out["image"])
+    out3 = g(ws, c, seed=seed + 1)
+    assert not torch.equal(out3["image_raw"], out["image_raw"])

@@ -47,3 +47,7 @@ t_sr, _ = timed(lambda: G.superresolution.forward_nhwc(feat[..., :3].contiguous(
 print(f"N={N} R={R} D={D}+{Di} math={math}: mapping {t_map:.2f} ms, backbone {t_bb:.2f} ms, SR {t_sr:.2f} ms, synthesis total {t_all:.2f} ms "
       f"-> {N / t_all * 1e3:.1f} views/s; backbone {46.55 * 2 * N / t_bb:.1f} TFLOP/s, SR {98.0 * 2 * N / t_sr:.1f} TFLOP/s (algorithmic)")
 print("finite:", bool(torch.isfinite(out["image"]).all()), out["image"].shape)
+from nerffaceediting_amd.graphs import GraphedSynthesis
+g = GraphedSynthesis(G, batch=N, neural_rendering_resolution=R, noise_mode="const")
+t_graph, _ = timed(lambda: g(ws, c))
+print(f"  hipGraph replay of synthesis: {t_graph:.2f} ms -> {N / t_graph * 1e3:.1f} views/s")
