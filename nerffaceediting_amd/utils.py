@@ -1,0 +1,104 @@
+"""demo.ipynb helpers with the reference's names (utils.py:32-88,146-199): encode / decode tri-planes,
+normalise / denormalise them (appearance transfer = swapping mean/std between identities), and the orbit of
+`render_video`.  File writing (imageio) is out of scope: `render_video_frames` returns the uint8 frames."""
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import dense_ops, ops, sharding
+from .camera_utils import FOV_to_intrinsics, LookAtPoseSampler
+
+
+def _stats5(planes):
+    N, P, C, H, W = planes.shape
+    mean, var = ops.plane_stats(planes.reshape(N, P * C, H, W))
+    return mean.reshape(N, P, C, 1, 1), var.reshape(N, P, C, 1, 1)
+
+
+def compute_mean_var(planes):
+    """utils.py:146-150 on (N,3,C,H,W) planes."""
+    return _stats5(planes)
+
+
+def normalize_plane(planes):
+    """utils.py:152-155."""
+    N, P, C, H, W = planes.shape
+    mean, var = _stats5(planes)
+    gs, gb, _, _ = ops.make_affine(mean.reshape(N, P * C, 1, 1), var.reshape(N, P * C, 1, 1))
+    out = ops.plane_affine(planes.reshape(N, P * C, H, W), gs.reshape(N, P * C, 1, 1), gb.reshape(N, P * C, 1, 1))
+    return out.reshape(N, P, C, H, W), mean, var
+
+
+def denormalize_plane(planes, mean, var):
+    """utils.py:157-158."""
+    N, P, C, H, W = planes.shape
+    out = ops.plane_affine(planes.reshape(N, P * C, H, W), var.reshape(-1, P * C, 1, 1).contiguous(),
+                           mean.reshape(-1, P * C, 1, 1).contiguous())
+    return out.reshape(N, P, C, H, W)
+
+
+def encode(G, ws, **synthesis_kwargs):
+    """utils.py:160-163: ws -> planes (N,3,32,256,256)."""
+    planes = G.backbone.synthesis(ws, **synthesis_kwargs)
+    return planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
+
+
+def decode(G, ws, cam, norm_planes, denorm_planes, **synthesis_kwargs):
+    """utils.py:165-199: render (possibly edited) planes from camera(s) `cam` [N,25].  One plane set may serve
+    several cameras (planes batch 1, N cameras)."""
+    cam2world_matrix = cam[:, :16].reshape(-1, 4, 4).contiguous()
+    intrinsics = cam[:, 16:25].reshape(-1, 3, 3).contiguous()
+    R = G.neural_rendering_resolution
+    ray_origins, ray_directions = G.ray_sampler(cam2world_matrix, intrinsics, R)
+    N = ray_origins.shape[0]
+    feature_samples, seg_samples, depth_samples, _ = G.renderer(norm_planes, denorm_planes, G.decoder, ray_origins,
+                                                                ray_directions, G.rendering_kwargs)
+    feat = feature_samples.view(N, R, R, 32)                      # NHWC already
+    rgb = feat[..., :3].contiguous()
+    if ws.shape[0] == 1 and N > 1:
+        ws = ws.expand(N, -1, -1).contiguous()
+    sr = G.superresolution.forward_nhwc(rgb, feat, ws, noise_mode=G.rendering_kwargs["superresolution_noise_mode"],
+                                        **{k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"})
+    return {"image_raw": dense_ops.nhwc_to_nchw(rgb), "image": dense_ops.nhwc_to_nchw(sr),
+            "image_depth": depth_samples.permute(0, 2, 1).reshape(N, 1, R, R),
+            "image_seg": dense_ops.nhwc_to_nchw(seg_samples.view(N, R, R, 15))}
+
+
+def video_camera_schedule(frames=150, a_degree=15.0, b_degree=12.0, init_pitch=5 * np.pi / 12, init_yaw=np.pi / 2):
+    """The (pitch, yaw) list of utils.render_video (utils.py:45-73)."""
+    frames_interp = frames // 4
+    a, b = a_degree / 180 * np.pi, b_degree / 180 * np.pi
+    start_pitch, start_yaw = np.pi / 2 - a, np.pi / 2
+    sched = []
+    if start_pitch != init_pitch:
+        for index in range(frames_interp):
+            ratio = index / (frames_interp - 1)
+            sched.append((start_pitch * ratio + init_pitch * (1 - ratio), start_yaw * ratio + init_yaw * (1 - ratio)))
+    for index in range(frames):
+        theta = index / (frames - 1) * 2 * np.pi
+        sched.append((np.pi / 2 - a * np.cos(theta), np.pi / 2 + b * np.sin(theta)))
+    return sched
+
+
+@torch.no_grad()
+def render_video_frames(G, ws, norm_planes, denorm_planes, frames=150, a_degree=15.0, b_degree=12.0,
+                        init_pitch=5 * np.pi / 12, init_yaw=np.pi / 2, batch=4):
+    """utils.render_video (utils.py:32-88) without the mp4 writer: uint8 frames [F,512,512,3].  Cameras are
+    batched, and sharded over torch.distributed ranks when a process group is up (one plane set, many cameras)."""
+    dev = ws.device
+    intrinsics = FOV_to_intrinsics(18.837, device=dev)
+    pivot = torch.tensor(G.rendering_kwargs.get("avg_camera_pivot", [0, 0, 0]), device=dev, dtype=torch.float32)
+    radius = G.rendering_kwargs.get("avg_camera_radius", 2.7)
+    sched = video_camera_schedule(frames, a_degree, b_degree, init_pitch, init_yaw)
+    cams = torch.cat([torch.cat([LookAtPoseSampler.sample(p, y, pivot, radius=radius, device=dev).reshape(-1, 16),
+                                 intrinsics.reshape(-1, 9)], 1) for p, y in sched], 0)
+    V = cams.shape[0]
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    a, b = sharding.shard_range(V, rank, world)
+    out = []
+    for i in range(a, b, batch):
+        img = decode(G, ws, cams[i:min(b, i + batch)], norm_planes, denorm_planes, noise_mode="const")["image"]
+        img = torch.round((img + 1) * (255 / 2)).clamp(0, 255).to(torch.uint8)          # utils.py:81-83
+        out.append(img.permute(0, 2, 3, 1))
+    local = torch.cat(out, 0) if out else torch.zeros(0, G.img_resolution, G.img_resolution, 3, dtype=torch.uint8, device=dev)
+    return sharding.all_gather_frames(local, V) if world > 1 else local

@@ -138,3 +138,30 @@ def test_graphed_synthesis_matches_eager(setup):
     assert torch.equal(out2["image"], eager2["image"]) and not torch.equal(out2["image"], out["image"])
     out3 = g(ws, c, seed=seed + 1)
     assert not torch.equal(out3["image_raw"], out["image_raw"])
+
+
+def test_demo_helpers_encode_decode(setup):
+    """utils.encode -> normalize -> decode reproduces synthesis(); swapping statistics between the two
+    identities reproduces the (int,int) appearance override."""
+    from nerffaceediting_amd import utils as U
+    G, z, dev = setup
+    ws, c = t(z["ws"], dev), t(z["c"], dev)
+    uc, uf = t(z["u_coarse"], dev), t(z["u_fine"], dev)
+    G.neural_rendering_resolution = int(z["R"])
+    planes = U.encode(G, ws, noise_mode="const")
+    assert planes.shape == (2, 3, 32, 256, 256)
+    norm, mean, var = U.normalize_plane(planes)
+    assert err(mean.reshape(2, 96, 1, 1), z["plain.plane_mean"]) <= 1e-4 and err(var.reshape(2, 96, 1, 1), z["plain.plane_var"]) <= 1e-4
+    G.renderer.inject_jitter(uc, uf)
+    out = U.decode(G, ws, c, norm, planes, noise_mode="const")
+    for k in ("image_raw", "image_seg", "image_depth"):
+        assert err(out[k], z["plain." + k]) <= TOL, k
+    assert err(out["image"][:, :, ::4, ::4], z["plain.image_s4"]) <= TOL
+    swapped = U.denormalize_plane(norm, mean[1:2], var[0:1])              # == planes_mean=1, planes_var=0
+    G.renderer.inject_jitter(uc, uf)
+    out = U.decode(G, ws, c, norm, swapped, noise_mode="const")
+    assert err(out["image_raw"], z["swap.image_raw"]) <= TOL
+    # default start pose == orbit start (pi/2 - 15deg == 5pi/12): no lead-in frames; another init pose adds frames//4
+    frames = U.render_video_frames(G, ws[:1], norm[:1], planes[:1], frames=4, batch=3)
+    assert frames.shape == (4, 512, 512, 3) and frames.dtype == torch.uint8
+    assert len(U.video_camera_schedule(8, init_pitch=1.0)) == 10

@@ -4,11 +4,12 @@
 set -u
 OUT=gpurun_out/${1:-pmc}; shift || true
 ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
+PROG=${PMC_PROG:-bench.py}          # PMC_PROG=tools/time_full.py tools/pmc.sh out 4 128 48 48 bf16x3
 export TMPDIR=/tmp
 mkdir -p $OUT
 pass() {
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py $ARGS > $OUT/$name.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $PROG $ARGS > $OUT/$name.log 2>&1
   echo "pass $name rc=$?"
 }
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES
