@@ -36,11 +36,12 @@ struct RenderK {
     unsigned* depth_minmax;        // ordered-uint {min, max}
 };
 
-// LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then AFF_FLOATS of view
-// affines per wave.
+// LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then per wave AFF_FLOATS of
+// view affines and a 32-point x 32-channel exchange tile (gather layout -> MFMA operand layout, eval_point).
 constexpr int LDS_AFF = DEC_FLOATS;
 constexpr int AFF_FLOATS = 4 * 96;
-constexpr int WAVE_LDS_FLOATS = AFF_FLOATS;
+constexpr int XCHG_FLOATS = 32 * 32;
+constexpr int WAVE_LDS_FLOATS = AFF_FLOATS + XCHG_FLOATS;
 constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * WAVE_LDS_FLOATS) * 4;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -113,47 +114,110 @@ __device__ __forceinline__ Taps tap_geometry(int H, int W, float u, float v) {
     return t;
 }
 
-// Direct gather: this lane's 16 channels (half a 128-byte texel) of the 4 taps straight from global memory.
-template <bool DUAL, int TAPS_IN_FLIGHT>
-__device__ __forceinline__ void fetch_direct(const float* __restrict__ pg, const float* __restrict__ pa, int W, const Taps& t,
-                                             int hoff, f32x2 (&sg)[8], f32x2 (&sa)[8]) {
-    const int offs[4] = {(t.yc0 * W + t.xc0) * 32 + hoff, (t.yc0 * W + t.xc1) * 32 + hoff,
-                         (t.yc1 * W + t.xc0) * 32 + hoff, (t.yc1 * W + t.xc1) * 32 + hoff};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); if (DUAL) sa[c] = splat(0.0f); }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const f32x2 w2 = splat(t.w[k]);
-        const float4* tg = reinterpret_cast<const float4*>(pg + offs[k]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-#ifdef NFE_ABLATE_GATHER   // timing experiment only (tools/ablate.sh): no plane loads
-            float4 a = make_float4(t.w[k], t.wsum, (float)k, (float)q);
-#else
-            float4 a = tg[q];
-#endif
-            sg[2 * q + 0] = pk_fma(w2, f32x2{a.x, a.y}, sg[2 * q + 0]);
-            sg[2 * q + 1] = pk_fma(w2, f32x2{a.z, a.w}, sg[2 * q + 1]);
-        }
-        if (DUAL) {
-            const float4* ta = reinterpret_cast<const float4*>(pa + offs[k]);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 a = ta[q];
-                sa[2 * q + 0] = pk_fma(w2, f32x2{a.x, a.y}, sa[2 * q + 0]);
-                sa[2 * q + 1] = pk_fma(w2, f32x2{a.z, a.w}, sa[2 * q + 1]);
-            }
-        }
-        // Register discipline: at most TAPS_IN_FLIGHT taps' loads (4 float4 = 16 VGPRs each, x2 with
-        // two plane sets) are outstanding; the other wave on the SIMD covers the latency.
-        if (((k + 1) % TAPS_IN_FLIGHT) == 0) __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
 // Launder a value through an empty asm: the optimiser can no longer prove it loop-invariant, so addresses
 // and constants derived from it are recomputed at the point of use (a few VALU ops) instead of being hoisted
 // to the kernel prologue and spilled to scratch (which is what happens at 256 VGPRs otherwise).
 __device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+
+// ---- quad-cooperative gather ------------------------------------------------------------------------
+// The vector L1 retires one 64-byte request per clock and merges only ADJACENT lanes (4 lanes x 16 contiguous
+// bytes = one request; anything else is one request per lane: profiles/r01_gather_rate_microbench.txt).  So
+// a texel is never read by "its" lane alone: the 4 lanes of a quad read one 64-byte half texel together, for
+// each of the quad's 4 points in turn.  Lane l = (quad Q = l>>2, c = l&3) owns point l&31 (as the MFMA
+// layout wants); quads Q and Q+8 own the same 4 points and read the two halves (h = l>>5) of their texels.
+// Load i of a tap: every lane of the quad fetches bytes [64h+16c, +16) of point (4(Q&7)+i)'s texel; the
+// address and the bilinear weight come from lane i of the quad by DPP quad-broadcast.  A lane therefore
+// accumulates channels 16h+4c..+3 of FOUR points; exchange_to_own() moves them to the owners through LDS.
+template <int I> __device__ __forceinline__ int quad_bcast(int v) { return __builtin_amdgcn_mov_dpp(v, I * 0x55, 0xf, 0xf, true); }
+template <int I> __device__ __forceinline__ float quad_bcast(float v) { return __int_as_float(quad_bcast<I>(__float_as_int(v))); }
+
+// One 16-byte piece of a texel: uniform base (SGPR pair) + 32-bit byte offset (the saddr form of global_load).
+__device__ __forceinline__ float4 texel_piece(const float* __restrict__ base, unsigned byte_off) {
+#ifdef NFE_ABLATE_GATHER   // timing experiment only (tools/ablate.sh): no plane loads
+    return make_float4((float)byte_off, 1.0f, 2.0f, 3.0f);
+#else
+    return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+#endif
+}
+
+#define NFE_QUAD_ADDR(K, I) o[K][I] = (unsigned)quad_bcast<I>((int)offs[k0 + K]) + qoff_bytes;
+#define NFE_QUAD_FMA(K, I)                                                                                 \
+    {                                                                                                      \
+        const f32x2 w2 = splat(quad_bcast<I>(t.w[k0 + K]));                                                \
+        sg[2 * I + 0] = pk_fma(w2, f32x2{vg[K][I].x, vg[K][I].y}, sg[2 * I + 0]);                          \
+        sg[2 * I + 1] = pk_fma(w2, f32x2{vg[K][I].z, vg[K][I].w}, sg[2 * I + 1]);                          \
+        if (DUAL) {                                                                                        \
+            sa[2 * I + 0] = pk_fma(w2, f32x2{va[K][I].x, va[K][I].y}, sa[2 * I + 0]);                      \
+            sa[2 * I + 1] = pk_fma(w2, f32x2{va[K][I].z, va[K][I].w}, sa[2 * I + 1]);                      \
+        }                                                                                                  \
+    }
+
+// sg[2i], sg[2i+1]: channels (16h+4c)..+3 of quad point i, bilinear-interpolated on this plane (raw values).
+// TAPS_IN_FLIGHT taps (4 loads each, x2 with two plane sets) are issued back to back, then consumed; the
+// scheduling fences keep the compiler from serialising load -> wait -> use, or from hoisting all 16.
+template <bool DUAL, int TAPS_IN_FLIGHT>
+__device__ __forceinline__ void fetch_quad(const float* __restrict__ pg, const float* __restrict__ pa, int W, const Taps& t,
+                                           unsigned qoff_bytes, f32x2 (&sg)[8], f32x2 (&sa)[8]) {
+    const unsigned offs[4] = {(unsigned)(t.yc0 * W + t.xc0) * 128u, (unsigned)(t.yc0 * W + t.xc1) * 128u,
+                              (unsigned)(t.yc1 * W + t.xc0) * 128u, (unsigned)(t.yc1 * W + t.xc1) * 128u};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); if (DUAL) sa[c] = splat(0.0f); }
+#pragma unroll
+    for (int k0 = 0; k0 < 4; k0 += TAPS_IN_FLIGHT) {
+        unsigned o[TAPS_IN_FLIGHT][4];
+        float4 vg[TAPS_IN_FLIGHT][4], va[TAPS_IN_FLIGHT][4];
+#pragma unroll
+        for (int K = 0; K < TAPS_IN_FLIGHT; ++K) {
+            NFE_QUAD_ADDR(K, 0) NFE_QUAD_ADDR(K, 1) NFE_QUAD_ADDR(K, 2) NFE_QUAD_ADDR(K, 3)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vg[K][i] = texel_piece(pg, o[K][i]);
+                if (DUAL) va[K][i] = texel_piece(pa, o[K][i]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int K = 0; K < TAPS_IN_FLIGHT; ++K) {
+            NFE_QUAD_FMA(K, 0) NFE_QUAD_FMA(K, 1) NFE_QUAD_FMA(K, 2) NFE_QUAD_FMA(K, 3)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Exchange tile: row = point (0..31), 8 granules of 4 channels per row, granule g of row r stored at position
+// g ^ swz(r).  swz makes both sides conflict-free under the b128 lane groupings (MI355X guide, LDS table):
+// writers = 8 consecutive lanes (2 quads, rows r and r+4) on 32 banks, readers = 16 rows per cycle on 64 banks.
+__device__ __forceinline__ int xchg_swz(int row) {
+    const int x = (row >> 1) & 7;
+    return (x & 1) | ((x & 2) << 1) | ((x & 4) >> 1);
+}
+
+// f_quad[2i], f_quad[2i+1] (channels 16h+4c.. of quad point i)  ->  f_own[2q], f_own[2q+1] (channels 16h+4q.. of
+// this lane's own point).  LDS operations of one wave execute in order, so no wait is needed between the
+// stores and the loads; the fences only pin the compiler's ordering.
+__device__ __forceinline__ void exchange_to_own(float* __restrict__ xp, int lane, const f32x2 (&fq)[8], f32x2 (&fo)[8]) {
+    lane = launder(lane);
+    const int Q = lane >> 2, c = lane & 3, h = lane >> 5, j = lane & 31;
+    const int row0 = 4 * (Q & 7);
+    float* wr = xp + row0 * 32 + 4 * ((4 * h + c) ^ xchg_swz(row0));       // rows row0, row0+1 (same swizzle)
+    float* wr2 = xp + row0 * 32 + 4 * ((4 * h + c) ^ xchg_swz(row0 + 2));  // rows row0+2, row0+3
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    *reinterpret_cast<float4*>(wr) = make_float4(fq[0][0], fq[0][1], fq[1][0], fq[1][1]);
+    *reinterpret_cast<float4*>(wr + 32) = make_float4(fq[2][0], fq[2][1], fq[3][0], fq[3][1]);
+    *reinterpret_cast<float4*>(wr2 + 64) = make_float4(fq[4][0], fq[4][1], fq[5][0], fq[5][1]);
+    *reinterpret_cast<float4*>(wr2 + 96) = make_float4(fq[6][0], fq[6][1], fq[7][0], fq[7][1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int rd = j * 32 + 4 * ((4 * h) ^ xchg_swz(j));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + (rd ^ (4 * q)));
+        fo[2 * q + 0] = f32x2{v.x, v.y};
+        fo[2 * q + 1] = f32x2{v.z, v.w};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // ---- decoder, exact-fp32 MFMA (v_mfma_f32_32x32x2_f32) ---------------------------------------------
 // FC 32->64, softplus, FC 64->32 rows; weights are the A operand (LDS), the per-point vectors are the
@@ -282,15 +346,16 @@ __device__ __forceinline__ void mlp_bf16(const float* __restrict__ lds, const f3
 //   og[0] = sigma; og[2..] = seg channels (h=0: seg 0..7 in og[2..9]; h=1: seg 8..14 in og[2..8]); og[1] unused
 //   (seg starts on an even register so packed-fp32 pairs need no realigning moves)
 //   oa[r] = rgb channel 16h + r   (after the sigmoid clamp, triplane.py:269)
+// All 64 lanes must be active (quad broadcasts and the LDS exchange involve the whole wave).
 template <bool DUAL, bool SIGMA_ONLY, int MATH>
 __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const float* __restrict__ pa,
                                            int H, int W, const float* __restrict__ lds,
-                                           const float* __restrict__ aff,
+                                           const float* __restrict__ aff, float* __restrict__ xp,
                                            float gx, float gy, float gz,
                                            int lane, f32x16& og, f32x16& oa) {
-    f32x2 fn[8], fd[8];
+    f32x2 qn[8], qd[8];          // quad layout: [2i], [2i+1] = channels 16h+4c.. of quad point i
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { fn[c] = splat(0.0f); fd[c] = splat(0.0f); }
+    for (int c = 0; c < 8; ++c) { qn[c] = splat(0.0f); qd[c] = splat(0.0f); }
     const long long plane_elems = (long long)H * W * 32;
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
 #pragma unroll
@@ -298,30 +363,34 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
         float u = (p == 2) ? gz : gx;
         float v = (p == 0) ? gy : ((p == 1) ? gz : gx);
         f32x2 sg[8], sa[8];
-        const int hoff = (launder(lane) >> 5) * 16;
+        const int ll = launder(lane);
+        const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
         const Taps tp = tap_geometry(H, W, u, v);
         constexpr bool TWO_SETS = DUAL && !SIGMA_ONLY;
-        fetch_direct<TWO_SETS, TWO_SETS ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, W, tp, hoff, sg, sa);
-        const f32x2 w2 = splat(tp.wsum);
-        const float4* gs = reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + hoff);
-        const float4* gb = reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + hoff);
+        fetch_quad<TWO_SETS, TWO_SETS ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, W, tp, (unsigned)qoff * 4u, sg, sa);
+        const float ws[4] = {quad_bcast<0>(tp.wsum), quad_bcast<1>(tp.wsum), quad_bcast<2>(tp.wsum), quad_bcast<3>(tp.wsum)};
+        {
+            const float4 s = *reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + qoff);
+            const float4 b = *reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + qoff);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float4 s = gs[q], b = gb[q];
-            fn[2 * q + 0] = pk_fma(sg[2 * q + 0], f32x2{s.x, s.y}, pk_fma(w2, f32x2{b.x, b.y}, fn[2 * q + 0]));
-            fn[2 * q + 1] = pk_fma(sg[2 * q + 1], f32x2{s.z, s.w}, pk_fma(w2, f32x2{b.z, b.w}, fn[2 * q + 1]));
+            for (int i = 0; i < 4; ++i) {
+                qn[2 * i + 0] = pk_fma(sg[2 * i + 0], f32x2{s.x, s.y}, pk_fma(splat(ws[i]), f32x2{b.x, b.y}, qn[2 * i + 0]));
+                qn[2 * i + 1] = pk_fma(sg[2 * i + 1], f32x2{s.z, s.w}, pk_fma(splat(ws[i]), f32x2{b.z, b.w}, qn[2 * i + 1]));
+            }
         }
         if (!SIGMA_ONLY) {
-            const float4* as = reinterpret_cast<const float4*>(aff + 2 * 96 + p * 32 + hoff);
-            const float4* ab = reinterpret_cast<const float4*>(aff + 3 * 96 + p * 32 + hoff);
+            const float4 s = *reinterpret_cast<const float4*>(aff + 2 * 96 + p * 32 + qoff);
+            const float4 b = *reinterpret_cast<const float4*>(aff + 3 * 96 + p * 32 + qoff);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float4 s = as[q], b = ab[q];
-                fd[2 * q + 0] = pk_fma(DUAL ? sa[2 * q + 0] : sg[2 * q + 0], f32x2{s.x, s.y}, pk_fma(w2, f32x2{b.x, b.y}, fd[2 * q + 0]));
-                fd[2 * q + 1] = pk_fma(DUAL ? sa[2 * q + 1] : sg[2 * q + 1], f32x2{s.z, s.w}, pk_fma(w2, f32x2{b.z, b.w}, fd[2 * q + 1]));
+            for (int i = 0; i < 4; ++i) {
+                qd[2 * i + 0] = pk_fma(DUAL ? sa[2 * i + 0] : sg[2 * i + 0], f32x2{s.x, s.y}, pk_fma(splat(ws[i]), f32x2{b.x, b.y}, qd[2 * i + 0]));
+                qd[2 * i + 1] = pk_fma(DUAL ? sa[2 * i + 1] : sg[2 * i + 1], f32x2{s.z, s.w}, pk_fma(splat(ws[i]), f32x2{b.z, b.w}, qd[2 * i + 1]));
             }
         }
     }
+    f32x2 fn[8], fd[8];          // own layout: channels 16h..16h+15 of this lane's point
+    exchange_to_own(xp, lane, qn, fn);
+    if (!SIGMA_ONLY) exchange_to_own(xp, lane, qd, fd);
 #ifdef NFE_ABLATE_MLP      // timing experiment only (tools/ablate.sh): no decoder
 #pragma unroll
     for (int r = 0; r < 16; ++r) { og[r] = fn[r >> 1][r & 1]; oa[r] = fd[r >> 1][r & 1]; }
@@ -371,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     float* aff = lds + LDS_AFF + wave * WAVE_LDS_FLOATS;
+    float* xp = aff + AFF_FLOATS;
     __syncthreads();
 
     const int S = P.S;
@@ -474,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             // would pin >200 VGPRs per lane and spill.
             int opq;
             asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
-            eval_point<DUAL, SIGMA_ONLY, MATH>(pg, pa, P.H, P.W, lds + opq, aff + opq, gx, gy, gz, lane, og, oa);
+            eval_point<DUAL, SIGMA_ONLY, MATH>(pg, pa, P.H, P.W, lds + opq, aff + opq, xp + opq, gx, gy, gz, lane, og, oa);
 
             if (k > 0) {
                 const float dlt = t - prev_t;
@@ -701,6 +771,7 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     float* aff = lds + LDS_AFF + wave * WAVE_LDS_FLOATS;
+    float* xp = aff + AFF_FLOATS;
     __syncthreads();
     const int blocks_per_view = (P.Pn + 31) >> 5;
     const long long total = (long long)P.N * blocks_per_view;
@@ -715,7 +786,7 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
         const float* c = P.coords + pt * 3;
         f32x16 og, oa;
         eval_point<DUAL, false, MATH>(P.planes_g + (long long)n * P.plane_view_stride,
-                                P.planes_a + (long long)n * P.plane_view_stride, P.H, P.W, lds, aff,
+                                P.planes_a + (long long)n * P.plane_view_stride, P.H, P.W, lds, aff, xp,
                                 P.coord_scale * c[0], P.coord_scale * c[1], P.coord_scale * c[2], lane, og, oa);
         if (valid) {
             float4* o = reinterpret_cast<float4*>(P.rgb + pt * 32 + 16 * h);
@@ -794,7 +865,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a->struct_size == sizeof(nfe_render_args), "nfe_render: struct_size %u != %zu (ABI mismatch)",
                 a->struct_size, sizeof(nfe_render_args));
     NFE_REQUIRE(a->planes_geo && a->planes_app && a->decoder_packed, "nfe_render: planes/decoder pointers are null");
-    NFE_REQUIRE(a->plane_h > 0 && a->plane_w > 0 && a->plane_h <= 16384 && a->plane_w <= 16384, "nfe_render: bad plane size %dx%d", a->plane_h, a->plane_w);
+    NFE_REQUIRE(a->plane_h > 0 && a->plane_w > 0 && (long long)a->plane_h * a->plane_w <= (1ll << 25), "nfe_render: bad plane size %dx%d (texel byte offsets are 32-bit: H*W <= 2^25)", a->plane_h, a->plane_w);
     NFE_REQUIRE(a->n_views > 0 && a->n_rays > 0, "nfe_render: n_views=%d n_rays=%d must be positive", a->n_views, a->n_rays);
     const int D = a->depth_resolution, Di = a->depth_resolution_importance;
     NFE_REQUIRE(D >= 2 && D <= NFE_MAX_SAMPLES, "nfe_render: depth_resolution=%d out of [2,%d]", D, NFE_MAX_SAMPLES);
@@ -895,7 +966,7 @@ extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app,
                                float* rgb, float* sigma, float* seg, nfe_stream_t stream) {
     NFE_REQUIRE(planes_geo && planes_app && decoder_packed && coords, "nfe_point_query: null input pointer");
     NFE_REQUIRE(rgb && sigma && seg, "nfe_point_query: null output pointer");
-    NFE_REQUIRE(plane_h > 0 && plane_w > 0, "nfe_point_query: bad plane size");
+    NFE_REQUIRE(plane_h > 0 && plane_w > 0 && (long long)plane_h * plane_w <= (1ll << 25), "nfe_point_query: bad plane size %dx%d", plane_h, plane_w);
     NFE_REQUIRE(n_views > 0 && n_points >= 0, "nfe_point_query: bad sizes N=%d P=%d", n_views, n_points);
     NFE_REQUIRE(box_warp > 0.0f, "nfe_point_query: box_warp must be positive");
     NFE_REQUIRE(decoder_math == NFE_MATH_BF16X3 || decoder_math == NFE_MATH_FP32, "nfe_point_query: unknown decoder_math %d", decoder_math);
