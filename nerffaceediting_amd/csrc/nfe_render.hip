@@ -39,7 +39,8 @@ struct RenderK {
 // LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then per wave AFF_FLOATS of
 // view affines and a 32-point x 32-channel exchange tile (gather layout -> MFMA operand layout, eval_point).
 constexpr int LDS_AFF = DEC_FLOATS;
-constexpr int AFF_FLOATS = 4 * 96;
+constexpr int AFF_FLOATS = 4 * 96 + 2 * 32;   // + per-channel sums over planes of the two shifts
+constexpr int AFF_BSUM = 4 * 96;
 constexpr int XCHG_FLOATS = 32 * 32;
 constexpr int WAVE_LDS_FLOATS = AFF_FLOATS + XCHG_FLOATS;
 constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * WAVE_LDS_FLOATS) * 4;
@@ -69,14 +70,19 @@ __device__ __forceinline__ float softplus_log2(float y) {
     return y > 20.0f * LOG2E ? y : r;
 }
 
-// softplus_log2 over a whole accumulator; the "+1" runs as packed adds (v_pk_add_f32), two values per issue
+// max(y, 0) as one integer max on the bit pattern (negative floats are negative ints; fmaxf would add a
+// canonicalising v_max before the real one)
+__device__ __forceinline__ float relu_bits(float y) { return __int_as_float(max(__float_as_int(y), 0)); }
+
+// softplus_log2 over a whole accumulator as max(y,0) + log2(1 + 2^-|y|): no overflow, so torch's threshold
+// select (y > 20 -> y, where the two agree to fp32 rounding) needs no compare/select pair; -|y| is a free
+// source modifier and the two adds run packed (v_pk_add_f32).
 __device__ __forceinline__ void softplus_log2_x16(f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-        const f32x2 e = f32x2{exp2_fast(a[r]), exp2_fast(a[r + 1])} + splat(1.0f);
-        const float r0 = log2_fast(e[0]), r1 = log2_fast(e[1]);
-        a[r] = a[r] > 20.0f * LOG2E ? a[r] : r0;
-        a[r + 1] = a[r + 1] > 20.0f * LOG2E ? a[r + 1] : r1;
+        const f32x2 e = f32x2{exp2_fast(-__builtin_fabsf(a[r])), exp2_fast(-__builtin_fabsf(a[r + 1]))} + splat(1.0f);
+        const f32x2 l = f32x2{log2_fast(e[0]), log2_fast(e[1])} + f32x2{relu_bits(a[r]), relu_bits(a[r + 1])};
+        a[r] = l[0]; a[r + 1] = l[1];
     }
 }
 
@@ -91,7 +97,7 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 // Bilinear tap geometry of one sample on one plane: F.grid_sample(bilinear, zeros, align_corners=False),
 // renderer.py:64, unnormalised as ATen's CPU kernel does.  Clamped coordinates are always addressable;
 // out-of-range taps carry weight 0.
-struct Taps { int xc0, xc1, yc0, yc1; float w[4]; float wsum; };
+struct Taps { int xc0, xc1, yc0, yc1; float w[4]; float wdef; };   // wdef = (sum of weights) - 1, exactly 0 when all 4 taps are inside
 
 __device__ __forceinline__ Taps tap_geometry(int H, int W, float u, float v) {
     Taps t;
@@ -110,7 +116,7 @@ __device__ __forceinline__ Taps tap_geometry(int H, int W, float u, float v) {
     t.w[3] = (vx1 && vy1) ? dx * dy : 0.0f;
     t.xc0 = min(max(x0, 0), W - 1); t.xc1 = min(max(x1, 0), W - 1);
     t.yc0 = min(max(y0, 0), H - 1); t.yc1 = min(max(y1, 0), H - 1);
-    t.wsum = (t.w[0] + t.w[1]) + (t.w[2] + t.w[3]);
+    t.wdef = (vx0 && vx1 && vy0 && vy1) ? 0.0f : ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3])) - 1.0f;
     return t;
 }
 
@@ -354,8 +360,18 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
                                            float gx, float gy, float gz,
                                            int lane, f32x16& og, f32x16& oa) {
     f32x2 qn[8], qd[8];          // quad layout: [2i], [2i+1] = channels 16h+4c.. of quad point i
+    const int l0 = launder(lane);
+    const int qoff0 = (l0 >> 5) * 16 + (l0 & 3) * 4;
+    {   // Start from the plane-summed shift (all taps inside: sum of weights == 1); out-of-range samples are
+        // corrected below.  sample(norm) = scale * sample(raw) + shift * sum(weights), DESIGN.md section 3.
+        const float4 bn = *reinterpret_cast<const float4*>(aff + AFF_BSUM + qoff0);
+        const float4 bd = *reinterpret_cast<const float4*>(aff + AFF_BSUM + 32 + qoff0);
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { qn[c] = splat(0.0f); qd[c] = splat(0.0f); }
+        for (int i = 0; i < 4; ++i) {
+            qn[2 * i] = f32x2{bn.x, bn.y}; qn[2 * i + 1] = f32x2{bn.z, bn.w};
+            qd[2 * i] = f32x2{bd.x, bd.y}; qd[2 * i + 1] = f32x2{bd.z, bd.w};
+        }
+    }
     const long long plane_elems = (long long)H * W * 32;
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
 #pragma unroll
@@ -368,23 +384,37 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
         const Taps tp = tap_geometry(H, W, u, v);
         constexpr bool TWO_SETS = DUAL && !SIGMA_ONLY;
         fetch_quad<TWO_SETS, TWO_SETS ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, W, tp, (unsigned)qoff * 4u, sg, sa);
-        const float ws[4] = {quad_bcast<0>(tp.wsum), quad_bcast<1>(tp.wsum), quad_bcast<2>(tp.wsum), quad_bcast<3>(tp.wsum)};
         {
-            const float4 s = *reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + qoff);
-            const float4 b = *reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + qoff);
+            const float4 sc = *reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + qoff);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                qn[2 * i + 0] = pk_fma(sg[2 * i + 0], f32x2{s.x, s.y}, pk_fma(splat(ws[i]), f32x2{b.x, b.y}, qn[2 * i + 0]));
-                qn[2 * i + 1] = pk_fma(sg[2 * i + 1], f32x2{s.z, s.w}, pk_fma(splat(ws[i]), f32x2{b.z, b.w}, qn[2 * i + 1]));
+                qn[2 * i + 0] = pk_fma(sg[2 * i + 0], f32x2{sc.x, sc.y}, qn[2 * i + 0]);
+                qn[2 * i + 1] = pk_fma(sg[2 * i + 1], f32x2{sc.z, sc.w}, qn[2 * i + 1]);
             }
         }
         if (!SIGMA_ONLY) {
-            const float4 s = *reinterpret_cast<const float4*>(aff + 2 * 96 + p * 32 + qoff);
-            const float4 b = *reinterpret_cast<const float4*>(aff + 3 * 96 + p * 32 + qoff);
+            const float4 sc = *reinterpret_cast<const float4*>(aff + 2 * 96 + p * 32 + qoff);
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                qd[2 * i + 0] = pk_fma(DUAL ? sa[2 * i + 0] : sg[2 * i + 0], f32x2{s.x, s.y}, pk_fma(splat(ws[i]), f32x2{b.x, b.y}, qd[2 * i + 0]));
-                qd[2 * i + 1] = pk_fma(DUAL ? sa[2 * i + 1] : sg[2 * i + 1], f32x2{s.z, s.w}, pk_fma(splat(ws[i]), f32x2{b.z, b.w}, qd[2 * i + 1]));
+                qd[2 * i + 0] = pk_fma(DUAL ? sa[2 * i + 0] : sg[2 * i + 0], f32x2{sc.x, sc.y}, qd[2 * i + 0]);
+                qd[2 * i + 1] = pk_fma(DUAL ? sa[2 * i + 1] : sg[2 * i + 1], f32x2{sc.z, sc.w}, qd[2 * i + 1]);
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(tp.wdef != 0.0f) != 0) {     // rare: some sample of the wave left the plane
+            const float wd[4] = {quad_bcast<0>(tp.wdef), quad_bcast<1>(tp.wdef), quad_bcast<2>(tp.wdef), quad_bcast<3>(tp.wdef)};
+            const float4 b = *reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + qoff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qn[2 * i + 0] = pk_fma(splat(wd[i]), f32x2{b.x, b.y}, qn[2 * i + 0]);
+                qn[2 * i + 1] = pk_fma(splat(wd[i]), f32x2{b.z, b.w}, qn[2 * i + 1]);
+            }
+            if (!SIGMA_ONLY) {
+                const float4 e = *reinterpret_cast<const float4*>(aff + 3 * 96 + p * 32 + qoff);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    qd[2 * i + 0] = pk_fma(splat(wd[i]), f32x2{e.x, e.y}, qd[2 * i + 0]);
+                    qd[2 * i + 1] = pk_fma(splat(wd[i]), f32x2{e.z, e.w}, qd[2 * i + 1]);
+                }
             }
         }
     }
@@ -428,6 +458,13 @@ __device__ __forceinline__ void stage_affine(const float* const (&src)[4], int n
             float v = p ? p[(long long)n * 96 + c] : dflt;
             aff[arr * 96 + c] = v * (1.0f / 3.0f);
         }
+    }
+    if (lane < 64) {   // plane-summed shifts: [0,32) geometry set, [32,64) appearance set
+        const float* p = src[(lane < 32) ? 1 : 3];
+        const int c = lane & 31;
+        float b = 0.0f;
+        if (p) b = (p[(long long)n * 96 + c] * (1.0f / 3.0f) + p[(long long)n * 96 + 32 + c] * (1.0f / 3.0f)) + p[(long long)n * 96 + 64 + c] * (1.0f / 3.0f);
+        aff[AFF_BSUM + lane] = b;
     }
     __threadfence_block();
 }
@@ -831,7 +868,12 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
 static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math, hipStream_t st) {
     const long long total_rb = (long long)P.N * ((P.M + 31) / 32);
     long long blocks = (total_rb + 3) / 4;
-    const long long cap = (long long)num_cus() * 2;      // 2 blocks (8 waves) per CU, grid-stride beyond
+    static const int blocks_per_cu = [] {                // tuning/diagnostic knob; default 2 blocks (8 waves) per CU
+        const char* e = getenv("NFE_RENDER_BLOCKS_PER_CU");
+        const int v = e ? atoi(e) : 0;
+        return (v >= 1 && v <= 8) ? v : 2;
+    }();
+    const long long cap = (long long)num_cus() * blocks_per_cu;      // grid-stride beyond
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks);
     if (sigma_only) {

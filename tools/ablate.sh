@@ -5,7 +5,7 @@ set -e
 cd nerffaceediting_amd/csrc
 for v in GATHER MLP; do
   mkdir -p build_$v
-  for f in nfe_api.cpp nfe_render.hip nfe_planes.hip; do
+  for f in nfe_api.cpp nfe_render.hip nfe_planes.hip nfe_dense.hip; do
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -I../../include -I. -DNFE_ABLATE_$v -x hip -c $f -o build_$v/$f.o
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o /tmp/libnfe_ablate_$v.so build_$v/*.o
