@@ -46,14 +46,18 @@ def synth_inputs(torch, dev, seed):
     """Synthetic inputs of the config-2 shape: planes ~ N(0,1) with a per-channel mean/std spread
     (stands in for the random-init backbone output), random-init decoder (randn weights, zero bias),
     cameras on the gen_samples.py:166 yaw set at pitch -0.2, radius 2.7, pivot (0,0,0.2), fov 18.837."""
-    from oracle import render_oracle as orc       # camera helpers only (test infrastructure, CPU side)
+    from nerffaceediting_amd.camera_utils import FOV_to_intrinsics, LookAtPoseSampler
     g = torch.Generator(device="cpu").manual_seed(seed)
     planes = torch.randn(VIEWS_PER_GPU, 96, PLANE, PLANE, generator=g)
     planes = planes * torch.exp(0.5 * torch.randn(1, 96, 1, 1, generator=g)) + 0.7 * torch.randn(1, 96, 1, 1, generator=g)
-    dec = orc.random_decoder(seed)
+    rng = np.random.RandomState(seed)                # FullyConnectedLayer init: randn weights, zero bias (networks_stylegan2.py:108-109)
+    shapes = {"geo_net.0.weight": (64, 32), "geo_net.0.bias": (64,), "geo_net.2.weight": (16, 64), "geo_net.2.bias": (16,),
+              "app_net.0.weight": (64, 32), "app_net.0.bias": (64,), "app_net.2.weight": (32, 64), "app_net.2.bias": (32,)}
+    dec = {k: (rng.randn(*shp) if k.endswith("weight") else np.zeros(shp)).astype(np.float32) for k, shp in shapes.items()}
     yaws = [0.4, 0.0, -0.4, 0.2]
-    c2w = np.concatenate([orc.lookat_pose(math.pi / 2 + y, math.pi / 2 - 0.2, [0, 0, 0.2], 2.7) for y in yaws], 0)
-    K = np.tile(orc.fov_to_intrinsics(18.837)[None], (VIEWS_PER_GPU, 1, 1))
+    pivot = torch.tensor([0.0, 0.0, 0.2])
+    c2w = torch.cat([LookAtPoseSampler.sample(math.pi / 2 + y, math.pi / 2 - 0.2, pivot, radius=2.7) for y in yaws], 0).numpy()
+    K = np.tile(FOV_to_intrinsics(18.837).numpy()[None], (VIEWS_PER_GPU, 1, 1))
     to = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
     return planes.to(dev), {k: to(v) for k, v in dec.items()}, dec, to(c2w), to(K), planes.numpy(), c2w, K
 

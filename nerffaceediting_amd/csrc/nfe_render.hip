@@ -347,6 +347,112 @@ __device__ __forceinline__ void mlp_bf16(const float* __restrict__ lds, const f3
     }
 }
 
+// ---- both decoder heads, split-bf16, software-pipelined against each other ---------------------------
+// One wave runs MFMAs and VALU work in order, so a head evaluated on its own alternates between the two
+// pipes (MFMA chain -> softplus -> split -> MFMA chain).  The two heads are independent: each stage below
+// pairs the MFMAs of one head with the VALU work of the other, so the matrix pipe runs under the vector work.
+//   S2: geometry layer 0 (12 MFMA)    | appearance features -> bf16 pairs
+//   S3: appearance layer 0 (12 MFMA)  | softplus of the geometry hidden layer
+//   S4: geometry layer 1 (12 MFMA)    | geometry hidden -> bf16 pairs, softplus of the appearance hidden layer
+//   S5: appearance layer 1 (12 MFMA)  | appearance hidden -> bf16 pairs
+#define NFE_L0_FRAG(NET, MB, S, PART) F[((((NET) * 2 + (MB)) * 2 + (S)) * 2 + (PART)) * 64]
+#define NFE_L1_FRAG(NET, S, PART) F[(16 + ((NET) * 4 + (S)) * 2 + (PART)) * 64]
+
+__device__ __forceinline__ void load_bias0(const float* __restrict__ lds, int net, int h, f32x16& a0, f32x16& a1) {
+    const float4* b0 = reinterpret_cast<const float4*>(lds + (net ? DEC_B_A0 : DEC_B_G0) + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 x = b0[2 * q], y = b0[8 + 2 * q];
+        a0[4 * q + 0] = x.x; a0[4 * q + 1] = x.y; a0[4 * q + 2] = x.z; a0[4 * q + 3] = x.w;
+        a1[4 * q + 0] = y.x; a1[4 * q + 1] = y.y; a1[4 * q + 2] = y.z; a1[4 * q + 3] = y.w;
+    }
+}
+__device__ __forceinline__ void load_bias1(const float* __restrict__ lds, int net, int h, f32x16& out) {
+    const float4* b1 = reinterpret_cast<const float4*>(lds + (net ? DEC_B_A1 : DEC_B_G1) + 4 * h);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float4 x = b1[2 * q];
+        out[4 * q + 0] = x.x; out[4 * q + 1] = x.y; out[4 * q + 2] = x.z; out[4 * q + 3] = x.w;
+    }
+}
+// hidden registers 8(s&1)..+7 of M-block s>>1 -> B operand of layer-1 k-step s
+__device__ __forceinline__ void split_hidden(const f32x16& a0, const f32x16& a1, int s, Frag& hh, Frag& hl) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const int r = 8 * (s & 1) + 2 * w;
+        if (s < 2) split_pair(a0[r], a0[r + 1], hh.u[w], hl.u[w]);
+        else split_pair(a1[r], a1[r + 1], hh.u[w], hl.u[w]);
+    }
+}
+
+__device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
+                                              int lane, f32x16& og, f32x16& oa) {
+    lane = launder(lane);
+    const int h = lane >> 5;
+    const uint4* F = reinterpret_cast<const uint4*>(lds) + lane;
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S1
+    Frag gh[2], gl[2], ah[2], al[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) split_pair(fn[4 * s + w][0], fn[4 * s + w][1], gh[s].u[w], gl[s].u[w]);
+    f32x16 g0, g1, p0, p1;
+    load_bias0(lds, 0, h, g0, g1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S2
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        Frag h0, l0, h1, l1;
+        h0.q = NFE_L0_FRAG(0, 0, s, 0); l0.q = NFE_L0_FRAG(0, 0, s, 1);
+        h1.q = NFE_L0_FRAG(0, 1, s, 0); l1.q = NFE_L0_FRAG(0, 1, s, 1);
+        g0 = NFE_MFMA_BF16(h0, gh[s], g0); g1 = NFE_MFMA_BF16(h1, gh[s], g1);
+        g0 = NFE_MFMA_BF16(h0, gl[s], g0); g1 = NFE_MFMA_BF16(h1, gl[s], g1);
+        g0 = NFE_MFMA_BF16(l0, gh[s], g0); g1 = NFE_MFMA_BF16(l1, gh[s], g1);
+#pragma unroll
+        for (int w = 0; w < 4; ++w) split_pair(fd[4 * s + w][0], fd[4 * s + w][1], ah[s].u[w], al[s].u[w]);
+    }
+    load_bias0(lds, 1, h, p0, p1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S3
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        Frag h0, l0, h1, l1;
+        h0.q = NFE_L0_FRAG(1, 0, s, 0); l0.q = NFE_L0_FRAG(1, 0, s, 1);
+        h1.q = NFE_L0_FRAG(1, 1, s, 0); l1.q = NFE_L0_FRAG(1, 1, s, 1);
+        p0 = NFE_MFMA_BF16(h0, ah[s], p0); p1 = NFE_MFMA_BF16(h1, ah[s], p1);
+        p0 = NFE_MFMA_BF16(h0, al[s], p0); p1 = NFE_MFMA_BF16(h1, al[s], p1);
+        p0 = NFE_MFMA_BF16(l0, ah[s], p0); p1 = NFE_MFMA_BF16(l1, ah[s], p1);
+    }
+    softplus_log2_x16(g0); softplus_log2_x16(g1);
+    load_bias1(lds, 0, h, og);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S4
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        Frag hh, hl, wh, wl;
+        split_hidden(g0, g1, s, hh, hl);
+        wh.q = NFE_L1_FRAG(0, s, 0); wl.q = NFE_L1_FRAG(0, s, 1);
+        og = NFE_MFMA_BF16(wh, hh, og);
+        og = NFE_MFMA_BF16(wh, hl, og);
+        og = NFE_MFMA_BF16(wl, hh, og);
+    }
+    softplus_log2_x16(p0); softplus_log2_x16(p1);
+    load_bias1(lds, 1, h, oa);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S5
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        Frag hh, hl, wh, wl;
+        split_hidden(p0, p1, s, hh, hl);
+        wh.q = NFE_L1_FRAG(1, s, 0); wl.q = NFE_L1_FRAG(1, s, 1);
+        oa = NFE_MFMA_BF16(wh, hh, oa);
+        oa = NFE_MFMA_BF16(wh, hl, oa);
+        oa = NFE_MFMA_BF16(wl, hh, oa);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // Evaluate the implicit model at one point per lane PAIR (lanes j and j+32 share a point; lane half
 // h holds channels [16h,16h+16) of every 32-vector).  Returns, for this lane:
 //   og[0] = sigma; og[2..] = seg channels (h=0: seg 0..7 in og[2..9]; h=1: seg 8..14 in og[2..8]); og[1] unused
@@ -426,9 +532,11 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
     for (int r = 0; r < 16; ++r) { og[r] = fn[r >> 1][r & 1]; oa[r] = fd[r >> 1][r & 1]; }
     return;
 #endif
-    if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og); else mlp_bf16(lds, fn, 0, lane, og);
+    if (!SIGMA_ONLY && MATH == NFE_MATH_BF16X3) mlp_pair_bf16(lds, fn, fd, lane, og, oa);
+    else if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og);
+    else mlp_bf16(lds, fn, 0, lane, og);
     if (!SIGMA_ONLY) {
-        if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa); else mlp_bf16(lds, fd, 1, lane, oa);
+        if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {    // oa carries log2(e): sigmoid(x) = 1/(1 + 2^-(x log2 e))
             const f32x2 d = f32x2{exp2_fast(-oa[r]), exp2_fast(-oa[r + 1])} + splat(1.0f);
