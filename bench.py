@@ -11,6 +11,11 @@ batch-of-views path does.
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0.
+
+Other workloads of SURVEY.md section 8(d) (never the default; same JSON contract, lines kept in profiles/):
+    --workload full     config 3: full synthesis (a1-a14), 8 views/GPU/step, 512^2 x 64 render, bf16 convs -> views/s
+    --workload orbit    config 4: 512 (latent, camera) pairs sharded over the ranks (strong scaling), one all-gather
+    --workload twopass  config 5: render core, D=96 + 96 importance samples, dual plane sets, 512^2 -> rays/s
 """
 import argparse
 import json
@@ -81,12 +86,157 @@ def cpu_baseline(planes_np, dec_np, c2w, K, opts, seed):
                       f"(gcc -O3 -march=native -fopenmp, {threads} threads), {dt:.1f} s"}
 
 
+GFLOP_DENSE_PER_VIEW = 2 * (46.55 + 98.00)     # backbone + SuperresolutionHybrid8XDC MACs x 2
+MFMA_BF16_PEAK_TFLOPS = 2500.0                # MI355X_MICROARCH.md: dense bf16
+
+
+def full_generator(torch, dev, D, Di, conv_math):
+    """Full-width TriPlaneGenerator (train.py FFHQ config, SURVEY section 8c recipe), random init."""
+    from nerffaceediting_amd.training.triplane import TriPlaneGenerator
+    rk = dict(superresolution_module="training.superresolution.SuperresolutionHybrid8XDC", sr_antialias=True,
+              c_gen_conditioning_zero=False, c_scale=1, superresolution_noise_mode="none", depth_resolution=D,
+              depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1, disparity_space_sampling=False,
+              clamp_mode="softplus", decoder_lr_mul=1)
+    torch.manual_seed(0)
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default="inference_only"),
+                          channel_base=32768, channel_max=512, fused_modconv_default="inference_only", num_fp16_res=0,
+                          conv_clamp=None).to(dev).eval().requires_grad_(False)
+    G.backbone.synthesis.conv_math = conv_math
+    G.superresolution.conv_math = conv_math
+    return G
+
+
+def timed_steps(args, torch, dist, world, step):
+    """W untimed + exactly K timed steps between barrier + synchronize; MAX over ranks."""
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def extra_workload(args, torch, dist, dev, rank, world):
+    from nerffaceediting_amd import apps, ops, sharding
+    base = {"n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+            "data": "synthetic", "cpu_baseline": None}
+    if args.workload == "twopass":           # config 5: D = Di = 96 (projector.py:33-34), norm planes != normalised(denorm planes)
+        Dc = 96
+        seed = 1000 + rank
+        planes, dec_t, _, c2w_t, K_t, _, _, _ = synth_inputs(torch, dev, seed)
+        mean, std = ops.plane_stats(planes)
+        gs, gb, as_, ab = ops.make_affine(mean, std, mean.roll(1, 0).contiguous(), std.roll(1, 0).contiguous())   # appearance of the next view
+        norm = ops.plane_pack(ops.plane_affine(planes, gs, gb))
+        denorm = ops.plane_pack(ops.plane_affine(planes, as_, ab))
+        names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
+                 "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+        dec_packed = ops.decoder_pack(*[dec_t[k] for k in names])
+        opts = dict(depth_resolution=Dc, depth_resolution_importance=Dc, ray_start=2.25, ray_end=3.3, box_warp=1,
+                    disparity_space_sampling=False, clamp_mode="softplus")
+        ev = {}
+
+        def step(i):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            ops.render(norm, denorm, dec_packed, opts, cam2world=c2w_t, intrinsics=K_t, resolution=R, seed=seed + i, channels_first=True)
+            b.record()
+            ev[i] = (a, b)
+        dt = timed_steps(args, torch, dist, world, step)
+        ms = sum(ev[args.warmup + i][0].elapsed_time(ev[args.warmup + i][1]) for i in range(args.steps)) / args.steps
+        n_total, M = world * VIEWS_PER_GPU, R * R
+        bytes_ray = (Dc + Dc) * 2 * 1536 + Dc * 1536 + 196      # final pass: 192 samples x 2 plane sets; coarse pass: 96 x geometry set
+        ach = VIEWS_PER_GPU * M * bytes_ray / (ms * 1e-3) / 1e9
+        return dict(base, metric="rays/s, 512^2 x (96+96)-sample two-pass dual-plane render", value=n_total * M * args.steps / dt,
+                    unit="rays/s", ms_per_step=dt / args.steps * 1e3, scaling="weak", dtype="f32",
+                    config={"workload": "BASELINE config 5: render core through the (norm, denorm) entry, appearance statistics swapped "
+                                        "between views, 4 views/GPU/step, 512^2 rays, 96 coarse + 96 importance samples",
+                            "views_per_step": n_total, "parallelism": f"views-dp{world}"},
+                    roofline={"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": None, "kernel": "sigma-only pass + importance_kernel + nfe::render_kernel<true,false>",
+                              "kernel_ms": ms, "note": "logical gather bytes of all three passes / their total time (L2-resident planes)"})
+
+    conv_math = "bf16"
+    G = full_generator(torch, dev, D, 0, conv_math)
+    if args.workload == "full":              # config 3
+        NV = 8
+        g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+        z = torch.randn(NV, 512, generator=g).to(dev)
+        c = apps.orbit_cameras(NV, dev)
+        ws = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=14)
+        ev = {}
+
+        def step(i):
+            # stage events inside the timed region: [0] backbone [1] stats + render [2] SR [3]
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            wsi = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=14)
+            e[0].record()
+            G.stage_events = e
+            out = G.synthesis(wsi, c, neural_rendering_resolution=R, noise_mode="const")
+            e[3].record()
+            ev[i] = e
+            return out
+        dt = timed_steps(args, torch, dist, world, step)
+        G.stage_events = None
+        timed = [ev[args.warmup + i] for i in range(args.steps)]
+        avg = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in timed) / args.steps
+        syn_ms = avg(0, 3)
+        stage = {"backbone": avg(0, 1), "stats_render": avg(1, 2), "sr": avg(2, 3)}
+        dense_ms = stage["backbone"] + stage["sr"]
+        n_total = world * NV
+        flops = GFLOP_DENSE_PER_VIEW * NV * 1e9
+        ach = flops / (dense_ms * 1e-3) / 1e12
+        return dict(base, metric="512^2 views/s, full synthesis (mapping + backbone + 512^2 x 64 render + SR)",
+                    value=n_total * args.steps / dt, unit="views/s", ms_per_step=dt / args.steps * 1e3, scaling="weak", dtype="bf16",
+                    config={"workload": "BASELINE config 3: a1-a14, 8 views/GPU/step, neural render 512^2 x 64 -> antialias resize -> "
+                                        "SuperresolutionHybrid8XDC to 512^2, bf16 MFMA convs (fp32 accumulate), fp32 render",
+                            "views_per_step": n_total, "synthesis_ms": syn_ms, "stage_ms": stage, "parallelism": f"views-dp{world}"},
+                    roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv_kernel<*,1> (backbone + SR stages)",
+                              "kernel_ms": dense_ms, "note": "289.1 GFLOP per view (SURVEY 8d) / time of the backbone + SR stages"})
+
+    # orbit: config 4, strong scaling: 512 frames in total
+    V = 512
+    c_all = apps.orbit_cameras(V, dev)
+    a, b = sharding.shard_range(V, rank, world)
+    ws_local = torch.stack([torch.from_numpy(np.random.RandomState(f).randn(14, 512).astype(np.float32)) for f in range(a, b)]).to(dev)
+    G.neural_rendering_resolution = R
+
+    def step(i):
+        frames = []
+        for j in range(0, b - a, 8):
+            frames.append(G.synthesis(ws_local[j:j + 8].contiguous(), c_all[a + j:a + j + 8].contiguous(), noise_mode="const")["image"])
+        local = torch.cat(frames, 0)
+        return sharding.all_gather_frames(local, V) if world > 1 else local
+    dt = timed_steps(args, torch, dist, world, step)
+    ach = GFLOP_DENSE_PER_VIEW * (b - a) * args.steps * 1e9 / dt / 1e12
+    return dict(base, metric="512^2 views/s, 512-frame orbit (gen_videos camera path)", value=V * args.steps / dt, unit="views/s",
+                ms_per_step=dt / args.steps * 1e3, scaling="strong", dtype="bf16",
+                config={"workload": "BASELINE config 4: 512 (per-frame ws, camera) pairs, gen_videos.py:128-133 path, contiguous blocks per "
+                                    "rank, one all-gather of [512,3,512,512] fp32 frames per step", "frames": V, "frames_per_rank": b - a,
+                        "parallelism": f"frames-dp{world}"},
+                roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                          "traffic": None, "kernel": "whole step (dense flops of this rank / wall time)", "kernel_ms": None})
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["render", "full", "orbit", "twopass"], default="render")
     args = ap.parse_args()
 
     import torch
@@ -104,6 +254,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+
+    if args.workload != "render":
+        out = extra_workload(args, torch, dist, dev, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        if world > 1:
+            dist.destroy_process_group()
+        return
 
     seed = 1000 + rank
     planes, dec_t, dec_np, c2w_t, K_t, planes_np, c2w, K = synth_inputs(torch, dev, seed)

@@ -124,6 +124,9 @@ class TriPlaneGenerator(torch.nn.Module):
             packed, mean, var = self._planes(ws, synthesis_kwargs)
         if cache_backbone:
             self._last_planes = (packed, mean, var)
+        stage_events = getattr(self, "stage_events", None)      # bench.py: [.., after backbone, after render, ..]
+        if stage_events is not None:
+            stage_events[1].record()
 
         # normalisation + optional appearance override as per-channel affines on the sampled values
         # (single-gather identity; triplane.py:93-103 incl. the (int,int) special case)
@@ -138,6 +141,8 @@ class TriPlaneGenerator(torch.nn.Module):
         feature_samples, seg_samples, depth_samples, _ = self.renderer.render_raw_planes(
             packed, affines, self.decoder, cam2world_matrix, intrinsics, R, self.rendering_kwargs, channels_first=False)
 
+        if stage_events is not None:
+            stage_events[2].record()
         # [N,M,32] is already NHWC for the SR head; the reference's NCHW images are produced for the output dict
         feat_nhwc = feature_samples.view(N, R, R, 32)
         rgb_nhwc = feat_nhwc[..., :3].contiguous()
