@@ -358,6 +358,163 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fast path of the plain 3x3 layers (W >= 32, Cin % 16 == 0, Cout % 64 == 0): the activations are modulated
+// and split to bf16 ONCE (modsplit_kernel, an HBM-bound elementwise pass) instead of once per M-block
+// workgroup, so the implicit-GEMM loop has no VALU staging left: weights and the input patch go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4, double-buffered over the 16-channel K-groups), fragments
+// LDS -> registers with immediate offsets, MFMA.  Workgroup = 4 waves = 64 output channels x (32 x 8) pixels;
+// a wave owns two image rows of 32 pixels (two N-blocks) x two M-blocks.  A 32-pixel row read is conflict-free
+// under the b128 lane groups with a compact patch layout.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict__ x, const float* __restrict__ styles, long long n_vec,
+                                                       long long hw_vec, int c4, uint2* __restrict__ hi, uint2* __restrict__ lo) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(i % c4);
+        const long long n = i / hw_vec;
+        const float4 s = *reinterpret_cast<const float4*>(styles + (n * c4 + q) * 4);
+        float4 v = x[i];
+        v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
+        unsigned h0, l0, h1, l1;
+        if (lo) { split2<3>(v.x, v.y, h0, l0); split2<3>(v.z, v.w, h1, l1); lo[i] = make_uint2(l0, l1); }
+        else { split2<1>(v.x, v.y, h0, l0); split2<1>(v.z, v.w, h1, l1); }
+        hi[i] = make_uint2(h0, h1);
+    }
+}
+
+__device__ uint4 nfe_zero16[4];                                  // source of the zero padding for LDS-DMA
+
+struct Conv3K {
+    const unsigned short* xh; const unsigned short* xl; const uint4* packed; const float* dcoef; const float* noise;
+    long long noise_n_stride; float noise_strength; const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp;
+    float* out;
+};
+
+constexpr int C3_TW = 32, C3_TH = 8, C3_PW = C3_TW + 2, C3_PH = C3_TH + 2;
+constexpr int C3_HALF_ITEMS = C3_PW * C3_PH;                     // 16-byte items (8 bf16 channels of one pixel) per channel half
+constexpr int C3_B_CHUNKS = (2 * C3_HALF_ITEMS + 63) / 64;       // 1-KiB LDS-DMA chunks per part
+constexpr int C3_B_BYTES = C3_B_CHUNKS * 1024;
+
+__device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+}
+
+template <int TERMS, int MBW>
+__global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
+    constexpr int PARTS = TERMS == 3 ? 2 : 1;
+    constexpr int A_CHUNKS = MBW * 9 * PARTS;
+    constexpr int STAGE_BYTES = A_CHUNKS * 1024 + PARTS * C3_B_BYTES;
+    constexpr int STAGES = (2 * STAGE_BYTES <= 65536) ? 2 : 1;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE_BYTES];
+
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_x = (P.W + C3_TW - 1) / C3_TW;
+    const int ty0 = (blockIdx.x / tiles_x) * C3_TH, tx0 = (blockIdx.x % tiles_x) * C3_TW;
+    const int mb0 = blockIdx.y * MBW, n = blockIdx.z;
+    const int G = P.Cin >> 4;
+
+    // this wave's share of the patch chunks: chunk c = wave + 4k; per-lane element offset of the pixel (or -1 = padding)
+    long long boff[(C3_B_CHUNKS + 3) / 4];
+#pragma unroll
+    for (int k = 0; k < (C3_B_CHUNKS + 3) / 4; ++k) {
+        const int item = (wave + 4 * k) * 64 + lane;
+        const int hh = item / C3_HALF_ITEMS, r = item % C3_HALF_ITEMS, py = r / C3_PW, px = r % C3_PW;
+        const int y = ty0 - 1 + py, x = tx0 - 1 + px;
+        const bool ok = item < 2 * C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
+        boff[k] = ok ? (((long long)n * P.H + y) * P.W + x) * P.Cin + 8 * hh : -1;
+    }
+
+    auto issue = [&](int g, int stage) {
+        unsigned char* base = lds + stage * STAGE_BYTES;
+        // weights: chunk (m, t, part) <- packed[((mb0+m)*G + g)*18 + t*2 + part]
+        for (int c = wave; c < A_CHUNKS; c += 4) {
+            const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
+            const uint4* src = P.packed + (((long long)(mb0 + m) * G + g) * 18 + t * 2 + part) * 64 + lane;
+            lds_dma16(src, base + c * 1024);
+        }
+#pragma unroll
+        for (int k = 0; k < (C3_B_CHUNKS + 3) / 4; ++k) {
+            const int c = wave + 4 * k;
+            if (c < C3_B_CHUNKS) {
+#pragma unroll
+                for (int part = 0; part < PARTS; ++part) {
+                    const unsigned short* xs = part ? P.xl : P.xh;
+                    const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + 16 * g) : (const void*)nfe_zero16;
+                    lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
+                }
+            }
+        }
+    };
+
+    f32x16 acc[MBW][2];
+#pragma unroll
+    for (int m = 0; m < MBW; ++m)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.0f;
+
+    if (STAGES == 2) issue(0, 0);
+    for (int g = 0; g < G; ++g) {
+        const int stage = STAGES == 2 ? (g & 1) : 0;
+        if (STAGES == 1) { __syncthreads(); issue(g, 0); }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (STAGES == 2 && g + 1 < G) issue(g + 1, stage ^ 1);
+        const unsigned char* base = lds + stage * STAGE_BYTES;
+        const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
+        const unsigned char* ldsB = base + A_CHUNKS * 1024 + ((h * C3_HALF_ITEMS) + (2 * wave) * C3_PW + j) * 16;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int kh = t / 3, kw = t % 3;
+            Frag8 ah[MBW], al[MBW];
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) {
+                ah[m].q = ldsA[((m * 9 + t) * PARTS + 0) * 64];
+                if (TERMS == 3) al[m].q = ldsA[((m * 9 + t) * PARTS + 1) * 64];
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                Frag8 bh, bl;
+                bh.q = *reinterpret_cast<const uint4*>(ldsB + ((nb + kh) * C3_PW + kw) * 16);
+                if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + ((nb + kh) * C3_PW + kw) * 16);
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bh.v, acc[m][nb], 0, 0, 0);
+                    if (TERMS == 3) {
+                        acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bl.v, acc[m][nb], 0, 0, 0);
+                        acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m].v, bh.v, acc[m][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of pixel (row, j) ----
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const int y = ty0 + 2 * wave + nb, x = tx0 + j;
+        if (y >= P.H || x >= P.W) continue;
+        const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
+#pragma unroll
+        for (int m = 0; m < MBW; ++m)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int o0 = 32 * (mb0 + m) + 8 * qq + 4 * h;
+                const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + o0) : make_float4(1, 1, 1, 1);
+                const float4 b = *reinterpret_cast<const float4*>(P.bias + o0);
+                float4 v;
+                v.x = epilogue_act(acc[m][nb][4 * qq + 0] * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+                v.y = epilogue_act(acc[m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+                v.z = epilogue_act(acc[m][nb][4 * qq + 2] * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+                v.w = epilogue_act(acc[m][nb][4 * qq + 3] * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+                *reinterpret_cast<float4*>(P.out + (((long long)n * P.H + y) * P.W + x) * P.Cout + o0) = v;
+            }
+    }
+}
+
 // FIR + epilogue of the up-conv: out[Y][X] = act(dcoef * sum_ab F[a]F[b] T[Y+a-1][X+b-1] + noise + bias),
 // F = [1,3,3,1]/4 per axis (setup_filter/64 * gain 4; conv2d_resample.py:127, upfirdn2d.py:169-207)
 __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
@@ -540,6 +697,16 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL((conv_kernel<MODE, 3>), grid, dim3(256), 0, st, P);
 }
 
+extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout) {
+    if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
+    if (mode == NFE_CONV_3X3_UP2) return (uint64_t)n * (2 * h + 1) * (2 * w + 1) * cout;
+    if (mode == NFE_CONV_3X3 && w >= 32 && h >= 8 && cin % 16 == 0 && cout % 64 == 0) {
+        const uint64_t elems = (uint64_t)n * h * w * cin;           // bf16 hi (+ lo) image of the modulated input
+        return math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
+    }
+    return 0;
+}
+
 extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a != nullptr, "nfe_modulated_conv: args is null");
     NFE_REQUIRE(a->struct_size == sizeof(nfe_conv_args), "nfe_modulated_conv: struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(nfe_conv_args));
@@ -555,6 +722,23 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     P.noise_strength = a->noise_strength; P.bias = a->bias; P.N = a->n; P.H = a->h; P.W = a->w; P.Cin = a->cin; P.Cout = a->cout;
     P.lrelu = a->lrelu; P.act_gain = a->act_gain; P.clamp = a->clamp; P.skip = a->skip; P.out_planes = a->out_planes; P.out = a->out; P.scratch = a->scratch;
     hipStream_t st = (hipStream_t)stream;
+    if (a->mode == NFE_CONV_3X3 && a->scratch && nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout) > 0) {
+        // fast path: modulate + split once, then the LDS-DMA implicit GEMM
+        const long long elems = (long long)a->n * a->h * a->w * a->cin;
+        unsigned short* xh = reinterpret_cast<unsigned short*>(a->scratch);
+        unsigned short* xl = a->math == NFE_CONV_BF16X3 ? xh + elems : nullptr;
+        hipLaunchKernelGGL(modsplit_kernel, dim3(grid1d(elems / 4, 256, 1 << 15)), dim3(256), 0, st, reinterpret_cast<const float4*>(a->x), a->styles,
+                           elems / 4, (long long)a->h * a->w * (a->cin / 4), a->cin / 4, reinterpret_cast<uint2*>(xh), reinterpret_cast<uint2*>(xl));
+        Conv3K K{};
+        K.xh = xh; K.xl = xl; K.packed = reinterpret_cast<const uint4*>(a->packed); K.dcoef = a->dcoef; K.noise = a->noise;
+        K.noise_n_stride = a->noise_n_stride; K.noise_strength = a->noise_strength; K.bias = a->bias; K.N = a->n; K.H = a->h; K.W = a->w;
+        K.Cin = a->cin; K.Cout = a->cout; K.lrelu = a->lrelu; K.act_gain = a->act_gain; K.clamp = a->clamp; K.out = a->out;
+        dim3 g3(((a->h + C3_TH - 1) / C3_TH) * ((a->w + C3_TW - 1) / C3_TW), a->cout / 64, a->n);
+        if (a->math == NFE_CONV_BF16) hipLaunchKernelGGL((conv3_kernel<1, 2>), g3, dim3(256), 0, st, K);
+        else hipLaunchKernelGGL((conv3_kernel<3, 2>), g3, dim3(256), 0, st, K);
+        NFE_CHECK_LAUNCH("conv3 kernels");
+        return NFE_OK;
+    }
     const int up = a->mode == NFE_CONV_3X3_UP2;
     const int gh = a->h + up, gw = a->w + up;
     dim3 grid(((gh + 15) / 16) * ((gw + 15) / 16), (a->cout + 31) / 32, a->n);

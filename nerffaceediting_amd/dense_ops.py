@@ -131,6 +131,9 @@ def conv_demod(styles, wsq):
     return d
 
 
+FAST_PATH = True      # tests flip this to compare the LDS-DMA 3x3 path with the generic kernel
+
+
 def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, noise_strength=0.0, lrelu=True,
                    act_gain=1.0, clamp=None, skip=None, out_planes=False, math=None):
     """nfe_modulated_conv.  x [N,H,W,Cin] NHWC -> [N,Ho,Wo,Cout] (or [N,3,Ho,Wo,32] if out_planes)."""
@@ -162,8 +165,9 @@ def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, 
     out = torch.empty((N, 3, Ho, Wo, 32) if out_planes else (N, Ho, Wo, cout), device=x.device)
     a.out = out.data_ptr()
     scratch = None
-    if up == 2:
-        scratch = torch.empty(N * (2 * H + 1) * (2 * W + 1) * cout, device=x.device)
+    n_scratch = int(lib.nfe_conv_scratch_floats(a.mode, a.math, N, H, W, cin, cout)) if FAST_PATH else (N * (2 * H + 1) * (2 * W + 1) * cout if up == 2 else 0)
+    if n_scratch:                    # up-conv intermediate, or the pre-split input image of the 3x3 fast path
+        scratch = torch.empty(n_scratch, device=x.device)
         a.scratch = scratch.data_ptr()
     keep += [dcoef, noise, bias, skip, scratch]
     _call(x.device, lambda: lib.nfe_modulated_conv(ctypes.byref(a), _stream()), "nfe_modulated_conv")

@@ -141,3 +141,36 @@ def test_superresolution_8xdc(tag, dev):
     print("sr", tag, e)
     assert e <= TOL
     assert abs(float(y.mean()) - float(z[tag + ".out_mean"])) <= 1e-4
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 40, 72, 48, 128), (1, 8, 32, 16, 64), (3, 33, 95, 64, 64)])
+def test_conv3x3_fast_path_matches_generic(shape, math, dev):
+    """The LDS-DMA 3x3 path (pre-split activations) against the generic kernel on ragged tiles, and against a
+    torch fp32 conv of the same modulated/demodulated layer (modulated_conv2d, networks_stylegan2.py:34-91)."""
+    from nerffaceediting_amd import _lib, dense_ops as D
+    N, H, W, cin, cout = shape
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(N, H, W, cin, generator=g).to(dev)
+    styles = (torch.randn(N, cin, generator=g) * 0.5 + 1.0).to(dev)
+    weight = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    noise = torch.randn(H, W, generator=g).to(dev)
+    packed, wsq = D.conv_pack(weight)
+    dcoef = D.conv_demod(styles, wsq)
+    kw = dict(bias=bias, dcoef=dcoef, noise=noise, noise_strength=0.3, lrelu=True, act_gain=2 ** 0.5, clamp=256.0, math=math)
+    assert _lib.load().nfe_conv_scratch_floats(_lib.NFE_CONV_3X3, D.MATH[math], N, H, W, cin, cout) > 0
+    fast = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_3X3, **kw)
+    D.FAST_PATH = False
+    try:
+        slow = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_3X3, **kw)
+    finally:
+        D.FAST_PATH = True
+    assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
+    w = weight[None] * styles[:, None, :, None, None]
+    w = w * torch.rsqrt((w * w).sum(dim=(2, 3, 4), keepdim=True) + 1e-8)
+    ref = torch.cat([torch.nn.functional.conv2d(x[i:i + 1].permute(0, 3, 1, 2), w[i], padding=1) for i in range(N)], 0)
+    ref = ref + noise[None, None] * 0.3 + bias[None, :, None, None]
+    ref = (torch.nn.functional.leaky_relu(ref, 0.2) * 2 ** 0.5).clamp(-256, 256).permute(0, 2, 3, 1)
+    tol = (2e-5 if math == "bf16x3" else 2e-2) * float(ref.abs().max())
+    assert float((fast - ref).abs().max()) <= tol
