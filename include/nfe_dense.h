@@ -88,9 +88,11 @@ typedef struct nfe_conv_args {
                                      upsample2d()'d (upfirdn2d.py:315-350) and added, or NULL */
     int32_t out_planes;           /* mode 2 only: 1 = write [N,3,H,W,32] instead of [N,H,W,Cout] */
     float* out;
-    float* scratch;               /* nfe_conv_scratch_floats() floats.  mode 1 (required): [N,2H+1,2W+1,Cout]
-                                     transposed-conv result before the FIR.  mode 0 (optional): bf16 hi (+lo) image of
-                                     the modulated input; given, the layer runs the LDS-DMA fast path, NULL = generic path */
+    float* scratch;               /* mode 1 (required): at least N*(2H+1)*(2W+1)*Cout floats, the transposed-conv
+                                     result before the FIR.  With nfe_conv_scratch_floats() floats (modes 0 and 1) the
+                                     layer additionally keeps a bf16 hi (+lo) image of the modulated input there and
+                                     runs the LDS-DMA fast path; less (or NULL in mode 0) = generic path */
+    uint64_t scratch_floats;      /* capacity of `scratch` in floats */
 } nfe_conv_args;
 int nfe_modulated_conv(const nfe_conv_args* args, nfe_stream_t stream);
 /* floats of scratch a call with these sizes can use (0 = none) */

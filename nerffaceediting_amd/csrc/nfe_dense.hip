@@ -387,7 +387,7 @@ __device__ uint4 nfe_zero16[4];                                  // source of th
 struct Conv3K {
     const unsigned short* xh; const unsigned short* xl; const uint4* packed; const float* dcoef; const float* noise;
     long long noise_n_stride; float noise_strength; const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp;
-    float* out;
+    float* out; float* scratch;
 };
 
 constexpr int C3_TW = 32, C3_TH = 8, C3_PW = C3_TW + 2, C3_PH = C3_TH + 2;
@@ -400,9 +400,13 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
 }
 
-template <int TERMS, int MBW>
+// UP2: the stride-2 transposed convolution of the up-sampling layers as four output phases over the (H+1)x(W+1)
+// extended input grid (same tap -> phase map as conv_kernel<NFE_CONV_3X3_UP2>), written to the (2H+1)x(2W+1)
+// scratch that upfir_kernel filters.
+template <int TERMS, int MBW, bool UP2>
 __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
+    constexpr int NACC = UP2 ? 4 : 1;
     constexpr int A_CHUNKS = MBW * 9 * PARTS;
     constexpr int STAGE_BYTES = A_CHUNKS * 1024 + PARTS * C3_B_BYTES;
     constexpr int STAGES = (2 * STAGE_BYTES <= 65536) ? 2 : 1;
@@ -410,7 +414,8 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_x = (P.W + C3_TW - 1) / C3_TW;
+    const int gw = UP2 ? P.W + 1 : P.W;                       // tile grid: output pixels, or the extended input grid
+    const int tiles_x = (gw + C3_TW - 1) / C3_TW;
     const int ty0 = (blockIdx.x / tiles_x) * C3_TH, tx0 = (blockIdx.x % tiles_x) * C3_TW;
     const int mb0 = blockIdx.y * MBW, n = blockIdx.z;
     const int G = P.Cin >> 4;
@@ -448,13 +453,15 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
         }
     };
 
-    f32x16 acc[MBW][2];
+    f32x16 acc[NACC][MBW][2];
 #pragma unroll
-    for (int m = 0; m < MBW; ++m)
+    for (int a = 0; a < NACC; ++a)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb)
+        for (int m = 0; m < MBW; ++m)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[m][nb][r] = 0.0f;
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][m][nb][r] = 0.0f;
 
     if (STAGES == 2) issue(0, 0);
     for (int g = 0; g < G; ++g) {
@@ -478,14 +485,16 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 Frag8 bh, bl;
-                bh.q = *reinterpret_cast<const uint4*>(ldsB + ((nb + kh) * C3_PW + kw) * 16);
-                if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + ((nb + kh) * C3_PW + kw) * 16);
+                const int dy = UP2 ? 1 - (kh >> 1) : kh, dx = UP2 ? 1 - (kw >> 1) : kw;
+                const int a = UP2 ? (kh & 1) * 2 + (kw & 1) : 0;
+                bh.q = *reinterpret_cast<const uint4*>(ldsB + ((nb + dy) * C3_PW + dx) * 16);
+                if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + ((nb + dy) * C3_PW + dx) * 16);
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) {
-                    acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bh.v, acc[m][nb], 0, 0, 0);
+                    acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
                     if (TERMS == 3) {
-                        acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bl.v, acc[m][nb], 0, 0, 0);
-                        acc[m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m].v, bh.v, acc[m][nb], 0, 0, 0);
+                        acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bl.v, acc[a][m][nb], 0, 0, 0);
+                        acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
                     }
                 }
             }
@@ -496,6 +505,24 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
         const int y = ty0 + 2 * wave + nb, x = tx0 + j;
+        if (UP2) {
+            if (y > P.H || x > P.W) continue;
+            const int TH2 = 2 * P.H + 1, TW2 = 2 * P.W + 1;
+#pragma unroll
+            for (int a = 0; a < NACC; ++a) {
+                const int Y = 2 * y + (a >> 1), X = 2 * x + (a & 1);
+                if (Y >= TH2 || X >= TW2) continue;
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    float* dst = P.scratch + (((long long)n * TH2 + Y) * TW2 + X) * P.Cout + 32 * (mb0 + m) + 4 * h;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq)
+                        *reinterpret_cast<float4*>(dst + 8 * qq) = make_float4(acc[a][m][nb][4 * qq], acc[a][m][nb][4 * qq + 1],
+                                                                                acc[a][m][nb][4 * qq + 2], acc[a][m][nb][4 * qq + 3]);
+                }
+            }
+            continue;
+        }
         if (y >= P.H || x >= P.W) continue;
         const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
 #pragma unroll
@@ -506,10 +533,10 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
                 const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + o0) : make_float4(1, 1, 1, 1);
                 const float4 b = *reinterpret_cast<const float4*>(P.bias + o0);
                 float4 v;
-                v.x = epilogue_act(acc[m][nb][4 * qq + 0] * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
-                v.y = epilogue_act(acc[m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
-                v.z = epilogue_act(acc[m][nb][4 * qq + 2] * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
-                v.w = epilogue_act(acc[m][nb][4 * qq + 3] * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+                v.x = epilogue_act(acc[0][m][nb][4 * qq + 0] * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+                v.y = epilogue_act(acc[0][m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+                v.z = epilogue_act(acc[0][m][nb][4 * qq + 2] * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+                v.w = epilogue_act(acc[0][m][nb][4 * qq + 3] * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
                 *reinterpret_cast<float4*>(P.out + (((long long)n * P.H + y) * P.W + x) * P.Cout + o0) = v;
             }
     }
@@ -697,14 +724,19 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL((conv_kernel<MODE, 3>), grid, dim3(256), 0, st, P);
 }
 
+static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
+    if (cin % 16 != 0 || w < 32 || h < 8) return false;
+    return mode == NFE_CONV_3X3 ? cout % 64 == 0 : (mode == NFE_CONV_3X3_UP2 && cout % 32 == 0);
+}
+
 extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout) {
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
-    if (mode == NFE_CONV_3X3_UP2) return (uint64_t)n * (2 * h + 1) * (2 * w + 1) * cout;
-    if (mode == NFE_CONV_3X3 && w >= 32 && h >= 8 && cin % 16 == 0 && cout % 64 == 0) {
+    uint64_t fl = mode == NFE_CONV_3X3_UP2 ? (uint64_t)n * (2 * h + 1) * (2 * w + 1) * cout : 0;     // transposed-conv result
+    if (conv3_eligible(mode, h, w, cin, cout)) {
         const uint64_t elems = (uint64_t)n * h * w * cin;           // bf16 hi (+ lo) image of the modulated input
-        return math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
+        fl += math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
     }
-    return 0;
+    return fl;
 }
 
 extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
@@ -714,7 +746,8 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a->math == NFE_CONV_BF16X3 || a->math == NFE_CONV_BF16, "nfe_modulated_conv: unknown math %d", a->math);
     NFE_REQUIRE(a->x && a->styles && a->packed && a->bias && a->out, "nfe_modulated_conv: null pointer");
     NFE_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->cin > 0 && a->cout > 0 && a->cin % 4 == 0, "nfe_modulated_conv: bad sizes n=%d h=%d w=%d cin=%d cout=%d", a->n, a->h, a->w, a->cin, a->cout);
-    NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || (a->scratch && a->cout % 4 == 0), "nfe_modulated_conv: up-conv needs scratch and cout %% 4 == 0");
+    NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || (a->scratch && a->cout % 4 == 0 && a->scratch_floats >= (uint64_t)a->n * (2 * a->h + 1) * (2 * a->w + 1) * a->cout),
+                "nfe_modulated_conv: up-conv needs cout %% 4 == 0 and scratch of N*(2H+1)*(2W+1)*Cout floats");
     NFE_REQUIRE(!a->skip || (a->mode == NFE_CONV_1X1 && a->h % 2 == 0 && a->w % 2 == 0), "nfe_modulated_conv: skip needs mode 1x1 and even size");
     NFE_REQUIRE(!a->out_planes || (a->mode == NFE_CONV_1X1 && a->cout == 96), "nfe_modulated_conv: out_planes needs mode 1x1 and cout 96");
     ConvK P{};
@@ -722,20 +755,33 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     P.noise_strength = a->noise_strength; P.bias = a->bias; P.N = a->n; P.H = a->h; P.W = a->w; P.Cin = a->cin; P.Cout = a->cout;
     P.lrelu = a->lrelu; P.act_gain = a->act_gain; P.clamp = a->clamp; P.skip = a->skip; P.out_planes = a->out_planes; P.out = a->out; P.scratch = a->scratch;
     hipStream_t st = (hipStream_t)stream;
-    if (a->mode == NFE_CONV_3X3 && a->scratch && nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout) > 0) {
+    if (a->mode != NFE_CONV_1X1 && a->scratch && conv3_eligible(a->mode, a->h, a->w, a->cin, a->cout) &&
+        a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout)) {
         // fast path: modulate + split once, then the LDS-DMA implicit GEMM
+        const bool up2 = a->mode == NFE_CONV_3X3_UP2;
         const long long elems = (long long)a->n * a->h * a->w * a->cin;
-        unsigned short* xh = reinterpret_cast<unsigned short*>(a->scratch);
+        float* tail = a->scratch + (up2 ? (long long)a->n * (2 * a->h + 1) * (2 * a->w + 1) * a->cout : 0);   // split image sits after the FIR scratch
+        unsigned short* xh = reinterpret_cast<unsigned short*>(tail);
         unsigned short* xl = a->math == NFE_CONV_BF16X3 ? xh + elems : nullptr;
         hipLaunchKernelGGL(modsplit_kernel, dim3(grid1d(elems / 4, 256, 1 << 15)), dim3(256), 0, st, reinterpret_cast<const float4*>(a->x), a->styles,
                            elems / 4, (long long)a->h * a->w * (a->cin / 4), a->cin / 4, reinterpret_cast<uint2*>(xh), reinterpret_cast<uint2*>(xl));
         Conv3K K{};
         K.xh = xh; K.xl = xl; K.packed = reinterpret_cast<const uint4*>(a->packed); K.dcoef = a->dcoef; K.noise = a->noise;
         K.noise_n_stride = a->noise_n_stride; K.noise_strength = a->noise_strength; K.bias = a->bias; K.N = a->n; K.H = a->h; K.W = a->w;
-        K.Cin = a->cin; K.Cout = a->cout; K.lrelu = a->lrelu; K.act_gain = a->act_gain; K.clamp = a->clamp; K.out = a->out;
-        dim3 g3(((a->h + C3_TH - 1) / C3_TH) * ((a->w + C3_TW - 1) / C3_TW), a->cout / 64, a->n);
-        if (a->math == NFE_CONV_BF16) hipLaunchKernelGGL((conv3_kernel<1, 2>), g3, dim3(256), 0, st, K);
-        else hipLaunchKernelGGL((conv3_kernel<3, 2>), g3, dim3(256), 0, st, K);
+        K.Cin = a->cin; K.Cout = a->cout; K.lrelu = a->lrelu; K.act_gain = a->act_gain; K.clamp = a->clamp; K.out = a->out; K.scratch = a->scratch;
+        const int ext = up2 ? 1 : 0;
+        const unsigned tiles = ((a->h + ext + C3_TH - 1) / C3_TH) * ((a->w + ext + C3_TW - 1) / C3_TW);
+        if (up2) {
+            dim3 g3(tiles, a->cout / 32, a->n);
+            if (a->math == NFE_CONV_BF16) hipLaunchKernelGGL((conv3_kernel<1, 1, true>), g3, dim3(256), 0, st, K);
+            else hipLaunchKernelGGL((conv3_kernel<3, 1, true>), g3, dim3(256), 0, st, K);
+            const long long total = (long long)a->n * 4 * a->h * a->w * (a->cout / 4);
+            hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
+        } else {
+            dim3 g3(tiles, a->cout / 64, a->n);
+            if (a->math == NFE_CONV_BF16) hipLaunchKernelGGL((conv3_kernel<1, 2, false>), g3, dim3(256), 0, st, K);
+            else hipLaunchKernelGGL((conv3_kernel<3, 2, false>), g3, dim3(256), 0, st, K);
+        }
         NFE_CHECK_LAUNCH("conv3 kernels");
         return NFE_OK;
     }

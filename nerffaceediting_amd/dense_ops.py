@@ -168,7 +168,7 @@ def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, 
     n_scratch = int(lib.nfe_conv_scratch_floats(a.mode, a.math, N, H, W, cin, cout)) if FAST_PATH else (N * (2 * H + 1) * (2 * W + 1) * cout if up == 2 else 0)
     if n_scratch:                    # up-conv intermediate, or the pre-split input image of the 3x3 fast path
         scratch = torch.empty(n_scratch, device=x.device)
-        a.scratch = scratch.data_ptr()
+        a.scratch, a.scratch_floats = scratch.data_ptr(), n_scratch
     keep += [dcoef, noise, bias, skip, scratch]
     _call(x.device, lambda: lib.nfe_modulated_conv(ctypes.byref(a), _stream()), "nfe_modulated_conv")
     return out

@@ -174,3 +174,30 @@ def test_conv3x3_fast_path_matches_generic(shape, math, dev):
     ref = (torch.nn.functional.leaky_relu(ref, 0.2) * 2 ** 0.5).clamp(-256, 256).permute(0, 2, 3, 1)
     tol = (2e-5 if math == "bf16x3" else 2e-2) * float(ref.abs().max())
     assert float((fast - ref).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 40, 72, 48, 96), (1, 8, 32, 16, 32), (2, 33, 63, 32, 64)])
+def test_upconv_fast_path_matches_generic(shape, math, dev):
+    """Up-sampling layer (transposed conv + FIR, conv2d_resample.py:114-128) through the LDS-DMA path vs the generic kernel."""
+    from nerffaceediting_amd import _lib, dense_ops as D
+    N, H, W, cin, cout = shape
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(N, H, W, cin, generator=g).to(dev)
+    styles = (torch.randn(N, cin, generator=g) * 0.5 + 1.0).to(dev)
+    weight = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    noise = torch.randn(2 * H, 2 * W, generator=g).to(dev)
+    packed, wsq = D.conv_pack(weight)
+    dcoef = D.conv_demod(styles, wsq)
+    kw = dict(bias=bias, dcoef=dcoef, noise=noise, noise_strength=0.3, lrelu=True, act_gain=2 ** 0.5, clamp=None, math=math)
+    need = _lib.load().nfe_conv_scratch_floats(_lib.NFE_CONV_3X3_UP2, D.MATH[math], N, H, W, cin, cout)
+    assert need > N * (2 * H + 1) * (2 * W + 1) * cout
+    fast = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_3X3_UP2, **kw)
+    D.FAST_PATH = False
+    try:
+        slow = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_3X3_UP2, **kw)
+    finally:
+        D.FAST_PATH = True
+    assert fast.shape == (N, 2 * H, 2 * W, cout)
+    assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
