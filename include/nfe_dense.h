@@ -93,8 +93,16 @@ typedef struct nfe_conv_args {
                                      layer additionally keeps a bf16 hi (+lo) image of the modulated input there and
                                      runs the LDS-DMA fast path; less (or NULL in mode 0) = generic path */
     uint64_t scratch_floats;      /* capacity of `scratch` in floats */
+    /* Layer chaining without an fp32 round trip (conv0 -> conv1 of a SynthesisBlock): */
+    const float* next_styles;     /* [N,Cout] styles of the 3x3 layer that consumes this output, or NULL */
+    float* next_split;            /* out: bf16 hi(+lo) image of out * next_styles, nfe_conv_split_floats() floats; with it
+                                     `out` may be NULL (the fp32 output is then not written) */
+    const float* x_split;         /* in: such an image of this layer's modulated input (written by the producer with this
+                                     layer's styles); `x` may then be NULL.  Needs the fast path (scratch as above). */
 } nfe_conv_args;
 int nfe_modulated_conv(const nfe_conv_args* args, nfe_stream_t stream);
+/* floats of a bf16 hi(+lo) activation image [n,h,w,c] (hi only for NFE_CONV_BF16) */
+uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c);
 /* floats of scratch a call with these sizes can use (0 = none) */
 uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout);
 

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 2
+NFE_ABI_VERSION = 3
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_MATH_BF16X3, NFE_MATH_FP32 = 0, 1
@@ -49,6 +49,7 @@ class ConvArgs(ctypes.Structure):
         ("n", c_int32), ("h", c_int32), ("w", c_int32), ("cin", c_int32), ("cout", c_int32),
         ("lrelu", c_int32), ("act_gain", c_float), ("clamp", c_float),
         ("skip", FP), ("out_planes", c_int32), ("out", FP), ("scratch", FP), ("scratch_floats", c_uint64),
+        ("next_styles", FP), ("next_split", FP), ("x_split", FP),
     ]
 
 
@@ -80,6 +81,7 @@ _SIGNATURES = {
     "nfe_conv_demod": (c_int, [FP, FP, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_modulated_conv": (c_int, [POINTER(ConvArgs), c_void_p]),
     "nfe_conv_scratch_floats": (c_uint64, [c_int] * 7),
+    "nfe_conv_split_floats": (c_uint64, [c_int] * 5),
     "nfe_resize_bilinear": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
                                 FP, FP, FP, c_void_p]),

@@ -190,6 +190,7 @@ struct ConvK {
     const float* x; const float* styles; const uint4* packed; const float* dcoef; const float* noise; long long noise_n_stride; float noise_strength;
     const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp; const float* skip; int out_planes;
     float* out; float* scratch;
+    const float* next_styles; uint2* split_hi; uint2* split_lo;      // up-conv: modulated bf16 image for the consuming layer
 };
 
 constexpr int PATCH = 18;                                         // 16 + halo
@@ -403,14 +404,19 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
 // UP2: the stride-2 transposed convolution of the up-sampling layers as four output phases over the (H+1)x(W+1)
 // extended input grid (same tap -> phase map as conv_kernel<NFE_CONV_3X3_UP2>), written to the (2H+1)x(2W+1)
 // scratch that upfir_kernel filters.
-template <int TERMS, int MBW, bool UP2>
-__global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
+template <int TERMS, int MBW>
+constexpr int conv3_stage_bytes() { return (MBW * 9 + C3_B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
+
+// STAGES-deep ring of K-group buffers: the loads of K-group g+STAGES-1 are issued while g is computed, so a
+// load has STAGES-1 K-groups of MFMA time to land.
+template <int TERMS, int MBW, bool UP2, int STAGES>
+__global__ __launch_bounds__(256, ((STAGES * conv3_stage_bytes<TERMS, MBW>() > 80 * 1024) ? 1 : 2)) void conv3_kernel(Conv3K P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
     constexpr int NACC = UP2 ? 4 : 1;
     constexpr int A_CHUNKS = MBW * 9 * PARTS;
-    constexpr int STAGE_BYTES = A_CHUNKS * 1024 + PARTS * C3_B_BYTES;
-    constexpr int STAGES = (2 * STAGE_BYTES <= 65536) ? 2 : 1;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[STAGES * STAGE_BYTES];
+    constexpr int STAGE_BYTES = conv3_stage_bytes<TERMS, MBW>();
+    constexpr int MIN_LOADS = A_CHUNKS / 4 + (C3_B_CHUNKS / 4) * PARTS;      // fewest LDS-DMA instructions any wave issues per stage
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -463,13 +469,16 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][m][nb][r] = 0.0f;
 
-    if (STAGES == 2) issue(0, 0);
+    for (int pre = 0; pre < STAGES - 1; ++pre)
+        if (pre < G) issue(pre, pre);
+    int stage = 0;
     for (int g = 0; g < G; ++g) {
-        const int stage = STAGES == 2 ? (g & 1) : 0;
         if (STAGES == 1) { __syncthreads(); issue(g, 0); }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
+        if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
         __syncthreads();
-        if (STAGES == 2 && g + 1 < G) issue(g + 1, stage ^ 1);
+        if (STAGES >= 2 && g + STAGES - 1 < G) issue(g + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
         const unsigned char* ldsB = base + A_CHUNKS * 1024 + ((h * C3_HALF_ITEMS) + (2 * wave) * C3_PW + j) * 16;
@@ -499,6 +508,7 @@ __global__ __launch_bounds__(256, 2) void conv3_kernel(Conv3K P) {
                 }
             }
         }
+        stage = stage + 1 == STAGES ? 0 : stage + 1;
     }
 
     // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of pixel (row, j) ----
@@ -574,7 +584,14 @@ __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
         o.y = epilogue_act(s.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
         o.z = epilogue_act(s.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
         o.w = epilogue_act(s.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-        *reinterpret_cast<float4*>(P.out + (((long long)n * OH + Y) * OW + X) * P.Cout + 4 * c4) = o;
+        if (P.out) *reinterpret_cast<float4*>(P.out + (((long long)n * OH + Y) * OW + X) * P.Cout + 4 * c4) = o;
+        if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer
+            const float4 s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
+            unsigned h0, l0, h1, l1;
+            if (P.split_lo) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[i] = make_uint2(l0, l1); }
+            else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
+            P.split_hi[i] = make_uint2(h0, h1);
+        }
     }
 }
 
@@ -724,9 +741,31 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL((conv_kernel<MODE, 3>), grid, dim3(256), 0, st, P);
 }
 
+#ifndef C3_STAGES_BF16
+#define C3_STAGES_BF16 2
+#define C3_STAGES_BF16_UP 2
+#define C3_STAGES_X3 1
+#define C3_STAGES_X3_UP 1
+#endif
+template <int TERMS, int MBW, bool UP2, int STAGES>
+static void launch_conv3(const Conv3K& K, dim3 grid, hipStream_t st) {
+    constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW>();
+    static bool once = [] {
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES>), grid, dim3(256), bytes, st, K);
+}
+
 static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
     if (cin % 16 != 0 || w < 32 || h < 8) return false;
     return mode == NFE_CONV_3X3 ? cout % 64 == 0 : (mode == NFE_CONV_3X3_UP2 && cout % 32 == 0);
+}
+
+extern "C" uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c) {
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return 0;
+    const uint64_t elems = (uint64_t)n * h * w * c;
+    return math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
 }
 
 extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout) {
@@ -744,7 +783,8 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a->struct_size == sizeof(nfe_conv_args), "nfe_modulated_conv: struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(nfe_conv_args));
     NFE_REQUIRE(a->mode >= 0 && a->mode <= 2, "nfe_modulated_conv: unknown mode %d", a->mode);
     NFE_REQUIRE(a->math == NFE_CONV_BF16X3 || a->math == NFE_CONV_BF16, "nfe_modulated_conv: unknown math %d", a->math);
-    NFE_REQUIRE(a->x && a->styles && a->packed && a->bias && a->out, "nfe_modulated_conv: null pointer");
+    NFE_REQUIRE((a->x || a->x_split) && a->styles && a->packed && a->bias && (a->out || a->next_split), "nfe_modulated_conv: null pointer");
+    NFE_REQUIRE(!a->next_split || (a->next_styles && a->mode != NFE_CONV_1X1), "nfe_modulated_conv: next_split needs next_styles and a 3x3 mode");
     NFE_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->cin > 0 && a->cout > 0 && a->cin % 4 == 0, "nfe_modulated_conv: bad sizes n=%d h=%d w=%d cin=%d cout=%d", a->n, a->h, a->w, a->cin, a->cout);
     NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || (a->scratch && a->cout % 4 == 0 && a->scratch_floats >= (uint64_t)a->n * (2 * a->h + 1) * (2 * a->w + 1) * a->cout),
                 "nfe_modulated_conv: up-conv needs cout %% 4 == 0 and scratch of N*(2H+1)*(2W+1)*Cout floats");
@@ -755,35 +795,56 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     P.noise_strength = a->noise_strength; P.bias = a->bias; P.N = a->n; P.H = a->h; P.W = a->w; P.Cin = a->cin; P.Cout = a->cout;
     P.lrelu = a->lrelu; P.act_gain = a->act_gain; P.clamp = a->clamp; P.skip = a->skip; P.out_planes = a->out_planes; P.out = a->out; P.scratch = a->scratch;
     hipStream_t st = (hipStream_t)stream;
-    if (a->mode != NFE_CONV_1X1 && a->scratch && conv3_eligible(a->mode, a->h, a->w, a->cin, a->cout) &&
-        a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout)) {
+    const int upf = a->mode == NFE_CONV_3X3_UP2 ? 2 : 1;
+    const long long out_elems = (long long)a->n * a->h * upf * a->w * upf * a->cout;
+    if (a->next_split && a->mode == NFE_CONV_3X3_UP2) {            // fused into the FIR epilogue
+        P.next_styles = a->next_styles; P.split_hi = reinterpret_cast<uint2*>(a->next_split);
+        P.split_lo = a->math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a->next_split) + out_elems) : nullptr;
+    }
+    // plain 3x3 with a consumer image: one extra elementwise pass over the fp32 output
+    auto split_tail = [&]() -> int {
+        if (!(a->next_split && a->mode == NFE_CONV_3X3)) return NFE_OK;
+        NFE_REQUIRE(a->out && a->cout % 4 == 0, "nfe_modulated_conv: next_split on a 3x3 layer needs `out` and cout %% 4 == 0");
+        unsigned short* sh = reinterpret_cast<unsigned short*>(a->next_split);
+        hipLaunchKernelGGL(modsplit_kernel, dim3(grid1d(out_elems / 4, 256, 1 << 15)), dim3(256), 0, st, reinterpret_cast<const float4*>(a->out), a->next_styles,
+                           out_elems / 4, (long long)a->h * a->w * (a->cout / 4), a->cout / 4, reinterpret_cast<uint2*>(sh),
+                           a->math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(sh + out_elems) : nullptr);
+        NFE_CHECK_LAUNCH("modsplit_kernel");
+        return NFE_OK;
+    };
+    const bool fast = a->mode != NFE_CONV_1X1 && a->scratch && conv3_eligible(a->mode, a->h, a->w, a->cin, a->cout) &&
+                      a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout);
+    NFE_REQUIRE(!a->x_split || fast, "nfe_modulated_conv: x_split needs the fast path (eligible sizes and nfe_conv_scratch_floats() of scratch)");
+    NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || a->out || a->next_split, "nfe_modulated_conv: no output requested");
+    NFE_REQUIRE(a->mode == NFE_CONV_3X3_UP2 || a->out, "nfe_modulated_conv: `out` may only be NULL on up-sampling layers with next_split");
+    if (fast) {
         // fast path: modulate + split once, then the LDS-DMA implicit GEMM
         const bool up2 = a->mode == NFE_CONV_3X3_UP2;
         const long long elems = (long long)a->n * a->h * a->w * a->cin;
         float* tail = a->scratch + (up2 ? (long long)a->n * (2 * a->h + 1) * (2 * a->w + 1) * a->cout : 0);   // split image sits after the FIR scratch
-        unsigned short* xh = reinterpret_cast<unsigned short*>(tail);
+        unsigned short* xh = reinterpret_cast<unsigned short*>(a->x_split ? const_cast<float*>(a->x_split) : tail);
         unsigned short* xl = a->math == NFE_CONV_BF16X3 ? xh + elems : nullptr;
-        hipLaunchKernelGGL(modsplit_kernel, dim3(grid1d(elems / 4, 256, 1 << 15)), dim3(256), 0, st, reinterpret_cast<const float4*>(a->x), a->styles,
-                           elems / 4, (long long)a->h * a->w * (a->cin / 4), a->cin / 4, reinterpret_cast<uint2*>(xh), reinterpret_cast<uint2*>(xl));
+        if (!a->x_split)
+            hipLaunchKernelGGL(modsplit_kernel, dim3(grid1d(elems / 4, 256, 1 << 15)), dim3(256), 0, st, reinterpret_cast<const float4*>(a->x), a->styles,
+                               elems / 4, (long long)a->h * a->w * (a->cin / 4), a->cin / 4, reinterpret_cast<uint2*>(xh), reinterpret_cast<uint2*>(xl));
         Conv3K K{};
         K.xh = xh; K.xl = xl; K.packed = reinterpret_cast<const uint4*>(a->packed); K.dcoef = a->dcoef; K.noise = a->noise;
         K.noise_n_stride = a->noise_n_stride; K.noise_strength = a->noise_strength; K.bias = a->bias; K.N = a->n; K.H = a->h; K.W = a->w;
         K.Cin = a->cin; K.Cout = a->cout; K.lrelu = a->lrelu; K.act_gain = a->act_gain; K.clamp = a->clamp; K.out = a->out; K.scratch = a->scratch;
         const int ext = up2 ? 1 : 0;
         const unsigned tiles = ((a->h + ext + C3_TH - 1) / C3_TH) * ((a->w + ext + C3_TW - 1) / C3_TW);
+        const bool bf16 = a->math == NFE_CONV_BF16;
         if (up2) {
             dim3 g3(tiles, a->cout / 32, a->n);
-            if (a->math == NFE_CONV_BF16) hipLaunchKernelGGL((conv3_kernel<1, 1, true>), g3, dim3(256), 0, st, K);
-            else hipLaunchKernelGGL((conv3_kernel<3, 1, true>), g3, dim3(256), 0, st, K);
+            if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP>(K, g3, st); else launch_conv3<3, 1, true, C3_STAGES_X3_UP>(K, g3, st);
             const long long total = (long long)a->n * 4 * a->h * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
         } else {
             dim3 g3(tiles, a->cout / 64, a->n);
-            if (a->math == NFE_CONV_BF16) hipLaunchKernelGGL((conv3_kernel<1, 2, false>), g3, dim3(256), 0, st, K);
-            else hipLaunchKernelGGL((conv3_kernel<3, 2, false>), g3, dim3(256), 0, st, K);
+            if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16>(K, g3, st); else launch_conv3<3, 2, false, C3_STAGES_X3>(K, g3, st);
         }
         NFE_CHECK_LAUNCH("conv3 kernels");
-        return NFE_OK;
+        return split_tail();
     }
     const int up = a->mode == NFE_CONV_3X3_UP2;
     const int gh = a->h + up, gw = a->w + up;
@@ -796,7 +857,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
     }
     NFE_CHECK_LAUNCH("conv kernels");
-    return NFE_OK;
+    return split_tail();
 }
 
 extern "C" int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int ow, int antialias, float* out, nfe_stream_t stream) {

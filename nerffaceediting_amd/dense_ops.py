@@ -134,17 +134,43 @@ def conv_demod(styles, wsq):
 FAST_PATH = True      # tests flip this to compare the LDS-DMA 3x3 path with the generic kernel
 
 
-def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, noise_strength=0.0, lrelu=True,
-                   act_gain=1.0, clamp=None, skip=None, out_planes=False, math=None):
-    """nfe_modulated_conv.  x [N,H,W,Cin] NHWC -> [N,Ho,Wo,Cout] (or [N,3,Ho,Wo,32] if out_planes)."""
+class SplitImage:
+    """bf16 hi(+lo) image of a modulated NHWC activation, produced by one layer for the 3x3 layer that consumes it."""
+
+    def __init__(self, data, shape, math):
+        self.data, self.shape, self.math = data, tuple(shape), math
+
+
+def can_chain(mode, math, n, h, w, cin, cout):
+    """True if a layer of these sizes runs the fast path and can therefore take a SplitImage input."""
+    if not FAST_PATH:
+        return False
     lib = _lib.load()
-    x = _dev(x, "x", (None, None, None, None))
-    N, H, W, cin = x.shape
-    styles = _dev(styles, "styles", (N, cin))
+    base = n * (2 * h + 1) * (2 * w + 1) * cout if mode == _lib.NFE_CONV_3X3_UP2 else 0
+    return int(lib.nfe_conv_scratch_floats(int(mode), MATH[math], n, h, w, cin, cout)) > base
+
+
+def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, noise_strength=0.0, lrelu=True,
+                   act_gain=1.0, clamp=None, skip=None, out_planes=False, math=None, next_styles=None, want_out=True):
+    """nfe_modulated_conv.  x [N,H,W,Cin] NHWC (or a SplitImage of the modulated input) -> [N,Ho,Wo,Cout]
+    (or [N,3,Ho,Wo,32] if out_planes).  With next_styles [N,Cout] also returns the SplitImage for the consuming
+    3x3 layer: (out, split); out is None if want_out is False (up-sampling layers only)."""
+    lib = _lib.load()
     a = _lib.ConvArgs()
     a.struct_size = ctypes.sizeof(_lib.ConvArgs)
     a.mode, a.math = int(mode), MATH[math]
-    a.x, a.styles, a.packed = x.data_ptr(), styles.data_ptr(), _dev(packed, "packed").data_ptr()
+    if isinstance(x, SplitImage):
+        assert x.math == MATH[math], "SplitImage was produced for another math mode"
+        N, H, W, cin = x.shape
+        a.x_split = x.data.data_ptr()
+        dev = x.data.device
+    else:
+        x = _dev(x, "x", (None, None, None, None))
+        N, H, W, cin = x.shape
+        a.x = x.data_ptr()
+        dev = x.device
+    styles = _dev(styles, "styles", (N, cin))
+    a.styles, a.packed = styles.data_ptr(), _dev(packed, "packed").data_ptr()
     keep = [x, styles, packed]
     if dcoef is not None:
         dcoef = _dev(dcoef, "dcoef", (N, cout)); a.dcoef = dcoef.data_ptr()
@@ -162,16 +188,23 @@ def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, 
     if skip is not None:
         skip = _dev(skip, "skip", (N, H // 2, W // 2, cout)); a.skip = skip.data_ptr()
     a.out_planes = int(bool(out_planes))
-    out = torch.empty((N, 3, Ho, Wo, 32) if out_planes else (N, Ho, Wo, cout), device=x.device)
-    a.out = out.data_ptr()
+    out = None
+    if want_out or next_styles is None:
+        out = torch.empty((N, 3, Ho, Wo, 32) if out_planes else (N, Ho, Wo, cout), device=dev)
+        a.out = out.data_ptr()
+    split = None
+    if next_styles is not None:
+        next_styles = _dev(next_styles, "next_styles", (N, cout))
+        split = SplitImage(torch.empty(int(lib.nfe_conv_split_floats(a.math, N, Ho, Wo, cout)), device=dev), (N, Ho, Wo, cout), a.math)
+        a.next_styles, a.next_split = next_styles.data_ptr(), split.data.data_ptr()
     scratch = None
     n_scratch = int(lib.nfe_conv_scratch_floats(a.mode, a.math, N, H, W, cin, cout)) if FAST_PATH else (N * (2 * H + 1) * (2 * W + 1) * cout if up == 2 else 0)
     if n_scratch:                    # up-conv intermediate, or the pre-split input image of the 3x3 fast path
-        scratch = torch.empty(n_scratch, device=x.device)
+        scratch = torch.empty(n_scratch, device=dev)
         a.scratch, a.scratch_floats = scratch.data_ptr(), n_scratch
-    keep += [dcoef, noise, bias, skip, scratch]
-    _call(x.device, lambda: lib.nfe_modulated_conv(ctypes.byref(a), _stream()), "nfe_modulated_conv")
-    return out
+    keep += [dcoef, noise, bias, skip, scratch, next_styles, split]
+    _call(dev, lambda: lib.nfe_modulated_conv(ctypes.byref(a), _stream()), "nfe_modulated_conv")
+    return out if next_styles is None else (out, split)
 
 
 def resize_bilinear(x, oh, ow, antialias=True):

@@ -115,16 +115,19 @@ class SynthesisLayer(torch.nn.Module):
             self._ns, self._ns_key = float(self.noise_strength.detach()), key
         return self._ns
 
-    def forward_nhwc(self, x, w, noise_mode="random", gain=1, conv_math=None):
+    def forward_nhwc(self, x, w, noise_mode="random", gain=1, conv_math=None, styles=None, next_styles=None, want_out=True):
+        """x: NHWC tensor, or a dense_ops.SplitImage made by the producing layer with this layer's `styles`.  With
+        next_styles (the styles of the 3x3 layer consuming the output) returns (out, SplitImage)."""
         assert noise_mode in ["random", "const", "none"]
         in_res = self.resolution // self.up
-        assert x.shape[1:] == (in_res, in_res, self.in_channels), f"wrong input shape {list(x.shape)}"       # misc.assert_shape :314
-        styles = self.affine(w)
+        assert tuple(x.shape[1:]) == (in_res, in_res, self.in_channels), f"wrong input shape {list(x.shape)}"       # misc.assert_shape :314
+        if styles is None:
+            styles = self.affine(w)
         packed, wsq = _pack_cached(self, self.weight)
         dcoef = dense_ops.conv_demod(styles, wsq)
         noise, strength = None, 0.0
         if self.use_noise and noise_mode == "random":
-            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=x.device)
+            noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=styles.device)
             strength = self._strength()
         if self.use_noise and noise_mode == "const":
             noise, strength = self.noise_const, self._strength()
@@ -132,7 +135,7 @@ class SynthesisLayer(torch.nn.Module):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return dense_ops.modulated_conv(x, styles, packed, self.out_channels, mode, self.bias.detach(), dcoef=dcoef, noise=noise,
                                         noise_strength=strength, lrelu=True, act_gain=self.act_gain * gain, clamp=clamp,
-                                        math=conv_math)
+                                        math=conv_math, next_styles=next_styles, want_out=want_out)
 
     def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1):
         return dense_ops.nhwc_to_nchw(self.forward_nhwc(dense_ops.nchw_to_nhwc(x), w, noise_mode=noise_mode, gain=gain))
@@ -200,9 +203,18 @@ class SynthesisBlock(torch.nn.Module):
                 self._const_nhwc = self.const.detach().permute(1, 2, 0).contiguous()
                 self._const_key = (self.const.data_ptr(), self.const._version)
             x = self._const_nhwc.unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
+            x = self.conv1.forward_nhwc(x, next(it), noise_mode=noise_mode, conv_math=conv_math)
         else:
-            x = self.conv0.forward_nhwc(x, next(it), noise_mode=noise_mode, conv_math=conv_math)
-        x = self.conv1.forward_nhwc(x, next(it), noise_mode=noise_mode, conv_math=conv_math)
+            w0, w1 = next(it), next(it)
+            N, r, c1 = ws.shape[0], self.resolution, self.conv1.in_channels
+            if dense_ops.can_chain(_lib.NFE_CONV_3X3, conv_math, N, r, r, c1, self.conv1.out_channels) and c1 % 4 == 0:
+                # conv0's FIR epilogue writes conv1's modulated bf16 input directly: no fp32 round trip between them
+                s1 = self.conv1.affine(w1)
+                _, xs = self.conv0.forward_nhwc(x, w0, noise_mode=noise_mode, conv_math=conv_math, next_styles=s1, want_out=False)
+                x = self.conv1.forward_nhwc(xs, w1, noise_mode=noise_mode, conv_math=conv_math, styles=s1)
+            else:
+                x = self.conv0.forward_nhwc(x, w0, noise_mode=noise_mode, conv_math=conv_math)
+                x = self.conv1.forward_nhwc(x, w1, noise_mode=noise_mode, conv_math=conv_math)
         img = self.torgb.forward_nhwc(x, next(it), skip=img, out_planes=out_planes, conv_math=conv_math)   # upsample2d(img) + y
         return x, img
 
