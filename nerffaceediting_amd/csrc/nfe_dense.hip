@@ -555,43 +555,69 @@ __global__ __launch_bounds__(256, ((STAGES * conv3_stage_bytes<TERMS, MBW>() > 8
 // FIR + epilogue of the up-conv: out[Y][X] = act(dcoef * sum_ab F[a]F[b] T[Y+a-1][X+b-1] + noise + bias),
 // F = [1,3,3,1]/4 per axis (setup_filter/64 * gain 4; conv2d_resample.py:127, upfirdn2d.py:169-207)
 __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
+    // One thread = 4 channels of a 2x2 output block: 25 loads of T for 4 outputs (separable 4-tap filter per axis)
+    // instead of 16 per output; lanes run over channels, so every load is a contiguous 512-byte row piece.
     const int OH = 2 * P.H, OW = 2 * P.W, TH = OH + 1, TW = OW + 1, C4 = P.Cout >> 2;
-    const long long total = (long long)P.N * OH * OW * C4;
+    const long long total = (long long)P.N * P.H * P.W * C4;
     const float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4); long long r = i / C4;
-        const int X = (int)(r % OW); r /= OW;
-        const int Y = (int)(r % OH); const int n = (int)(r / OH);
-        float4 s = make_float4(0, 0, 0, 0);
+        const int bx = (int)(r % P.W); r /= P.W;
+        const int by = (int)(r % P.H); const int n = (int)(r / P.H);
+        const int Y0 = 2 * by, X0 = 2 * bx;
+        float4 rf[5][2];                                   // row-filtered: rf[i][dx] = sum_b F[b] T[Y0-1+i][X0+dx+b-1]
 #pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            const int ty = Y + a - 1;
-            if (ty < 0 || ty >= TH) continue;
+        for (int ii = 0; ii < 5; ++ii) {
+            const int ty = Y0 - 1 + ii;
+            float4 t[5];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int tx = X + b - 1;
-                if (tx < 0 || tx >= TW) continue;
-                const float4 t = *reinterpret_cast<const float4*>(P.scratch + (((long long)n * TH + ty) * TW + tx) * P.Cout + 4 * c4);
-                const float wgt = F[a] * F[b];
-                s.x = fmaf(wgt, t.x, s.x); s.y = fmaf(wgt, t.y, s.y); s.z = fmaf(wgt, t.z, s.z); s.w = fmaf(wgt, t.w, s.w);
+            for (int jj = 0; jj < 5; ++jj) {
+                const int tx = X0 - 1 + jj;
+                t[jj] = (ty >= 0 && ty < TH && tx >= 0 && tx < TW)
+                            ? *reinterpret_cast<const float4*>(P.scratch + (((long long)n * TH + ty) * TW + tx) * P.Cout + 4 * c4)
+                            : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float4 a = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int bb = 0; bb < 4; ++bb) {
+                    a.x = fmaf(F[bb], t[dx + bb].x, a.x); a.y = fmaf(F[bb], t[dx + bb].y, a.y);
+                    a.z = fmaf(F[bb], t[dx + bb].z, a.z); a.w = fmaf(F[bb], t[dx + bb].w, a.w);
+                }
+                rf[ii][dx] = a;
             }
         }
-        const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
         const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + 4 * c4) : make_float4(1, 1, 1, 1);
         const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
-        float4 o;
-        o.x = epilogue_act(s.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
-        o.y = epilogue_act(s.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
-        o.z = epilogue_act(s.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
-        o.w = epilogue_act(s.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-        if (P.out) *reinterpret_cast<float4*>(P.out + (((long long)n * OH + Y) * OW + X) * P.Cout + 4 * c4) = o;
-        if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer
-            const float4 s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
-            unsigned h0, l0, h1, l1;
-            if (P.split_lo) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[i] = make_uint2(l0, l1); }
-            else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
-            P.split_hi[i] = make_uint2(h0, h1);
-        }
+        float4 s2 = make_float4(0, 0, 0, 0);
+        if (P.split_hi) s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                float4 sm = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    sm.x = fmaf(F[aa], rf[dy + aa][dx].x, sm.x); sm.y = fmaf(F[aa], rf[dy + aa][dx].y, sm.y);
+                    sm.z = fmaf(F[aa], rf[dy + aa][dx].z, sm.z); sm.w = fmaf(F[aa], rf[dy + aa][dx].w, sm.w);
+                }
+                const int Y = Y0 + dy, X = X0 + dx;
+                const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
+                float4 o;
+                o.x = epilogue_act(sm.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+                o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+                o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+                o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+                const long long oi = (((long long)n * OH + Y) * OW + X) * C4 + c4;
+                if (P.out) reinterpret_cast<float4*>(P.out)[oi] = o;
+                if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer
+                    unsigned h0, l0, h1, l1;
+                    if (P.split_lo) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[oi] = make_uint2(l0, l1); }
+                    else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
+                    P.split_hi[oi] = make_uint2(h0, h1);
+                }
+            }
     }
 }
 
@@ -837,7 +863,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         if (up2) {
             dim3 g3(tiles, a->cout / 32, a->n);
             if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP>(K, g3, st); else launch_conv3<3, 1, true, C3_STAGES_X3_UP>(K, g3, st);
-            const long long total = (long long)a->n * 4 * a->h * a->w * (a->cout / 4);
+            const long long total = (long long)a->n * a->h * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
         } else {
             dim3 g3(tiles, a->cout / 64, a->n);
@@ -853,7 +879,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, a->math, grid, st);
     else {
         launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st);
-        const long long total = (long long)a->n * 4 * a->h * a->w * (a->cout / 4);
+        const long long total = (long long)a->n * a->h * a->w * (a->cout / 4);
         hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
     }
     NFE_CHECK_LAUNCH("conv kernels");
