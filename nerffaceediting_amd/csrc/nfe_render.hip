@@ -146,10 +146,16 @@ __device__ __forceinline__ float4 texel_piece(const float* __restrict__ base, un
 #endif
 }
 
+// Bilinear weights travel through the LDS crossbar (ds_swizzle, quad-perm mode: no LDS memory, no VALU issue
+// slot) while the texel loads are in flight; only the address broadcast stays on DPP (it feeds the load).
+template <int I> __device__ __forceinline__ float quad_swizzle(float v) {
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x8000 | (I * 0x55)));
+}
 #define NFE_QUAD_ADDR(K, I) o[K][I] = (unsigned)quad_bcast<I>((int)offs[k0 + K]) + qoff_bytes;
+#define NFE_QUAD_WGT(K, I) wq[K][I] = quad_swizzle<I>(t.w[k0 + K]);
 #define NFE_QUAD_FMA(K, I)                                                                                 \
     {                                                                                                      \
-        const f32x2 w2 = splat(quad_bcast<I>(t.w[k0 + K]));                                                \
+        const f32x2 w2 = splat(wq[K][I]);                                                                  \
         sg[2 * I + 0] = pk_fma(w2, f32x2{vg[K][I].x, vg[K][I].y}, sg[2 * I + 0]);                          \
         sg[2 * I + 1] = pk_fma(w2, f32x2{vg[K][I].z, vg[K][I].w}, sg[2 * I + 1]);                          \
         if (DUAL) {                                                                                        \
@@ -171,6 +177,7 @@ __device__ __forceinline__ void fetch_quad(const float* __restrict__ pg, const f
 #pragma unroll
     for (int k0 = 0; k0 < 4; k0 += TAPS_IN_FLIGHT) {
         unsigned o[TAPS_IN_FLIGHT][4];
+        float wq[TAPS_IN_FLIGHT][4];
         float4 vg[TAPS_IN_FLIGHT][4], va[TAPS_IN_FLIGHT][4];
 #pragma unroll
         for (int K = 0; K < TAPS_IN_FLIGHT; ++K) {
@@ -180,6 +187,7 @@ __device__ __forceinline__ void fetch_quad(const float* __restrict__ pg, const f
                 vg[K][i] = texel_piece(pg, o[K][i]);
                 if (DUAL) va[K][i] = texel_piece(pa, o[K][i]);
             }
+            NFE_QUAD_WGT(K, 0) NFE_QUAD_WGT(K, 1) NFE_QUAD_WGT(K, 2) NFE_QUAD_WGT(K, 3)
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
