@@ -102,3 +102,26 @@ def render_video_frames(G, ws, norm_planes, denorm_planes, frames=150, a_degree=
         out.append(img.permute(0, 2, 3, 1))
     local = torch.cat(out, 0) if out else torch.zeros(0, G.img_resolution, G.img_resolution, 3, dtype=torch.uint8, device=dev)
     return sharding.all_gather_frames(local, V) if world > 1 else local
+
+
+PART_COLORS = [[0, 0, 0], [127, 212, 255], [255, 212, 255], [255, 255, 170], [255, 255, 130], [76, 153, 0], [0, 255, 170],
+               [244, 124, 244], [30, 162, 230], [127, 255, 255], [127, 170, 255], [85, 0, 255], [255, 170, 127], [212, 127, 255],
+               [0, 170, 255], [255, 255, 255]]
+
+
+@torch.no_grad()
+def vis_parsing_maps(im, inverse=False, argmax=True):
+    """utils.py:91-128: seg logits [N,15+,H,W] (or label map) -> colour image in [-1,1]; inverse: colours -> labels."""
+    colors = torch.tensor(PART_COLORS, device=im.device, dtype=torch.float32)
+    if not inverse:
+        if argmax:
+            im = torch.argmax(im, dim=1, keepdim=True)
+        idx = im[:, 0].long().clamp(0, len(PART_COLORS) - 1)
+        out = colors[idx].permute(0, 3, 1, 2)
+        out = torch.where((im >= 0) & (im < len(PART_COLORS)), out, torch.zeros_like(out))
+        return out / 255.0 * 2 - 1
+    out = torch.zeros((im.size(0), 1, im.size(2), im.size(3)), device=im.device, dtype=torch.int64)
+    for index in range(len(PART_COLORS)):
+        color = colors[index].to(im.dtype).view(1, 3, 1, 1) / 255.0 * 2 - 1
+        out = torch.where(torch.all((im - color).abs() <= 1e-2, dim=1, keepdim=True), torch.full_like(out, index), out)
+    return out
