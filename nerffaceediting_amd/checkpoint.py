@@ -13,9 +13,6 @@ def load_generator(prefix, device="cuda"):
     with open(prefix + ".json") as f:
         meta = json.load(f)
     kwargs = dict(meta["init_kwargs"])
-    for k in ("disable_disentangle", "disable_alignment"):
-        if kwargs.get(k):
-            raise NotImplementedError(f"{k}=True selects an ablation decoder that is not on this path (DESIGN.md section 9)")
     G = TriPlaneGenerator(*meta["init_args"], **kwargs).eval().requires_grad_(False)
     with np.load(prefix + ".npz") as z:
         state = {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}

@@ -59,15 +59,17 @@ class TriPlaneGenerator(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={},
                  rendering_kwargs={}, sr_kwargs={}, disable_disentangle=False, disable_alignment=False, **synthesis_kwargs):
         super().__init__()
-        if disable_disentangle or disable_alignment:
-            raise NotImplementedError("the disable_disentangle / disable_alignment ablations (triplane.py:48-51,93) are not built")
+        if disable_alignment:
+            raise NotImplementedError("disable_alignment (SegmentationOSGDecoder, triplane.py:48-51) is not built: its sigma and seg "
+                                      "come from two different hidden layers, the fused kernel has one geometry head")
         self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
         self.img_resolution, self.img_channels = img_resolution, img_channels
-        self.disable_disentangle, self.disable_alignment = False, False
+        # disable_disentangle (triplane.py:93,104-107,119): no normalisation, both decoder heads read the raw planes
+        self.disable_disentangle, self.disable_alignment = bool(disable_disentangle), False
         self.init_args, self.init_kwargs = (), dict(                      # what persistence.persistent_class records
             z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels,
             sr_num_fp16_res=sr_num_fp16_res, mapping_kwargs=mapping_kwargs, rendering_kwargs=rendering_kwargs,
-            sr_kwargs=sr_kwargs, **synthesis_kwargs)
+            sr_kwargs=sr_kwargs, disable_disentangle=bool(disable_disentangle), disable_alignment=False, **synthesis_kwargs)
         self.renderer = DisentangledImportanceRenderer()
         self.ray_sampler = RaySampler()
         self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3,
@@ -137,6 +139,9 @@ class TriPlaneGenerator(torch.nn.Module):
             else:
                 new_mean, new_var = planes_mean, planes_var
         affines = ops.make_affine(mean, var, new_mean, new_var)
+        if self.disable_disentangle:                # identity affines: sampled raw values go to both heads; no statistics returned
+            affines = tuple(torch.ones_like(a) if i % 2 == 0 else torch.zeros_like(a) for i, a in enumerate(affines))
+            mean = var = None
 
         feature_samples, seg_samples, depth_samples, _ = self.renderer.render_raw_planes(
             packed, affines, self.decoder, cam2world_matrix, intrinsics, R, self.rendering_kwargs, channels_first=False)
@@ -160,8 +165,11 @@ class TriPlaneGenerator(torch.nn.Module):
 
     def _sample_planes(self, ws, coordinates, synthesis_kwargs):
         packed, mean, var = self._planes(ws, synthesis_kwargs)
+        affines = ops.make_affine(mean, var)
+        if self.disable_disentangle:
+            affines = tuple(torch.ones_like(a) if i % 2 == 0 else torch.zeros_like(a) for i, a in enumerate(affines))
         return ops.point_query(packed, packed, self.decoder.packed(), coordinates.to(torch.float32),
-                               self.rendering_kwargs["box_warp"], affines=ops.make_affine(mean, var),
+                               self.rendering_kwargs["box_warp"], affines=affines,
                                decoder_math=self.renderer.decoder_math)
 
     def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):

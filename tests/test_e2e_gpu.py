@@ -165,3 +165,28 @@ def test_demo_helpers_encode_decode(setup):
     frames = U.render_video_frames(G, ws[:1], norm[:1], planes[:1], frames=4, batch=3)
     assert frames.shape == (4, 512, 512, 3) and frames.dtype == torch.uint8
     assert len(U.video_camera_schedule(8, init_pitch=1.0)) == 10
+
+
+def test_disable_disentangle_ablation(setup):
+    """disable_disentangle=True (triplane.py:93,104-107,119): both heads read the raw planes; equals the renderer called
+    with norm_planes = denorm_planes = raw planes, and returns no plane statistics."""
+    from nerffaceediting_amd.training.triplane import TriPlaneGenerator
+    G, z, dev = setup
+    kw = dict(G.init_kwargs); kw["disable_disentangle"] = True
+    G2 = TriPlaneGenerator(*G.init_args, **kw).to(dev).eval().requires_grad_(False)
+    G2.load_state_dict(G.state_dict())
+    ws, c = t(z["ws"], dev), t(z["c"], dev)
+    uc, uf = t(z["u_coarse"], dev), t(z["u_fine"], dev)
+    R = int(z["R"])
+    G2.renderer.inject_jitter(uc, uf)
+    out = G2.synthesis(ws, c, neural_rendering_resolution=R, noise_mode="const", planes_mean=1, planes_var=0)   # override ignored, :93
+    assert out["plane_mean"] is None and out["plane_var"] is None
+    planes = G.backbone.synthesis(ws, noise_mode="const").view(2, 3, 32, 256, 256)
+    o, d = G.ray_sampler(c[:, :16].reshape(-1, 4, 4), c[:, 16:25].reshape(-1, 3, 3), R)
+    G.renderer.inject_jitter(uc, uf)
+    feat, seg, depth, _ = G.renderer(planes, planes, G.decoder, o, d, G.rendering_kwargs)
+    assert err(out["image_raw"], feat[..., :3].permute(0, 2, 1).reshape(2, 3, R, R).cpu().numpy()) <= 1e-4
+    assert err(out["image_seg"], seg.permute(0, 2, 1).reshape(2, 15, R, R).cpu().numpy()) <= 1e-4
+    assert err(out["image_raw"], z["plain.image_raw"]) > 1e-2                     # and it differs from the disentangled render
+    sig = G2.sample_mixed(t(z["sample.coords"], dev), None, ws, noise_mode="const")["sigma"]
+    assert torch.isfinite(sig).all()
