@@ -391,10 +391,14 @@ struct Conv3K {
     float* out; float* scratch;
 };
 
-constexpr int C3_TW = 32, C3_TH = 8, C3_PW = C3_TW + 2, C3_PH = C3_TH + 2;
-constexpr int C3_HALF_ITEMS = C3_PW * C3_PH;                     // 16-byte items (8 bf16 channels of one pixel) per channel half
-constexpr int C3_B_CHUNKS = (2 * C3_HALF_ITEMS + 63) / 64;       // 1-KiB LDS-DMA chunks per part
-constexpr int C3_B_BYTES = C3_B_CHUNKS * 1024;
+// WV waves per workgroup, each owning two image rows of 32 pixels: tile = 32 x 2WV pixels.
+constexpr int C3_TW = 32, C3_PW = C3_TW + 2;
+template <int WV> struct C3Tile {
+    static constexpr int TH = 2 * WV, PH = TH + 2;
+    static constexpr int HALF_ITEMS = C3_PW * PH;                 // 16-byte items (8 bf16 channels of one pixel) per channel half
+    static constexpr int B_CHUNKS = (2 * HALF_ITEMS + 63) / 64;   // 1-KiB LDS-DMA chunks per part
+    static constexpr int B_BYTES = B_CHUNKS * 1024;
+};
 
 __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -404,18 +408,20 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
 // UP2: the stride-2 transposed convolution of the up-sampling layers as four output phases over the (H+1)x(W+1)
 // extended input grid (same tap -> phase map as conv_kernel<NFE_CONV_3X3_UP2>), written to the (2H+1)x(2W+1)
 // scratch that upfir_kernel filters.
-template <int TERMS, int MBW>
-constexpr int conv3_stage_bytes() { return (MBW * 9 + C3_B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
+template <int TERMS, int MBW, int WV>
+constexpr int conv3_stage_bytes() { return (MBW * 9 + C3Tile<WV>::B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
 
 // STAGES-deep ring of K-group buffers: the loads of K-group g+STAGES-1 are issued while g is computed, so a
 // load has STAGES-1 K-groups of MFMA time to land.
-template <int TERMS, int MBW, bool UP2, int STAGES>
-__global__ __launch_bounds__(256, ((STAGES * conv3_stage_bytes<TERMS, MBW>() > 80 * 1024) ? 1 : 2)) void conv3_kernel(Conv3K P) {
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV>
+__global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, WV>() > 80 * 1024) ? 1 : 2) * WV / 4) void conv3_kernel(Conv3K P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
     constexpr int NACC = UP2 ? 4 : 1;
     constexpr int A_CHUNKS = MBW * 9 * PARTS;
-    constexpr int STAGE_BYTES = conv3_stage_bytes<TERMS, MBW>();
-    constexpr int MIN_LOADS = A_CHUNKS / 4 + (C3_B_CHUNKS / 4) * PARTS;      // fewest LDS-DMA instructions any wave issues per stage
+    constexpr int STAGE_BYTES = conv3_stage_bytes<TERMS, MBW, WV>();
+    constexpr int C3_TH = C3Tile<WV>::TH, C3_HALF_ITEMS = C3Tile<WV>::HALF_ITEMS, C3_B_CHUNKS = C3Tile<WV>::B_CHUNKS, C3_B_BYTES = C3Tile<WV>::B_BYTES;
+    constexpr int B_PER_WAVE = (C3_B_CHUNKS + WV - 1) / WV;
+    constexpr int MIN_LOADS = A_CHUNKS / WV + (C3_B_CHUNKS / WV) * PARTS;    // fewest LDS-DMA instructions any wave issues per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
@@ -426,11 +432,11 @@ __global__ __launch_bounds__(256, ((STAGES * conv3_stage_bytes<TERMS, MBW>() > 8
     const int mb0 = blockIdx.y * MBW, n = blockIdx.z;
     const int G = P.Cin >> 4;
 
-    // this wave's share of the patch chunks: chunk c = wave + 4k; per-lane element offset of the pixel (or -1 = padding)
-    long long boff[(C3_B_CHUNKS + 3) / 4];
+    // this wave's share of the patch chunks: chunk c = wave + WV k; per-lane element offset of the pixel (or -1 = padding)
+    long long boff[B_PER_WAVE];
 #pragma unroll
-    for (int k = 0; k < (C3_B_CHUNKS + 3) / 4; ++k) {
-        const int item = (wave + 4 * k) * 64 + lane;
+    for (int k = 0; k < B_PER_WAVE; ++k) {
+        const int item = (wave + WV * k) * 64 + lane;
         const int hh = item / C3_HALF_ITEMS, r = item % C3_HALF_ITEMS, py = r / C3_PW, px = r % C3_PW;
         const int y = ty0 - 1 + py, x = tx0 - 1 + px;
         const bool ok = item < 2 * C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
@@ -440,14 +446,14 @@ __global__ __launch_bounds__(256, ((STAGES * conv3_stage_bytes<TERMS, MBW>() > 8
     auto issue = [&](int g, int stage) {
         unsigned char* base = lds + stage * STAGE_BYTES;
         // weights: chunk (m, t, part) <- packed[((mb0+m)*G + g)*18 + t*2 + part]
-        for (int c = wave; c < A_CHUNKS; c += 4) {
+        for (int c = wave; c < A_CHUNKS; c += WV) {
             const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
             const uint4* src = P.packed + (((long long)(mb0 + m) * G + g) * 18 + t * 2 + part) * 64 + lane;
             lds_dma16(src, base + c * 1024);
         }
 #pragma unroll
-        for (int k = 0; k < (C3_B_CHUNKS + 3) / 4; ++k) {
-            const int c = wave + 4 * k;
+        for (int k = 0; k < B_PER_WAVE; ++k) {
+            const int c = wave + WV * k;
             if (c < C3_B_CHUNKS) {
 #pragma unroll
                 for (int part = 0; part < PARTS; ++part) {
@@ -773,14 +779,19 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
 #define C3_STAGES_X3 1
 #define C3_STAGES_X3_UP 1
 #endif
-template <int TERMS, int MBW, bool UP2, int STAGES>
-static void launch_conv3(const Conv3K& K, dim3 grid, hipStream_t st) {
-    constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW>();
+#ifndef C3_TALL_MIN_TILES
+#define C3_TALL_MIN_TILES 4          // use the 8-wave 32x16 tile from 64 rows up
+#endif
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV>
+static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st) {
+    constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW, WV>();
     static bool once = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     (void)once;
-    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES>), grid, dim3(256), bytes, st, K);
+    const unsigned tiles = ((mode_h + C3Tile<WV>::TH - 1) / C3Tile<WV>::TH) * ((mode_w + C3_TW - 1) / C3_TW);
+    dim3 grid(tiles, K.Cout / (32 * MBW), K.N);
+    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV>), grid, dim3(64 * WV), bytes, st, K);
 }
 
 static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
@@ -858,16 +869,18 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         K.noise_n_stride = a->noise_n_stride; K.noise_strength = a->noise_strength; K.bias = a->bias; K.N = a->n; K.H = a->h; K.W = a->w;
         K.Cin = a->cin; K.Cout = a->cout; K.lrelu = a->lrelu; K.act_gain = a->act_gain; K.clamp = a->clamp; K.out = a->out; K.scratch = a->scratch;
         const int ext = up2 ? 1 : 0;
-        const unsigned tiles = ((a->h + ext + C3_TH - 1) / C3_TH) * ((a->w + ext + C3_TW - 1) / C3_TW);
         const bool bf16 = a->math == NFE_CONV_BF16;
         if (up2) {
-            dim3 g3(tiles, a->cout / 32, a->n);
-            if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP>(K, g3, st); else launch_conv3<3, 1, true, C3_STAGES_X3_UP>(K, g3, st);
+            if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext, st);
+            else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext, st);
             const long long total = (long long)a->n * a->h * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
+        } else if (a->h >= 16 * C3_TALL_MIN_TILES) {           // 32 x 16 tiles (8 waves): half the weight bytes per MFMA
+            if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);
+            else launch_conv3<3, 2, false, C3_STAGES_X3, 8>(K, a->h, a->w, st);
         } else {
-            dim3 g3(tiles, a->cout / 64, a->n);
-            if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16>(K, g3, st); else launch_conv3<3, 2, false, C3_STAGES_X3>(K, g3, st);
+            if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 4>(K, a->h, a->w, st);
+            else launch_conv3<3, 2, false, C3_STAGES_X3, 4>(K, a->h, a->w, st);
         }
         NFE_CHECK_LAUNCH("conv3 kernels");
         return split_tail();
