@@ -218,6 +218,11 @@ __device__ __forceinline__ float4 skip_up2(const float* __restrict__ skip, int n
             if (ys[a] < 0 || ys[a] >= hs || xs[b] < 0 || xs[b] >= ws) continue;
             const float* p = skip + (((long long)n * hs + ys[a]) * ws + xs[b]) * c + o;
             const float wgt = wy[a] * wx[b];
+            if ((c & 3) == 0) {                 // o is a multiple of 4: one 16-byte load
+                const float4 t = *reinterpret_cast<const float4*>(p);
+                r.x = fmaf(wgt, t.x, r.x); r.y = fmaf(wgt, t.y, r.y); r.z = fmaf(wgt, t.z, r.z); r.w = fmaf(wgt, t.w, r.w);
+                continue;
+            }
             r.x = fmaf(wgt, p[0], r.x);
             if (o + 1 < c) r.y = fmaf(wgt, p[1], r.y);
             if (o + 2 < c) r.z = fmaf(wgt, p[2], r.z);
@@ -558,6 +563,100 @@ __global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, W
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ToRGB fast path (1x1, Cin % 16 == 0, the layer's weight fragments fit LDS): HBM-bound, so every input pixel
+// is read exactly once.  The weight fragments of all M-blocks are staged in LDS once per workgroup; a wave walks
+// over 32-pixel N-blocks, loads its B operand (8 channels per lane, fp32) straight from global memory,
+// applies the styles, converts to bf16 (hi[+lo]) in registers and feeds the MFMAs of all M-blocks.
+// ------------------------------------------------------------------------------------------------
+template <int TERMS, int MB>
+__global__ __launch_bounds__(256, 2) void torgb_kernel(ConvK P) {
+    constexpr int PARTS = TERMS == 3 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    uint4* ldsA = reinterpret_cast<uint4*>(lds);                     // [mb][g][part][lane]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = P.Cin >> 4;
+    for (int i = tid; i < MB * G * PARTS * 64; i += 256) {
+        const int ln = i & 63, part = (i >> 6) % PARTS, r = (i >> 6) / PARTS, g = r % G, mb = r / G;
+        ldsA[i] = P.packed[(((long long)mb * G + g) * 2 + part) * 64 + ln];      // packed image: [mb][g][tap 0][part 2][lane]
+    }
+    __syncthreads();
+    const int HW = P.H * P.W, nblk = (HW + 31) >> 5;
+    const long long total = (long long)P.N * nblk;
+    for (long long blk = (long long)blockIdx.x * 4 + wave; blk < total; blk += (long long)gridDim.x * 4) {
+        const int n = (int)(blk / nblk), p = (int)(blk % nblk) * 32 + j;
+        const bool valid = p < HW;
+        const float* xp = P.x + ((long long)n * HW + min(p, HW - 1)) * P.Cin + 8 * h;
+        const float* sp = P.styles + (long long)n * P.Cin + 8 * h;
+        f32x16 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+#pragma unroll 2
+        for (int g = 0; g < G; ++g) {
+            const float4 x0 = *reinterpret_cast<const float4*>(xp + 16 * g), x1 = *reinterpret_cast<const float4*>(xp + 16 * g + 4);
+            const float4 s0 = *reinterpret_cast<const float4*>(sp + 16 * g), s1 = *reinterpret_cast<const float4*>(sp + 16 * g + 4);
+            Frag8 bh, bl;
+            split2<TERMS>(x0.x * s0.x, x0.y * s0.y, bh.u[0], bl.u[0]);
+            split2<TERMS>(x0.z * s0.z, x0.w * s0.w, bh.u[1], bl.u[1]);
+            split2<TERMS>(x1.x * s1.x, x1.y * s1.y, bh.u[2], bl.u[2]);
+            split2<TERMS>(x1.z * s1.z, x1.w * s1.w, bh.u[3], bl.u[3]);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                Frag8 ah, al;
+                ah.q = ldsA[((mb * G + g) * PARTS + 0) * 64 + lane];
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[mb], 0, 0, 0);
+                if (TERMS == 3) {
+                    al.q = ldsA[((mb * G + g) * PARTS + 1) * 64 + lane];
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[mb], 0, 0, 0);
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[mb], 0, 0, 0);
+                }
+            }
+        }
+        if (!valid) continue;
+        const int y = p / P.W, x = p % P.W;
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int o0 = 32 * mb + 8 * qq + 4 * h;
+                if (o0 >= P.Cout) continue;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int o = o0 + i;
+                    v[i] = o < P.Cout ? epilogue_act(acc[mb][4 * qq + i] + P.bias[o], 0, P.act_gain, P.clamp) : 0.0f;
+                }
+                if (P.skip) {
+                    const float4 sk = skip_up2(P.skip, n, P.H >> 1, P.W >> 1, P.Cout, y, x, o0);
+                    v[0] += sk.x; v[1] += sk.y; v[2] += sk.z; v[3] += sk.w;
+                }
+                float* dst = P.out_planes ? P.out + ((((long long)n * 3 + mb) * P.H + y) * P.W + x) * 32 + 8 * qq + 4 * h
+                                          : P.out + ((long long)n * HW + p) * P.Cout + o0;
+                if (o0 + 3 < P.Cout && (P.Cout & 3) == 0) {
+                    *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (o0 + i < P.Cout) dst[i] = v[i];
+                }
+            }
+    }
+}
+
+template <int TERMS, int MB>
+static void launch_torgb(const ConvK& P, hipStream_t st) {
+    const int bytes = MB * (P.Cin / 16) * (TERMS == 3 ? 2 : 1) * 1024;
+    static int allowed = 0;
+    if (bytes > allowed) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(torgb_kernel<TERMS, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        allowed = bytes;
+    }
+    const long long blocks = ((long long)P.N * ((P.H * P.W + 31) / 32) + 3) / 4;
+    hipLaunchKernelGGL((torgb_kernel<TERMS, MB>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), bytes, st, P);
+}
+
 // FIR + epilogue of the up-conv: out[Y][X] = act(dcoef * sum_ab F[a]F[b] T[Y+a-1][X+b-1] + noise + bias),
 // F = [1,3,3,1]/4 per axis (setup_filter/64 * gain 4; conv2d_resample.py:127, upfirdn2d.py:169-207)
 __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
@@ -888,7 +987,14 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     const int up = a->mode == NFE_CONV_3X3_UP2;
     const int gh = a->h + up, gw = a->w + up;
     dim3 grid(((gh + 15) / 16) * ((gw + 15) / 16), (a->cout + 31) / 32, a->n);
+    const int mb1 = (a->cout + 31) / 32, parts1 = a->math == NFE_CONV_BF16 ? 1 : 2;
+    const bool torgb_fast = a->mode == NFE_CONV_1X1 && a->cin % 16 == 0 && (mb1 == 1 || mb1 == 3) && a->lrelu == 0 && !a->dcoef && !a->noise &&
+                            (long long)mb1 * (a->cin / 16) * parts1 * 1024 <= 64 * 1024 && (long long)a->h * a->w >= 1024;
     if (a->mode == NFE_CONV_3X3) launch_conv<NFE_CONV_3X3>(P, a->math, grid, st);
+    else if (torgb_fast) {
+        if (mb1 == 1) { if (parts1 == 1) launch_torgb<1, 1>(P, st); else launch_torgb<3, 1>(P, st); }
+        else { if (parts1 == 1) launch_torgb<1, 3>(P, st); else launch_torgb<3, 3>(P, st); }
+    }
     else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, a->math, grid, st);
     else {
         launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st);

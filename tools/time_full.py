@@ -23,10 +23,9 @@ dev = torch.device("cuda:0")
 G = G.to(dev).eval().requires_grad_(False)
 G.backbone.synthesis.conv_math = math
 G.superresolution.conv_math = math
-from oracle import render_oracle as orc
-import numpy as np, math as m
-c2w = np.concatenate([orc.lookat_pose(m.pi / 2 + 0.1 * i, m.pi / 2 - 0.2, [0, 0, 0.2], 2.7) for i in range(N)], 0)
-c = torch.from_numpy(orc.make_c(c2w, orc.fov_to_intrinsics(18.837))).to(dev)
+from nerffaceediting_amd import apps
+
+c = apps.orbit_cameras(max(N, 2), dev)[:N]
 z = torch.randn(N, 512, device=dev)
 
 
