@@ -198,6 +198,114 @@ __device__ __forceinline__ void fetch_quad(const float* __restrict__ pg, const f
     }
 }
 
+// ---- the same gather, software-pipelined over the three planes (one plane set) ----------------------------
+// Six batches of 8 loads (plane p, tap pair): two batches are in flight; the loads of batch b+2 are issued right
+// after batch b has been consumed, so only the first batch's latency is exposed per sample instead of one per plane.
+#ifndef NFE_PIPE_SWIZZLE
+#define NFE_PIPE_SWIZZLE 1
+#endif
+#define NFE_PIPE_ISSUE_I(S, K, I)                                                                          \
+    vg[S][(K) * 4 + I] = texel_piece(base_, (unsigned)quad_bcast<I>((int)off_) + qoff_bytes);                \
+    if (NFE_PIPE_SWIZZLE) wq[S][(K) * 4 + I] = quad_swizzle<I>(wk_); else if (I == 0) wq[S][K] = wk_;
+#define NFE_PIPE_ISSUE(S, PL, K0)                                                                          \
+    {                                                                                                      \
+        const float* base_ = pg + (PL) * plane_elems;                                                      \
+        _Pragma("unroll") for (int K = 0; K < 2; ++K) {                                                    \
+            const unsigned off_ = offs[PL][(K0) + K];                                                      \
+            const float wk_ = tp[PL].w[(K0) + K];                                                          \
+            NFE_PIPE_ISSUE_I(S, K, 0) NFE_PIPE_ISSUE_I(S, K, 1) NFE_PIPE_ISSUE_I(S, K, 2) NFE_PIPE_ISSUE_I(S, K, 3)  \
+        }                                                                                                  \
+    }
+#define NFE_PIPE_FMA(S, K, I)                                                                              \
+    {                                                                                                      \
+        const f32x2 w2 = splat(NFE_PIPE_SWIZZLE ? wq[S][(K) * 4 + I] : quad_bcast<I>(wq[S][K]));            \
+        sg[2 * I + 0] = pk_fma(w2, f32x2{vg[S][(K) * 4 + I].x, vg[S][(K) * 4 + I].y}, sg[2 * I + 0]);      \
+        sg[2 * I + 1] = pk_fma(w2, f32x2{vg[S][(K) * 4 + I].z, vg[S][(K) * 4 + I].w}, sg[2 * I + 1]);      \
+    }
+#define NFE_PIPE_CONSUME(S)                                                                                \
+    NFE_PIPE_FMA(S, 0, 0) NFE_PIPE_FMA(S, 0, 1) NFE_PIPE_FMA(S, 0, 2) NFE_PIPE_FMA(S, 0, 3)                \
+    NFE_PIPE_FMA(S, 1, 0) NFE_PIPE_FMA(S, 1, 1) NFE_PIPE_FMA(S, 1, 2) NFE_PIPE_FMA(S, 1, 3)
+
+template <bool SIGMA_ONLY, int PL>
+__device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, int qoff, const Taps& tp, f32x2 (&sg)[8],
+                                                 f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+    {
+        const float4 sc = *reinterpret_cast<const float4*>(aff + 0 * 96 + PL * 32 + qoff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qn[2 * i + 0] = pk_fma(sg[2 * i + 0], f32x2{sc.x, sc.y}, qn[2 * i + 0]);
+            qn[2 * i + 1] = pk_fma(sg[2 * i + 1], f32x2{sc.z, sc.w}, qn[2 * i + 1]);
+        }
+    }
+    if (!SIGMA_ONLY) {
+        const float4 sc = *reinterpret_cast<const float4*>(aff + 2 * 96 + PL * 32 + qoff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qd[2 * i + 0] = pk_fma(sg[2 * i + 0], f32x2{sc.x, sc.y}, qd[2 * i + 0]);
+            qd[2 * i + 1] = pk_fma(sg[2 * i + 1], f32x2{sc.z, sc.w}, qd[2 * i + 1]);
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(tp.wdef != 0.0f) != 0) {     // rare: some sample of the wave left the plane
+        const float wd[4] = {quad_bcast<0>(tp.wdef), quad_bcast<1>(tp.wdef), quad_bcast<2>(tp.wdef), quad_bcast<3>(tp.wdef)};
+        const float4 b = *reinterpret_cast<const float4*>(aff + 1 * 96 + PL * 32 + qoff);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            qn[2 * i + 0] = pk_fma(splat(wd[i]), f32x2{b.x, b.y}, qn[2 * i + 0]);
+            qn[2 * i + 1] = pk_fma(splat(wd[i]), f32x2{b.z, b.w}, qn[2 * i + 1]);
+        }
+        if (!SIGMA_ONLY) {
+            const float4 e = *reinterpret_cast<const float4*>(aff + 3 * 96 + PL * 32 + qoff);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qd[2 * i + 0] = pk_fma(splat(wd[i]), f32x2{e.x, e.y}, qd[2 * i + 0]);
+                qd[2 * i + 1] = pk_fma(splat(wd[i]), f32x2{e.z, e.w}, qd[2 * i + 1]);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
+}
+
+template <bool SIGMA_ONLY>
+__device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, int H, int W, long long plane_elems,
+                                                 const float* __restrict__ aff, int lane, float gx, float gy, float gz,
+                                                 f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+    // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
+    Taps tp[3];
+    unsigned offs[3][4];
+#define NFE_PIPE_GEOM(PL, U, V)                                                                            \
+    tp[PL] = tap_geometry(H, W, U, V);                                                                     \
+    offs[PL][0] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc0) * 128u; offs[PL][1] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc1) * 128u; \
+    offs[PL][2] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc0) * 128u; offs[PL][3] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc1) * 128u;
+    NFE_PIPE_GEOM(0, gx, gy)
+    const int ll = launder(lane);
+    const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
+    const unsigned qoff_bytes = (unsigned)qoff * 4u;
+    float4 vg[2][8];
+    float wq[2][8];
+    f32x2 sg[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
+    NFE_PIPE_ISSUE(0, 0, 0) NFE_PIPE_ISSUE(1, 0, 2)
+    NFE_PIPE_GEOM(1, gx, gz)                       // the next plane's tap geometry runs under the loads in flight
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(0) NFE_PIPE_ISSUE(0, 1, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(1) NFE_PIPE_ISSUE(1, 1, 2)
+    plane_affine_acc<SIGMA_ONLY, 0>(aff, qoff, tp[0], sg, qn, qd);
+    NFE_PIPE_GEOM(2, gz, gx)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(0) NFE_PIPE_ISSUE(0, 2, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(1) NFE_PIPE_ISSUE(1, 2, 2)
+    plane_affine_acc<SIGMA_ONLY, 1>(aff, qoff, tp[1], sg, qn, qd);
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(1)
+    plane_affine_acc<SIGMA_ONLY, 2>(aff, qoff, tp[2], sg, qn, qd);
+}
+
 // Exchange tile: row = point (0..31), 8 granules of 4 channels per row, granule g of row r stored at position
 // g ^ swz(r).  swz makes both sides conflict-free under the b128 lane groupings (MI355X guide, LDS table):
 // writers = 8 consecutive lanes (2 quads, rows r and r+4) on 32 banks, readers = 16 rows per cycle on 64 banks.
@@ -487,9 +595,11 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
         }
     }
     const long long plane_elems = (long long)H * W * 32;
+    constexpr bool PIPELINED = !(DUAL && !SIGMA_ONLY);
+    if (PIPELINED) gather_pipelined<SIGMA_ONLY>(pg, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
+    for (int p = 0; p < (PIPELINED ? 0 : 3); ++p) {
         float u = (p == 2) ? gz : gx;
         float v = (p == 0) ? gy : ((p == 1) ? gz : gx);
         f32x2 sg[8], sa[8];
@@ -540,11 +650,16 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
     for (int r = 0; r < 16; ++r) { og[r] = fn[r >> 1][r & 1]; oa[r] = fd[r >> 1][r & 1]; }
     return;
 #endif
-    if (!SIGMA_ONLY && MATH == NFE_MATH_BF16X3) mlp_pair_bf16(lds, fn, fd, lane, og, oa);
+#ifndef NFE_MLP_PAIR
+#define NFE_MLP_PAIR 1
+#endif
+    constexpr bool PAIR = NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3;
+    if (PAIR) mlp_pair_bf16(lds, fn, fd, lane, og, oa);
     else if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og);
     else mlp_bf16(lds, fn, 0, lane, og);
     if (!SIGMA_ONLY) {
         if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa);
+        else if (!PAIR) mlp_bf16(lds, fd, 1, lane, oa);
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {    // oa carries log2(e): sigmoid(x) = 1/(1 + 2^-(x log2 e))
             const f32x2 d = f32x2{exp2_fast(-oa[r]), exp2_fast(-oa[r + 1])} + splat(1.0f);
