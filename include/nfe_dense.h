@@ -103,6 +103,8 @@ typedef struct nfe_conv_args {
 int nfe_modulated_conv(const nfe_conv_args* args, nfe_stream_t stream);
 /* floats of a bf16 hi(+lo) activation image [n,h,w,c] (hi only for NFE_CONV_BF16) */
 uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c);
+/* 1 if a 3x3 layer of these sizes can take a pre-split input image (x_split), i.e. runs the LDS-DMA path */
+int nfe_conv_accepts_split(int mode, int h, int w, int cin, int cout);
 /* floats of scratch a call with these sizes can use (0 = none) */
 uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout);
 

@@ -191,6 +191,7 @@ struct ConvK {
     const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp; const float* skip; int out_planes;
     float* out; float* scratch;
     const float* next_styles; uint2* split_hi; uint2* split_lo;      // up-conv: modulated bf16 image for the consuming layer
+    float* partial; int ksplit;                                       // split-K: raw partial sums [ksplit][...], reduced by splitk_reduce_kernel
 };
 
 constexpr int PATCH = 18;                                         // 16 + halo
@@ -245,9 +246,12 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
     // tile grid: output pixels (modes 0,2) or the (H+1)x(W+1) extended input grid (mode 1)
     const int gh = MODE == NFE_CONV_3X3_UP2 ? P.H + 1 : P.H, gw = MODE == NFE_CONV_3X3_UP2 ? P.W + 1 : P.W;
     const int tiles_x = (gw + 15) >> 4;
-    const int ty0 = (blockIdx.x / tiles_x) * 16, tx0 = (blockIdx.x % tiles_x) * 16;
+    const int KS = P.ksplit > 1 ? P.ksplit : 1;                  // split-K: blockIdx.x = tile * KS + ks
+    const int tile = blockIdx.x / KS, ks = blockIdx.x % KS;
+    const int ty0 = (tile / tiles_x) * 16, tx0 = (tile % tiles_x) * 16;
     const int mb = blockIdx.y, n = blockIdx.z;
     const int G = (P.Cin + 15) >> 4;          // a ragged last K-group is zero-filled (Cin % 4 == 0)
+    const int g_per = (G + KS - 1) / KS, g_lo = ks * g_per, g_hi = min(G, g_lo + g_per);
 
     f32x16 acc[NACC][2];
 #pragma unroll
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
             for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.0f;
 
     const int q = tid & 3;                                    // staging: this thread's 4-channel quarter
-    for (int g = 0; g < G; ++g) {
+    for (int g = g_lo; g < g_hi; ++g) {
         __syncthreads();
         // (a) weight fragments of this M-block / K-group: TAPS*2 KiB, contiguous in the packed image
         const uint4* src = P.packed + ((long long)mb * G + g) * (TAPS * 2 * 64);
@@ -312,6 +316,15 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
     for (int nb = 0; nb < 2; ++nb) {
         const int ly = 4 * wave + 2 * nb + (j >> 4), lx = j & 15;
         const int y = ty0 + ly, x = tx0 + lx;
+        if (MODE == NFE_CONV_3X3 && P.ksplit > 1) {              // raw partial sums of this K slice; epilogue in splitk_reduce_kernel
+            if (y >= P.H || x >= P.W) continue;
+            float* dst = P.partial + ((((long long)ks * P.N + n) * P.H + y) * P.W + x) * P.Cout + 32 * mb + 4 * h;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq)
+                if (32 * mb + 8 * qq + 4 * h < P.Cout)
+                    *reinterpret_cast<float4*>(dst + 8 * qq) = make_float4(acc[0][nb][4 * qq], acc[0][nb][4 * qq + 1], acc[0][nb][4 * qq + 2], acc[0][nb][4 * qq + 3]);
+            continue;
+        }
         if (MODE == NFE_CONV_3X3_UP2) {
             if (y > P.H || x > P.W) continue;
             const int TH = 2 * P.H + 1, TW = 2 * P.W + 1;
@@ -319,7 +332,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
             for (int a = 0; a < 4; ++a) {
                 const int Y = 2 * y + (a >> 1), X = 2 * x + (a & 1);
                 if (Y >= TH || X >= TW) continue;
-                float* dst = P.scratch + (((long long)n * TH + Y) * TW + X) * P.Cout + 32 * mb + 4 * h;
+                float* dst = (P.ksplit > 1 ? P.partial + (long long)ks * P.N * TH * TW * P.Cout : P.scratch) + (((long long)n * TH + Y) * TW + X) * P.Cout + 32 * mb + 4 * h;
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq)
                     if (32 * mb + 8 * qq + 4 * h < P.Cout)       // Cout % 4 == 0 on up-conv layers (checked on host)
@@ -657,6 +670,32 @@ static void launch_torgb(const ConvK& P, hipStream_t st) {
     hipLaunchKernelGGL((torgb_kernel<TERMS, MB>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), bytes, st, P);
 }
 
+// Split-K reduction (4^2..16^2 layers: one tile per sample, so the K loop is the only parallelism left).  Partial
+// sums are added in slice order, so results do not depend on scheduling.  up: -> transposed-conv scratch (the FIR
+// epilogue follows); else: demod + noise + bias + lrelu + clamp -> out.
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK P, long long n_vec, int up) {
+    const int C4 = P.Cout >> 2;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
+        float4 s = reinterpret_cast<const float4*>(P.partial)[i];
+        for (int k = 1; k < P.ksplit; ++k) {
+            const float4 t = reinterpret_cast<const float4*>(P.partial)[i + k * n_vec];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        if (up) { reinterpret_cast<float4*>(P.scratch)[i] = s; continue; }
+        const int c4 = (int)(i % C4); const long long pix = i / C4;
+        const int n = (int)(pix / ((long long)P.H * P.W)); const long long yx = pix % ((long long)P.H * P.W);
+        const float nz = P.noise ? P.noise[n * P.noise_n_stride + yx] * P.noise_strength : 0.0f;
+        const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + 4 * c4) : make_float4(1, 1, 1, 1);
+        const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
+        float4 o;
+        o.x = epilogue_act(s.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+        o.y = epilogue_act(s.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+        o.z = epilogue_act(s.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+        o.w = epilogue_act(s.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+        reinterpret_cast<float4*>(P.out)[i] = o;
+    }
+}
+
 // FIR + epilogue of the up-conv: out[Y][X] = act(dcoef * sum_ab F[a]F[b] T[Y+a-1][X+b-1] + noise + bias),
 // F = [1,3,3,1]/4 per axis (setup_filter/64 * gain 4; conv2d_resample.py:127, upfirdn2d.py:169-207)
 __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
@@ -904,12 +943,23 @@ extern "C" uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c) 
     return math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
 }
 
+extern "C" int nfe_conv_accepts_split(int mode, int h, int w, int cin, int cout) { return conv3_eligible(mode, h, w, cin, cout) ? 1 : 0; }
+
+// Small 3x3 layers (at most one 16x16 tile per sample) split their K loop over this many workgroups.
+static int splitk_slices(int mode, int h, int w, int cin, int cout) {
+    if (mode == NFE_CONV_1X1 || h > 16 || w > 16 || cout % 4 != 0) return 0;
+    const int G = (cin + 15) / 16;
+    return G >= 16 ? 8 : (G >= 8 ? 4 : 0);
+}
+
 extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout) {
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
     uint64_t fl = mode == NFE_CONV_3X3_UP2 ? (uint64_t)n * (2 * h + 1) * (2 * w + 1) * cout : 0;     // transposed-conv result
     if (conv3_eligible(mode, h, w, cin, cout)) {
         const uint64_t elems = (uint64_t)n * h * w * cin;           // bf16 hi (+ lo) image of the modulated input
         fl += math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
+    } else if (const int ks = splitk_slices(mode, h, w, cin, cout)) {
+        fl += (uint64_t)ks * n * (mode == NFE_CONV_3X3_UP2 ? (uint64_t)(2 * h + 1) * (2 * w + 1) : (uint64_t)h * w) * cout;   // partial sums
     }
     return fl;
 }
@@ -987,6 +1037,20 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     const int up = a->mode == NFE_CONV_3X3_UP2;
     const int gh = a->h + up, gw = a->w + up;
     dim3 grid(((gh + 15) / 16) * ((gw + 15) / 16), (a->cout + 31) / 32, a->n);
+    const int ks = splitk_slices(a->mode, a->h, a->w, a->cin, a->cout);
+    if (ks && a->scratch && a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout)) {
+        const long long slice = (long long)a->n * (up ? (long long)(2 * a->h + 1) * (2 * a->w + 1) : (long long)a->h * a->w) * a->cout;
+        P.ksplit = ks; P.partial = a->scratch + (up ? slice : 0);      // after the transposed-conv scratch
+        grid.x *= ks;
+        if (up) launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st); else launch_conv<NFE_CONV_3X3>(P, a->math, grid, st);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, up);
+        if (up) {
+            const long long total = (long long)a->n * a->h * a->w * (a->cout / 4);
+            hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
+        }
+        NFE_CHECK_LAUNCH("split-K conv kernels");
+        return split_tail();
+    }
     const int mb1 = (a->cout + 31) / 32, parts1 = a->math == NFE_CONV_BF16 ? 1 : 2;
     const bool torgb_fast = a->mode == NFE_CONV_1X1 && a->cin % 16 == 0 && (mb1 == 1 || mb1 == 3) && a->lrelu == 0 && !a->dcoef && !a->noise &&
                             (long long)mb1 * (a->cin / 16) * parts1 * 1024 <= 64 * 1024 && (long long)a->h * a->w >= 1024;

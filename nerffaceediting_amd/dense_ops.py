@@ -145,9 +145,7 @@ def can_chain(mode, math, n, h, w, cin, cout):
     """True if a layer of these sizes runs the fast path and can therefore take a SplitImage input."""
     if not FAST_PATH:
         return False
-    lib = _lib.load()
-    base = n * (2 * h + 1) * (2 * w + 1) * cout if mode == _lib.NFE_CONV_3X3_UP2 else 0
-    return int(lib.nfe_conv_scratch_floats(int(mode), MATH[math], n, h, w, cin, cout)) > base
+    return bool(_lib.load().nfe_conv_accepts_split(int(mode), h, w, cin, cout))
 
 
 def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, noise_strength=0.0, lrelu=True,

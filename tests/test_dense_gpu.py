@@ -144,7 +144,7 @@ def test_superresolution_8xdc(tag, dev):
 
 
 @pytest.mark.parametrize("math", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 40, 72, 48, 128), (1, 8, 32, 16, 64), (3, 33, 95, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 40, 72, 48, 128), (1, 8, 32, 16, 64), (3, 33, 95, 64, 64), (2, 8, 8, 256, 64), (1, 16, 16, 512, 96), (3, 4, 4, 128, 32)])
 def test_conv3x3_fast_path_matches_generic(shape, math, dev):
     """The LDS-DMA 3x3 path (pre-split activations) against the generic kernel on ragged tiles, and against a
     torch fp32 conv of the same modulated/demodulated layer (modulated_conv2d, networks_stylegan2.py:34-91)."""
@@ -177,7 +177,7 @@ def test_conv3x3_fast_path_matches_generic(shape, math, dev):
 
 
 @pytest.mark.parametrize("math", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 40, 72, 48, 96), (1, 8, 32, 16, 32), (2, 33, 63, 32, 64)])
+@pytest.mark.parametrize("shape", [(2, 40, 72, 48, 96), (1, 8, 32, 16, 32), (2, 33, 63, 32, 64), (2, 4, 4, 256, 64), (1, 16, 16, 128, 32)])
 def test_upconv_fast_path_matches_generic(shape, math, dev):
     """Up-sampling layer (transposed conv + FIR, conv2d_resample.py:114-128) through the LDS-DMA path vs the generic kernel."""
     from nerffaceediting_amd import _lib, dense_ops as D
