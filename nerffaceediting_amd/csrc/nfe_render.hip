@@ -932,7 +932,9 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int D = P.D, Di = P.Di;
-    const int stride = 3 * D + Di;                       // per-wave LDS floats
+    int P2 = 64;                                         // fine depths are sorted on a power-of-two array padded with +inf
+    while (P2 < Di) P2 <<= 1;
+    const int stride = 3 * D + P2;                       // per-wave LDS floats
     float* tc = lds + wave * stride;                     // [D] coarse depths
     float* wq = tc + D;                                  // [D] weights, then smoothed weights
     float* cdf = wq + D;                                 // [D] cdf knots (D-2 used)
@@ -1001,22 +1003,36 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
             if (P.tap_fine) P.tap_fine[ray * Di + e] = t;
         }
         __threadfence_block();
-        // merge by rank counting: stable, coarse before fine on ties
+        // merge (unify_samples, renderer.py:288-300: only the sorted depths leave this kernel, so ties need no order).
+        // 1. bitonic sort of the fine depths in LDS (padded to a power of two with +inf),
+        // 2. rank of each fine depth = its sorted index + #coarse <= it (binary search: coarse depths are ascending),
+        //    rank of each coarse depth = its index + #fine < it.
+        for (int i = Di + lane; i < P2; i += 64) tf[i] = INFINITY;
+        __threadfence_block();
+        for (int k = 2; k <= P2; k <<= 1)
+            for (int jj = k >> 1; jj > 0; jj >>= 1) {
+                for (int i = lane; i < P2; i += 64) {
+                    const int partner = i ^ jj;
+                    if (partner > i) {
+                        const float a = tf[i], c = tf[partner];
+                        const bool up = (i & k) == 0;
+                        if ((a > c) == up) { tf[i] = c; tf[partner] = a; }
+                    }
+                }
+                __threadfence_block();
+            }
         float* out = P.t_all + ray * (D + Di);
-        for (int e = lane; e < D + Di; e += 64) {
-            const bool is_f = e >= D;
-            const int idx = is_f ? e - D : e;
-            const float v = is_f ? tf[idx] : tc[idx];
-            int pos = 0;
-            for (int k = 0; k < D; ++k) {
-                const float o = tc[k];
-                pos += (o < v) || (o == v && (is_f || k < idx));
-            }
-            for (int k = 0; k < Di; ++k) {
-                const float o = tf[k];
-                pos += (o < v) || (o == v && is_f && k < idx);
-            }
-            out[pos] = v;
+        for (int e = lane; e < Di; e += 64) {            // fine: #coarse <= v (upper bound)
+            const float v = tf[e];
+            int lo = 0, hi = D;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (tc[mid] <= v) lo = mid + 1; else hi = mid; }
+            out[e + lo] = v;
+        }
+        for (int e = lane; e < D; e += 64) {             // coarse: #fine < v (lower bound)
+            const float v = tc[e];
+            int lo = 0, hi = Di;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (tf[mid] < v) lo = mid + 1; else hi = mid; }
+            out[e + lo] = v;
         }
         __threadfence_block();
     }
@@ -1210,7 +1226,9 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         ImportanceK I{};
         I.t_coarse = t_c; I.w_coarse = w_c; I.u_fine = a->u_fine; I.seed = a->seed; I.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device); I.n_rays_total = (long long)nr;
         I.D = D; I.Di = Di; I.t_all = t_all; I.tap_fine = a->tap_depths_fine;
-        const int lds_bytes = 4 * (3 * D + Di) * 4;
+        int p2 = 64;
+        while (p2 < Di) p2 <<= 1;
+        const int lds_bytes = 4 * (3 * D + p2) * 4;
         long long blocks = ((long long)nr + 3) / 4;
         if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
         hipLaunchKernelGGL(importance_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, st, I);
