@@ -226,9 +226,9 @@ __device__ __forceinline__ void fetch_quad(const float* __restrict__ pg, const f
     NFE_PIPE_FMA(S, 0, 0) NFE_PIPE_FMA(S, 0, 1) NFE_PIPE_FMA(S, 0, 2) NFE_PIPE_FMA(S, 0, 3)                \
     NFE_PIPE_FMA(S, 1, 0) NFE_PIPE_FMA(S, 1, 1) NFE_PIPE_FMA(S, 1, 2) NFE_PIPE_FMA(S, 1, 3)
 
-template <bool SIGMA_ONLY, int PL>
+template <bool SIGMA_ONLY, int PL, bool DUAL = false>
 __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, int qoff, const Taps& tp, f32x2 (&sg)[8],
-                                                 f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+                                                 f32x2 (&qn)[8], f32x2 (&qd)[8], f32x2* sa = nullptr) {
     {
         const float4 sc = *reinterpret_cast<const float4*>(aff + 0 * 96 + PL * 32 + qoff);
 #pragma unroll
@@ -241,8 +241,8 @@ __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, 
         const float4 sc = *reinterpret_cast<const float4*>(aff + 2 * 96 + PL * 32 + qoff);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            qd[2 * i + 0] = pk_fma(sg[2 * i + 0], f32x2{sc.x, sc.y}, qd[2 * i + 0]);
-            qd[2 * i + 1] = pk_fma(sg[2 * i + 1], f32x2{sc.z, sc.w}, qd[2 * i + 1]);
+            qd[2 * i + 0] = pk_fma(DUAL ? sa[2 * i + 0] : sg[2 * i + 0], f32x2{sc.x, sc.y}, qd[2 * i + 0]);
+            qd[2 * i + 1] = pk_fma(DUAL ? sa[2 * i + 1] : sg[2 * i + 1], f32x2{sc.z, sc.w}, qd[2 * i + 1]);
         }
     }
     if (__builtin_amdgcn_ballot_w64(tp.wdef != 0.0f) != 0) {     // rare: some sample of the wave left the plane
@@ -263,7 +263,81 @@ __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, 
         }
     }
 #pragma unroll
-    for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
+    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); if (DUAL) sa[c] = splat(0.0f); }
+}
+
+#define NFE_PIPE_GEOM(PL, U, V)                                                                            \
+    tp[PL] = tap_geometry(H, W, U, V);                                                                     \
+    offs[PL][0] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc0) * 128u; offs[PL][1] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc1) * 128u; \
+    offs[PL][2] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc0) * 128u; offs[PL][3] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc1) * 128u;
+
+// Two plane sets (norm_planes != normalised denorm_planes): twelve batches of one tap = 4 + 4 loads, two in flight.
+#define NFE_PIPE2_ISSUE_I(S, I)                                                                            \
+    {                                                                                                      \
+        const unsigned o_ = (unsigned)quad_bcast<I>((int)off_) + qoff_bytes;                               \
+        vg[S][I] = texel_piece(bg_, o_); vg[S][4 + I] = texel_piece(ba_, o_);                              \
+        wq[S][I] = quad_swizzle<I>(wk_);                                                                   \
+    }
+#define NFE_PIPE2_ISSUE(S, PL, K)                                                                          \
+    {                                                                                                      \
+        const float* bg_ = pg + (PL) * plane_elems; const float* ba_ = pa + (PL) * plane_elems;            \
+        const unsigned off_ = offs[PL][K];                                                                 \
+        const float wk_ = tp[PL].w[K];                                                                     \
+        NFE_PIPE2_ISSUE_I(S, 0) NFE_PIPE2_ISSUE_I(S, 1) NFE_PIPE2_ISSUE_I(S, 2) NFE_PIPE2_ISSUE_I(S, 3)    \
+    }
+#define NFE_PIPE2_CONSUME(S)                                                                               \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+        const f32x2 w2 = splat(wq[S][i_]);                                                                 \
+        sg[2 * i_ + 0] = pk_fma(w2, f32x2{vg[S][i_].x, vg[S][i_].y}, sg[2 * i_ + 0]);                      \
+        sg[2 * i_ + 1] = pk_fma(w2, f32x2{vg[S][i_].z, vg[S][i_].w}, sg[2 * i_ + 1]);                      \
+        sa[2 * i_ + 0] = pk_fma(w2, f32x2{vg[S][4 + i_].x, vg[S][4 + i_].y}, sa[2 * i_ + 0]);              \
+        sa[2 * i_ + 1] = pk_fma(w2, f32x2{vg[S][4 + i_].z, vg[S][4 + i_].w}, sa[2 * i_ + 1]);              \
+    }
+
+__device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ pg, const float* __restrict__ pa, int H, int W,
+                                                      long long plane_elems, const float* __restrict__ aff, int lane,
+                                                      float gx, float gy, float gz, f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+    Taps tp[3];
+    unsigned offs[3][4];
+    NFE_PIPE_GEOM(0, gx, gy)
+    const int ll = launder(lane);
+    const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
+    const unsigned qoff_bytes = (unsigned)qoff * 4u;
+    float4 vg[2][8];
+    float wq[2][4];
+    f32x2 sg[8], sa[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); sa[c] = splat(0.0f); }
+    NFE_PIPE2_ISSUE(0, 0, 0) NFE_PIPE2_ISSUE(1, 0, 1)
+    NFE_PIPE_GEOM(1, gx, gz)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 0, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 0, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 1, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 1, 1)
+    plane_affine_acc<false, 0, true>(aff, qoff, tp[0], sg, qn, qd, sa);
+    NFE_PIPE_GEOM(2, gz, gx)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 1, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 1, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 2, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 2, 1)
+    plane_affine_acc<false, 1, true>(aff, qoff, tp[1], sg, qn, qd, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 2, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 2, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1)
+    plane_affine_acc<false, 2, true>(aff, qoff, tp[2], sg, qn, qd, sa);
 }
 
 template <bool SIGMA_ONLY>
@@ -273,10 +347,6 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
     Taps tp[3];
     unsigned offs[3][4];
-#define NFE_PIPE_GEOM(PL, U, V)                                                                            \
-    tp[PL] = tap_geometry(H, W, U, V);                                                                     \
-    offs[PL][0] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc0) * 128u; offs[PL][1] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc1) * 128u; \
-    offs[PL][2] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc0) * 128u; offs[PL][3] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc1) * 128u;
     NFE_PIPE_GEOM(0, gx, gy)
     const int ll = launder(lane);
     const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
@@ -595,8 +665,13 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
         }
     }
     const long long plane_elems = (long long)H * W * 32;
-    constexpr bool PIPELINED = !(DUAL && !SIGMA_ONLY);
-    if (PIPELINED) gather_pipelined<SIGMA_ONLY>(pg, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
+#ifndef NFE_PIPE_DUAL
+#define NFE_PIPE_DUAL 1
+#endif
+    constexpr bool TWO = DUAL && !SIGMA_ONLY;
+    constexpr bool PIPELINED = !TWO || NFE_PIPE_DUAL;
+    if (TWO && PIPELINED) gather_pipelined_dual(pg, pa, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
+    else if (PIPELINED) gather_pipelined<SIGMA_ONLY>(pg, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
 #pragma unroll
     for (int p = 0; p < (PIPELINED ? 0 : 3); ++p) {
