@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
     for (int nb = 0; nb < 2; ++nb) {
         const int ly = 4 * wave + 2 * nb + (j >> 4), lx = j & 15;
         const int y = ty0 + ly, x = tx0 + lx;
-        if (MODE == NFE_CONV_3X3 && P.ksplit > 1) {              // raw partial sums of this K slice; epilogue in splitk_reduce_kernel
+        if (MODE != NFE_CONV_3X3_UP2 && P.ksplit > 1) {          // raw partial sums of this K slice; epilogue in splitk_reduce_kernel
             if (y >= P.H || x >= P.W) continue;
             float* dst = P.partial + ((((long long)ks * P.N + n) * P.H + y) * P.W + x) * P.Cout + 32 * mb + 4 * h;
 #pragma unroll
@@ -692,6 +692,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK P, long long n
         o.y = epilogue_act(s.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
         o.z = epilogue_act(s.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
         o.w = epilogue_act(s.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+        if (P.skip) {                              // ToRGB: + upsample2d(previous image)
+            const int y = (int)(yx / P.W), x = (int)(yx % P.W);
+            const float4 sk = skip_up2(P.skip, n, P.H >> 1, P.W >> 1, P.Cout, y, x, 4 * c4);
+            o.x += sk.x; o.y += sk.y; o.z += sk.z; o.w += sk.w;
+        }
         reinterpret_cast<float4*>(P.out)[i] = o;
     }
 }
@@ -947,7 +952,8 @@ extern "C" int nfe_conv_accepts_split(int mode, int h, int w, int cin, int cout)
 
 // Small 3x3 layers (at most one 16x16 tile per sample) split their K loop over this many workgroups.
 static int splitk_slices(int mode, int h, int w, int cin, int cout) {
-    if (mode == NFE_CONV_1X1 || h > 16 || w > 16 || cout % 4 != 0) return 0;
+    const int lim = mode == NFE_CONV_1X1 ? 32 : 16;            // ToRGB has 9x less work per K-group: worth it up to 32^2
+    if (h > lim || w > lim || cout % 4 != 0) return 0;
     const int G = (cin + 15) / 16;
     return G >= 16 ? 8 : (G >= 8 ? 4 : 0);
 }
@@ -1037,12 +1043,14 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     const int up = a->mode == NFE_CONV_3X3_UP2;
     const int gh = a->h + up, gw = a->w + up;
     dim3 grid(((gh + 15) / 16) * ((gw + 15) / 16), (a->cout + 31) / 32, a->n);
-    const int ks = splitk_slices(a->mode, a->h, a->w, a->cin, a->cout);
+    const int ks = a->out_planes ? 0 : splitk_slices(a->mode, a->h, a->w, a->cin, a->cout);
     if (ks && a->scratch && a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout)) {
         const long long slice = (long long)a->n * (up ? (long long)(2 * a->h + 1) * (2 * a->w + 1) : (long long)a->h * a->w) * a->cout;
         P.ksplit = ks; P.partial = a->scratch + (up ? slice : 0);      // after the transposed-conv scratch
         grid.x *= ks;
-        if (up) launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st); else launch_conv<NFE_CONV_3X3>(P, a->math, grid, st);
+        if (up) launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st);
+        else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, a->math, grid, st);
+        else launch_conv<NFE_CONV_3X3>(P, a->math, grid, st);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, up);
         if (up) {
             const long long total = (long long)a->n * a->h * a->w * (a->cout / 4);

@@ -201,3 +201,26 @@ def test_upconv_fast_path_matches_generic(shape, math, dev):
         D.FAST_PATH = True
     assert fast.shape == (N, 2 * H, 2 * W, cout)
     assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 8, 8, 512, 96), (1, 32, 32, 256, 3), (3, 4, 4, 128, 96), (2, 64, 64, 128, 96), (1, 96, 40, 64, 3)])
+def test_torgb_fast_paths_match_generic(shape, math, dev):
+    """ToRGB (1x1 + bias + clamp + upsample2d(skip)): split-K (small layers) and the LDS-weights kernel vs the generic kernel."""
+    from nerffaceediting_amd import _lib, dense_ops as D
+    N, H, W, cin, cout = shape
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(N, H, W, cin, generator=g).to(dev)
+    styles = (torch.randn(N, cin, generator=g) * 0.05).to(dev)
+    weight = torch.randn(cout, cin, 1, 1, generator=g).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    skip = torch.randn(N, H // 2, W // 2, cout, generator=g).to(dev)
+    packed, _ = D.conv_pack(weight)
+    kw = dict(bias=bias, lrelu=False, act_gain=1.0, clamp=256.0, skip=skip, math=math)
+    fast = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_1X1, **kw)
+    D.FAST_PATH = False
+    try:
+        slow = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_1X1, **kw)
+    finally:
+        D.FAST_PATH = True
+    assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
