@@ -274,6 +274,12 @@ def main():
     n_total = world * VIEWS_PER_GPU
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
+    pending = []                                                # outstanding frame exchanges (work, gathered frames)
+
+    def drain():
+        while pending:
+            pending.pop(0)[0].wait()
+
     def step(i, timed):
         mean, std = ops.plane_stats(planes)                     # a4
         aff = ops.make_affine(mean, std)
@@ -284,13 +290,16 @@ def main():
                                            resolution=R, affines=aff, seed=seed + i, channels_first=True)
         if timed:
             ev[i][1].record()
-        if world > 1:                                           # frames of every rank, in view order
-            frames = rgb[:, :3].reshape(VIEWS_PER_GPU, 3, R, R)
-            sharding.all_gather_frames(frames, n_total)
+        if world > 1:                                           # frames of every rank, in view order; the exchange of step i
+            frames = rgb[:, :3].reshape(VIEWS_PER_GPU, 3, R, R)  # runs under the render of step i+1 (two in flight at most)
+            if len(pending) >= 2:
+                pending.pop(0)[0].wait()
+            pending.append(sharding.all_gather_frames_async(frames, n_total))
         return rgb
 
     for i in range(args.warmup):
         step(i, False)
+    drain()
 
     def barrier():
         if world > 1:
@@ -299,6 +308,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i, True)
+    drain()                                                     # every frame exchange of the timed steps has completed
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
     if world > 1:

@@ -34,3 +34,20 @@ def all_gather_frames(local_frames, n_views, group=None):
     out = block.new_empty((world * per,) + tuple(block.shape[1:]))
     dist.all_gather_into_tensor(out, block.contiguous(), group=group)
     return out[:n_views]
+
+
+def all_gather_frames_async(local_frames, n_views, group=None):
+    """Same exchange, not waited for: returns (work, frames).  The collective runs on the backend's own stream
+    (RCCL: overlapped with whatever the caller launches next); call work.wait() before reading `frames`."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        assert local_frames.shape[0] == n_views
+        return None, local_frames
+    world = dist.get_world_size(group)
+    per = -(-int(n_views) // world)
+    pad = per - local_frames.shape[0]
+    block = local_frames
+    if pad:
+        block = torch.cat([local_frames, local_frames.new_zeros((pad,) + tuple(local_frames.shape[1:]))], 0)
+    out = block.new_empty((world * per,) + tuple(block.shape[1:]))
+    work = dist.all_gather_into_tensor(out, block.contiguous(), group=group, async_op=True)
+    return work, out[:n_views]

@@ -26,6 +26,10 @@ def _worker(rank, world, port, V, q):
         local = torch.stack([torch.full((3, 4, 4), float(i)) for i in range(a, b)]) if b > a else torch.zeros(0, 3, 4, 4)
         out = sharding.all_gather_frames(local, V)
         ok = out.shape == (V, 3, 4, 4) and all(float(out[i, 0, 0, 0]) == i for i in range(V))
+        works = [sharding.all_gather_frames_async(local + k, V) for k in range(3)]          # bench.py keeps two in flight
+        for k, (w, o) in enumerate(works):
+            w.wait()
+            ok = ok and o.shape == (V, 3, 4, 4) and all(float(o[i, 0, 0, 0]) == i + k for i in range(V))
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -48,3 +52,5 @@ def test_all_gather_frames_world2(V):
 def test_all_gather_single_process_is_identity():
     x = torch.arange(24.0).reshape(2, 3, 2, 2)
     assert sharding.all_gather_frames(x, 2) is x
+    w, y = sharding.all_gather_frames_async(x, 2)
+    assert w is None and y is x
