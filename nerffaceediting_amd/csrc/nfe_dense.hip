@@ -455,11 +455,24 @@ __global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, W
 #pragma unroll
     for (int k = 0; k < B_PER_WAVE; ++k) {
         const int item = (wave + WV * k) * 64 + lane;
-        const int hh = item / C3_HALF_ITEMS, r = item % C3_HALF_ITEMS, py = r / C3_PW, px = r % C3_PW;
+        // LDS item 2p + (hh ^ bit3(p)) holds channel half hh of patch pixel p: the two halves of a pixel (32 contiguous
+        // bytes in NHWC) are fetched by adjacent lanes = one L1 request, and the XOR keeps the 32-byte-stride fragment
+        // reads conflict-free (pixels p and p+8 share a bank pair, their halves are swapped).
+        const int pp = item >> 1, hh = (item & 1) ^ ((pp >> 3) & 1), py = pp / C3_PW, px = pp % C3_PW;
         const int y = ty0 - 1 + py, x = tx0 - 1 + px;
-        const bool ok = item < 2 * C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
+        const bool ok = pp < C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
         boff[k] = ok ? (((long long)n * P.H + y) * P.W + x) * P.Cin + 8 * hh : -1;
     }
+
+    // byte offsets of this lane's B fragments inside the patch: rows 2*wave + (0..3), columns j + (0..2)
+    int brd[4][3];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            const int pp = (2 * wave + rr) * C3_PW + j + cc;
+            brd[rr][cc] = (2 * pp + (h ^ ((pp >> 3) & 1))) * 16;
+        }
 
     auto issue = [&](int g, int stage) {
         unsigned char* base = lds + stage * STAGE_BYTES;
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, W
         if (STAGES >= 2 && g + STAGES - 1 < G) issue(g + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
-        const unsigned char* ldsB = base + A_CHUNKS * 1024 + ((h * C3_HALF_ITEMS) + (2 * wave) * C3_PW + j) * 16;
+        const unsigned char* ldsB = base + A_CHUNKS * 1024;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int kh = t / 3, kw = t % 3;
@@ -520,8 +533,8 @@ __global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, W
                 Frag8 bh, bl;
                 const int dy = UP2 ? 1 - (kh >> 1) : kh, dx = UP2 ? 1 - (kw >> 1) : kw;
                 const int a = UP2 ? (kh & 1) * 2 + (kw & 1) : 0;
-                bh.q = *reinterpret_cast<const uint4*>(ldsB + ((nb + dy) * C3_PW + dx) * 16);
-                if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + ((nb + dy) * C3_PW + dx) * 16);
+                bh.q = *reinterpret_cast<const uint4*>(ldsB + brd[nb + dy][dx]);
+                if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brd[nb + dy][dx]);
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) {
                     acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
