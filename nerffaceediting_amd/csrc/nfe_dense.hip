@@ -716,21 +716,28 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK P, long long n
 
 // FIR + epilogue of the up-conv: out[Y][X] = act(dcoef * sum_ab F[a]F[b] T[Y+a-1][X+b-1] + noise + bias),
 // F = [1,3,3,1]/4 per axis (setup_filter/64 * gain 4; conv2d_resample.py:127, upfirdn2d.py:169-207)
+constexpr int UPFIR_ROWS = 4;     // 2-row output blocks per thread: consecutive blocks share 3 of their 5 filtered rows
+
 __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
-    // One thread = 4 channels of a 2x2 output block: 25 loads of T for 4 outputs (separable 4-tap filter per axis)
-    // instead of 16 per output; lanes run over channels, so every load is a contiguous 512-byte row piece.
+    // One thread = 4 channels x 2 output columns x 2*UPFIR_ROWS output rows, walking down the image with a sliding
+    // window of row-filtered values: 10 loads of T per 4 outputs (separable 4-tap filter per axis) instead of 64,
+    // and each T row is fetched by one workgroup instead of by the two that own the rows above and below it.
+    // Lanes run over channels, so every load is a contiguous 512-byte row piece.
     const int OH = 2 * P.H, OW = 2 * P.W, TH = OH + 1, TW = OW + 1, C4 = P.Cout >> 2;
-    const long long total = (long long)P.N * P.H * P.W * C4;
+    const int groups = (P.H + UPFIR_ROWS - 1) / UPFIR_ROWS;
+    const long long total = (long long)P.N * groups * P.W * C4;
     const float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % C4); long long r = i / C4;
         const int bx = (int)(r % P.W); r /= P.W;
-        const int by = (int)(r % P.H); const int n = (int)(r / P.H);
-        const int Y0 = 2 * by, X0 = 2 * bx;
-        float4 rf[5][2];                                   // row-filtered: rf[i][dx] = sum_b F[b] T[Y0-1+i][X0+dx+b-1]
-#pragma unroll
-        for (int ii = 0; ii < 5; ++ii) {
-            const int ty = Y0 - 1 + ii;
+        const int bg = (int)(r % groups); const int n = (int)(r / groups);
+        const int X0 = 2 * bx;
+        const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + 4 * c4) : make_float4(1, 1, 1, 1);
+        const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
+        float4 s2 = make_float4(0, 0, 0, 0);
+        if (P.split_hi) s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
+        // row-filtered T row ty: rf[dx] = sum_b F[b] T[ty][X0+dx+b-1]
+        auto filter_row = [&](int ty, float4 (&rf)[2]) {
             float4 t[5];
 #pragma unroll
             for (int jj = 0; jj < 5; ++jj) {
@@ -747,39 +754,47 @@ __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
                     a.x = fmaf(F[bb], t[dx + bb].x, a.x); a.y = fmaf(F[bb], t[dx + bb].y, a.y);
                     a.z = fmaf(F[bb], t[dx + bb].z, a.z); a.w = fmaf(F[bb], t[dx + bb].w, a.w);
                 }
-                rf[ii][dx] = a;
+                rf[dx] = a;
             }
+        };
+        const int by0 = bg * UPFIR_ROWS;
+        float4 win[5][2];                                  // filtered rows 2by-1 .. 2by+3
+        filter_row(2 * by0 - 1, win[0]); filter_row(2 * by0, win[1]); filter_row(2 * by0 + 1, win[2]);
+#pragma unroll
+        for (int rr = 0; rr < UPFIR_ROWS; ++rr) {
+            const int by = by0 + rr;
+            if (by >= P.H) break;
+            const int Y0 = 2 * by;
+            filter_row(Y0 + 2, win[3]); filter_row(Y0 + 3, win[4]);
+#pragma unroll
+            for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) {
+                    float4 sm = make_float4(0, 0, 0, 0);
+#pragma unroll
+                    for (int aa = 0; aa < 4; ++aa) {
+                        sm.x = fmaf(F[aa], win[dy + aa][dx].x, sm.x); sm.y = fmaf(F[aa], win[dy + aa][dx].y, sm.y);
+                        sm.z = fmaf(F[aa], win[dy + aa][dx].z, sm.z); sm.w = fmaf(F[aa], win[dy + aa][dx].w, sm.w);
+                    }
+                    const int Y = Y0 + dy, X = X0 + dx;
+                    const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
+                    float4 o;
+                    o.x = epilogue_act(sm.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+                    o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+                    o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+                    o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+                    const long long oi = (((long long)n * OH + Y) * OW + X) * C4 + c4;
+                    if (P.out) reinterpret_cast<float4*>(P.out)[oi] = o;
+                    if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer
+                        unsigned h0, l0, h1, l1;
+                        if (P.split_lo) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[oi] = make_uint2(l0, l1); }
+                        else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
+                        P.split_hi[oi] = make_uint2(h0, h1);
+                    }
+                }
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) { win[0][dx] = win[2][dx]; win[1][dx] = win[3][dx]; win[2][dx] = win[4][dx]; }
         }
-        const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + 4 * c4) : make_float4(1, 1, 1, 1);
-        const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
-        float4 s2 = make_float4(0, 0, 0, 0);
-        if (P.split_hi) s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-            for (int dx = 0; dx < 2; ++dx) {
-                float4 sm = make_float4(0, 0, 0, 0);
-#pragma unroll
-                for (int aa = 0; aa < 4; ++aa) {
-                    sm.x = fmaf(F[aa], rf[dy + aa][dx].x, sm.x); sm.y = fmaf(F[aa], rf[dy + aa][dx].y, sm.y);
-                    sm.z = fmaf(F[aa], rf[dy + aa][dx].z, sm.z); sm.w = fmaf(F[aa], rf[dy + aa][dx].w, sm.w);
-                }
-                const int Y = Y0 + dy, X = X0 + dx;
-                const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
-                float4 o;
-                o.x = epilogue_act(sm.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
-                o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
-                o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
-                o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-                const long long oi = (((long long)n * OH + Y) * OW + X) * C4 + c4;
-                if (P.out) reinterpret_cast<float4*>(P.out)[oi] = o;
-                if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer
-                    unsigned h0, l0, h1, l1;
-                    if (P.split_lo) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[oi] = make_uint2(l0, l1); }
-                    else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
-                    P.split_hi[oi] = make_uint2(h0, h1);
-                }
-            }
     }
 }
 
@@ -1041,7 +1056,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         if (up2) {
             if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext, st);
             else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext, st);
-            const long long total = (long long)a->n * a->h * a->w * (a->cout / 4);
+            const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
         } else if (a->h >= 16 * C3_TALL_MIN_TILES) {           // 32 x 16 tiles (8 waves): half the weight bytes per MFMA
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);
@@ -1066,7 +1081,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         else launch_conv<NFE_CONV_3X3>(P, a->math, grid, st);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, up);
         if (up) {
-            const long long total = (long long)a->n * a->h * a->w * (a->cout / 4);
+            const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
         }
         NFE_CHECK_LAUNCH("split-K conv kernels");
@@ -1083,7 +1098,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, a->math, grid, st);
     else {
         launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st);
-        const long long total = (long long)a->n * a->h * a->w * (a->cout / 4);
+        const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
         hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
     }
     NFE_CHECK_LAUNCH("conv kernels");
