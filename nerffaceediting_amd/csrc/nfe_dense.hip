@@ -409,10 +409,10 @@ struct Conv3K {
     float* out; float* scratch;
 };
 
-// WV waves per workgroup, each owning two image rows of 32 pixels: tile = 32 x 2WV pixels.
+// WV waves per workgroup, each owning NBW image rows of 32 pixels: tile = 32 x (NBW * WV) pixels (ROWS rows).
 constexpr int C3_TW = 32, C3_PW = C3_TW + 2;
-template <int WV> struct C3Tile {
-    static constexpr int TH = 2 * WV, PH = TH + 2;
+template <int ROWS> struct C3Tile {
+    static constexpr int TH = ROWS, PH = TH + 2;
     static constexpr int HALF_ITEMS = C3_PW * PH;                 // 16-byte items (8 bf16 channels of one pixel) per channel half
     static constexpr int B_CHUNKS = (2 * HALF_ITEMS + 63) / 64;   // 1-KiB LDS-DMA chunks per part
     static constexpr int B_BYTES = B_CHUNKS * 1024;
@@ -426,18 +426,22 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
 // UP2: the stride-2 transposed convolution of the up-sampling layers as four output phases over the (H+1)x(W+1)
 // extended input grid (same tap -> phase map as conv_kernel<NFE_CONV_3X3_UP2>), written to the (2H+1)x(2W+1)
 // scratch that upfir_kernel filters.
-template <int TERMS, int MBW, int WV>
-constexpr int conv3_stage_bytes() { return (MBW * 9 + C3Tile<WV>::B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
+template <int TERMS, int MBW, int ROWS>
+constexpr int conv3_stage_bytes() { return (MBW * 9 + C3Tile<ROWS>::B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
 
 // STAGES-deep ring of K-group buffers: the loads of K-group g+STAGES-1 are issued while g is computed, so a
 // load has STAGES-1 K-groups of MFMA time to land.
-template <int TERMS, int MBW, bool UP2, int STAGES, int WV>
-__global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, WV>() > 80 * 1024) ? 1 : 2) * WV / 4) void conv3_kernel(Conv3K P) {
+// NBW = 2: up to four waves per SIMD (two workgroups per CU).  NBW = 4 with MBW = 4 is the big tile: 128 channels x
+// 32 x 16 pixels on four waves, ONE wave per SIMD with 256 accumulator registers - half the LDS reads and half the
+// L1->LDS bytes per MFMA of the small tiles.
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
+__global__ __launch_bounds__(64 * WV, (NBW > 2 ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
     constexpr int NACC = UP2 ? 4 : 1;
     constexpr int A_CHUNKS = MBW * 9 * PARTS;
-    constexpr int STAGE_BYTES = conv3_stage_bytes<TERMS, MBW, WV>();
-    constexpr int C3_TH = C3Tile<WV>::TH, C3_HALF_ITEMS = C3Tile<WV>::HALF_ITEMS, C3_B_CHUNKS = C3Tile<WV>::B_CHUNKS, C3_B_BYTES = C3Tile<WV>::B_BYTES;
+    constexpr int ROWS = NBW * WV;
+    constexpr int STAGE_BYTES = conv3_stage_bytes<TERMS, MBW, ROWS>();
+    constexpr int C3_TH = C3Tile<ROWS>::TH, C3_HALF_ITEMS = C3Tile<ROWS>::HALF_ITEMS, C3_B_CHUNKS = C3Tile<ROWS>::B_CHUNKS, C3_B_BYTES = C3Tile<ROWS>::B_BYTES;
     constexpr int B_PER_WAVE = (C3_B_CHUNKS + WV - 1) / WV;
     constexpr int MIN_LOADS = A_CHUNKS / WV + (C3_B_CHUNKS / WV) * PARTS;    // fewest LDS-DMA instructions any wave issues per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -464,13 +468,13 @@ __global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, W
         boff[k] = ok ? (((long long)n * P.H + y) * P.W + x) * P.Cin + 8 * hh : -1;
     }
 
-    // byte offsets of this lane's B fragments inside the patch: rows 2*wave + (0..3), columns j + (0..2)
-    int brd[4][3];
+    // byte offsets of this lane's B fragments inside the patch: rows NBW*wave + (0..NBW+1), columns j + (0..2)
+    int brd[NBW + 2][3];
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr)
+    for (int rr = 0; rr < NBW + 2; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
-            const int pp = (2 * wave + rr) * C3_PW + j + cc;
+            const int pp = (NBW * wave + rr) * C3_PW + j + cc;
             brd[rr][cc] = (2 * pp + (h ^ ((pp >> 3) & 1))) * 16;
         }
 
@@ -496,13 +500,13 @@ __global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, W
         }
     };
 
-    f32x16 acc[NACC][MBW][2];
+    f32x16 acc[NACC][MBW][NBW];
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
 #pragma unroll
         for (int m = 0; m < MBW; ++m)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][m][nb][r] = 0.0f;
 
@@ -529,7 +533,7 @@ __global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, W
                 if (TERMS == 3) al[m].q = ldsA[((m * 9 + t) * PARTS + 1) * 64];
             }
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NBW; ++nb) {
                 Frag8 bh, bl;
                 const int dy = UP2 ? 1 - (kh >> 1) : kh, dx = UP2 ? 1 - (kw >> 1) : kw;
                 const int a = UP2 ? (kh & 1) * 2 + (kw & 1) : 0;
@@ -550,8 +554,8 @@ __global__ __launch_bounds__(64 * WV, ((STAGES * conv3_stage_bytes<TERMS, MBW, W
 
     // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of pixel (row, j) ----
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const int y = ty0 + 2 * wave + nb, x = tx0 + j;
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int y = ty0 + NBW * wave + nb, x = tx0 + j;
         if (UP2) {
             if (y > P.H || x > P.W) continue;
             const int TH2 = 2 * P.H + 1, TW2 = 2 * P.W + 1;
@@ -950,19 +954,32 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
 #define C3_STAGES_X3 1
 #define C3_STAGES_X3_UP 1
 #endif
+#ifndef C3_BIG
+#define C3_BIG 0          // measured slower (1 wave per SIMD, compiler-scheduled): bf16 SR 3.8 -> 4.0 ms, split-bf16 3.26 -> 3.45 ms
+#endif
+static int num_cus_dense() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
 #ifndef C3_TALL_MIN_TILES
 #define C3_TALL_MIN_TILES 4          // use the 8-wave 32x16 tile from 64 rows up
 #endif
-template <int TERMS, int MBW, bool UP2, int STAGES, int WV>
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st) {
-    constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW, WV>();
+    constexpr int ROWS = NBW * WV;
+    constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>();
     static bool once = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     (void)once;
-    const unsigned tiles = ((mode_h + C3Tile<WV>::TH - 1) / C3Tile<WV>::TH) * ((mode_w + C3_TW - 1) / C3_TW);
+    const unsigned tiles = ((mode_h + ROWS - 1) / ROWS) * ((mode_w + C3_TW - 1) / C3_TW);
     dim3 grid(tiles, K.Cout / (32 * MBW), K.N);
-    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV>), grid, dim3(64 * WV), bytes, st, K);
+    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW>), grid, dim3(64 * WV), bytes, st, K);
 }
 
 static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
@@ -1058,6 +1075,11 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext, st);
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
+        } else if (C3_BIG && a->cout % 128 == 0 && a->h >= 16 &&
+                   (long long)((a->h + 15) / 16) * ((a->w + 31) / 32) * (a->cout / 128) * a->n >= 2LL * num_cus_dense()) {
+            // big tile, one wave per SIMD: 128 channels x 32x16 pixels on 4 waves, as long as the grid still fills the chip twice
+            if (bf16) launch_conv3<1, 4, false, 2, 4, 4>(K, a->h, a->w, st);
+            else launch_conv3<3, 2, false, 2, 4, 4>(K, a->h, a->w, st);
         } else if (a->h >= 16 * C3_TALL_MIN_TILES) {           // 32 x 16 tiles (8 waves): half the weight bytes per MFMA
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, C3_STAGES_X3, 8>(K, a->h, a->w, st);

@@ -144,7 +144,7 @@ def test_superresolution_8xdc(tag, dev):
 
 
 @pytest.mark.parametrize("math", ["bf16x3", "bf16"])
-@pytest.mark.parametrize("shape", [(2, 40, 72, 48, 128), (1, 8, 32, 16, 64), (3, 33, 95, 64, 64), (2, 8, 8, 256, 64), (1, 16, 16, 512, 96), (3, 4, 4, 128, 32)])
+@pytest.mark.parametrize("shape", [(2, 40, 72, 48, 128), (1, 8, 32, 16, 64), (3, 33, 95, 64, 64), (2, 8, 8, 256, 64), (1, 16, 16, 512, 96), (3, 4, 4, 128, 32), (4, 250, 255, 32, 128)])
 def test_conv3x3_fast_path_matches_generic(shape, math, dev):
     """The LDS-DMA 3x3 path (pre-split activations) against the generic kernel on ragged tiles, and against a
     torch fp32 conv of the same modulated/demodulated layer (modulated_conv2d, networks_stylegan2.py:34-91)."""
