@@ -435,7 +435,7 @@ constexpr int conv3_stage_bytes() { return (MBW * 9 + C3Tile<ROWS>::B_CHUNKS) * 
 // 32 x 16 pixels on four waves, ONE wave per SIMD with 256 accumulator registers - half the LDS reads and half the
 // L1->LDS bytes per MFMA of the small tiles.
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
-__global__ __launch_bounds__(64 * WV, (NBW > 2 ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
+__global__ __launch_bounds__(64 * WV, (NBW * MBW > 8 ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
     constexpr int NACC = UP2 ? 4 : 1;
     constexpr int A_CHUNKS = MBW * 9 * PARTS;
@@ -954,6 +954,9 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
 #define C3_STAGES_X3 1
 #define C3_STAGES_X3_UP 1
 #endif
+#ifndef C3_MID
+#define C3_MID 0
+#endif
 #ifndef C3_BIG
 #define C3_BIG 0          // measured slower (1 wave per SIMD, compiler-scheduled): bf16 SR 3.8 -> 4.0 ms, split-bf16 3.26 -> 3.45 ms
 #endif
@@ -1080,6 +1083,8 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             // big tile, one wave per SIMD: 128 channels x 32x16 pixels on 4 waves, as long as the grid still fills the chip twice
             if (bf16) launch_conv3<1, 4, false, 2, 4, 4>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, 2, 4, 4>(K, a->h, a->w, st);
+        } else if (C3_MID && a->h >= 16 * C3_TALL_MIN_TILES && bf16) {   // 32 x 16 tiles on 4 waves (2 x 4 blocks per wave)
+            launch_conv3<1, 2, false, 2, 4, 4>(K, a->h, a->w, st);
         } else if (a->h >= 16 * C3_TALL_MIN_TILES) {           // 32 x 16 tiles (8 waves): half the weight bytes per MFMA
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, C3_STAGES_X3, 8>(K, a->h, a->w, st);
