@@ -128,6 +128,26 @@ def gen_synthesis():
     print("  wrote dense_synthesis.npz")
 
 
+def gen_synthesis_full():
+    """Full-width backbone (train.py FFHQ: 256 px, channels min(32768//res, 512), 96 output channels, w_dim 512), one
+    sample.  Only a strided sub-sample of the 25 MB output is stored; it pins the wide-layer kernels (512-channel
+    split-K layers, LDS-DMA conv path, chained up-sampling layers) against the reference itself."""
+    w_dim, res, cb, cm = 512, 256, 32768, 512
+    net = ref_sg2.SynthesisNetwork(w_dim, res, 96, channel_base=cb, channel_max=cm, num_fp16_res=0, conv_clamp=None,
+                                   fused_modconv_default="inference_only")
+    p = synthesis_params(61, w_dim, res, 96, cb, cm)
+    load(net, p)
+    rng = np.random.RandomState(62)
+    ws = t(rng.randn(1, net.num_ws, w_dim))
+    ref = net(ws, noise_mode="const")
+    mine = dor.synthesis_network(p, ws, net.block_resolutions)
+    check("synthesis(256px, full)", mine, ref, 2e-4 * float(ref.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "dense_synthesis_full.npz"), ws=ws.numpy(), out_s8=ref[:, :, 3::8, 5::8].numpy(),
+                        ch_mean=ref.mean(dim=(2, 3)).numpy(), ch_std=ref.std(dim=(2, 3)).numpy(), absmax=float(ref.abs().max()),
+                        seed=61, w_dim=w_dim, res=res, channel_base=cb, channel_max=cm, num_ws=net.num_ws)
+    print("  wrote dense_synthesis_full.npz")
+
+
 def gen_sr():
     sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=4, sr_antialias=True,
                                    channel_base=32768, channel_max=512, fused_modconv_default="inference_only")
@@ -205,9 +225,14 @@ def gen_e2e():
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
+    only = sys.argv[1] if len(sys.argv) > 1 else None         # e.g. `python oracle/gen_golden_dense.py synthesis_full`
+    if only:
+        globals()["gen_" + only]()
+        sys.exit(0)
     gen_mapping()
     gen_layers()
     gen_synthesis()
+    gen_synthesis_full()
     gen_sr()
     gen_e2e()
     for f in sorted(os.listdir(OUT)):

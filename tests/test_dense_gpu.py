@@ -129,6 +129,24 @@ def test_reduced_synthesis_network(dev):
     assert torch.equal(planes, ops.plane_pack(out))
 
 
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+def test_full_width_synthesis_network(math, dev):
+    """FFHQ-width backbone (512 channels, 256 px: split-K small layers, LDS-DMA conv path, chained up-sampling layers)
+    against the sub-sampled output of the reference SynthesisNetwork."""
+    from nerffaceediting_amd.training.networks_stylegan2 import SynthesisNetwork
+    z = load("dense_synthesis_full")
+    p = synthesis_params(int(z["seed"]), int(z["w_dim"]), int(z["res"]), 96, int(z["channel_base"]), int(z["channel_max"]))
+    net = load_module(SynthesisNetwork(int(z["w_dim"]), int(z["res"]), 96, channel_base=int(z["channel_base"]),
+                                       channel_max=int(z["channel_max"]), num_fp16_res=0, conv_clamp=None), p, dev)
+    net.conv_math = math
+    out = net(t(z["ws"], dev), noise_mode="const")
+    scale = float(z["absmax"])
+    e = maxerr(out[:, :, 3::8, 5::8], z["out_s8"])
+    print("full-width synthesis", math, e, "of", scale)
+    assert e <= (1e-4 if math == "bf16x3" else 3e-2) * scale
+    assert maxerr(out.mean(dim=(2, 3)), z["ch_mean"]) <= (1e-4 if math == "bf16x3" else 5e-2)
+
+
 @pytest.mark.parametrize("tag", ["r64", "r128"])
 def test_superresolution_8xdc(tag, dev):
     from nerffaceediting_amd.training.superresolution import SuperresolutionHybrid8XDC

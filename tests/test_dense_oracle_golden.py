@@ -64,6 +64,15 @@ def test_reduced_synthesis_network():
     assert err(dor.synthesis_network(p, t(z["ws"]), res), z["out"]) <= 5e-5
 
 
+def test_full_width_synthesis_network():
+    """The oracle at the FFHQ backbone width (512 channels, 256 px) against the sub-sampled reference output."""
+    z = load("dense_synthesis_full")
+    p = synthesis_params(int(z["seed"]), int(z["w_dim"]), int(z["res"]), 96, int(z["channel_base"]), int(z["channel_max"]))
+    out = dor.synthesis_network(p, t(z["ws"]), [4, 8, 16, 32, 64, 128, 256])
+    assert err(out[:, :, 3::8, 5::8], z["out_s8"]) <= 2e-4 * float(z["absmax"])
+    assert err(out.mean(dim=(2, 3)), z["ch_mean"]) <= 1e-4
+
+
 def test_superresolution_r64():
     z = load("dense_sr")
     p = sr_params(int(z["seed"]))
