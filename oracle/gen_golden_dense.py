@@ -223,6 +223,40 @@ def gen_e2e():
     print("  wrote dense_e2e.npz")
 
 
+def gen_e2e_full():
+    """The FFHQ-size generator (channel_base 32768, channel_max 512: 30.7 M parameters) end to end, one view, 64^2
+    neural render, 24+24 samples, injected jitter.  Reference outputs only (sub-sampled where large)."""
+    import math
+    from camera_utils import FOV_to_intrinsics, LookAtPoseSampler
+    from training.triplane import TriPlaneGenerator
+    from oracle.dense_params import generator_params
+    from oracle.gen_golden import InjectRand
+    rk = dict(E2E_KW["rendering_kwargs"], depth_resolution=24, depth_resolution_importance=24)
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default="inference_only"),
+                          channel_base=32768, channel_max=512, fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+    p = generator_params(71, 32768, 512)
+    load(G, p)
+    assert sum(v.numel() for v in G.parameters()) == 30665223          # SURVEY.md section 8c
+    rng = np.random.RandomState(72)
+    N, R, D, Di = 1, 64, 24, 24
+    z = t(rng.randn(N, 512))
+    c2w = LookAtPoseSampler.sample(math.pi / 2 + 0.25, math.pi / 2 - 0.15, torch.tensor([0, 0, 0.2]), radius=2.7)
+    c = torch.cat([c2w.reshape(N, 16), FOV_to_intrinsics(18.837).reshape(1, 9)], 1)
+    u_c = rng.rand(N, R * R, D).astype(np.float32)
+    u_f = rng.rand(N * R * R, Di).astype(np.float32)
+    with InjectRand([u_c, u_f]):
+        ref = G(z, c, truncation_psi=0.7, truncation_cutoff=14, neural_rendering_resolution=R, noise_mode="const")
+    data = dict(z=z.numpy(), c=c.numpy(), u_coarse=u_c, u_fine=u_f, seed=71, R=R, D=D, Di=Di,
+                image_s4=ref["image"][:, :, 1::4, 2::4].numpy(), image_mean=float(ref["image"].mean()),
+                image_seg=ref["image_seg"].numpy(), image_raw=ref["image_raw"].numpy(), image_depth=ref["image_depth"].numpy(),
+                plane_mean=ref["plane_mean"].numpy(), plane_var=ref["plane_var"].numpy())
+    for k in ("image", "image_seg", "image_raw", "image_depth"):
+        print(f"    reference {k:12s} |max| {float(ref[k].abs().max()):.3g}")
+    np.savez_compressed(os.path.join(OUT, "dense_e2e_full.npz"), **data)
+    print("  wrote dense_e2e_full.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None         # e.g. `python oracle/gen_golden_dense.py synthesis_full`
@@ -235,6 +269,7 @@ if __name__ == "__main__":
     gen_synthesis_full()
     gen_sr()
     gen_e2e()
+    gen_e2e_full()
     for f in sorted(os.listdir(OUT)):
         if f.startswith("dense_"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
