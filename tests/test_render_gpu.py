@@ -225,3 +225,39 @@ def test_errors_raise(dev):
         ops.render(packed, packed, dec, bad, origins=o, dirs=d)
     with pytest.raises(RuntimeError):                      # CPU tensors are refused: no fallback path
         ops.plane_stats(torch.zeros(1, 96, 4, 4))
+
+
+@pytest.mark.parametrize("math", MATHS)
+def test_render_full_size_vs_reference(math, dev):
+    """BASELINE config-2 size (512^2 rays x 64 samples, 256^2 planes) against the reference renderer: planes, decoder and
+    jitter are regenerated from the fixture's seed (same numpy draws as oracle/gen_golden.py gen_render_full_size), the
+    fixture holds every 61st ray of the reference outputs."""
+    import ast
+    import torch
+    from nerffaceediting_amd import ops
+    z = load("fullsize_render")
+    seed, R, H, D, stride = (int(z[k]) for k in ("seed", "R", "H", "D", "stride"))
+    rng = np.random.RandomState(seed)
+    base = rng.randn(1, 96, H, H).astype(np.float32)                 # gen_golden.smooth_planes
+    mu = rng.randn(1, 96, 1, 1).astype(np.float32) * 0.7
+    sd = np.exp(rng.randn(1, 96, 1, 1).astype(np.float32) * 0.5)
+    planes = (base * sd + mu).astype(np.float32)
+    dec = orc.random_decoder(seed + 1, bias_scale=0.3)
+    u_c = rng.rand(1, R * R, D).astype(np.float32)
+    opts = ast.literal_eval(str(z["options"]))
+    p = _t(planes, dev)
+    mean, std = ops.plane_stats(p)
+    packed = ops.plane_pack(p)
+    names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
+             "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+    decp = ops.decoder_pack(*[_t(dec[k], dev) for k in names])
+    rgb, seg, depth, wsum = ops.render(packed, packed, decp, opts, cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev),
+                                       resolution=R, affines=ops.make_affine(mean, std), u_coarse=_t(u_c, dev), decoder_math=math)[:4]
+    idx = torch.arange(0, R * R, stride, device=dev)
+    errs = {"rgb": max_abs(rgb[:, idx].cpu().numpy(), z["rgb"]), "seg": max_abs(seg[:, idx].cpu().numpy(), z["seg"]),
+            "depth": max_abs(depth[:, idx].cpu().numpy(), z["depth"]), "wsum": max_abs(wsum[:, idx].cpu().numpy(), z["wsum"])}
+    print("full size", math, errs)
+    for k, e in errs.items():
+        assert e <= TIGHT[math] or (k == "depth" and e <= TOL), (k, e)
+    assert max_abs(rgb.double().mean(dim=(0, 1)).cpu().numpy(), z["rgb_mean"]) <= 1e-5
+    assert abs(float(wsum.double().mean()) - float(z["wsum_mean"])) <= 1e-5
