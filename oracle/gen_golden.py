@@ -155,38 +155,46 @@ def gen_render_case(tag, seed, N, R, H, D, Ni, angles, white_back=False, swap=Fa
     print(f"  wrote render_{tag}.npz")
 
 
-def gen_render_full_size(seed=401, R=512, H=256, D=64, stride=61, chunk=32768):
-    """BASELINE config-2 size (512^2 rays x 64 samples, 256^2 planes), one view, through the reference renderer in ray
-    chunks (the only cross-ray term, the depth clamp to the call's [min,max] of sampled depths, cannot bind a weighted
-    mean of those depths).  Planes, decoder and jitter are regenerated from the seed by the test; the fixture keeps
-    every `stride`-th ray of the reference outputs."""
+def gen_render_full_size(name="fullsize_render", seed=401, N=1, R=512, H=256, D=64, Ni=0, swap=False, stride=61, chunk=32768,
+                         angles=((0.3, -0.2),)):
+    """Real-size render cases through the reference renderer, in ray chunks (the only cross-ray term, the depth clamp to
+    the call's [min,max] of sampled depths, cannot bind a weighted mean of those depths).  Planes, decoder and jitter are
+    regenerated from the seed by the tests; the fixture keeps every `stride`-th ray of the reference outputs.
+      fullsize_render: BASELINE config-2 size, 512^2 rays x 64 samples, 256^2 planes, one view;
+      ffhq_render:     the FFHQ rendering_kwargs (train.py:306-307: 128^2 rays, 48 + 48 samples), two views with
+                       swapped appearance statistics (norm_planes != normalised denorm_planes: the editing path)."""
     rng = np.random.RandomState(seed)
-    planes = smooth_planes(rng, 1, H)
+    planes = smooth_planes(rng, N, H)
     dec_np = orc.random_decoder(seed + 1, bias_scale=0.3)
-    c2w, K = cams([(0.3, -0.2)])
+    c2w, K = cams(list(angles))
     M = R * R
-    u_c = rng.rand(1, M, D).astype(np.float32)
-    opts = dict(depth_resolution=D, depth_resolution_importance=0, ray_start=2.25, ray_end=3.3, box_warp=1.0,
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, max(Ni, 1)).astype(np.float32)[:, :Ni]
+    opts = dict(depth_resolution=D, depth_resolution_importance=Ni, ray_start=2.25, ray_end=3.3, box_warp=1.0,
                 disparity_space_sampling=False, clamp_mode="softplus", white_back=False)
     G = TriPlaneGenerator.__new__(TriPlaneGenerator)
     tp = torch.from_numpy(planes)
     norm, mean, std = TriPlaneGenerator.normalize_plane(G, tp)
-    norm5, den5 = norm.view(1, 3, 32, H, H), tp.reshape(1, 3, 32, H, H)
+    denorm = TriPlaneGenerator.denormalize_plane(G, norm, mean.flip(0), std.flip(0)) if swap else tp
+    norm5, den5 = norm.view(N, 3, 32, H, H), denorm.reshape(N, 3, 32, H, H)
     o, d = RaySampler()(c2w, K, R)
     rend, dec = DisentangledImportanceRenderer(), ref_decoder(dec_np)
     outs = []
     for a in range(0, M, chunk):
-        with InjectRand([u_c[:, a:a + chunk]]):
-            outs.append([x.numpy() for x in rend(norm5, den5, dec, o[:, a:a + chunk], d[:, a:a + chunk], opts)])
-        print(f"    reference rays {a}..{a + chunk}")
+        e = min(M, a + chunk)
+        q = [u_c[:, a:e]] + ([u_f.reshape(N, M, Ni)[:, a:e].reshape(-1, Ni)] if Ni > 0 else [])
+        with InjectRand(q):
+            outs.append([x.numpy() for x in rend(norm5, den5, dec, o[:, a:e], d[:, a:e], opts)])
+        print(f"    reference rays {a}..{e}")
     rgb, seg, depth, wsum = (np.concatenate([o_[i] for o_ in outs], 1) for i in range(4))
     idx = np.arange(0, M, stride)
     opts_s = {k: (v if not isinstance(v, bool) else int(v)) for k, v in opts.items()}
-    np.savez_compressed(os.path.join(OUT, "fullsize_render.npz"), seed=seed, R=R, H=H, D=D, stride=stride,
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), seed=seed, N=N, R=R, H=H, D=D, Ni=Ni, swap=int(swap), stride=stride,
                         cam2world=c2w.numpy(), intrinsics=K.numpy(), options=np.array(repr(opts_s)),
                         rgb=rgb[:, idx], seg=seg[:, idx], depth=depth[:, idx], wsum=wsum[:, idx],
-                        rgb_mean=rgb.astype(np.float64).mean(axis=(0, 1)), wsum_mean=float(wsum.astype(np.float64).mean()), torch_version=np.array(torch.__version__))
-    print("  wrote fullsize_render.npz")
+                        rgb_mean=rgb.astype(np.float64).mean(axis=(0, 1)), wsum_mean=float(wsum.astype(np.float64).mean()),
+                        torch_version=np.array(torch.__version__))
+    print(f"  wrote {name}.npz")
 
 
 def gen_point_query(seed=7, N=2, H=16, P=500):
@@ -279,8 +287,10 @@ def main():
     gen_render_case("oob_boxwarp", 6, 1, 8, 16, 16, 16, [(0.9, 0.3)], box_warp=0.6)
     gen_render_case("disparity", 8, 1, 8, 16, 10, 6, front3[:1], disparity=True)
     gen_render_case("auto_limits", 9, 2, 8, 16, 12, 12, [(0.4, -0.2), (1.2, 0.5)], auto=True)
-    print("render core, BASELINE config-2 size:")
+    print("render core, real sizes:")
     gen_render_full_size()
+    gen_render_full_size("ffhq_render", seed=411, N=2, R=128, H=256, D=48, Ni=48, swap=True, stride=7, chunk=16384,
+                         angles=((0.35, -0.15), (-0.3, 0.1)))
     print("point query:")
     gen_point_query()
     print("plane stats:")
@@ -295,5 +305,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "render_full_size":       # one fixture only
         os.makedirs(OUT, exist_ok=True)
         gen_render_full_size()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ffhq_render":
+        os.makedirs(OUT, exist_ok=True)
+        gen_render_full_size("ffhq_render", seed=411, N=2, R=128, H=256, D=48, Ni=48, swap=True, stride=7, chunk=16384,
+                             angles=((0.35, -0.15), (-0.3, 0.1)))
     else:
         main()

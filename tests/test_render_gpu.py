@@ -261,3 +261,46 @@ def test_render_full_size_vs_reference(math, dev):
         assert e <= TIGHT[math] or (k == "depth" and e <= TOL), (k, e)
     assert max_abs(rgb.double().mean(dim=(0, 1)).cpu().numpy(), z["rgb_mean"]) <= 1e-5
     assert abs(float(wsum.double().mean()) - float(z["wsum_mean"])) <= 1e-5
+
+
+def test_render_ffhq_config_dual_vs_reference(dev):
+    """The FFHQ rendering_kwargs (128^2 rays, 48 coarse + 48 importance samples) with swapped appearance statistics (two plane
+    sets: the editing path through renderer(norm_planes, denorm_planes, ...)) against the reference renderer."""
+    import ast
+    import torch
+    from nerffaceediting_amd import ops
+    z = load("ffhq_render")
+    seed, N, R, H, D, Ni, stride = (int(z[k]) for k in ("seed", "N", "R", "H", "D", "Ni", "stride"))
+    rng = np.random.RandomState(seed)
+    base = rng.randn(N, 96, H, H).astype(np.float32)                 # gen_golden.smooth_planes
+    mu = rng.randn(1, 96, 1, 1).astype(np.float32) * 0.7
+    sd = np.exp(rng.randn(1, 96, 1, 1).astype(np.float32) * 0.5)
+    planes = (base * sd + mu).astype(np.float32)
+    dec = orc.random_decoder(seed + 1, bias_scale=0.3)
+    u_c = rng.rand(N, R * R, D).astype(np.float32)
+    u_f = rng.rand(N * R * R, Ni).astype(np.float32)
+    opts = ast.literal_eval(str(z["options"]))
+    p = _t(planes, dev)
+    mean, std = ops.plane_stats(p)
+    # explicit norm / denorm plane sets, as utils.decode() hands them to the renderer
+    normed = (p - mean) / (std + 1e-8)
+    denormed = normed * std.flip(0) + mean.flip(0)
+    names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
+             "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+    decp = ops.decoder_pack(*[_t(dec[k], dev) for k in names])
+    rgb, seg, depth, wsum = ops.render(ops.plane_pack(normed.contiguous()), ops.plane_pack(denormed.contiguous()), decp, opts,
+                                       cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev), resolution=R,
+                                       u_coarse=_t(u_c, dev), u_fine=_t(u_f, dev))[:4]
+    idx = torch.arange(0, R * R, stride, device=dev)
+    errs = {"rgb": max_abs(rgb[:, idx].cpu().numpy(), z["rgb"]), "seg": max_abs(seg[:, idx].cpu().numpy(), z["seg"]),
+            "depth": max_abs(depth[:, idx].cpu().numpy(), z["depth"]), "wsum": max_abs(wsum[:, idx].cpu().numpy(), z["wsum"])}
+    print("ffhq dual", errs)
+    for k, e in errs.items():
+        assert e <= TIGHT["bf16x3"] or (k == "depth" and e <= TOL), (k, e)
+    assert max_abs(rgb.double().mean(dim=(0, 1)).cpu().numpy(), z["rgb_mean"]) <= 2e-5
+    # the single-gather form of the same render (raw planes + affines) agrees with the two-plane-set form
+    aff = ops.make_affine(mean, std, mean.flip(0).contiguous(), std.flip(0).contiguous())
+    packed = ops.plane_pack(p)
+    rgb1 = ops.render(packed, packed, decp, opts, cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev), resolution=R,
+                      affines=aff, u_coarse=_t(u_c, dev), u_fine=_t(u_f, dev))[0]
+    assert max_abs(rgb1[:, idx].cpu().numpy(), z["rgb"]) <= TIGHT["bf16x3"]
