@@ -819,7 +819,7 @@ __device__ __forceinline__ AxisW axis_setup(int i, int in, int out, int aa) {
         if (src < 0.0f) src = 0.0f;
         a.lo = min((int)src, in - 1);
         a.n = (a.lo + 1 < in) ? 2 : 1;
-        a.support = src - (float)a.lo;                 // lambda1 (weight of lo+1)
+        a.support = a.n == 2 ? src - (float)a.lo : 0.0f;   // lambda1 (weight of lo+1; at the far edge lo+1 clamps onto lo)
         a.inv = 0.0f;
     }
     return a;

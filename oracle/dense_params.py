@@ -80,3 +80,25 @@ def generator_params(seed, channel_base=4096, channel_max=32, z_dim=512, c_dim=2
         if k.startswith("backbone.synthesis.") and k.endswith("torgb.weight"):
             p[k] = p[k] * 0.3
     return p
+
+
+def params_by_name(seed, shapes):
+    """Seeded parameters for any module of the dense path, keyed by state_dict name (order-independent: each tensor's
+    generator is seeded with crc32(name) ^ seed).  shapes: {name: shape}; resample filters are left alone."""
+    import zlib
+    out = {}
+    for k, shp in shapes.items():
+        if k.endswith("resample_filter"):
+            continue
+        rng = np.random.RandomState((zlib.crc32(k.encode()) ^ int(seed)) & 0x7FFFFFFF)
+        shp = tuple(shp)
+        if k.endswith("affine.bias"):
+            v = 1.0 + 0.2 * rng.randn(*shp)
+        elif k.endswith("noise_strength"):
+            v = 0.1 * rng.randn(*shp) if shp else np.float64(0.1 * rng.randn())
+        elif k.endswith(".bias"):
+            v = 0.1 * rng.randn(*shp)
+        else:
+            v = rng.randn(*shp)
+        out[k] = torch.from_numpy(np.asarray(v, dtype=np.float32).reshape(shp).copy())
+    return out

@@ -223,6 +223,33 @@ def gen_e2e():
     print("  wrote dense_e2e.npz")
 
 
+def gen_sr_variants():
+    """The other super-resolution heads (superresolution.py:29-155): 8X, 4X, 2X, Deepfp32.  Reference outputs only."""
+    from training import superresolution as ref_sr
+    from oracle.dense_params import params_by_name
+    data = {}
+    for name, res, in_res, kw in (("SuperresolutionHybrid8X", 512, 64, dict(sr_antialias=True)), ("SuperresolutionHybrid4X", 256, 64, dict(sr_antialias=True)),
+                                  ("SuperresolutionHybrid4X", 256, 128, dict(sr_antialias=False)), ("SuperresolutionHybrid2X", 128, 96, dict(sr_antialias=True)),
+                                  ("SuperresolutionHybridDeepfp32", 256, 64, dict())):
+        tag = f"{name}.{in_res}"
+        net = getattr(ref_sr, name)(channels=32, img_resolution=res, sr_num_fp16_res=4, **kw)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        load(net, params_by_name(81, shapes))
+        rng = np.random.RandomState(zlib_crc(tag))
+        x = t(rng.randn(1, 32, in_res, in_res)); ws = t(rng.randn(1, 14, 512))
+        out = net(x[:, :3].contiguous(), x, ws, noise_mode="const")
+        print(f"    reference {tag:36s} out {tuple(out.shape)} |max| {float(out.abs().max()):.3g}")
+        data.update({tag + ".out_s4": out[:, :, 1::4, 3::4].numpy(),       # x, ws: regenerated from crc32(tag) by the test
+                     tag + ".out_mean": float(out.double().mean()), tag + ".keys": np.array(sorted(shapes))})
+    np.savez_compressed(os.path.join(OUT, "dense_sr_variants.npz"), seed=81, **data)
+    print("  wrote dense_sr_variants.npz")
+
+
+def zlib_crc(s):
+    import zlib
+    return zlib.crc32(s.encode()) & 0x7FFFFFFF
+
+
 def gen_e2e_full():
     """The FFHQ-size generator (channel_base 32768, channel_max 512: 30.7 M parameters) end to end, one view, 64^2
     neural render, 24+24 samples, injected jitter.  Reference outputs only (sub-sampled where large)."""
@@ -270,6 +297,7 @@ if __name__ == "__main__":
     gen_sr()
     gen_e2e()
     gen_e2e_full()
+    gen_sr_variants()
     for f in sorted(os.listdir(OUT)):
         if f.startswith("dense_"):
             print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")

@@ -112,6 +112,15 @@ def test_resize_bilinear(dev):
         y = dense_ops.resize_bilinear(dense_ops.nchw_to_nhwc(t(z[f"resize.{tag}.x"], dev)), out.shape[2], out.shape[3],
                                       bool(int(z[f"resize.{tag}.aa"])))
         assert maxerr(dense_ops.nhwc_to_nchw(y), out) <= 2e-6, tag
+    # every (direction, antialias) combination against torch's own kernel on the device (the far edge of a plain bilinear
+    # up-sampling clamps its second tap onto the first: SuperresolutionHybridDeepfp32, superresolution.py:146-149)
+    g = torch.Generator(device="cpu").manual_seed(3)
+    x = torch.randn(2, 40, 56, 8, generator=g).to(dev)
+    for aa in (True, False):
+        for oh, ow in ((80, 112), (128, 128), (20, 33), (40, 56), (41, 57)):
+            y = dense_ops.resize_bilinear(x, oh, ow, aa)
+            ref = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(oh, ow), mode="bilinear", align_corners=False, antialias=aa)
+            assert float((y - ref.permute(0, 2, 3, 1)).abs().max()) <= 1e-5, (aa, oh, ow)
 
 
 def test_reduced_synthesis_network(dev):
@@ -242,3 +251,28 @@ def test_torgb_fast_paths_match_generic(shape, math, dev):
     finally:
         D.FAST_PATH = True
     assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
+
+
+@pytest.mark.parametrize("tag", ["SuperresolutionHybrid8X.64", "SuperresolutionHybrid4X.64", "SuperresolutionHybrid4X.128",
+                                 "SuperresolutionHybrid2X.96", "SuperresolutionHybridDeepfp32.64"])
+def test_superresolution_variants(tag, dev):
+    """The other SR heads (superresolution.py:29-155) against outputs of the reference classes; same state_dict names."""
+    import zlib
+    from nerffaceediting_amd.training import superresolution as sr
+    from oracle.dense_params import params_by_name
+    z = load("dense_sr_variants")
+    name, in_res = tag.split(".")
+    in_res = int(in_res)
+    res = {"SuperresolutionHybrid8X": 512, "SuperresolutionHybrid4X": 256, "SuperresolutionHybrid2X": 128, "SuperresolutionHybridDeepfp32": 256}[name]
+    kw = {} if name.endswith("Deepfp32") else dict(sr_antialias=(tag != "SuperresolutionHybrid4X.128"))
+    net = getattr(sr, name)(channels=32, img_resolution=res, sr_num_fp16_res=4, **kw)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert sorted(shapes) == [str(k) for k in z[tag + ".keys"]]
+    net = load_module(net, params_by_name(int(z["seed"]), shapes), dev)
+    rng = np.random.RandomState(zlib.crc32(tag.encode()) & 0x7FFFFFFF)
+    x = t(rng.randn(1, 32, in_res, in_res), dev); ws = t(rng.randn(1, 14, 512), dev)
+    out = net(x[:, :3].contiguous(), x, ws, noise_mode="const")
+    assert out.shape == (1, 3, res, res)
+    e = maxerr(out[:, :, 1::4, 3::4], z[tag + ".out_s4"])
+    print(tag, e)
+    assert e <= 3e-4 and abs(float(out.double().mean()) - float(z[tag + ".out_mean"])) <= 1e-5
