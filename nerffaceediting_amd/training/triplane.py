@@ -55,6 +55,35 @@ class DisentangledOSGDecoder(torch.nn.Module):
                                   "or TriPlaneGenerator.sample(...)")
 
 
+class OSGDecoder(torch.nn.Module):
+    """training/triplane.py:167-190 (the EG3D decoder: one MLP 32 -> 64 -> 1 + 32, no segmentation).  For the fused kernels
+    it is presented as two heads over the same hidden layer: geometry = output row 0 (sigma; seg rows zero), appearance
+    = rows 1..32 - the split the reference applies when it resumes from such a pickle (training_loop.py:202-214)."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        assert n_features == 32 and options["decoder_output_dim"] == 32
+        self.hidden_dim = 64
+        lr = options["decoder_lr_mul"]
+        self.lr_mul = lr
+        self.net = torch.nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr), torch.nn.Softplus(),
+                                       FullyConnectedLayer(self.hidden_dim, 1 + options["decoder_output_dim"], lr_multiplier=lr))
+
+    def packed(self):
+        ps = [self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias]
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_packed_key", None) != key:
+            w0, b0, w2, b2 = (p.detach() for p in ps)
+            gw = torch.zeros(16, 64, device=w2.device); gb = torch.zeros(16, device=w2.device)
+            gw[:1], gb[:1] = w2[:1], b2[:1]
+            self._packed = ops.decoder_pack(w0, b0, gw, gb, w0, b0, w2[1:].contiguous(), b2[1:].contiguous(), lr_mul=self.lr_mul)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, sampled_features, ray_directions):
+        raise NotImplementedError("the decoder is evaluated inside the fused kernels: use ImportanceRenderer.run_model(...)")
+
+
 class TriPlaneGenerator(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={},
                  rendering_kwargs={}, sr_kwargs={}, disable_disentangle=False, disable_alignment=False, **synthesis_kwargs):

@@ -97,3 +97,18 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         pg, pa = self._pack_pair(norm_planes, denorm_planes)
         return ops.point_query(pg, pa, decoder.packed(), sample_coordinates, options["box_warp"],
                                decoder_math=self.decoder_math)
+
+
+class ImportanceRenderer(DisentangledImportanceRenderer):
+    """The single-plane-set renderer the disentangled one derives from (renderer.py:81-167): `forward(planes, decoder,
+    ray_origins, ray_directions, rendering_options)` with an `OSGDecoder` -> (rgb [N,M,32], depth [N,M,1],
+    weights.sum(2) [N,M,1]).  Same fused kernel: the decoder's one MLP serves as both heads (sigma from row 0, rgb from
+    rows 1..32), the segmentation head is all zeros and dropped."""
+
+    def forward(self, planes, decoder, ray_origins, ray_directions, rendering_options):
+        rgb, _, depth, wsum = super().forward(planes, planes, decoder, ray_origins, ray_directions, rendering_options)
+        return rgb, depth, wsum
+
+    def run_model(self, planes, decoder, sample_coordinates, sample_directions, options):
+        out = super().run_model(planes, planes, decoder, sample_coordinates, sample_directions, options)
+        return {"rgb": out["rgb"], "sigma": out["sigma"]}

@@ -197,6 +197,35 @@ def gen_render_full_size(name="fullsize_render", seed=401, N=1, R=512, H=256, D=
     print(f"  wrote {name}.npz")
 
 
+def gen_legacy_renderer(seed=21, N=2, R=8, H=16, D=12, Ni=12):
+    """ImportanceRenderer + OSGDecoder (renderer.py:81-140, triplane.py:167-190): the single-plane-set, single-MLP path."""
+    from training.volumetric_rendering.renderer import ImportanceRenderer
+    from training.triplane import OSGDecoder
+    rng = np.random.RandomState(seed)
+    planes = smooth_planes(rng, N, H).reshape(N, 3, 32, H, H)
+    c2w, K = cams([(0.4, -0.2), (-0.3, 0.1)][:N])
+    M = R * R
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, Ni).astype(np.float32)
+    dec = OSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32})
+    w = {"net.0.weight": rng.randn(64, 32), "net.0.bias": rng.randn(64) * 0.3, "net.2.weight": rng.randn(33, 64), "net.2.bias": rng.randn(33) * 0.3}
+    dec.load_state_dict({k: torch.from_numpy(v.astype(np.float32)) for k, v in w.items()})
+    opts = dict(depth_resolution=D, depth_resolution_importance=Ni, ray_start=2.25, ray_end=3.3, box_warp=1.0,
+                disparity_space_sampling=False, clamp_mode="softplus", white_back=False)
+    o, d = RaySampler()(c2w, K, R)
+    rend = ImportanceRenderer()
+    with InjectRand([u_c, u_f]):
+        rgb, depth, wsum = rend(torch.from_numpy(planes), dec.eval(), o, d, opts)
+    coords = torch.from_numpy(((rng.rand(N, 200, 3) - 0.5) * 1.1).astype(np.float32))
+    pq = rend.run_model(torch.from_numpy(planes), dec, coords, None, opts)
+    opts_s = {k: (v if not isinstance(v, bool) else int(v)) for k, v in opts.items()}
+    np.savez_compressed(os.path.join(OUT, "legacy_renderer.npz"), planes=planes, cam2world=c2w.numpy(), intrinsics=K.numpy(), R=R,
+                        u_coarse=u_c, u_fine=u_f, options=np.array(repr(opts_s)), coords=coords.numpy(),
+                        rgb=rgb.numpy(), depth=depth.numpy(), wsum=wsum.numpy(), pq_rgb=pq["rgb"].numpy(), pq_sigma=pq["sigma"].numpy(),
+                        **{"dec." + k: v.astype(np.float32) for k, v in w.items()})
+    print("  wrote legacy_renderer.npz")
+
+
 def gen_point_query(seed=7, N=2, H=16, P=500):
     rng = np.random.RandomState(seed)
     planes = smooth_planes(rng, N, H)
@@ -291,6 +320,7 @@ def main():
     gen_render_full_size()
     gen_render_full_size("ffhq_render", seed=411, N=2, R=128, H=256, D=48, Ni=48, swap=True, stride=7, chunk=16384,
                          angles=((0.35, -0.15), (-0.3, 0.1)))
+    gen_legacy_renderer()
     print("point query:")
     gen_point_query()
     print("plane stats:")
@@ -305,6 +335,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "render_full_size":       # one fixture only
         os.makedirs(OUT, exist_ok=True)
         gen_render_full_size()
+    elif len(sys.argv) > 1 and sys.argv[1] == "legacy_renderer":
+        os.makedirs(OUT, exist_ok=True)
+        gen_legacy_renderer()
     elif len(sys.argv) > 1 and sys.argv[1] == "ffhq_render":
         os.makedirs(OUT, exist_ok=True)
         gen_render_full_size("ffhq_render", seed=411, N=2, R=128, H=256, D=48, Ni=48, swap=True, stride=7, chunk=16384,
