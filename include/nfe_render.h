@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NFE_ABI_VERSION 3
+#define NFE_ABI_VERSION 4
 
 #define NFE_OK 0
 #define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */
@@ -144,6 +144,9 @@ typedef struct nfe_render_args {
     float* tap_depths_fine;            /* optional [N,M,Di] */
     float* tap_depths_all;             /* optional [N,M,D+Di] sorted */
     void* workspace; uint64_t workspace_bytes;
+    float density_noise;               /* renderer.py:285-286: sigma += N(0,1) * density_noise; the normals are Philox
+                                          draws keyed by (seed, ray, draw index), 0 = off.  With importance sampling the
+                                          workspace must hold N*M*(D+Di)*4 more bytes (rounded up to 256). */
 } nfe_render_args;
 
 /* bytes of workspace nfe_render needs for these sizes */

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 3
+NFE_ABI_VERSION = 4
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_MATH_BF16X3, NFE_MATH_FP32 = 0, 1
@@ -36,7 +36,7 @@ class RenderArgs(ctypes.Structure):
         ("rgb", FP), ("seg", FP), ("depth", FP), ("wsum", FP),
         ("channels_first", c_int32),
         ("tap_weights_coarse", FP), ("tap_depths_fine", FP), ("tap_depths_all", FP),
-        ("workspace", FP), ("workspace_bytes", c_uint64),
+        ("workspace", FP), ("workspace_bytes", c_uint64), ("density_noise", c_float),
     ]
 
 

@@ -34,6 +34,8 @@ struct RenderK {
     float* out_depths;             // optional [N*M, S]
     float* out_weights;            // optional [N*M, S-1]
     unsigned* depth_minmax;        // ordered-uint {min, max}
+    float density_noise;           // std of the Gaussian added to sigma (renderer.py:285-286), NOISE variants only
+    const int* src_buf;            // DEPTH_BUFFER + NOISE: [N*M, S] which draw each merged sample is (k, or D + fine rank)
 };
 
 // LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then per wave AFF_FLOATS of
@@ -775,7 +777,17 @@ __device__ __forceinline__ void stage_affine(const float* const (&src)[4], int n
     __threadfence_block();
 }
 
-template <bool DUAL, bool SIGMA_ONLY, int MATH>
+// N(0,1) attached to a sample by (seed, ray, draw index): coarse sample k -> k, fine sample of ascending rank r -> D + r.
+// The coarse samples re-evaluated in the final pass of a two-pass render therefore get the very noise they had in the
+// coarse pass, as in the reference, where the coarse sigmas (noise included) are the ones merged (renderer.py:333-358).
+// Box-Muller on two Philox words (stream 2).
+__device__ __forceinline__ float sample_gaussian(unsigned long long seed, unsigned ray, unsigned draw) {
+    const u32x4 r = philox4x32_10(ray, draw, 2u, 0u, (unsigned)seed, (unsigned)(seed >> 32));
+    const float u1 = ((float)(r.x >> 8) + 0.5f) * (1.0f / 16777216.0f), u2 = u01(r.y);
+    return sqrtf(-2.0f * LN2 * log2_fast(u1)) * __builtin_amdgcn_cosf(u2);       // v_cos_f32 takes revolutions
+}
+
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_decoder<MATH>(P.dec, lds);
@@ -889,6 +901,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
             eval_point<DUAL, SIGMA_ONLY, MATH>(pg, pa, P.H, P.W, lds + opq, aff + opq, xp + opq, gx, gy, gz, lane, og, oa);
 
+            if (NOISE) {
+                const unsigned draw = (P.depth_mode == DEPTH_BUFFER && P.src_buf) ? (unsigned)P.src_buf[ray * S + k] : (unsigned)k;
+                og[0] = fmaf(P.density_noise, sample_gaussian(seed, (unsigned)ray, draw), og[0]);
+            }
             if (k > 0) {
                 const float dlt = t - prev_t;
                 const float dens = softplus_f((prev_sig + og[0]) * 0.5f - 1.0f);
@@ -991,6 +1007,7 @@ struct ImportanceK {
     long long n_rays_total;
     int D, Di;
     float* t_all;            // [NR, D+Di] sorted ascending
+    int* src_all;            // optional [NR, D+Di]: coarse index k, or D + ascending rank of the fine sample
     float* tap_fine;         // optional [NR, Di] in draw order
 };
 
@@ -1102,12 +1119,14 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
             int lo = 0, hi = D;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (tc[mid] <= v) lo = mid + 1; else hi = mid; }
             out[e + lo] = v;
+            if (P.src_all) P.src_all[ray * (D + Di) + e + lo] = D + e;
         }
         for (int e = lane; e < D; e += 64) {             // coarse: #fine < v (lower bound)
             const float v = tc[e];
             int lo = 0, hi = Di;
             while (lo < hi) { const int mid = (lo + hi) >> 1; if (tf[mid] < v) lo = mid + 1; else hi = mid; }
             out[e + lo] = v;
+            if (P.src_all) P.src_all[ray * (D + Di) + e + lo] = e;
         }
         __threadfence_block();
     }
@@ -1181,10 +1200,14 @@ static void allow_lds(K kernel, int bytes) {
 
 template <bool DUAL, bool SIGMA_ONLY>
 static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_t st) {
-    if (math == NFE_MATH_FP32)
-        hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
-    else
-        hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+    const bool noise = P.density_noise > 0.0f;
+    if (math == NFE_MATH_FP32) {
+        if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+        else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+    } else {
+        if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+        else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+    }
 }
 
 static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math, hipStream_t st) {
@@ -1248,8 +1271,11 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a->box_warp > 0.0f, "nfe_render: box_warp must be positive");
     NFE_REQUIRE(a->decoder_math == NFE_MATH_BF16X3 || a->decoder_math == NFE_MATH_FP32, "nfe_render: unknown decoder_math %d", a->decoder_math);
     NFE_REQUIRE(a->rgb && a->seg && a->depth && a->wsum, "nfe_render: output pointers are null");
+    NFE_REQUIRE(a->density_noise >= 0.0f, "nfe_render: density_noise must be >= 0");
     NFE_REQUIRE(a->workspace != nullptr, "nfe_render: workspace is null");
-    const uint64_t need = nfe_render_workspace_bytes(a->n_views, a->n_rays, D, Di);
+    uint64_t need = nfe_render_workspace_bytes(a->n_views, a->n_rays, D, Di);
+    const uint64_t nr0 = (uint64_t)a->n_views * a->n_rays;
+    if (Di > 0 && a->density_noise > 0.0f) need += align256(nr0 * (uint64_t)(D + Di) * 4);   // draw index of every merged sample
     if (a->workspace_bytes < need) return fail(NFE_EWORKSPACE, "nfe_render: workspace %llu < %llu bytes",
                                                (unsigned long long)a->workspace_bytes, (unsigned long long)need);
     hipStream_t st = (hipStream_t)stream;
@@ -1271,6 +1297,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.white_back = a->white_back;
     P.rgb = a->rgb; P.seg = a->seg; P.depth = a->depth; P.wsum = a->wsum; P.channels_first = a->channels_first;
     P.seed = a->seed; P.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device);
+    P.density_noise = a->density_noise;
     const int mode = a->ray_start_per_ray ? DEPTH_PER_RAY : (a->disparity_space_sampling ? DEPTH_DISPARITY : DEPTH_STRATIFIED);
     const bool dual = a->planes_geo != a->planes_app;
     const int math = a->decoder_math;
@@ -1286,7 +1313,8 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     } else {
         float* t_c = (float*)ws; ws += align256(nr * (uint64_t)D * 4);
         float* w_c = (float*)ws; ws += align256(nr * (uint64_t)(D - 1) * 4);
-        float* t_all = (float*)ws;
+        float* t_all = (float*)ws; ws += align256(nr * (uint64_t)(D + Di) * 4);
+        int* src_all = a->density_noise > 0.0f ? (int*)ws : nullptr;      // present only with density_noise (checked above)
         // pass 1: coarse densities -> weights (only sigma is needed: geometry net, geometry planes)
         RenderK C = P;
         C.S = D; C.depth_mode = mode; C.u = a->u_coarse; C.depth_minmax = nullptr;
@@ -1300,7 +1328,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         // pass 2: importance sampling + merge
         ImportanceK I{};
         I.t_coarse = t_c; I.w_coarse = w_c; I.u_fine = a->u_fine; I.seed = a->seed; I.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device); I.n_rays_total = (long long)nr;
-        I.D = D; I.Di = Di; I.t_all = t_all; I.tap_fine = a->tap_depths_fine;
+        I.D = D; I.Di = Di; I.t_all = t_all; I.src_all = src_all; I.tap_fine = a->tap_depths_fine;
         int p2 = 64;
         while (p2 < Di) p2 <<= 1;
         const int lds_bytes = 4 * (3 * D + p2) * 4;
@@ -1310,7 +1338,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         NFE_CHECK_LAUNCH("importance_kernel");
         // pass 3: march the merged samples
         RenderK F = P;
-        F.S = D + Di; F.depth_mode = DEPTH_BUFFER; F.depth_buf = t_all; F.depth_minmax = minmax;
+        F.S = D + Di; F.depth_mode = DEPTH_BUFFER; F.depth_buf = t_all; F.src_buf = src_all; F.depth_minmax = minmax;
         rc = launch_render(F, dual, false, math, st);
         if (rc) return rc;
         if (a->tap_depths_all) {

@@ -180,10 +180,9 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
     Di = int(options.get("depth_resolution_importance", 0) or 0)
     if options.get("clamp_mode", "softplus") != "softplus":
         raise AssertionError("MipRayMarcher only supports `clamp_mode`=`softplus`!")      # ray_marcher.py:78
-    if options.get("density_noise", 0):
-        raise RuntimeError("density_noise > 0 is not supported by the fused renderer")
     a = _lib.RenderArgs()
     a.struct_size = ctypes.sizeof(_lib.RenderArgs)
+    a.density_noise = float(options.get("density_noise", 0) or 0)          # renderer.py:285-286 (Philox normals, see header)
     a.planes_geo, a.planes_app = planes_geo.data_ptr(), planes_app.data_ptr()
     a.plane_h, a.plane_w = H, W
     a.plane_view_stride = 0 if (Np == 1 and N > 1) else 3 * H * W * 32
@@ -239,6 +238,8 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
             tap["depths_fine"] = torch.empty(N, M, Di, device=dev)
             a.tap_weights_coarse, a.tap_depths_fine = tap["weights_coarse"].data_ptr(), tap["depths_fine"].data_ptr()
     need = lib.nfe_render_workspace_bytes(N, M, D, Di)
+    if Di > 0 and a.density_noise > 0:                      # draw index of every merged sample (include/nfe_render.h)
+        need += (N * M * (D + Di) * 4 + 255) // 256 * 256
     ws = _workspace(dev, need)
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):

@@ -423,8 +423,21 @@ def unify_samples(d1, c1, s1, den1, d2, c2, s2, den2):
     return take(d), take(c), take(s), take(den)
 
 
+def density_noise_normals(seed, n_rays_shape, draw):
+    """N(0,1) per sample as the HIP kernel draws them: Philox counter (ray, draw index, stream 2), Box-Muller on the first
+    two words.  draw [N,M,S] uint32: coarse sample k -> k, fine sample of ascending rank r -> D + r; ray = n*M + m."""
+    N, M = n_rays_shape
+    ray = np.arange(N * M, dtype=np.uint32).reshape(N, M, 1)
+    draw = np.asarray(draw, dtype=np.uint32)
+    x, y, _, _ = philox4x32(np.broadcast_to(ray, draw.shape), draw, np.uint32(2), np.uint32(0), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    u1 = ((x >> np.uint32(8)).astype(F32) + F32(0.5)) * F32(1.0 / 16777216.0)
+    u2 = (y >> np.uint32(8)).astype(F32) * F32(1.0 / 16777216.0)
+    z = np.sqrt(F32(-2.0) * np.log(u1)) * np.cos(F32(2.0 * np.pi) * u2)
+    return z.astype(F32)[..., None]
+
+
 def render(norm_planes, denorm_planes, dec, origins, dirs, options, u_coarse, u_fine=None,
-           return_taps=False, clamp=True):
+           return_taps=False, clamp=True, noise_seed=0):
     """DisentangledImportanceRenderer.forward, renderer.py:301-363.
 
     norm_planes/denorm_planes [N,3,32,H,W]; origins/dirs [N,M,3]; u_coarse [N,M,D];
@@ -449,19 +462,27 @@ def render(norm_planes, denorm_planes, dec, origins, dirs, options, u_coarse, u_
                                      options.get("disparity_space_sampling", False))
     depths_c = depths_c.reshape(N, M, D, 1)
     coords = (origins[:, :, None, :] + depths_c * dirs[:, :, None, :]).reshape(N, -1, 3)   # :326
-    rgb_c, sig_c, seg_c = run_model(norm_planes, denorm_planes, dec, coords, options)
+    noise = F32(options.get("density_noise", 0) or 0)                   # renderer.py:285-286
+    model_opts = {k: v for k, v in options.items() if k != "density_noise"}
+    rgb_c, sig_c, seg_c = run_model(norm_planes, denorm_planes, dec, coords, model_opts)
     rgb_c = rgb_c.reshape(N, M, D, -1)
     sig_c = sig_c.reshape(N, M, D, 1)
+    if noise > 0:
+        sig_c = (sig_c + noise * density_noise_normals(noise_seed, (N, M), np.broadcast_to(np.arange(D, dtype=np.uint32), (N, M, D)))).astype(F32)
     seg_c = seg_c.reshape(N, M, D, -1)
     taps = {"depths_coarse": depths_c}
     if Ni > 0:
         _, _, _, w_c = ray_march(rgb_c, seg_c, sig_c, depths_c, wb)        # :340
         depths_f = sample_importance(depths_c, w_c, Ni, u_fine)           # :342
         coords = (origins[:, :, None, :] + depths_f * dirs[:, :, None, :]).reshape(N, -1, 3)
-        rgb_f, sig_f, seg_f = run_model(norm_planes, denorm_planes, dec, coords, options)
+        rgb_f, sig_f, seg_f = run_model(norm_planes, denorm_planes, dec, coords, model_opts)
+        sig_f = sig_f.reshape(N, M, Ni, 1)
+        if noise > 0:
+            rank = np.argsort(np.argsort(depths_f[..., 0], axis=-1, kind="stable"), axis=-1, kind="stable")   # ascending rank of each fine draw
+            sig_f = (sig_f + noise * density_noise_normals(noise_seed, (N, M), (rank + D).astype(np.uint32))).astype(F32)
         all_d, all_c, all_s, all_den = unify_samples(
             depths_c, rgb_c, seg_c, sig_c, depths_f,
-            rgb_f.reshape(N, M, Ni, -1), seg_f.reshape(N, M, Ni, -1), sig_f.reshape(N, M, Ni, 1))
+            rgb_f.reshape(N, M, Ni, -1), seg_f.reshape(N, M, Ni, -1), sig_f)
         rgb, seg, depth, w = ray_march(all_c, all_s, all_den, all_d, wb, clamp)   # :360
         taps.update(weights_coarse=w_c, depths_fine=depths_f, depths_all=all_d)
     else:
