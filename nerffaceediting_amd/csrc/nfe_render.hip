@@ -153,54 +153,7 @@ __device__ __forceinline__ float4 texel_piece(const float* __restrict__ base, un
 template <int I> __device__ __forceinline__ float quad_swizzle(float v) {
     return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x8000 | (I * 0x55)));
 }
-#define NFE_QUAD_ADDR(K, I) o[K][I] = (unsigned)quad_bcast<I>((int)offs[k0 + K]) + qoff_bytes;
-#define NFE_QUAD_WGT(K, I) wq[K][I] = quad_swizzle<I>(t.w[k0 + K]);
-#define NFE_QUAD_FMA(K, I)                                                                                 \
-    {                                                                                                      \
-        const f32x2 w2 = splat(wq[K][I]);                                                                  \
-        sg[2 * I + 0] = pk_fma(w2, f32x2{vg[K][I].x, vg[K][I].y}, sg[2 * I + 0]);                          \
-        sg[2 * I + 1] = pk_fma(w2, f32x2{vg[K][I].z, vg[K][I].w}, sg[2 * I + 1]);                          \
-        if (DUAL) {                                                                                        \
-            sa[2 * I + 0] = pk_fma(w2, f32x2{va[K][I].x, va[K][I].y}, sa[2 * I + 0]);                      \
-            sa[2 * I + 1] = pk_fma(w2, f32x2{va[K][I].z, va[K][I].w}, sa[2 * I + 1]);                      \
-        }                                                                                                  \
-    }
-
-// sg[2i], sg[2i+1]: channels (16h+4c)..+3 of quad point i, bilinear-interpolated on this plane (raw values).
-// TAPS_IN_FLIGHT taps (4 loads each, x2 with two plane sets) are issued back to back, then consumed; the
-// scheduling fences keep the compiler from serialising load -> wait -> use, or from hoisting all 16.
-template <bool DUAL, int TAPS_IN_FLIGHT>
-__device__ __forceinline__ void fetch_quad(const float* __restrict__ pg, const float* __restrict__ pa, int W, const Taps& t,
-                                           unsigned qoff_bytes, f32x2 (&sg)[8], f32x2 (&sa)[8]) {
-    const unsigned offs[4] = {(unsigned)(t.yc0 * W + t.xc0) * 128u, (unsigned)(t.yc0 * W + t.xc1) * 128u,
-                              (unsigned)(t.yc1 * W + t.xc0) * 128u, (unsigned)(t.yc1 * W + t.xc1) * 128u};
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); if (DUAL) sa[c] = splat(0.0f); }
-#pragma unroll
-    for (int k0 = 0; k0 < 4; k0 += TAPS_IN_FLIGHT) {
-        unsigned o[TAPS_IN_FLIGHT][4];
-        float wq[TAPS_IN_FLIGHT][4];
-        float4 vg[TAPS_IN_FLIGHT][4], va[TAPS_IN_FLIGHT][4];
-#pragma unroll
-        for (int K = 0; K < TAPS_IN_FLIGHT; ++K) {
-            NFE_QUAD_ADDR(K, 0) NFE_QUAD_ADDR(K, 1) NFE_QUAD_ADDR(K, 2) NFE_QUAD_ADDR(K, 3)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                vg[K][i] = texel_piece(pg, o[K][i]);
-                if (DUAL) va[K][i] = texel_piece(pa, o[K][i]);
-            }
-            NFE_QUAD_WGT(K, 0) NFE_QUAD_WGT(K, 1) NFE_QUAD_WGT(K, 2) NFE_QUAD_WGT(K, 3)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int K = 0; K < TAPS_IN_FLIGHT; ++K) {
-            NFE_QUAD_FMA(K, 0) NFE_QUAD_FMA(K, 1) NFE_QUAD_FMA(K, 2) NFE_QUAD_FMA(K, 3)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// ---- the same gather, software-pipelined over the three planes (one plane set) ----------------------------
+// ---- the gather, software-pipelined over the three planes (one plane set) ---------------------------------
 // Six batches of 8 loads (plane p, tap pair): two batches are in flight; the loads of batch b+2 are issued right
 // after batch b has been consumed, so only the first batch's latency is exposed per sample instead of one per plane.
 #ifndef NFE_PIPE_SWIZZLE
@@ -667,58 +620,8 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
         }
     }
     const long long plane_elems = (long long)H * W * 32;
-#ifndef NFE_PIPE_DUAL
-#define NFE_PIPE_DUAL 1
-#endif
-    constexpr bool TWO = DUAL && !SIGMA_ONLY;
-    constexpr bool PIPELINED = !TWO || NFE_PIPE_DUAL;
-    if (TWO && PIPELINED) gather_pipelined_dual(pg, pa, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
-    else if (PIPELINED) gather_pipelined<SIGMA_ONLY>(pg, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
-    // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
-#pragma unroll
-    for (int p = 0; p < (PIPELINED ? 0 : 3); ++p) {
-        float u = (p == 2) ? gz : gx;
-        float v = (p == 0) ? gy : ((p == 1) ? gz : gx);
-        f32x2 sg[8], sa[8];
-        const int ll = launder(lane);
-        const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
-        const Taps tp = tap_geometry(H, W, u, v);
-        constexpr bool TWO_SETS = DUAL && !SIGMA_ONLY;
-        fetch_quad<TWO_SETS, TWO_SETS ? 1 : 2>(pg + p * plane_elems, pa + p * plane_elems, W, tp, (unsigned)qoff * 4u, sg, sa);
-        {
-            const float4 sc = *reinterpret_cast<const float4*>(aff + 0 * 96 + p * 32 + qoff);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                qn[2 * i + 0] = pk_fma(sg[2 * i + 0], f32x2{sc.x, sc.y}, qn[2 * i + 0]);
-                qn[2 * i + 1] = pk_fma(sg[2 * i + 1], f32x2{sc.z, sc.w}, qn[2 * i + 1]);
-            }
-        }
-        if (!SIGMA_ONLY) {
-            const float4 sc = *reinterpret_cast<const float4*>(aff + 2 * 96 + p * 32 + qoff);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                qd[2 * i + 0] = pk_fma(DUAL ? sa[2 * i + 0] : sg[2 * i + 0], f32x2{sc.x, sc.y}, qd[2 * i + 0]);
-                qd[2 * i + 1] = pk_fma(DUAL ? sa[2 * i + 1] : sg[2 * i + 1], f32x2{sc.z, sc.w}, qd[2 * i + 1]);
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(tp.wdef != 0.0f) != 0) {     // rare: some sample of the wave left the plane
-            const float wd[4] = {quad_bcast<0>(tp.wdef), quad_bcast<1>(tp.wdef), quad_bcast<2>(tp.wdef), quad_bcast<3>(tp.wdef)};
-            const float4 b = *reinterpret_cast<const float4*>(aff + 1 * 96 + p * 32 + qoff);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                qn[2 * i + 0] = pk_fma(splat(wd[i]), f32x2{b.x, b.y}, qn[2 * i + 0]);
-                qn[2 * i + 1] = pk_fma(splat(wd[i]), f32x2{b.z, b.w}, qn[2 * i + 1]);
-            }
-            if (!SIGMA_ONLY) {
-                const float4 e = *reinterpret_cast<const float4*>(aff + 3 * 96 + p * 32 + qoff);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    qd[2 * i + 0] = pk_fma(splat(wd[i]), f32x2{e.x, e.y}, qd[2 * i + 0]);
-                    qd[2 * i + 1] = pk_fma(splat(wd[i]), f32x2{e.z, e.w}, qd[2 * i + 1]);
-                }
-            }
-        }
-    }
+    if (DUAL && !SIGMA_ONLY) gather_pipelined_dual(pg, pa, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
+    else gather_pipelined<SIGMA_ONLY>(pg, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
     f32x2 fn[8], fd[8];          // own layout: channels 16h..16h+15 of this lane's point
     exchange_to_own(xp, lane, qn, fn);
     if (!SIGMA_ONLY) exchange_to_own(xp, lane, qd, fd);
