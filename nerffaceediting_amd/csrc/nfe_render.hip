@@ -1,5 +1,6 @@
-// Fused tri-plane volume renderer for MI355X (gfx950): stratified depths -> tri-plane bilinear
-// gather -> dual MLP decoder (fp32 MFMA) -> mid-point alpha compositing, one kernel.
+// Fused tri-plane volume renderer for MI355X (gfx950): stratified depths -> quad-cooperative tri-plane bilinear
+// gather (pipelined over the planes) -> dual MLP decoder on MFMA (split-bf16 or exact fp32) -> mid-point alpha
+// compositing, one kernel; importance sampling + merge in a second kernel between the two passes.
 //
 // Replaces DisentangledImportanceRenderer.forward (training/volumetric_rendering/renderer.py:301-363)
 // and everything it calls: sample_stratified (:169-192), sample_from_planes (:55-65),
