@@ -50,6 +50,23 @@ int nfe_plane_stats_nhwc(const float* x, int n, int hw, int c, float* mean, floa
 int nfe_fully_connected(const float* x, const float* w, const float* b, int n, int in_features, int out_features,
                         float weight_gain, float bias_gain, int lrelu, float* y, int y_stride, nfe_stream_t stream);
 
+/* Every style affine of a network in one launch (SynthesisLayer.affine / ToRGBLayer.affine, networks_stylegan2.py:316,354:
+ * linear FullyConnectedLayers of the rows ws[:, i]): y_g[n,:] = (x_g[n,:] . w_g^T) * weight_gain + b_g * bias_gain.
+ * `groups` is a host array of at most NFE_MAX_GROUPS entries (passed by value to the kernel). */
+#define NFE_MAX_GROUPS 32
+typedef struct nfe_fc_group {
+    const float* x; int64_t x_stride;     /* [n, in_features] rows x_stride floats apart (a column block of ws) */
+    const float* w; const float* b;       /* [out_features, in_features], [out_features] or NULL */
+    float* y;                             /* [n, out_features] */
+    int32_t in_features, out_features;
+    float weight_gain, bias_gain;
+} nfe_fc_group;
+int nfe_fully_connected_grouped(const nfe_fc_group* groups, int n_groups, int n, nfe_stream_t stream);
+
+/* nfe_conv_demod for several layers in one launch */
+typedef struct nfe_demod_group { const float* styles; const float* wsq; float* dcoef; int32_t cin, cout; } nfe_demod_group;
+int nfe_conv_demod_grouped(const nfe_demod_group* groups, int n_groups, int n, nfe_stream_t stream);
+
 /* normalize_2nd_moment (networks_stylegan2.py:24-26): y = x * rsqrt(mean(x^2, dim=1) + 1e-8) */
 int nfe_normalize_2nd_moment(const float* x, int n, int features, float* y, int y_stride, nfe_stream_t stream);
 

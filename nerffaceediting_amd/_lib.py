@@ -53,6 +53,18 @@ class ConvArgs(ctypes.Structure):
     ]
 
 
+class FcGroup(ctypes.Structure):
+    """Mirror of ``nfe_fc_group``."""
+    _fields_ = [("x", FP), ("x_stride", c_int64), ("w", FP), ("b", FP), ("y", FP), ("in_features", c_int32), ("out_features", c_int32),
+                ("weight_gain", c_float), ("bias_gain", c_float)]
+
+
+class DemodGroup(ctypes.Structure):
+    """Mirror of ``nfe_demod_group``."""
+    _fields_ = [("styles", FP), ("wsq", FP), ("dcoef", FP), ("cin", c_int32), ("cout", c_int32)]
+
+
+NFE_MAX_GROUPS = 32
 NFE_CONV_BF16X3, NFE_CONV_BF16 = 0, 1
 NFE_CONV_3X3, NFE_CONV_3X3_UP2, NFE_CONV_1X1 = 0, 1, 2
 
@@ -74,6 +86,8 @@ _SIGNATURES = {
     "nfe_nhwc_to_planes": (c_int, [FP, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_plane_stats_nhwc": (c_int, [FP, c_int, c_int, c_int, FP, FP, FP, c_void_p]),
     "nfe_fully_connected": (c_int, [FP, FP, FP, c_int, c_int, c_int, c_float, c_float, c_int, FP, c_int, c_void_p]),
+    "nfe_fully_connected_grouped": (c_int, [POINTER(FcGroup), c_int, c_int, c_void_p]),
+    "nfe_conv_demod_grouped": (c_int, [POINTER(DemodGroup), c_int, c_int, c_void_p]),
     "nfe_normalize_2nd_moment": (c_int, [FP, c_int, c_int, FP, c_int, c_void_p]),
     "nfe_broadcast_truncate": (c_int, [FP, FP, c_int, c_int, c_int, c_float, c_int, FP, c_void_p]),
     "nfe_conv_packed_words": (c_uint64, [c_int, c_int, c_int]),

@@ -149,6 +149,38 @@ __global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ st
     if (lane == 0) dcoef[wid] = rsqrtf(acc + 1e-8f);
 }
 
+// All style affines / demodulation coefficients of a network in ONE launch each (they depend on ws only): a forward pass
+// has ~30 of these 5-microsecond kernels otherwise.  blockIdx.y = group.
+struct FcGroups { nfe_fc_group g[NFE_MAX_GROUPS]; };
+struct DemodGroups { nfe_demod_group g[NFE_MAX_GROUPS]; };
+
+__global__ __launch_bounds__(256) void fc_grouped_kernel(FcGroups G, int n) {
+    const nfe_fc_group g = G.g[blockIdx.y];
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long long)n * g.out_features) return;
+    const int row = (int)(wid / g.out_features), o = (int)(wid % g.out_features);
+    const float* xr = g.x + (long long)row * g.x_stride; const float* wr = g.w + (long long)o * g.in_features;
+    float acc = 0.0f;
+    for (int i = lane; i < g.in_features; i += 64) acc = fmaf(xr[i], wr[i], acc);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) g.y[(long long)row * g.out_features + o] = acc * g.weight_gain + (g.b ? g.b[o] * g.bias_gain : 0.0f);
+}
+
+__global__ __launch_bounds__(256) void demod_grouped_kernel(DemodGroups G, int n) {
+    const nfe_demod_group g = G.g[blockIdx.y];
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (wid >= (long long)n * g.cout) return;
+    const int row = (int)(wid / g.cout), o = (int)(wid % g.cout);
+    float acc = 0.0f;
+    for (int i = lane; i < g.cin; i += 64) { const float s = g.styles[(long long)row * g.cin + i]; acc = fmaf(s * s, g.wsq[(long long)o * g.cin + i], acc); }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+    if (lane == 0) g.dcoef[wid] = rsqrtf(acc + 1e-8f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // weights -> MFMA A-fragment image: [Cout/32][Cin/16][taps][part][lane 64][4 words]; word w of lane l
 // holds elements e = 2w, 2w+1 of the 8-vector: out channel 32*mb + (l&31), in channel 16g + 8(l>>5) + e.
@@ -906,6 +938,38 @@ extern "C" int nfe_fully_connected(const float* x, const float* w, const float* 
     NFE_CHECK_LAUNCH("fc_kernel");
     return NFE_OK;
 }
+extern "C" int nfe_fully_connected_grouped(const nfe_fc_group* groups, int n_groups, int n, nfe_stream_t stream) {
+    NFE_REQUIRE(groups && n_groups > 0 && n_groups <= NFE_MAX_GROUPS && n > 0, "nfe_fully_connected_grouped: bad arguments (at most %d groups)", NFE_MAX_GROUPS);
+    FcGroups G{};
+    int max_out = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const nfe_fc_group& g = groups[i];
+        NFE_REQUIRE(g.x && g.w && g.y && g.in_features > 0 && g.out_features > 0 && g.x_stride >= g.in_features, "nfe_fully_connected_grouped: bad group %d", i);
+        G.g[i] = g;
+        if (g.out_features > max_out) max_out = g.out_features;
+    }
+    const long long waves = (long long)n * max_out;
+    hipLaunchKernelGGL(fc_grouped_kernel, dim3((unsigned)((waves + 3) / 4), n_groups), dim3(256), 0, (hipStream_t)stream, G, n);
+    NFE_CHECK_LAUNCH("fc_grouped_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_conv_demod_grouped(const nfe_demod_group* groups, int n_groups, int n, nfe_stream_t stream) {
+    NFE_REQUIRE(groups && n_groups > 0 && n_groups <= NFE_MAX_GROUPS && n > 0, "nfe_conv_demod_grouped: bad arguments (at most %d groups)", NFE_MAX_GROUPS);
+    DemodGroups G{};
+    int max_out = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const nfe_demod_group& g = groups[i];
+        NFE_REQUIRE(g.styles && g.wsq && g.dcoef && g.cin > 0 && g.cout > 0, "nfe_conv_demod_grouped: bad group %d", i);
+        G.g[i] = g;
+        if (g.cout > max_out) max_out = g.cout;
+    }
+    const long long waves = (long long)n * max_out;
+    hipLaunchKernelGGL(demod_grouped_kernel, dim3((unsigned)((waves + 3) / 4), n_groups), dim3(256), 0, (hipStream_t)stream, G, n);
+    NFE_CHECK_LAUNCH("demod_grouped_kernel");
+    return NFE_OK;
+}
+
 extern "C" int nfe_normalize_2nd_moment(const float* x, int n, int features, float* y, int y_stride, nfe_stream_t stream) {
     NFE_REQUIRE(x && y && n > 0 && features > 0 && y_stride >= features, "nfe_normalize_2nd_moment: bad arguments");
     hipLaunchKernelGGL(norm2_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, x, features, y, y_stride);

@@ -78,6 +78,40 @@ def fully_connected(x, weight, bias, weight_gain, bias_gain=1.0, lrelu=False, ou
     return out
 
 
+def fully_connected_grouped(groups):
+    """nfe_fully_connected_grouped: groups = [(x [N,in] (rows may be strided: a column block of ws), weight, bias, weight_gain,
+    bias_gain)] -> list of [N,out] tensors, one launch for all of them."""
+    lib = _lib.load()
+    outs, keep = [], []
+    arr = (_lib.FcGroup * len(groups))()
+    N, dev = groups[0][0].shape[0], groups[0][0].device
+    for i, (x, w, b, wg, bg) in enumerate(groups):
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[0] == N and x.stride(1) == 1
+        w = _dev(w, "weight", (None, x.shape[1]))
+        y = torch.empty(N, w.shape[0], device=dev)
+        g = arr[i]
+        g.x, g.x_stride, g.w, g.b, g.y = x.data_ptr(), x.stride(0) if N > 1 else x.shape[1], w.data_ptr(), (b.data_ptr() if b is not None else None), y.data_ptr()
+        g.in_features, g.out_features, g.weight_gain, g.bias_gain = x.shape[1], w.shape[0], float(wg), float(bg)
+        outs.append(y); keep += [x, w, b]
+    _call(dev, lambda: lib.nfe_fully_connected_grouped(arr, len(groups), N, _stream()), "nfe_fully_connected_grouped")
+    return outs
+
+
+def conv_demod_grouped(pairs):
+    """nfe_conv_demod_grouped: pairs = [(styles [N,cin], wsq [cout,cin])] -> list of dcoef [N,cout], one launch."""
+    lib = _lib.load()
+    arr = (_lib.DemodGroup * len(pairs))()
+    N, dev = pairs[0][0].shape[0], pairs[0][0].device
+    outs = []
+    for i, (s, wsq) in enumerate(pairs):
+        d = torch.empty(N, wsq.shape[0], device=dev)
+        g = arr[i]
+        g.styles, g.wsq, g.dcoef, g.cin, g.cout = s.data_ptr(), wsq.data_ptr(), d.data_ptr(), s.shape[1], wsq.shape[0]
+        outs.append(d)
+    _call(dev, lambda: lib.nfe_conv_demod_grouped(arr, len(pairs), N, _stream()), "nfe_conv_demod_grouped")
+    return outs
+
+
 def normalize_2nd_moment(x, out=None, out_offset=0):
     lib = _lib.load()
     x = _dev(x, "x", (None, None))

@@ -115,16 +115,18 @@ class SynthesisLayer(torch.nn.Module):
             self._ns, self._ns_key = float(self.noise_strength.detach()), key
         return self._ns
 
-    def forward_nhwc(self, x, w, noise_mode="random", gain=1, conv_math=None, styles=None, next_styles=None, want_out=True):
+    def forward_nhwc(self, x, w, noise_mode="random", gain=1, conv_math=None, styles=None, next_styles=None, want_out=True, dcoef=None):
         """x: NHWC tensor, or a dense_ops.SplitImage made by the producing layer with this layer's `styles`.  With
-        next_styles (the styles of the 3x3 layer consuming the output) returns (out, SplitImage)."""
+        next_styles (the styles of the 3x3 layer consuming the output) returns (out, SplitImage).  styles / dcoef may
+        come precomputed (batch_styles: one launch for a whole network)."""
         assert noise_mode in ["random", "const", "none"]
         in_res = self.resolution // self.up
         assert tuple(x.shape[1:]) == (in_res, in_res, self.in_channels), f"wrong input shape {list(x.shape)}"       # misc.assert_shape :314
         if styles is None:
             styles = self.affine(w)
         packed, wsq = _pack_cached(self, self.weight)
-        dcoef = dense_ops.conv_demod(styles, wsq)
+        if dcoef is None:
+            dcoef = dense_ops.conv_demod(styles, wsq)
         noise, strength = None, 0.0
         if self.use_noise and noise_mode == "random":
             noise = torch.randn([x.shape[0], 1, self.resolution, self.resolution], device=styles.device)
@@ -153,17 +155,40 @@ class ToRGBLayer(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros([out_channels]))
         self.weight_gain = 1 / np.sqrt(in_channels * (kernel_size ** 2))
 
-    def forward_nhwc(self, x, w, skip=None, out_planes=False, conv_math=None):
+    def forward_nhwc(self, x, w, skip=None, out_planes=False, conv_math=None, styles=None):
         """y = torgb(x) (+ upsample2d(skip), the img path of SynthesisBlock.forward :450-457)."""
         lin = self.affine
-        styles = dense_ops.fully_connected(w, lin.weight.detach(), lin.bias.detach(), lin.weight_gain * self.weight_gain,
-                                           lin.bias_gain * self.weight_gain)          # affine(w) * weight_gain
+        if styles is None:
+            styles = dense_ops.fully_connected(w, lin.weight.detach(), lin.bias.detach(), lin.weight_gain * self.weight_gain,
+                                               lin.bias_gain * self.weight_gain)      # affine(w) * weight_gain
         packed, _ = _pack_cached(self, self.weight)
         return dense_ops.modulated_conv(x, styles, packed, self.out_channels, _lib.NFE_CONV_1X1, self.bias.detach(), lrelu=False,
                                         act_gain=1.0, clamp=self.conv_clamp, skip=skip, out_planes=out_planes, math=conv_math)
 
     def forward(self, x, w, fused_modconv=True):
         return dense_ops.nhwc_to_nchw(self.forward_nhwc(dense_ops.nchw_to_nhwc(x), w))
+
+
+def block_layers(block):
+    """The modulated layers of a SynthesisBlock (or SynthesisBlockNoUp) in ws order."""
+    return ([block.conv0] if hasattr(block, "conv0") else []) + [block.conv1, block.torgb]
+
+
+def batch_styles(layers, ws, cols):
+    """Styles (and demodulation coefficients) of many layers in two launches instead of two per layer: layer i reads
+    ws[:, cols[i]] (a strided column block, no copy).  -> ([styles], [dcoef or None])."""
+    groups = []
+    for L, col in zip(layers, cols):
+        lin = L.affine
+        gain = L.weight_gain if isinstance(L, ToRGBLayer) else 1.0
+        groups.append((ws[:, col], lin.weight.detach(), lin.bias.detach(), lin.weight_gain * gain, lin.bias_gain * gain))
+    styles = dense_ops.fully_connected_grouped(groups)
+    dcoefs = [None] * len(layers)
+    idx = [i for i, L in enumerate(layers) if isinstance(L, SynthesisLayer)]
+    if idx:
+        for d, i in zip(dense_ops.conv_demod_grouped([(styles[i], _pack_cached(layers[i], layers[i].weight)[1]) for i in idx]), idx):
+            dcoefs[i] = d
+    return styles, dcoefs
 
 
 class SynthesisBlock(torch.nn.Module):
@@ -193,29 +218,29 @@ class SynthesisBlock(torch.nn.Module):
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_torgb += 1
 
-    def forward_nhwc(self, x, img, ws, noise_mode="random", out_planes=False, conv_math=None, **_ignored):
+    def forward_nhwc(self, x, img, ws, noise_mode="random", out_planes=False, conv_math=None, pre=None, **_ignored):
+        """pre: (styles, dcoefs) of this block's layers when the caller batched them for the whole network."""
         assert ws.shape[1:] == (self.num_conv + self.num_torgb, self.w_dim), f"wrong ws shape {list(ws.shape)}"   # :419
         ws = ws.to(torch.float32)
-        it = iter([ws[:, i].contiguous() for i in range(ws.shape[1])])
+        st, dc = pre if pre is not None else batch_styles(block_layers(self), ws, range(ws.shape[1]))
         if self.in_channels == 0:
             const = getattr(self, "_const_nhwc", None)
             if const is None or self._const_key != (self.const.data_ptr(), self.const._version):
                 self._const_nhwc = self.const.detach().permute(1, 2, 0).contiguous()
                 self._const_key = (self.const.data_ptr(), self.const._version)
             x = self._const_nhwc.unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
-            x = self.conv1.forward_nhwc(x, next(it), noise_mode=noise_mode, conv_math=conv_math)
+            x = self.conv1.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0])
         else:
-            w0, w1 = next(it), next(it)
             N, r, c1 = ws.shape[0], self.resolution, self.conv1.in_channels
             if dense_ops.can_chain(_lib.NFE_CONV_3X3, conv_math, N, r, r, c1, self.conv1.out_channels) and c1 % 4 == 0:
                 # conv0's FIR epilogue writes conv1's modulated bf16 input directly: no fp32 round trip between them
-                s1 = self.conv1.affine(w1)
-                _, xs = self.conv0.forward_nhwc(x, w0, noise_mode=noise_mode, conv_math=conv_math, next_styles=s1, want_out=False)
-                x = self.conv1.forward_nhwc(xs, w1, noise_mode=noise_mode, conv_math=conv_math, styles=s1)
+                _, xs = self.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0],
+                                                next_styles=st[1], want_out=False)
+                x = self.conv1.forward_nhwc(xs, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1])
             else:
-                x = self.conv0.forward_nhwc(x, w0, noise_mode=noise_mode, conv_math=conv_math)
-                x = self.conv1.forward_nhwc(x, w1, noise_mode=noise_mode, conv_math=conv_math)
-        img = self.torgb.forward_nhwc(x, next(it), skip=img, out_planes=out_planes, conv_math=conv_math)   # upsample2d(img) + y
+                x = self.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0])
+                x = self.conv1.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1])
+        img = self.torgb.forward_nhwc(x, None, skip=img, out_planes=out_planes, conv_math=conv_math, styles=st[-1])   # upsample2d(img) + y
         return x, img
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
@@ -251,14 +276,24 @@ class SynthesisNetwork(torch.nn.Module):
         """-> NHWC image [N,R,R,img_channels], or the tri-plane gather layout [N,3,R,R,32] if out_planes."""
         assert ws.shape[1:] == (self.num_ws, self.w_dim), f"wrong ws shape {list(ws.shape)}"                # :506
         block_kwargs = {k: v for k, v in block_kwargs.items() if k in ("noise_mode",)}
+        ws = ws.to(torch.float32)
+        blocks = [getattr(self, f"b{res}") for res in self.block_resolutions]
+        layers, cols, w_idx = [], [], 0
+        for block in blocks:                        # one launch for every style affine, one for every demodulation
+            bl = block_layers(block)
+            layers += bl
+            cols += list(range(w_idx, w_idx + len(bl)))
+            w_idx += block.num_conv
+        st, dc = batch_styles(layers, ws, cols)
         x = img = None
-        w_idx = 0
-        for res in self.block_resolutions:
-            block = getattr(self, f"b{res}")
-            cur = ws.narrow(1, w_idx, block.num_conv + block.num_torgb)
+        w_idx = k = 0
+        for res, block in zip(self.block_resolutions, blocks):
+            n = block.num_conv + block.num_torgb
+            cur = ws.narrow(1, w_idx, n)
             w_idx += block.num_conv
             x, img = block.forward_nhwc(x, img, cur, out_planes=out_planes and res == self.img_resolution,
-                                        conv_math=self.conv_math, **block_kwargs)
+                                        conv_math=self.conv_math, pre=(st[k:k + n], dc[k:k + n]), **block_kwargs)
+            k += n
         return img
 
     def forward(self, ws, **block_kwargs):

@@ -4,7 +4,7 @@
 import torch
 
 from .. import dense_ops
-from .networks_stylegan2 import SynthesisBlock, SynthesisLayer, ToRGBLayer
+from .networks_stylegan2 import SynthesisBlock, SynthesisLayer, ToRGBLayer, batch_styles, block_layers
 
 
 def _fir_buffer():
@@ -30,13 +30,13 @@ class SynthesisBlockNoUp(torch.nn.Module):
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_conv, self.num_torgb = 2, 1
 
-    def forward_nhwc(self, x, img, ws, noise_mode="random", conv_math=None, **_ignored):
+    def forward_nhwc(self, x, img, ws, noise_mode="random", conv_math=None, pre=None, **_ignored):
         assert ws.shape[1:] == (self.num_conv + self.num_torgb, self.w_dim), f"wrong ws shape {list(ws.shape)}"
         ws = ws.to(torch.float32)
-        w0, w1, w2 = (ws[:, i].contiguous() for i in range(3))
-        x = self.conv0.forward_nhwc(x, w0, noise_mode=noise_mode, conv_math=conv_math)
-        x = self.conv1.forward_nhwc(x, w1, noise_mode=noise_mode, conv_math=conv_math)
-        y = self.torgb.forward_nhwc(x, w2, conv_math=conv_math)
+        st, dc = pre if pre is not None else batch_styles(block_layers(self), ws, range(3))
+        x = self.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0])
+        x = self.conv1.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1])
+        y = self.torgb.forward_nhwc(x, None, conv_math=conv_math, styles=st[2])
         return x, (img + y if img is not None else y)
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
@@ -62,8 +62,10 @@ class _TwoBlockSR(torch.nn.Module):
         if (x.shape[1] < r) if self.resize_if_smaller_only else (x.shape[1] != r):
             x = dense_ops.resize_bilinear(x, r, r, self.sr_antialias)
             rgb = dense_ops.resize_bilinear(rgb, r, r, self.sr_antialias)
-        x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math)
-        x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math)
+        ws = ws.to(torch.float32)
+        st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2])   # all six in one launch
+        x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]))
+        x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[3:], dc[3:]))
         return rgb
 
     def forward(self, rgb, x, ws, **block_kwargs):
@@ -144,8 +146,10 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
             r = self.input_resolution
             x = dense_ops.resize_bilinear(x, r, r, self.sr_antialias)                     # :283-286
             rgb = dense_ops.resize_bilinear(rgb, r, r, self.sr_antialias)
-        x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math)
-        x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math)
+        ws = ws.to(torch.float32)
+        st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2])   # all six in one launch
+        x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]))
+        x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[3:], dc[3:]))
         return rgb
 
     def forward(self, rgb, x, ws, **block_kwargs):
