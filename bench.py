@@ -203,7 +203,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
                                         "SuperresolutionHybrid8XDC to 512^2, bf16 MFMA convs (fp32 accumulate), fp32 render",
                             "views_per_step": n_total, "synthesis_ms": syn_ms, "stage_ms": stage, "parallelism": f"views-dp{world}"},
                     roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv_kernel<*,1> (backbone + SR stages)",
+                              "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv3_kernel<*> + upfir/torgb (backbone + SR stages)",
                               "kernel_ms": dense_ms, "note": "289.1 GFLOP per view (SURVEY 8d) / time of the backbone + SR stages"})
 
     # orbit: config 4, strong scaling: 512 frames in total
