@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NFE_ABI_VERSION 4
+#define NFE_ABI_VERSION 5
 
 #define NFE_OK 0
 #define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */
@@ -162,6 +162,55 @@ int nfe_point_query(const float* planes_geo, const float* planes_app, int plane_
                     const float* app_scale, const float* app_shift, const float* decoder_packed,
                     int decoder_math, const float* coords, int n_views, int n_points, float box_warp,
                     float* rgb, float* sigma, float* seg, nfe_stream_t stream);
+
+/* ---- backward of a5..a12 with respect to the plane sets ------------------------------------------
+ * The vector-Jacobian product torch autograd computes for DisentangledImportanceRenderer.forward
+ * (renderer.py:301-363) w.r.t. `norm_planes` / `denorm_planes`: through SegMipRayMarcher2.run_forward
+ * (ray_marcher.py:68-101), DisentangledOSGDecoder.forward (triplane.py:249-270) and F.grid_sample (renderer.py:64).
+ * This is what plane optimisation (geometry / appearance editing through utils.decode, utils.py:165-199) needs;
+ * decoder parameters are constants here.  The sample depths are constants too: stratified depths do not depend on
+ * the planes and importance depths are detached in the reference (renderer.py:198,211), so the caller passes the
+ * sorted depths the forward marched (nfe_render_args.tap_depths_all) and the gradient flows through that one march.
+ * Three launches: per-sample re-evaluation (sigma and the cotangent-weighted colour), a per-ray reverse recurrence
+ * (no divisions by 1 - alpha), per-sample decoder backward + scatter (fp32 atomics, one 128-byte texel row per
+ * half-wave instruction).  density_noise is not supported (absent from every shipped config). */
+typedef struct nfe_render_backward_args {
+    uint32_t struct_size;              /* = sizeof(nfe_render_backward_args) */
+    const float* planes_geo;           /* as in nfe_render_args (gather layout [Np,3,H,W,32]) */
+    const float* planes_app;
+    int32_t plane_h, plane_w;
+    int64_t plane_view_stride;
+    const float* geo_scale; const float* geo_shift;     /* optional affines [N,96], as in nfe_render_args */
+    const float* app_scale; const float* app_shift;
+    /* raw decoder parameters, as nfe_decoder_pack takes them */
+    const float* geo_w0; const float* geo_b0; const float* geo_w1; const float* geo_b1;
+    const float* app_w0; const float* app_b0; const float* app_w1; const float* app_b1;
+    float lr_mul;
+    int32_t n_views, n_rays;
+    const float* origins; const float* dirs;            /* [N,M,3] or both NULL: rays from cam2world/intrinsics */
+    const float* cam2world; const float* intrinsics;
+    int32_t resolution;
+    int32_t n_samples;                 /* S = depth_resolution + depth_resolution_importance */
+    const float* depths;               /* [N,M,S] ascending per ray: tap_depths_all of the forward call */
+    float box_warp;
+    int32_t white_back;
+    /* cotangents of the four outputs (NULL = zero) */
+    const float* grad_rgb;             /* [N,M,32] ([N,32,M] if channels_first) */
+    const float* grad_seg;             /* [N,M,15] ([N,15,M]) */
+    const float* grad_depth;           /* [N,M] */
+    const float* grad_wsum;            /* [N,M] */
+    int32_t channels_first;
+    /* outputs, ACCUMULATED INTO (the caller zeroes them): gradients w.r.t. the SAMPLED plane sets in gather layout.
+     * With affines the chain rule through `scale` is applied, i.e. these are gradients w.r.t. the stored planes.
+     * Either may be NULL (that decoder branch is skipped); both may point to the same buffer (single-gather mode). */
+    float* grad_planes_geo;
+    float* grad_planes_app;
+    int64_t grad_view_stride;          /* floats between views of the gradient buffers (0: all views add into one set) */
+    void* workspace; uint64_t workspace_bytes;
+} nfe_render_backward_args;
+
+uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples);
+int nfe_render_backward(const nfe_render_backward_args* args, nfe_stream_t stream);
 
 #ifdef __cplusplus
 }

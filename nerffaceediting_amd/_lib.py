@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 4
+NFE_ABI_VERSION = 5
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_MATH_BF16X3, NFE_MATH_FP32 = 0, 1
@@ -37,6 +37,30 @@ class RenderArgs(ctypes.Structure):
         ("channels_first", c_int32),
         ("tap_weights_coarse", FP), ("tap_depths_fine", FP), ("tap_depths_all", FP),
         ("workspace", FP), ("workspace_bytes", c_uint64), ("density_noise", c_float),
+    ]
+
+
+class RenderBackwardArgs(ctypes.Structure):
+    """Mirror of ``nfe_render_backward_args`` (include/nfe_render.h)."""
+    _fields_ = [
+        ("struct_size", c_uint32),
+        ("planes_geo", FP), ("planes_app", FP),
+        ("plane_h", c_int32), ("plane_w", c_int32),
+        ("plane_view_stride", c_int64),
+        ("geo_scale", FP), ("geo_shift", FP), ("app_scale", FP), ("app_shift", FP),
+        ("geo_w0", FP), ("geo_b0", FP), ("geo_w1", FP), ("geo_b1", FP),
+        ("app_w0", FP), ("app_b0", FP), ("app_w1", FP), ("app_b1", FP),
+        ("lr_mul", c_float),
+        ("n_views", c_int32), ("n_rays", c_int32),
+        ("origins", FP), ("dirs", FP), ("cam2world", FP), ("intrinsics", FP),
+        ("resolution", c_int32), ("n_samples", c_int32),
+        ("depths", FP),
+        ("box_warp", c_float), ("white_back", c_int32),
+        ("grad_rgb", FP), ("grad_seg", FP), ("grad_depth", FP), ("grad_wsum", FP),
+        ("channels_first", c_int32),
+        ("grad_planes_geo", FP), ("grad_planes_app", FP),
+        ("grad_view_stride", c_int64),
+        ("workspace", FP), ("workspace_bytes", c_uint64),
     ]
 
 
@@ -80,6 +104,8 @@ _SIGNATURES = {
     "nfe_decoder_pack": (c_int, [FP] * 8 + [c_float, FP, c_void_p]),
     "nfe_render_workspace_bytes": (c_uint64, [c_int, c_int, c_int, c_int]),
     "nfe_render": (c_int, [POINTER(RenderArgs), c_void_p]),
+    "nfe_render_backward_workspace_bytes": (c_uint64, [c_int, c_int, c_int]),
+    "nfe_render_backward": (c_int, [POINTER(RenderBackwardArgs), c_void_p]),
     # include/nfe_dense.h
     "nfe_nchw_to_nhwc": (c_int, [FP, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_nhwc_to_nchw": (c_int, [FP, c_int, c_int, c_int, c_int, FP, c_void_p]),

@@ -71,4 +71,30 @@ __device__ __forceinline__ u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigne
 }
 __device__ __forceinline__ float u01(unsigned bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
 
+// Bilinear tap geometry of one sample on one plane: F.grid_sample(bilinear, zeros, align_corners=False),
+// renderer.py:64, unnormalised as ATen's CPU kernel does.  Clamped coordinates are always addressable;
+// out-of-range taps carry weight 0.
+struct Taps { int xc0, xc1, yc0, yc1; float w[4]; float wdef; };   // wdef = (sum of weights) - 1, exactly 0 when all 4 taps are inside
+
+__device__ __forceinline__ Taps tap_geometry(int H, int W, float u, float v) {
+    Taps t;
+    const float ix = (u + 1.0f) * (0.5f * (float)W) - 0.5f;
+    const float iy = (v + 1.0f) * (0.5f * (float)H) - 0.5f;
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float dx = ix - x0f, dy = iy - y0f, ex = 1.0f - dx, ey = 1.0f - dy;
+    const int x0 = (int)fminf(fmaxf(x0f, -2.0f), (float)(W + 1));
+    const int y0 = (int)fminf(fmaxf(y0f, -2.0f), (float)(H + 1));
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
+    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
+    t.w[0] = (vx0 && vy0) ? ex * ey : 0.0f;
+    t.w[1] = (vx1 && vy0) ? dx * ey : 0.0f;
+    t.w[2] = (vx0 && vy1) ? ex * dy : 0.0f;
+    t.w[3] = (vx1 && vy1) ? dx * dy : 0.0f;
+    t.xc0 = min(max(x0, 0), W - 1); t.xc1 = min(max(x1, 0), W - 1);
+    t.yc0 = min(max(y0, 0), H - 1); t.yc1 = min(max(y1, 0), H - 1);
+    t.wdef = (vx0 && vx1 && vy0 && vy1) ? 0.0f : ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3])) - 1.0f;
+    return t;
+}
+
 }  // namespace nfe

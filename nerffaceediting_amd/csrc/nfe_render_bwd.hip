@@ -1,0 +1,450 @@
+// nfe_render_backward: gradient of the renderer's final compositing pass w.r.t. the two plane sets (gfx950).
+//
+// What autograd does in the reference for DisentangledImportanceRenderer.forward (renderer.py:301-363) with the
+// planes as leaves: backward of SegMipRayMarcher2.run_forward (ray_marcher.py:68-101), of the two decoder MLPs
+// (triplane.py:249-270) and of F.grid_sample (renderer.py:64, a scatter-add).  Sample depths are constants
+// (renderer.py:198,211 detach the importance depths), so everything is a function of the sorted depth buffer.
+//
+// Three passes, nothing per-sample wider than 3 floats is ever stored:
+//   eval    one lane per sample   gather + both MLPs in fp32 -> sigma_i and a_i = <2 G_rgb, rgb_i> + <G_seg, seg_i>
+//   ray     one lane per ray      forward march (T_j kept), cotangent of every weight, reverse recurrence
+//                                 R_j = g_{j+1} alpha_{j+1} + (1 - alpha_{j+1} + 1e-10) R_{j+1};  dL/dalpha_j = T_j (g_j - R_j)
+//                                 (no division by 1 - alpha, exact for opaque samples) -> dL/dsigma_i and
+//                                 omega_i = (w_{i-1} + w_i)/2, the weight of sample i's colour in the outputs
+//   scatter one lane per sample   gather + MLP forward again, MLP backward to the 32+32 feature gradients, then the
+//                                 wave transposes them through LDS so that each half-wave adds one 128-byte texel
+//                                 row per atomic instruction (global_atomic_add_f32, 12 taps x 2 sets per sample).
+// Decoder weights are read with wave-uniform addresses (scalar loads); the gains of FullyConnectedLayer
+// (networks_stylegan2.py:111-123) are applied once by prep_kernel.
+#include "nfe_common.h"
+
+namespace nfe {
+
+// scaled decoder image in the workspace (floats)
+constexpr int BW_G0 = 0;        // [64][32]   geo layer 0, weight * lr/sqrt(32)
+constexpr int BB_G0 = 2048;     // [64]
+constexpr int BW_G1T = 2112;    // [64][16]   geo layer 1 transposed (hidden-major), weight * lr/sqrt(64)
+constexpr int BB_G1 = 3136;     // [16]
+constexpr int BW_A0 = 3152;     // [64][32]
+constexpr int BB_A0 = 5200;     // [64]
+constexpr int BW_A1T = 5264;    // [64][32]
+constexpr int BB_A1 = 7312;     // [32]
+constexpr int BWD_DEC_FLOATS = 7344;
+constexpr int BWD_DEC_BYTES = 32768;
+
+struct BwdK {
+    const float* planes_g; const float* planes_a; long long plane_view_stride; int H, W;
+    const float* aff[4];
+    const float* dec;                  // scaled image above
+    int N, M, R;
+    const float* origins; const float* dirs; const float* cam2world; const float* intrinsics;
+    int S; const float* depths; float coord_scale; int white_back;
+    const float* g_rgb; const float* g_seg; const float* g_depth; const float* g_wsum; int channels_first;
+    float* grad_g; float* grad_a; long long grad_view_stride;
+    float* rec_sig; float* rec_a; float* rec_T;      // [N*M*S] each: (sigma, a, T) then (dL/dsigma, omega, -)
+};
+
+struct PrepK { const float* w[8]; float lr_mul; float* out; };
+
+__global__ void bwd_prep_kernel(PrepK P) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BWD_DEC_FLOATS) return;
+    const float g0 = P.lr_mul * 0.17677669529663687f /* 1/sqrt(32) */, g1 = P.lr_mul * 0.125f /* 1/sqrt(64) */;
+    float v;
+    if (i < BB_G0) v = P.w[0][i] * g0;
+    else if (i < BW_G1T) v = P.w[1][i - BB_G0] * P.lr_mul;
+    else if (i < BB_G1) { const int k = i - BW_G1T, j = k >> 4, o = k & 15; v = P.w[2][o * 64 + j] * g1; }
+    else if (i < BW_A0) v = P.w[3][i - BB_G1] * P.lr_mul;
+    else if (i < BB_A0) v = P.w[4][i - BW_A0] * g0;
+    else if (i < BW_A1T) v = P.w[5][i - BB_A0] * P.lr_mul;
+    else if (i < BB_A1) { const int k = i - BW_A1T, j = k >> 5, o = k & 31; v = P.w[6][o * 64 + j] * g1; }
+    else v = P.w[7][i - BB_A1] * P.lr_mul;
+    P.out[i] = v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-sample geometry and gather
+// ------------------------------------------------------------------------------------------------------------
+struct SampleGeo { int off[12]; float w[12]; };     // element offset of each tap's texel inside its view's plane set
+
+__device__ __forceinline__ void ray_of(const BwdK& P, int n, int m, float (&o)[3], float (&d)[3]) {
+    if (P.origins) {
+        const float* po = P.origins + ((long long)n * P.M + m) * 3; const float* pd = P.dirs + ((long long)n * P.M + m) * 3;
+        o[0] = po[0]; o[1] = po[1]; o[2] = po[2]; d[0] = pd[0]; d[1] = pd[1]; d[2] = pd[2];
+    } else {    // RaySampler.forward, ray_sampler.py:35-61 (same arithmetic as render_kernel)
+        const float* c = P.cam2world + n * 16; const float* K = P.intrinsics + n * 9;
+        const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+        const float inv = 1.0f / (float)P.R;
+        const int px = m % P.R, py = m / P.R;
+        const float xc = (float)px * inv + 0.5f * inv, yc = (float)py * inv + 0.5f * inv;
+        const float xl = (xc - cx + cy * sk / fy - sk * yc / fy) / fx;
+        const float yl = (yc - cy) / fy;
+        o[0] = c[3]; o[1] = c[7]; o[2] = c[11];
+        const float wx = c[0] * xl + c[1] * yl + c[2] + c[3];
+        const float wy = c[4] * xl + c[5] * yl + c[6] + c[7];
+        const float wz = c[8] * xl + c[9] * yl + c[10] + c[11];
+        d[0] = wx - o[0]; d[1] = wy - o[1]; d[2] = wz - o[2];
+        const float nrm = fmaxf(sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]), 1e-12f);
+        d[0] /= nrm; d[1] /= nrm; d[2] /= nrm;
+    }
+}
+
+__device__ __forceinline__ void sample_geometry(const BwdK& P, int n, int m, float t, SampleGeo& g) {
+    float o[3], d[3];
+    ray_of(P, n, m, o, d);
+    const float x = P.coord_scale * fmaf(t, d[0], o[0]);
+    const float y = P.coord_scale * fmaf(t, d[1], o[1]);
+    const float z = P.coord_scale * fmaf(t, d[2], o[2]);
+    const int plane_elems = P.H * P.W * 32;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {     // plane axes of generate_planes (renderer.py:23-37): (x,y), (x,z), (z,x)
+        const Taps tp = tap_geometry(P.H, P.W, p == 2 ? z : x, p == 0 ? y : (p == 1 ? z : x));
+        g.off[4 * p + 0] = p * plane_elems + (tp.yc0 * P.W + tp.xc0) * 32;
+        g.off[4 * p + 1] = p * plane_elems + (tp.yc0 * P.W + tp.xc1) * 32;
+        g.off[4 * p + 2] = p * plane_elems + (tp.yc1 * P.W + tp.xc0) * 32;
+        g.off[4 * p + 3] = p * plane_elems + (tp.yc1 * P.W + tp.xc1) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g.w[4 * p + k] = tp.w[k];
+    }
+}
+
+// Feature vector of one plane set: mean over planes of (bilinear sample * scale + in-bounds weight * shift)
+// (scale/shift NULL = identity).  aff_* point at this view's [96] rows.
+__device__ __forceinline__ void gather_set(const float* __restrict__ planes, const SampleGeo& g,
+                                           const float* __restrict__ scale, const float* __restrict__ shift, float (&f)[32]) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) f[c] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        float s[32];
+#pragma unroll
+        for (int c = 0; c < 32; ++c) s[c] = 0.0f;
+        float wsum = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4* tx = reinterpret_cast<const float4*>(planes + g.off[4 * p + k]);
+            const float w = g.w[4 * p + k];
+            wsum += w;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float4 v = tx[q];
+                s[4 * q] = fmaf(w, v.x, s[4 * q]); s[4 * q + 1] = fmaf(w, v.y, s[4 * q + 1]);
+                s[4 * q + 2] = fmaf(w, v.z, s[4 * q + 2]); s[4 * q + 3] = fmaf(w, v.w, s[4 * q + 3]);
+            }
+        }
+        if (scale) {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) f[c] += fmaf(s[c], scale[p * 32 + c], wsum * shift[p * 32 + c]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) f[c] += s[c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) f[c] *= (1.0f / 3.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// decoder heads in fp32, one sample per lane, weights at wave-uniform addresses
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float softplus_t(float x) {      // torch.nn.Softplus(beta=1, threshold=20)
+    return x > 20.0f ? x : log1pf(__expf(x));
+}
+__device__ __forceinline__ float sigmoid_t(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+__device__ __forceinline__ float hidden_pre(const float* __restrict__ w0, const float* __restrict__ b0, int j, const float (&f)[32]) {
+    float pre = b0[j];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) pre = fmaf(w0[j * 32 + c], f[c], pre);
+    return pre;
+}
+
+template <int NO>
+__device__ __forceinline__ void head_forward(const float* __restrict__ w0, const float* __restrict__ b0,
+                                             const float* __restrict__ w1t, const float* __restrict__ b1,
+                                             const float (&f)[32], float (&out)[NO]) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) out[o] = b1[o];
+#pragma unroll 2
+    for (int j = 0; j < 64; ++j) {
+        const float h = softplus_t(hidden_pre(w0, b0, j, f));
+#pragma unroll
+        for (int o = 0; o < NO; ++o) out[o] = fmaf(w1t[j * NO + o], h, out[o]);
+    }
+}
+
+// df = W0^T (softplus'(pre) * (W1^T dout)); the pre-activations are recomputed (cheaper than 64 live registers)
+template <int NO>
+__device__ __forceinline__ void head_backward(const float* __restrict__ w0, const float* __restrict__ b0,
+                                              const float* __restrict__ w1t, const float (&f)[32],
+                                              const float (&dout)[NO], float (&df)[32]) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) df[c] = 0.0f;
+#pragma unroll 2
+    for (int j = 0; j < 64; ++j) {
+        const float pre = hidden_pre(w0, b0, j, f);
+        float dh = 0.0f;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) dh = fmaf(w1t[j * NO + o], dout[o], dh);
+        const float dpre = dh * (pre > 20.0f ? 1.0f : sigmoid_t(pre));
+#pragma unroll
+        for (int c = 0; c < 32; ++c) df[c] = fmaf(w0[j * 32 + c], dpre, df[c]);
+    }
+}
+
+__device__ __forceinline__ float cot_rgb(const BwdK& P, int n, int m, int c) {      // includes the *2 of rgb*2-1
+    if (!P.g_rgb) return 0.0f;
+    return 2.0f * (P.channels_first ? P.g_rgb[((long long)n * 32 + c) * P.M + m] : P.g_rgb[((long long)n * P.M + m) * 32 + c]);
+}
+__device__ __forceinline__ float cot_seg(const BwdK& P, int n, int m, int c) {
+    if (!P.g_seg) return 0.0f;
+    return P.channels_first ? P.g_seg[((long long)n * 15 + c) * P.M + m] : P.g_seg[((long long)n * P.M + m) * 15 + c];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pass 1: sigma_i and a_i
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bwd_eval_kernel(BwdK P) {
+    const int n = blockIdx.y;
+    const long long per_view = (long long)P.M * P.S;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= per_view) return;
+    const int m = (int)(i / P.S);
+    const long long g = (long long)n * per_view + i;
+    SampleGeo geo;
+    sample_geometry(P, n, m, P.depths[g], geo);
+    const long long pv = (long long)n * P.plane_view_stride;
+    const float* dec = P.dec;
+    float f[32];
+    gather_set(P.planes_g + pv, geo, P.aff[0] ? P.aff[0] + n * 96 : nullptr, P.aff[1] ? P.aff[1] + n * 96 : nullptr, f);
+    float og[16];
+    head_forward<16>(dec + BW_G0, dec + BB_G0, dec + BW_G1T, dec + BB_G1, f, og);
+    float a = 0.0f;
+    if (P.g_seg) {
+#pragma unroll
+        for (int c = 0; c < 15; ++c) a = fmaf(cot_seg(P, n, m, c), og[1 + c], a);
+    }
+    if (P.g_rgb) {
+        gather_set(P.planes_a + pv, geo, P.aff[2] ? P.aff[2] + n * 96 : nullptr, P.aff[3] ? P.aff[3] + n * 96 : nullptr, f);
+        float oa[32];
+        head_forward<32>(dec + BW_A0, dec + BB_A0, dec + BW_A1T, dec + BB_A1, f, oa);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) a = fmaf(cot_rgb(P, n, m, c), sigmoid_t(oa[c]) * 1.002f - 0.001f, a);    // triplane.py:269
+    }
+    P.rec_sig[g] = og[0];
+    P.rec_a[g] = a;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pass 2: the march and its reverse, one lane per ray
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void segment(float s0, float s1, float t0, float t1, float& alpha, float& dalpha_dsmid) {
+    const float x = (s0 + s1) * 0.5f - 1.0f;                        // ray_marcher.py:72,76
+    const float dens = x > 20.0f ? x : log1pf(__expf(x));
+    const float dlt = t1 - t0;
+    const float e = __expf(-dens * dlt);
+    alpha = 1.0f - e;                                               // :80-82
+    dalpha_dsmid = dlt * e * (x > 20.0f ? 1.0f : sigmoid_t(x));
+}
+
+__global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
+    const long long ray = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (ray >= (long long)P.N * P.M) return;
+    const int S = P.S;
+    const float* t = P.depths + ray * S;
+    float* sig = P.rec_sig + ray * S; float* av = P.rec_a + ray * S; float* Tv = P.rec_T + ray * S;
+    // forward: transmittance of every segment, sum of weights, weighted depth
+    float T = 1.0f, wtot = 0.0f, dnum = 0.0f;
+    float s0 = sig[0], t0 = t[0];
+    for (int j = 0; j + 1 < S; ++j) {
+        const float s1 = sig[j + 1], t1 = t[j + 1];
+        float alpha, dummy;
+        segment(s0, s1, t0, t1, alpha, dummy);
+        Tv[j] = T;
+        const float w = alpha * T;
+        wtot += w; dnum = fmaf(w, (t0 + t1) * 0.5f, dnum);
+        T *= (1.0f - alpha + 1e-10f);                               // :85
+        s0 = s1; t0 = t1;
+    }
+    const float d0 = dnum / wtot;
+    const bool ok = wtot != 0.0f && isfinite(d0);                   // nan_to_num + clamp (:93-94) pass nothing otherwise
+    const float gd = (ok && P.g_depth) ? P.g_depth[ray] / wtot : 0.0f;
+    float gconst = P.g_wsum ? P.g_wsum[ray] : 0.0f;
+    if (P.white_back && P.g_rgb) {                                  // rgb + 1 - weight_total (:96-97)
+        const int n = (int)(ray / P.M), m = (int)(ray % P.M);
+        float s = 0.0f;
+        for (int c = 0; c < 32; ++c) s += cot_rgb(P, n, m, c);
+        gconst -= s;
+    }
+    // reverse: R_j = sum_{k>j} g_k alpha_k prod_{j<m<k} (1 - alpha_m + 1e-10)
+    float R = 0.0f;
+    float s1 = sig[S - 1], a1 = av[S - 1], t1 = t[S - 1];
+    float gs_hi = 0.0f, om_hi = 0.0f;          // contributions of segment j to sample j+1
+    for (int j = S - 2; j >= 0; --j) {
+        const float s0r = sig[j], a0 = av[j], t0r = t[j];
+        float alpha, dads;
+        segment(s0r, s1, t0r, t1, alpha, dads);
+        const float Tj = Tv[j];
+        const float gw = 0.5f * (a0 + a1) + gconst + (ok ? gd * ((t0r + t1) * 0.5f - d0) : 0.0f);
+        const float galpha = Tj * (gw - R);
+        R = fmaf(gw, alpha, (1.0f - alpha + 1e-10f) * R);
+        const float gs = 0.5f * galpha * dads, om = 0.5f * alpha * Tj;
+        sig[j + 1] = gs + gs_hi; av[j + 1] = om + om_hi;            // sample j+1 is complete: segments j and j+1 seen
+        gs_hi = gs; om_hi = om;
+        s1 = s0r; a1 = a0; t1 = t0r;
+    }
+    sig[0] = gs_hi; av[0] = om_hi;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// pass 3: decoder backward and scatter
+// ------------------------------------------------------------------------------------------------------------
+constexpr int TILE_STRIDE = 33;                 // floats per sample row in the transpose tile (conflict-free both ways)
+constexpr int SCATTER_LDS_FLOATS = 4 * 64 * TILE_STRIDE;
+
+// Adds df (this lane's sample, 32 channels, already / 3) into the gradient plane set: half-wave h handles sample
+// 2*it + h of the wave, lane&31 = channel, one 128-byte texel row per half-wave per atomic instruction.
+__device__ __forceinline__ void scatter_set(float* __restrict__ tile, const float (&df)[32], const SampleGeo& geo, bool live,
+                                            float* __restrict__ grad, const float* __restrict__ scale, int lane) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) tile[lane * TILE_STRIDE + c] = df[c];
+    __builtin_amdgcn_wave_barrier();
+    const int ch = lane & 31, hh = lane >> 5;
+    float sc[3] = {1.0f, 1.0f, 1.0f};
+    if (scale) { sc[0] = scale[ch]; sc[1] = scale[32 + ch]; sc[2] = scale[64 + ch]; }
+#pragma unroll 1
+    for (int it = 0; it < 32; ++it) {
+        const int src = 2 * it + hh;
+        const float v = tile[src * TILE_STRIDE + ch];
+        const int alive = __shfl((int)live, src);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int off = __shfl(geo.off[k], src);
+            const float w = __shfl(geo.w[k], src);
+            if (alive && w != 0.0f) unsafeAtomicAdd(grad + off + ch, v * w * sc[k >> 2]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(256) void bwd_scatter_kernel(BwdK P) {
+    __shared__ float tiles[SCATTER_LDS_FLOATS];
+    const int n = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    float* tile = tiles + (threadIdx.x >> 6) * 64 * TILE_STRIDE;
+    const long long per_view = (long long)P.M * P.S;
+    const long long i_raw = (long long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = i_raw < per_view;
+    const long long i = live ? i_raw : per_view - 1;              // dead lanes recompute the last sample, add nothing
+    const int m = (int)(i / P.S);
+    const long long g = (long long)n * per_view + i;
+    SampleGeo geo;
+    sample_geometry(P, n, m, P.depths[g], geo);
+    const float gsig = P.rec_sig[g], omega = P.rec_a[g];
+    const long long pv = (long long)n * P.plane_view_stride;
+    const long long gv = (long long)n * P.grad_view_stride;
+    const float* dec = P.dec;
+    float f[32], df[32];
+    if (P.grad_g) {
+        const float* scale = P.aff[0] ? P.aff[0] + n * 96 : nullptr;
+        gather_set(P.planes_g + pv, geo, scale, P.aff[1] ? P.aff[1] + n * 96 : nullptr, f);
+        float dout[16];
+        dout[0] = gsig;                                            // sigma = channel 0, seg = 1..15 (triplane.py:260-261)
+#pragma unroll
+        for (int c = 0; c < 15; ++c) dout[1 + c] = omega * cot_seg(P, n, m, c);
+        head_backward<16>(dec + BW_G0, dec + BB_G0, dec + BW_G1T, f, dout, df);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) df[c] *= (1.0f / 3.0f);      // mean over planes, triplane.py:251
+        scatter_set(tile, df, geo, live, P.grad_g + gv, scale, lane);
+    }
+    if (P.grad_a && P.g_rgb) {
+        const float* scale = P.aff[2] ? P.aff[2] + n * 96 : nullptr;
+        gather_set(P.planes_a + pv, geo, scale, P.aff[3] ? P.aff[3] + n * 96 : nullptr, f);
+        float y[32];
+        head_forward<32>(dec + BW_A0, dec + BB_A0, dec + BW_A1T, dec + BB_A1, f, y);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) {                             // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269)
+            const float s = sigmoid_t(y[c]);
+            y[c] = omega * cot_rgb(P, n, m, c) * 1.002f * s * (1.0f - s);
+        }
+        head_backward<32>(dec + BW_A0, dec + BB_A0, dec + BW_A1T, f, y, df);
+#pragma unroll
+        for (int c = 0; c < 32; ++c) df[c] *= (1.0f / 3.0f);
+        scatter_set(tile, df, geo, live, P.grad_a + gv, scale, lane);
+    }
+}
+
+static uint64_t align256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
+
+}  // namespace nfe
+
+using namespace nfe;
+
+extern "C" uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples) {
+    const uint64_t ns = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0) * (uint64_t)(n_samples > 0 ? n_samples : 0);
+    return BWD_DEC_BYTES + 3 * align256(ns * 4);
+}
+
+extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream_t stream) {
+    NFE_REQUIRE(a != nullptr, "nfe_render_backward: args is null");
+    NFE_REQUIRE(a->struct_size == sizeof(nfe_render_backward_args), "nfe_render_backward: struct_size %u != %zu (ABI mismatch)",
+                a->struct_size, sizeof(nfe_render_backward_args));
+    NFE_REQUIRE(a->planes_geo && a->planes_app, "nfe_render_backward: plane pointers are null");
+    NFE_REQUIRE(a->geo_w0 && a->geo_b0 && a->geo_w1 && a->geo_b1 && a->app_w0 && a->app_b0 && a->app_w1 && a->app_b1,
+                "nfe_render_backward: decoder parameter pointers are null");
+    NFE_REQUIRE(a->plane_h > 0 && a->plane_w > 0 && (long long)a->plane_h * a->plane_w * 96 < (1ll << 31),
+                "nfe_render_backward: bad plane size %dx%d (element offsets inside a view's plane set are 32-bit)", a->plane_h, a->plane_w);
+    NFE_REQUIRE(a->n_views > 0 && a->n_views <= 65535 && a->n_rays > 0, "nfe_render_backward: n_views=%d n_rays=%d out of range", a->n_views, a->n_rays);
+    NFE_REQUIRE(a->n_samples >= 2 && a->n_samples <= 2 * NFE_MAX_SAMPLES, "nfe_render_backward: n_samples=%d out of [2,%d]", a->n_samples, 2 * NFE_MAX_SAMPLES);
+    NFE_REQUIRE(a->depths != nullptr, "nfe_render_backward: depths is null");
+    NFE_REQUIRE((a->origins != nullptr) == (a->dirs != nullptr), "nfe_render_backward: origins and dirs must both be given or both null");
+    if (!a->origins) {
+        NFE_REQUIRE(a->cam2world && a->intrinsics, "nfe_render_backward: need origins/dirs or cam2world/intrinsics");
+        NFE_REQUIRE(a->resolution > 0 && (long long)a->resolution * a->resolution == a->n_rays,
+                    "nfe_render_backward: resolution^2 (%d^2) != n_rays (%d)", a->resolution, a->n_rays);
+    }
+    NFE_REQUIRE((a->geo_scale != nullptr) == (a->geo_shift != nullptr) && (a->app_scale != nullptr) == (a->app_shift != nullptr),
+                "nfe_render_backward: affine scale/shift must come in pairs");
+    NFE_REQUIRE(a->box_warp > 0.0f, "nfe_render_backward: box_warp must be positive");
+    NFE_REQUIRE(a->grad_planes_geo || a->grad_planes_app, "nfe_render_backward: no gradient output requested");
+    NFE_REQUIRE(a->workspace != nullptr, "nfe_render_backward: workspace is null");
+    const uint64_t need = nfe_render_backward_workspace_bytes(a->n_views, a->n_rays, a->n_samples);
+    if (a->workspace_bytes < need) return fail(NFE_EWORKSPACE, "nfe_render_backward: workspace %llu < %llu bytes",
+                                               (unsigned long long)a->workspace_bytes, (unsigned long long)need);
+    const uint64_t ns = (uint64_t)a->n_views * a->n_rays * a->n_samples;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)a->workspace;
+    float* dec = (float*)ws; ws += BWD_DEC_BYTES;
+    PrepK Q{};
+    Q.w[0] = a->geo_w0; Q.w[1] = a->geo_b0; Q.w[2] = a->geo_w1; Q.w[3] = a->geo_b1;
+    Q.w[4] = a->app_w0; Q.w[5] = a->app_b0; Q.w[6] = a->app_w1; Q.w[7] = a->app_b1;
+    Q.lr_mul = a->lr_mul; Q.out = dec;
+    hipLaunchKernelGGL(bwd_prep_kernel, dim3((BWD_DEC_FLOATS + 255) / 256), dim3(256), 0, st, Q);
+    NFE_CHECK_LAUNCH("bwd_prep_kernel");
+
+    BwdK P{};
+    P.planes_g = a->planes_geo; P.planes_a = a->planes_app; P.plane_view_stride = a->plane_view_stride;
+    P.H = a->plane_h; P.W = a->plane_w;
+    P.aff[0] = a->geo_scale; P.aff[1] = a->geo_shift; P.aff[2] = a->app_scale; P.aff[3] = a->app_shift;
+    P.dec = dec;
+    P.N = a->n_views; P.M = a->n_rays; P.R = a->resolution;
+    P.origins = a->origins; P.dirs = a->dirs; P.cam2world = a->cam2world; P.intrinsics = a->intrinsics;
+    P.S = a->n_samples; P.depths = a->depths; P.coord_scale = 2.0f / a->box_warp; P.white_back = a->white_back;
+    P.g_rgb = a->grad_rgb; P.g_seg = a->grad_seg; P.g_depth = a->grad_depth; P.g_wsum = a->grad_wsum;
+    P.channels_first = a->channels_first;
+    P.grad_g = a->grad_planes_geo; P.grad_a = a->grad_planes_app; P.grad_view_stride = a->grad_view_stride;
+    P.rec_sig = (float*)ws; ws += align256(ns * 4);
+    P.rec_a = (float*)ws; ws += align256(ns * 4);
+    P.rec_T = (float*)ws;
+
+    const long long per_view = (long long)a->n_rays * a->n_samples;
+    const dim3 sgrid((unsigned)((per_view + 255) / 256), (unsigned)a->n_views);
+    hipLaunchKernelGGL(bwd_eval_kernel, sgrid, dim3(256), 0, st, P);
+    NFE_CHECK_LAUNCH("bwd_eval_kernel");
+    const long long rays = (long long)a->n_views * a->n_rays;
+    hipLaunchKernelGGL(bwd_ray_kernel, dim3((unsigned)((rays + 255) / 256)), dim3(256), 0, st, P);
+    NFE_CHECK_LAUNCH("bwd_ray_kernel");
+    hipLaunchKernelGGL(bwd_scatter_kernel, sgrid, dim3(256), 0, st, P);
+    NFE_CHECK_LAUNCH("bwd_scatter_kernel");
+    return NFE_OK;
+}

@@ -247,6 +247,86 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
     return (rgb, seg, depth, wsum, tap) if taps else (rgb, seg, depth, wsum)
 
 
+def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, depths_all, grads, *, origins=None, dirs=None,
+                    cam2world=None, intrinsics=None, resolution=0, affines=None, channels_first=False, need=(True, True)):
+    """nfe_render_backward: the vector-Jacobian product of `render` w.r.t. the two plane sets (what autograd does for
+    renderer.py:301-363 with the planes as leaves; depths are constants, renderer.py:198,211).
+
+    planes_* packed [Np,3,H,W,32]; decoder_heads = the 8 raw decoder tensors (geo w0,b0,w1,b1, app w0,b0,w1,b1);
+    depths_all [N,M,S] = the `depths_all` tap of the forward call; grads = (g_rgb, g_seg, g_depth, g_wsum), entries may
+    be None.  Returns (grad_planes_geo, grad_planes_app) in gather layout [Np,3,H,W,32] (None where `need` is False; the
+    same tensor twice when planes_app is planes_geo)."""
+    lib = _lib.load()
+    if float(options.get("density_noise", 0) or 0) > 0:
+        raise RuntimeError("render_backward: density_noise > 0 is not supported")
+    planes_geo = _dev(planes_geo, "planes_geo", (None, 3, None, None, 32))
+    same = planes_app is planes_geo or planes_app.data_ptr() == planes_geo.data_ptr()
+    planes_app = planes_geo if same else _dev(planes_app, "planes_app", tuple(planes_geo.shape))
+    Np, _, H, W, _ = planes_geo.shape
+    dev = planes_geo.device
+    depths_all = _dev(depths_all, "depths_all", (None, None, None))
+    N, M, S = depths_all.shape
+    assert Np in (1, N), f"planes batch {Np} must be 1 or equal the ray batch {N}"
+    a = _lib.RenderBackwardArgs()
+    a.struct_size = ctypes.sizeof(_lib.RenderBackwardArgs)
+    a.planes_geo, a.planes_app = planes_geo.data_ptr(), planes_app.data_ptr()
+    a.plane_h, a.plane_w = H, W
+    bcast = Np == 1 and N > 1
+    a.plane_view_stride = 0 if bcast else 3 * H * W * 32
+    keep = [planes_geo, planes_app, depths_all]
+    if affines is not None:
+        affines = [_dev(t, "affine", (N, 96)) for t in affines]
+        a.geo_scale, a.geo_shift, a.app_scale, a.app_shift = [t.data_ptr() for t in affines]
+        keep += affines
+    names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
+             "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+    heads = [_dev(t, nm, sh) for t, nm, sh in zip(decoder_heads, names, shapes)]
+    (a.geo_w0, a.geo_b0, a.geo_w1, a.geo_b1, a.app_w0, a.app_b0, a.app_w1, a.app_b1) = [t.data_ptr() for t in heads]
+    a.lr_mul = float(lr_mul)
+    a.n_views, a.n_rays, a.n_samples = N, M, S
+    if origins is not None:
+        origins = _dev(origins, "ray_origins", (N, M, 3))
+        dirs = _dev(dirs, "ray_directions", (N, M, 3))
+        a.origins, a.dirs = origins.data_ptr(), dirs.data_ptr()
+    else:
+        cam2world = _dev(cam2world, "cam2world_matrix", (N, 4, 4))
+        intrinsics = _dev(intrinsics, "intrinsics", (N, 3, 3))
+        a.cam2world, a.intrinsics, a.resolution = cam2world.data_ptr(), intrinsics.data_ptr(), int(resolution)
+    keep += [origins, dirs, cam2world, intrinsics] + heads
+    a.depths = depths_all.data_ptr()
+    a.box_warp = float(options["box_warp"])
+    a.white_back = int(bool(options.get("white_back", False)))
+    g_rgb, g_seg, g_depth, g_wsum = grads
+    if g_rgb is not None:
+        g_rgb = _dev(g_rgb, "grad_rgb", (N, 32, M) if channels_first else (N, M, 32)); a.grad_rgb = g_rgb.data_ptr()
+    if g_seg is not None:
+        g_seg = _dev(g_seg, "grad_seg", (N, 15, M) if channels_first else (N, M, 15)); a.grad_seg = g_seg.data_ptr()
+    if g_depth is not None:
+        g_depth = _dev(g_depth, "grad_depth").reshape(N, M); a.grad_depth = g_depth.data_ptr()
+    if g_wsum is not None:
+        g_wsum = _dev(g_wsum, "grad_wsum").reshape(N, M); a.grad_wsum = g_wsum.data_ptr()
+    keep += [g_rgb, g_seg, g_depth, g_wsum]
+    a.channels_first = int(channels_first)
+    need_g, need_a = bool(need[0]), bool(need[1])
+    gg = ga = None
+    if same:
+        gg = ga = torch.zeros_like(planes_geo) if (need_g or need_a) else None
+    else:
+        gg = torch.zeros_like(planes_geo) if need_g else None
+        ga = torch.zeros_like(planes_app) if need_a else None
+    if gg is None and ga is None:
+        return None, None
+    a.grad_planes_geo = gg.data_ptr() if gg is not None else None
+    a.grad_planes_app = ga.data_ptr() if ga is not None else None
+    a.grad_view_stride = 0 if bcast else 3 * H * W * 32
+    ws = _workspace(dev, lib.nfe_render_backward_workspace_bytes(N, M, S))
+    a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
+    with torch.cuda.device(dev):
+        _lib.check(lib.nfe_render_backward(ctypes.byref(a), _stream()), "nfe_render_backward")
+    return gg, ga
+
+
 def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affines=None, decoder_math=None):
     """nfe_point_query: coords [N,P,3] -> dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15])."""
     lib = _lib.load()

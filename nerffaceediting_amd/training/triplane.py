@@ -42,6 +42,10 @@ class DisentangledOSGDecoder(torch.nn.Module):
         return [self.geo_net[0].weight, self.geo_net[0].bias, self.geo_net[2].weight, self.geo_net[2].bias,
                 self.app_net[0].weight, self.app_net[0].bias, self.app_net[2].weight, self.app_net[2].bias]
 
+    def heads(self):
+        """The two heads as the 8 raw parameter tensors (geo w0,b0,w1,b1, app w0,b0,w1,b1), for the backward kernels."""
+        return [p.detach() for p in self._params()]
+
     def packed(self):
         ps = self._params()
         key = tuple((p.data_ptr(), p._version) for p in ps)
@@ -69,14 +73,17 @@ class OSGDecoder(torch.nn.Module):
         self.net = torch.nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr), torch.nn.Softplus(),
                                        FullyConnectedLayer(self.hidden_dim, 1 + options["decoder_output_dim"], lr_multiplier=lr))
 
+    def heads(self):
+        w0, b0, w2, b2 = (p.detach() for p in (self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias))
+        gw = torch.zeros(16, 64, device=w2.device); gb = torch.zeros(16, device=w2.device)
+        gw[:1], gb[:1] = w2[:1], b2[:1]
+        return [w0, b0, gw, gb, w0, b0, w2[1:].contiguous(), b2[1:].contiguous()]
+
     def packed(self):
         ps = [self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias]
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_packed_key", None) != key:
-            w0, b0, w2, b2 = (p.detach() for p in ps)
-            gw = torch.zeros(16, 64, device=w2.device); gb = torch.zeros(16, device=w2.device)
-            gw[:1], gb[:1] = w2[:1], b2[:1]
-            self._packed = ops.decoder_pack(w0, b0, gw, gb, w0, b0, w2[1:].contiguous(), b2[1:].contiguous(), lr_mul=self.lr_mul)
+            self._packed = ops.decoder_pack(*self.heads(), lr_mul=self.lr_mul)
             self._packed_key = key
         return self._packed
 

@@ -20,6 +20,38 @@ def generate_planes():
                          [[0, 0, 1], [1, 0, 0], [0, 1, 0]]], dtype=torch.float32)
 
 
+class _RenderWithPlaneGrad(torch.autograd.Function):
+    """forward = the fused render (with the sorted depths kept), backward = nfe_render_backward: what autograd does in the
+    reference when `norm_planes` / `denorm_planes` are leaves being optimised (plane editing through utils.decode,
+    utils.py:165-199).  Rays, jitter and decoder parameters are constants of this function."""
+
+    @staticmethod
+    def forward(ctx, norm_planes, denorm_planes, renderer, decoder, ray_origins, ray_directions, options, jitter, seed, limits):
+        same = norm_planes is denorm_planes
+        pg, pa = renderer._pack_pair(norm_planes.detach(), norm_planes.detach() if same else denorm_planes.detach())
+        out = ops.render(pg, pa, decoder.packed(), options, origins=ray_origins, dirs=ray_directions, u_coarse=jitter[0],
+                         u_fine=jitter[1], seed=seed, ray_limits=limits, taps=True, decoder_math=renderer.decoder_math)
+        ctx.save_for_backward(pg, pa, ray_origins, ray_directions, out[4]["depths_all"])
+        ctx.decoder, ctx.options, ctx.same = decoder, dict(options), same
+        ctx.shape = tuple(norm_planes.shape)
+        if renderer.keep_taps:
+            renderer.last_taps = out[4]
+        return out[0], out[1], out[2], out[3]
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_seg, g_depth, g_wsum):
+        pg, pa, o, d, depths_all = ctx.saved_tensors
+        need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        gg, ga = ops.render_backward(pg, pg if ctx.same else pa, ctx.decoder.heads(), ctx.decoder.lr_mul, ctx.options, depths_all,
+                                     (g_rgb, g_seg, g_depth, g_wsum), origins=o, dirs=d,
+                                     need=(need[0] or (ctx.same and need[1]), need[1] and not ctx.same))
+        unpack = lambda g: None if g is None else g.permute(0, 1, 4, 2, 3).reshape(ctx.shape)   # gather layout -> [N,3,32,H,W]
+        if ctx.same:        # one tensor fed both inputs: its whole gradient goes to whichever slot autograd asked for first
+            g = unpack(gg)
+            return (g if need[0] else None, g if (need[1] and not need[0]) else None) + (None,) * 8
+        return (unpack(gg) if need[0] else None, unpack(ga) if need[1] else None) + (None,) * 8
+
+
 class DisentangledImportanceRenderer(torch.nn.Module):
     def __init__(self):
         super().__init__()
@@ -59,11 +91,14 @@ class DisentangledImportanceRenderer(torch.nn.Module):
     def forward(self, norm_planes, denorm_planes, decoder, ray_origins, ray_directions, rendering_options):
         """norm_planes/denorm_planes [N,3,32,H,W]; ray_origins/ray_directions [N,M,3] ->
         (rgb [N,M,32], seg [N,M,15], depth [N,M,1], weights.sum(2) [N,M,1])   (renderer.py:363)."""
-        pg, pa = self._pack_pair(norm_planes, denorm_planes)
         limits = None
         if rendering_options["ray_start"] == rendering_options["ray_end"] == "auto":      # renderer.py:312
             limits = ops.ray_limits_box(ray_origins, ray_directions, rendering_options["box_warp"])
         u_c, u_f = self._take_jitter(rendering_options)
+        if torch.is_grad_enabled() and (norm_planes.requires_grad or denorm_planes.requires_grad):
+            return _RenderWithPlaneGrad.apply(norm_planes, denorm_planes, self, decoder, ray_origins.detach(), ray_directions.detach(),
+                                              rendering_options, (u_c, u_f), self._seed(), limits)
+        pg, pa = self._pack_pair(norm_planes, denorm_planes)
         out = ops.render(pg, pa, decoder.packed(), rendering_options, origins=ray_origins, dirs=ray_directions,
                          u_coarse=u_c, u_fine=u_f, seed=self._seed(), ray_limits=limits, taps=self.keep_taps,
                          decoder_math=self.decoder_math)

@@ -71,6 +71,30 @@ def test_conv_args_struct_matches_header(tmp_path):
         assert name == f and int(off) == getattr(_lib.ConvArgs, f).offset, (line, f)
 
 
+def test_render_backward_args_struct_matches_header(tmp_path):
+    from nerffaceediting_amd import _lib
+    fields = [f[0] for f in _lib.RenderBackwardArgs._fields_]
+    prog = "#include <stdio.h>\n#include <stddef.h>\n#include \"nfe_render.h\"\nint main(){\n"
+    prog += 'printf("%zu\\n", sizeof(nfe_render_backward_args));\n'
+    for f in fields:
+        prog += f'printf("{f} %zu\\n", offsetof(nfe_render_backward_args, {f}));\n'
+    prog += "return 0;}\n"
+    c = tmp_path / "probe3.c"
+    c.write_text(prog)
+    exe = tmp_path / "probe3"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)]).decode().split("\n")
+    assert int(out[0]) == ctypes.sizeof(_lib.RenderBackwardArgs)
+    for line, f in zip(out[1:], fields):
+        name, off = line.split()
+        assert name == f and int(off) == getattr(_lib.RenderBackwardArgs, f).offset, (line, f)
+    lib = _lib.load()
+    assert lib.nfe_render_backward_workspace_bytes(2, 64, 24) >= 3 * 2 * 64 * 24 * 4
+    a = _lib.RenderBackwardArgs()
+    a.struct_size = 8
+    assert lib.nfe_render_backward(ctypes.byref(a), None) == -1 and b"struct_size" in lib.nfe_last_error()
+
+
 def test_workspace_query_and_argument_errors_without_gpu():
     from nerffaceediting_amd import _lib
     lib = _lib.load()
