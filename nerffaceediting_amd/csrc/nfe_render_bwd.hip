@@ -31,6 +31,9 @@ constexpr int BW_A1T = 5264;    // [64][32]
 constexpr int BB_A1 = 7312;     // [32]
 constexpr int BWD_DEC_FLOATS = 7344;
 constexpr int BWD_DEC_BYTES = 32768;
+#ifndef BWD_WAVES
+#define BWD_WAVES 2      // waves per SIMD the sample kernels are compiled for; 3 and 4 (168 / 128 VGPRs, spills) measured slower
+#endif
 
 struct BwdK {
     const float* planes_g; const float* planes_a; long long plane_view_stride; int H, W;
@@ -109,86 +112,98 @@ __device__ __forceinline__ void sample_geometry(const BwdK& P, int n, int m, flo
 }
 
 // Feature vector of one plane set: mean over planes of (bilinear sample * scale + in-bounds weight * shift)
-// (scale/shift NULL = identity).  aff_* point at this view's [96] rows.
+// (scale/shift NULL = identity).  aff_* point at this view's [96] rows.  Channels are kept
+// as pairs: the decoder below runs on v_pk_fma_f32.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
+
 __device__ __forceinline__ void gather_set(const float* __restrict__ planes, const SampleGeo& g,
-                                           const float* __restrict__ scale, const float* __restrict__ shift, float (&f)[32]) {
+                                           const float* __restrict__ scale, const float* __restrict__ shift, f32x2 (&f)[16]) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) f[c] = 0.0f;
+    for (int c = 0; c < 16; ++c) f[c] = splat(0.0f);
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        float s[32];
+        f32x2 s[16];
 #pragma unroll
-        for (int c = 0; c < 32; ++c) s[c] = 0.0f;
+        for (int c = 0; c < 16; ++c) s[c] = splat(0.0f);
         float wsum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float4* tx = reinterpret_cast<const float4*>(planes + g.off[4 * p + k]);
-            const float w = g.w[4 * p + k];
-            wsum += w;
+            const f32x2 w = splat(g.w[4 * p + k]);
+            wsum += g.w[4 * p + k];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const float4 v = tx[q];
-                s[4 * q] = fmaf(w, v.x, s[4 * q]); s[4 * q + 1] = fmaf(w, v.y, s[4 * q + 1]);
-                s[4 * q + 2] = fmaf(w, v.z, s[4 * q + 2]); s[4 * q + 3] = fmaf(w, v.w, s[4 * q + 3]);
+                s[2 * q] = pk_fma(w, f32x2{v.x, v.y}, s[2 * q]);
+                s[2 * q + 1] = pk_fma(w, f32x2{v.z, v.w}, s[2 * q + 1]);
             }
         }
         if (scale) {
+            const f32x2* sc = reinterpret_cast<const f32x2*>(scale + p * 32);
+            const f32x2* sh = reinterpret_cast<const f32x2*>(shift + p * 32);
 #pragma unroll
-            for (int c = 0; c < 32; ++c) f[c] += fmaf(s[c], scale[p * 32 + c], wsum * shift[p * 32 + c]);
+            for (int c = 0; c < 16; ++c) f[c] += pk_fma(s[c], sc[c], splat(wsum) * sh[c]);
         } else {
 #pragma unroll
-            for (int c = 0; c < 32; ++c) f[c] += s[c];
+            for (int c = 0; c < 16; ++c) f[c] += s[c];
         }
     }
 #pragma unroll
-    for (int c = 0; c < 32; ++c) f[c] *= (1.0f / 3.0f);
+    for (int c = 0; c < 16; ++c) f[c] *= splat(1.0f / 3.0f);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// decoder heads in fp32, one sample per lane, weights at wave-uniform addresses
+// decoder heads in fp32, one sample per lane, weights at wave-uniform addresses (scalar loads, SGPR operands)
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float softplus_t(float x) {      // torch.nn.Softplus(beta=1, threshold=20)
-    return x > 20.0f ? x : log1pf(__expf(x));
+    const float r = __builtin_amdgcn_logf(1.0f + __builtin_amdgcn_exp2f(x * LOG2E)) * LN2;
+    return x > 20.0f ? x : r;
 }
-__device__ __forceinline__ float sigmoid_t(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float sigmoid_t(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-x * LOG2E)); }
 
-__device__ __forceinline__ float hidden_pre(const float* __restrict__ w0, const float* __restrict__ b0, int j, const float (&f)[32]) {
-    float pre = b0[j];
+__device__ __forceinline__ float hidden_pre(const float* __restrict__ w0, const float* __restrict__ b0, int j, const f32x2 (&f)[16]) {
+    const f32x2* w = reinterpret_cast<const f32x2*>(w0 + j * 32);
+    f32x2 acc = f32x2{b0[j], 0.0f};
 #pragma unroll
-    for (int c = 0; c < 32; ++c) pre = fmaf(w0[j * 32 + c], f[c], pre);
-    return pre;
+    for (int c = 0; c < 16; ++c) acc = pk_fma(w[c], f[c], acc);
+    return acc[0] + acc[1];
 }
 
 template <int NO>
 __device__ __forceinline__ void head_forward(const float* __restrict__ w0, const float* __restrict__ b0,
                                              const float* __restrict__ w1t, const float* __restrict__ b1,
-                                             const float (&f)[32], float (&out)[NO]) {
+                                             const f32x2 (&f)[16], f32x2 (&out)[NO / 2]) {
 #pragma unroll
-    for (int o = 0; o < NO; ++o) out[o] = b1[o];
+    for (int o = 0; o < NO / 2; ++o) out[o] = f32x2{b1[2 * o], b1[2 * o + 1]};
 #pragma unroll 2
     for (int j = 0; j < 64; ++j) {
-        const float h = softplus_t(hidden_pre(w0, b0, j, f));
+        const f32x2 h = splat(softplus_t(hidden_pre(w0, b0, j, f)));
+        const f32x2* w = reinterpret_cast<const f32x2*>(w1t + j * NO);
 #pragma unroll
-        for (int o = 0; o < NO; ++o) out[o] = fmaf(w1t[j * NO + o], h, out[o]);
+        for (int o = 0; o < NO / 2; ++o) out[o] = pk_fma(w[o], h, out[o]);
     }
 }
 
 // df = W0^T (softplus'(pre) * (W1^T dout)); the pre-activations are recomputed (cheaper than 64 live registers)
 template <int NO>
 __device__ __forceinline__ void head_backward(const float* __restrict__ w0, const float* __restrict__ b0,
-                                              const float* __restrict__ w1t, const float (&f)[32],
-                                              const float (&dout)[NO], float (&df)[32]) {
+                                              const float* __restrict__ w1t, const f32x2 (&f)[16],
+                                              const f32x2 (&dout)[NO / 2], f32x2 (&df)[16]) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) df[c] = 0.0f;
+    for (int c = 0; c < 16; ++c) df[c] = splat(0.0f);
 #pragma unroll 2
     for (int j = 0; j < 64; ++j) {
         const float pre = hidden_pre(w0, b0, j, f);
-        float dh = 0.0f;
+        const f32x2* w1 = reinterpret_cast<const f32x2*>(w1t + j * NO);
+        f32x2 dh = splat(0.0f);
 #pragma unroll
-        for (int o = 0; o < NO; ++o) dh = fmaf(w1t[j * NO + o], dout[o], dh);
-        const float dpre = dh * (pre > 20.0f ? 1.0f : sigmoid_t(pre));
+        for (int o = 0; o < NO / 2; ++o) dh = pk_fma(w1[o], dout[o], dh);
+        const f32x2 dpre = splat((dh[0] + dh[1]) * (pre > 20.0f ? 1.0f : sigmoid_t(pre)));
+        const f32x2* w = reinterpret_cast<const f32x2*>(w0 + j * 32);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) df[c] = fmaf(w0[j * 32 + c], dpre, df[c]);
+        for (int c = 0; c < 16; ++c) df[c] = pk_fma(w[c], dpre, df[c]);
     }
 }
 
@@ -204,7 +219,7 @@ __device__ __forceinline__ float cot_seg(const BwdK& P, int n, int m, int c) {
 // ------------------------------------------------------------------------------------------------------------
 // pass 1: sigma_i and a_i
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bwd_eval_kernel(BwdK P) {
+__global__ __launch_bounds__(256, BWD_WAVES) void bwd_eval_kernel(BwdK P) {
     const int n = blockIdx.y;
     const long long per_view = (long long)P.M * P.S;
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -215,23 +230,24 @@ __global__ __launch_bounds__(256) void bwd_eval_kernel(BwdK P) {
     sample_geometry(P, n, m, P.depths[g], geo);
     const long long pv = (long long)n * P.plane_view_stride;
     const float* dec = P.dec;
-    float f[32];
+    f32x2 f[16];
     gather_set(P.planes_g + pv, geo, P.aff[0] ? P.aff[0] + n * 96 : nullptr, P.aff[1] ? P.aff[1] + n * 96 : nullptr, f);
-    float og[16];
+    f32x2 og[8];
     head_forward<16>(dec + BW_G0, dec + BB_G0, dec + BW_G1T, dec + BB_G1, f, og);
     float a = 0.0f;
     if (P.g_seg) {
 #pragma unroll
-        for (int c = 0; c < 15; ++c) a = fmaf(cot_seg(P, n, m, c), og[1 + c], a);
+        for (int c = 0; c < 15; ++c) a = fmaf(cot_seg(P, n, m, c), og[(1 + c) >> 1][(1 + c) & 1], a);
     }
+    const float sigma = og[0][0];
     if (P.g_rgb) {
         gather_set(P.planes_a + pv, geo, P.aff[2] ? P.aff[2] + n * 96 : nullptr, P.aff[3] ? P.aff[3] + n * 96 : nullptr, f);
-        float oa[32];
+        f32x2 oa[16];
         head_forward<32>(dec + BW_A0, dec + BB_A0, dec + BW_A1T, dec + BB_A1, f, oa);
 #pragma unroll
-        for (int c = 0; c < 32; ++c) a = fmaf(cot_rgb(P, n, m, c), sigmoid_t(oa[c]) * 1.002f - 0.001f, a);    // triplane.py:269
+        for (int c = 0; c < 32; ++c) a = fmaf(cot_rgb(P, n, m, c), sigmoid_t(oa[c >> 1][c & 1]) * 1.002f - 0.001f, a);    // triplane.py:269
     }
-    P.rec_sig[g] = og[0];
+    P.rec_sig[g] = sigma;
     P.rec_a[g] = a;
 }
 
@@ -240,9 +256,9 @@ __global__ __launch_bounds__(256) void bwd_eval_kernel(BwdK P) {
 // ------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void segment(float s0, float s1, float t0, float t1, float& alpha, float& dalpha_dsmid) {
     const float x = (s0 + s1) * 0.5f - 1.0f;                        // ray_marcher.py:72,76
-    const float dens = x > 20.0f ? x : log1pf(__expf(x));
+    const float dens = softplus_t(x);
     const float dlt = t1 - t0;
-    const float e = __expf(-dens * dlt);
+    const float e = __builtin_amdgcn_exp2f(-dens * dlt * LOG2E);
     alpha = 1.0f - e;                                               // :80-82
     dalpha_dsmid = dlt * e * (x > 20.0f ? 1.0f : sigmoid_t(x));
 }
@@ -304,10 +320,10 @@ constexpr int SCATTER_LDS_FLOATS = 4 * 64 * TILE_STRIDE;
 
 // Adds df (this lane's sample, 32 channels, already / 3) into the gradient plane set: half-wave h handles sample
 // 2*it + h of the wave, lane&31 = channel, one 128-byte texel row per half-wave per atomic instruction.
-__device__ __forceinline__ void scatter_set(float* __restrict__ tile, const float (&df)[32], const SampleGeo& geo, bool live,
+__device__ __forceinline__ void scatter_set(float* __restrict__ tile, const f32x2 (&df)[16], const SampleGeo& geo, bool live,
                                             float* __restrict__ grad, const float* __restrict__ scale, int lane) {
 #pragma unroll
-    for (int c = 0; c < 32; ++c) tile[lane * TILE_STRIDE + c] = df[c];
+    for (int c = 0; c < 32; ++c) tile[lane * TILE_STRIDE + c] = df[c >> 1][c & 1] * (1.0f / 3.0f);   // mean over planes, triplane.py:251
     __builtin_amdgcn_wave_barrier();
     const int ch = lane & 31, hh = lane >> 5;
     float sc[3] = {1.0f, 1.0f, 1.0f};
@@ -321,13 +337,19 @@ __device__ __forceinline__ void scatter_set(float* __restrict__ tile, const floa
         for (int k = 0; k < 12; ++k) {
             const int off = __shfl(geo.off[k], src);
             const float w = __shfl(geo.w[k], src);
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 1      // timing experiments only: plain stores / no memory operation
+            if (alive && w != 0.0f) grad[off + ch] = v * w * sc[k >> 2];
+#elif defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 2
+            if (alive && w != 0.0f) asm volatile("" :: "v"(v * w * sc[k >> 2]), "v"(off));
+#else
             if (alive && w != 0.0f) unsafeAtomicAdd(grad + off + ch, v * w * sc[k >> 2]);
+#endif
         }
     }
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(256) void bwd_scatter_kernel(BwdK P) {
+__global__ __launch_bounds__(256, BWD_WAVES) void bwd_scatter_kernel(BwdK P) {
     __shared__ float tiles[SCATTER_LDS_FLOATS];
     const int n = blockIdx.y;
     const int lane = threadIdx.x & 63;
@@ -344,32 +366,28 @@ __global__ __launch_bounds__(256) void bwd_scatter_kernel(BwdK P) {
     const long long pv = (long long)n * P.plane_view_stride;
     const long long gv = (long long)n * P.grad_view_stride;
     const float* dec = P.dec;
-    float f[32], df[32];
+    f32x2 f[16], df[16];
     if (P.grad_g) {
         const float* scale = P.aff[0] ? P.aff[0] + n * 96 : nullptr;
         gather_set(P.planes_g + pv, geo, scale, P.aff[1] ? P.aff[1] + n * 96 : nullptr, f);
-        float dout[16];
-        dout[0] = gsig;                                            // sigma = channel 0, seg = 1..15 (triplane.py:260-261)
+        f32x2 dout[8];
+        dout[0][0] = gsig;                                         // sigma = channel 0, seg = 1..15 (triplane.py:260-261)
 #pragma unroll
-        for (int c = 0; c < 15; ++c) dout[1 + c] = omega * cot_seg(P, n, m, c);
+        for (int c = 0; c < 15; ++c) dout[(1 + c) >> 1][(1 + c) & 1] = omega * cot_seg(P, n, m, c);
         head_backward<16>(dec + BW_G0, dec + BB_G0, dec + BW_G1T, f, dout, df);
-#pragma unroll
-        for (int c = 0; c < 32; ++c) df[c] *= (1.0f / 3.0f);      // mean over planes, triplane.py:251
         scatter_set(tile, df, geo, live, P.grad_g + gv, scale, lane);
     }
     if (P.grad_a && P.g_rgb) {
         const float* scale = P.aff[2] ? P.aff[2] + n * 96 : nullptr;
         gather_set(P.planes_a + pv, geo, scale, P.aff[3] ? P.aff[3] + n * 96 : nullptr, f);
-        float y[32];
+        f32x2 y[16];
         head_forward<32>(dec + BW_A0, dec + BB_A0, dec + BW_A1T, dec + BB_A1, f, y);
 #pragma unroll
         for (int c = 0; c < 32; ++c) {                             // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269)
-            const float s = sigmoid_t(y[c]);
-            y[c] = omega * cot_rgb(P, n, m, c) * 1.002f * s * (1.0f - s);
+            const float s = sigmoid_t(y[c >> 1][c & 1]);
+            y[c >> 1][c & 1] = omega * cot_rgb(P, n, m, c) * 1.002f * s * (1.0f - s);
         }
         head_backward<32>(dec + BW_A0, dec + BB_A0, dec + BW_A1T, f, y, df);
-#pragma unroll
-        for (int c = 0; c < 32; ++c) df[c] *= (1.0f / 3.0f);
         scatter_set(tile, df, geo, live, P.grad_a + gv, scale, lane);
     }
 }
