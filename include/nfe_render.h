@@ -156,12 +156,13 @@ int nfe_render(const nfe_render_args* args, nfe_stream_t stream);
 
 /* ---- a15: renderer.run_model on caller-supplied points (triplane.py:140-157, renderer.py:259-287)
  * coords [N,P,3] -> rgb [N,P,32], sigma [N,P], seg [N,P,15]. Plane/affine/decoder arguments as in
- * nfe_render_args. */
+ * nfe_render_args.  density_noise > 0 (renderer.py:285-286): sigma += N(0,1) * density_noise, the normal of point
+ * (n, m) being the Philox draw keyed by (seed; n*P + m, draw 0), as in nfe_render. */
 int nfe_point_query(const float* planes_geo, const float* planes_app, int plane_h, int plane_w,
                     int64_t plane_view_stride, const float* geo_scale, const float* geo_shift,
                     const float* app_scale, const float* app_shift, const float* decoder_packed,
                     int decoder_math, const float* coords, int n_views, int n_points, float box_warp,
-                    float* rgb, float* sigma, float* seg, nfe_stream_t stream);
+                    float* rgb, float* sigma, float* seg, float density_noise, uint64_t seed, nfe_stream_t stream);
 
 /* ---- backward of a5..a12 with respect to the plane sets ------------------------------------------
  * The vector-Jacobian product torch autograd computes for DisentangledImportanceRenderer.forward

@@ -125,7 +125,7 @@ _SIGNATURES = {
     "nfe_conv_accepts_split": (c_int, [c_int] * 5),
     "nfe_resize_bilinear": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
-                                FP, FP, FP, c_void_p]),
+                                FP, FP, FP, c_float, c_uint64, c_void_p]),
 }
 
 _lib = None

@@ -1018,6 +1018,7 @@ struct PointK {
     const float* aff[4]; const float* dec;
     const float* coords; int N, Pn; float coord_scale;
     float* rgb; float* sigma; float* seg;
+    float density_noise; unsigned long long seed;      // renderer.py:285-286 on points: Philox key (seed; point n*P+m, draw 0)
 };
 
 template <bool DUAL, int MATH>
@@ -1052,7 +1053,7 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
 #pragma unroll
             for (int cc = 0; cc < 8; ++cc)
                 if (cc < nseg) P.seg[pt * 15 + 8 * h + cc] = og[2 + cc];
-            if (h == 0) P.sigma[pt] = og[0];
+            if (h == 0) P.sigma[pt] = P.density_noise > 0.0f ? fmaf(P.density_noise, sample_gaussian(P.seed, (unsigned)pt, 0u), og[0]) : og[0];
         }
     }
 }
@@ -1235,19 +1236,21 @@ extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app,
                                int64_t plane_view_stride, const float* geo_scale, const float* geo_shift,
                                const float* app_scale, const float* app_shift, const float* decoder_packed,
                                int decoder_math, const float* coords, int n_views, int n_points, float box_warp,
-                               float* rgb, float* sigma, float* seg, nfe_stream_t stream) {
+                               float* rgb, float* sigma, float* seg, float density_noise, uint64_t seed, nfe_stream_t stream) {
     NFE_REQUIRE(planes_geo && planes_app && decoder_packed && coords, "nfe_point_query: null input pointer");
     NFE_REQUIRE(rgb && sigma && seg, "nfe_point_query: null output pointer");
     NFE_REQUIRE(plane_h > 0 && plane_w > 0 && (long long)plane_h * plane_w <= (1ll << 25), "nfe_point_query: bad plane size %dx%d", plane_h, plane_w);
     NFE_REQUIRE(n_views > 0 && n_points >= 0, "nfe_point_query: bad sizes N=%d P=%d", n_views, n_points);
     NFE_REQUIRE(box_warp > 0.0f, "nfe_point_query: box_warp must be positive");
     NFE_REQUIRE(decoder_math == NFE_MATH_BF16X3 || decoder_math == NFE_MATH_FP32, "nfe_point_query: unknown decoder_math %d", decoder_math);
+    NFE_REQUIRE(density_noise >= 0.0f, "nfe_point_query: density_noise must be >= 0");
+    NFE_REQUIRE((long long)n_views * n_points < (1ll << 32) || density_noise == 0.0f, "nfe_point_query: density_noise needs N*P < 2^32");
     if (n_points == 0) return NFE_OK;
     PointK P{};
     P.planes_g = planes_geo; P.planes_a = planes_app; P.plane_view_stride = plane_view_stride; P.H = plane_h; P.W = plane_w;
     P.aff[0] = geo_scale; P.aff[1] = geo_shift; P.aff[2] = app_scale; P.aff[3] = app_shift;
     P.dec = decoder_packed; P.coords = coords; P.N = n_views; P.Pn = n_points; P.coord_scale = 2.0f / box_warp;
-    P.rgb = rgb; P.sigma = sigma; P.seg = seg;
+    P.rgb = rgb; P.sigma = sigma; P.seg = seg; P.density_noise = density_noise; P.seed = seed;
     const long long total = (long long)n_views * ((n_points + 31) / 32);
     long long blocks = (total + 3) / 4;
     if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;

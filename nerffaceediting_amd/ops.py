@@ -327,8 +327,9 @@ def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, dept
     return gg, ga
 
 
-def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affines=None, decoder_math=None):
-    """nfe_point_query: coords [N,P,3] -> dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15])."""
+def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affines=None, decoder_math=None, density_noise=0.0, seed=0):
+    """nfe_point_query: coords [N,P,3] -> dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15]).  density_noise > 0 adds
+    N(0,1) * density_noise to sigma (renderer.py:285-286; Philox normals keyed by `seed` and the point index)."""
     lib = _lib.load()
     planes_geo = _dev(planes_geo, "planes_geo", (None, 3, None, None, 32))
     planes_app = planes_geo if planes_app is planes_geo else _dev(planes_app, "planes_app", tuple(planes_geo.shape))
@@ -350,5 +351,6 @@ def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affine
     with torch.cuda.device(dev):
         _lib.check(lib.nfe_point_query(_ptr(planes_geo), _ptr(planes_app), H, W, stride, *[_ptr(t) for t in aff],
                                        _ptr(decoder_packed), _math_mode(decoder_math), _ptr(coords), N, P, float(box_warp),
-                                       _ptr(rgb), _ptr(sigma), _ptr(seg), _stream()), "nfe_point_query")
+                                       _ptr(rgb), _ptr(sigma), _ptr(seg), float(density_noise), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()),
+                   "nfe_point_query")
     return {"rgb": rgb, "sigma": sigma, "seg": seg}

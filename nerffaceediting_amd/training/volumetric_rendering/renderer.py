@@ -127,11 +127,11 @@ class DisentangledImportanceRenderer(torch.nn.Module):
     def run_model(self, norm_planes, denorm_planes, decoder, sample_coordinates, sample_directions, options):
         """renderer.py:259-287: dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15]) at arbitrary points.
         sample_directions is unused, as in every decoder of the reference (triplane.py:249)."""
-        if options.get("density_noise", 0) > 0:
-            raise RuntimeError("density_noise > 0 is not supported")
+        noise = float(options.get("density_noise", 0) or 0)                       # renderer.py:285-286
         pg, pa = self._pack_pair(norm_planes, denorm_planes)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if noise > 0 else 0
         return ops.point_query(pg, pa, decoder.packed(), sample_coordinates, options["box_warp"],
-                               decoder_math=self.decoder_math)
+                               decoder_math=self.decoder_math, density_noise=noise, seed=seed)
 
 
 class ImportanceRenderer(DisentangledImportanceRenderer):

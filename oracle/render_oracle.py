@@ -271,13 +271,18 @@ def decoder_disentangled(f_norm, f_denorm, dec, lr_mul=1.0):
     return rgb.astype(F32), sigma.astype(F32), seg.astype(F32)
 
 
-def run_model(norm_planes, denorm_planes, dec, coords, options):
-    """DisentangledImportanceRenderer.run_model, renderer.py:259-287 (density_noise unsupported: key
-    absent from every shipped config, train.py:288-323)."""
-    assert options.get("density_noise", 0) == 0
+def run_model(norm_planes, denorm_planes, dec, coords, options, noise_seed=0):
+    """DisentangledImportanceRenderer.run_model, renderer.py:259-287.  density_noise (:285-286; absent from every shipped
+    config, train.py:288-323): the reference's randn_like stream is torch's; here the normal of point (n, m) is the Philox
+    draw the HIP library makes (density_noise_normals with ray = n*P + m, draw 0)."""
     fn = sample_from_planes(norm_planes, coords, options["box_warp"])
     fd = sample_from_planes(denorm_planes, coords, options["box_warp"])
-    return decoder_disentangled(fn, fd, dec, options.get("decoder_lr_mul", 1))
+    rgb, sigma, seg = decoder_disentangled(fn, fd, dec, options.get("decoder_lr_mul", 1))
+    noise = F32(options.get("density_noise", 0) or 0)
+    if noise > 0:
+        N, P = coords.shape[:2]
+        sigma = (sigma + noise * density_noise_normals(noise_seed, (N, P), np.zeros((N, P, 1), np.uint32))[..., 0]).astype(F32)
+    return rgb, sigma, seg
 
 
 # --------------------------------------------------------------------------------------

@@ -132,3 +132,40 @@ def test_density_noise_matches_oracle(Di, dev):
     assert max_abs(got[0], other[0]) > 1e-3 and max_abs(got[0], quiet[0]) > 1e-3
     with pytest.raises(RuntimeError):
         ops.render(pg, pa, decp, dict(opts, density_noise=-1.0), seed=seed, **kw)
+
+
+def test_point_query_density_noise_matches_oracle(dev):
+    """run_model with rendering_options['density_noise'] (renderer.py:285-286) on caller-supplied points: the normal of
+    point (n, m) is the Philox draw keyed by (seed; n*P + m, 0), which the oracle restates."""
+    from nerffaceediting_amd import ops
+    rng = np.random.RandomState(12)
+    N, H, P = 2, 16, 777
+    planes = (rng.randn(N, 96, H, H) * 1.1).astype(np.float32)
+    dec = orc.random_decoder(13, bias_scale=0.2)
+    coords = (rng.rand(N, P, 3).astype(np.float32) - 0.5) * 1.1
+    seed = 0xABCDEF0123
+    opts = dict(box_warp=1, density_noise=0.6)
+    want = orc.run_model(*orc.synthesis_planes(planes)[:2], dec, coords, opts, noise_seed=seed)
+    quiet = orc.run_model(*orc.synthesis_planes(planes)[:2], dec, coords, dict(opts, density_noise=0))
+    assert float(np.abs(want[1] - quiet[1]).std()) > 0.2                    # the noise is really there
+    p = t(planes, dev)
+    mean, std = ops.plane_stats(p)
+    packed = ops.plane_pack(p)
+    decp = ops.decoder_pack(*[t(dec[k], dev) for k in NAMES])
+    got = ops.point_query(packed, packed, decp, t(coords, dev), 1.0, affines=ops.make_affine(mean, std), density_noise=0.6, seed=seed)
+    assert float(np.abs(got["sigma"].cpu().numpy() - want[1]).max()) <= 1e-3
+    assert float(np.abs(got["rgb"].cpu().numpy() - want[0]).max()) <= 1e-3
+    # through the module interface (seed drawn from torch's generator: reproducible under manual_seed)
+    from nerffaceediting_amd.training.triplane import DisentangledOSGDecoder
+    from nerffaceediting_amd.training.volumetric_rendering.renderer import DisentangledImportanceRenderer
+    d = DisentangledOSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32, "decoder_seg_dim": 15})
+    d.load_state_dict({k: torch.from_numpy(v) for k, v in dec.items()})
+    d = d.to(dev)
+    norm5, den5 = (t(a, dev) for a in orc.synthesis_planes(planes)[:2])
+    rend = DisentangledImportanceRenderer()
+    torch.manual_seed(5); a = rend.run_model(norm5, den5, d, t(coords, dev), None, opts)["sigma"]
+    torch.manual_seed(5); b = rend.run_model(norm5, den5, d, t(coords, dev), None, opts)["sigma"]
+    c = rend.run_model(norm5, den5, d, t(coords, dev), None, opts)["sigma"]
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    with pytest.raises(RuntimeError, match="density_noise"):
+        ops.point_query(packed, packed, decp, t(coords, dev), 1.0, density_noise=-0.5)
