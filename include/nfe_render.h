@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NFE_ABI_VERSION 5
+#define NFE_ABI_VERSION 6
 
 #define NFE_OK 0
 #define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */
@@ -101,6 +101,15 @@ int nfe_decoder_pack(const float* geo_w0, const float* geo_b0, const float* geo_
                      const float* app_w0, const float* app_b0, const float* app_w1, const float* app_b1,
                      float lr_mul, float* packed, nfe_stream_t stream);
 
+/* ---- SegmentationOSGDecoder (triplane.py:192-230, the `disable_alignment` ablation): sigma and rgb come from `net`,
+ * seg from `seg_net`, both reading the same features.  For the fused kernels `seg_net` is the geometry head (its sigma
+ * row zero, sigma's bias in geo_b1[0]), `net` rows 1..32 the appearance head, and the sigma row of `net` is this CROSS
+ * matrix: cross_w1 [16,64], row r = weights of geometry output r (0 = sigma, 1..15 = seg) on the APPEARANCE head's
+ * hidden units -> packed_cross [NFE_DECODER_CROSS_FLOATS].  Pass it as nfe_render_args.decoder_cross /
+ * nfe_point_query(decoder_cross); needs planes_geo == planes_app, NFE_MATH_BF16X3, density_noise == 0. */
+#define NFE_DECODER_CROSS_FLOATS 2048
+int nfe_decoder_pack_cross(const float* cross_w1, float lr_mul, float* packed_cross, nfe_stream_t stream);
+
 /* ---- a5..a12: DisentangledImportanceRenderer.forward (renderer.py:301-363) --------------------*/
 typedef struct nfe_render_args {
     uint32_t struct_size;              /* = sizeof(nfe_render_args) */
@@ -147,6 +156,7 @@ typedef struct nfe_render_args {
     float density_noise;               /* renderer.py:285-286: sigma += N(0,1) * density_noise; the normals are Philox
                                           draws keyed by (seed, ray, draw index), 0 = off.  With importance sampling the
                                           workspace must hold N*M*(D+Di)*4 more bytes (rounded up to 256). */
+    const float* decoder_cross;        /* optional, from nfe_decoder_pack_cross (SegmentationOSGDecoder); NULL = none */
 } nfe_render_args;
 
 /* bytes of workspace nfe_render needs for these sizes */
@@ -162,7 +172,8 @@ int nfe_point_query(const float* planes_geo, const float* planes_app, int plane_
                     int64_t plane_view_stride, const float* geo_scale, const float* geo_shift,
                     const float* app_scale, const float* app_shift, const float* decoder_packed,
                     int decoder_math, const float* coords, int n_views, int n_points, float box_warp,
-                    float* rgb, float* sigma, float* seg, float density_noise, uint64_t seed, nfe_stream_t stream);
+                    float* rgb, float* sigma, float* seg, float density_noise, uint64_t seed,
+                    const float* decoder_cross /* optional, see nfe_decoder_pack_cross */, nfe_stream_t stream);
 
 /* ---- backward of a5..a12 with respect to the plane sets ------------------------------------------
  * The vector-Jacobian product torch autograd computes for DisentangledImportanceRenderer.forward

@@ -7,9 +7,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 5
+NFE_ABI_VERSION = 6
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
+NFE_DECODER_CROSS_FLOATS = 2048
 NFE_MATH_BF16X3, NFE_MATH_FP32 = 0, 1
 
 FP = c_void_p      # device pointers travel as integers
@@ -36,7 +37,7 @@ class RenderArgs(ctypes.Structure):
         ("rgb", FP), ("seg", FP), ("depth", FP), ("wsum", FP),
         ("channels_first", c_int32),
         ("tap_weights_coarse", FP), ("tap_depths_fine", FP), ("tap_depths_all", FP),
-        ("workspace", FP), ("workspace_bytes", c_uint64), ("density_noise", c_float),
+        ("workspace", FP), ("workspace_bytes", c_uint64), ("density_noise", c_float), ("decoder_cross", FP),
     ]
 
 
@@ -102,6 +103,7 @@ _SIGNATURES = {
     "nfe_make_affine": (c_int, [FP, FP, FP, FP, c_int, c_int, c_int, FP, FP, FP, FP, c_void_p]),
     "nfe_plane_pack": (c_int, [FP, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_decoder_pack": (c_int, [FP] * 8 + [c_float, FP, c_void_p]),
+    "nfe_decoder_pack_cross": (c_int, [FP, c_float, FP, c_void_p]),
     "nfe_render_workspace_bytes": (c_uint64, [c_int, c_int, c_int, c_int]),
     "nfe_render": (c_int, [POINTER(RenderArgs), c_void_p]),
     "nfe_render_backward_workspace_bytes": (c_uint64, [c_int, c_int, c_int]),
@@ -125,7 +127,7 @@ _SIGNATURES = {
     "nfe_conv_accepts_split": (c_int, [c_int] * 5),
     "nfe_resize_bilinear": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
-                                FP, FP, FP, c_float, c_uint64, c_void_p]),
+                                FP, FP, FP, c_float, c_uint64, FP, c_void_p]),
 }
 
 _lib = None

@@ -74,6 +74,7 @@ def extract_density(G, ws, shape_res=128, max_batch=1 << 20, cube_length=None, *
     """gen_samples.py:79-101,186-205 shape extraction: sigma on a shape_res^3 grid -> [R,R,R].
     The tri-planes are synthesised ONCE and reused for every chunk (the reference re-runs the backbone per chunk)."""
     from . import ops
+    from .training.triplane import packed_cross_of
     L = cube_length if cube_length is not None else G.rendering_kwargs["box_warp"]
     R = shape_res
     lin = torch.arange(R, device=ws.device, dtype=torch.float32)
@@ -82,10 +83,13 @@ def extract_density(G, ws, shape_res=128, max_batch=1 << 20, cube_length=None, *
     pts = torch.stack([(idx % R).float(), ((idx // R) % R).float(), ((idx // R) // R % R).float()], 1) * voxel - L / 2
     packed, mean, var = G._planes(ws, synthesis_kwargs)
     aff = ops.make_affine(mean, var)
+    if G.disable_disentangle:                  # triplane.py:144-148: both heads read the raw planes
+        aff = tuple(torch.ones_like(a) if i % 2 == 0 else torch.zeros_like(a) for i, a in enumerate(aff))
     out = torch.empty(R ** 3, device=ws.device)
     for s in range(0, R ** 3, max_batch):
         e = min(R ** 3, s + max_batch)
         out[s:e] = ops.point_query(packed, packed, G.decoder.packed(), pts[None, s:e].contiguous(), G.rendering_kwargs["box_warp"],
-                                   affines=aff)["sigma"].reshape(-1)
+                                   affines=aff, decoder_math=G.renderer.decoder_math,
+                                   decoder_cross=packed_cross_of(G.decoder))["sigma"].reshape(-1)
     del lin
     return out.reshape(R, R, R)

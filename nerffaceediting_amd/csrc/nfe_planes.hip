@@ -300,6 +300,33 @@ extern "C" int nfe_plane_pack(const float* planes_nchw, int n, int h, int w, flo
     return NFE_OK;
 }
 
+// Cross fragments: the layer-1 geometry-head layout (frag = ks*2 + part) with weights that multiply the APPEARANCE head's
+// hidden units (which carry 1/ln2, like the geometry head's: same ln2 folding as dec_w1(net 0)).
+__global__ void decoder_pack_cross_kernel(const float* cross_w1, float lr_mul, float* out) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= NFE_DECODER_CROSS_FLOATS) return;
+    const int frag = x / 256, lane = (x % 256) / 4, word = x % 4;
+    const int i = lane & 31, h = lane >> 5, part = frag & 1, ks = frag >> 1;
+    const float g1 = lr_mul / sqrtf(64.0f);
+    unsigned bits[2];
+    for (int t = 0; t < 2; ++t) {
+        const int el = 2 * word + t;
+        const int o = geo_row_to_out(i);
+        const float w = o >= 0 ? cross_w1[o * 64 + hidden_unit(ks >> 1, 8 * (ks & 1) + el, h)] * g1 * LN2 : 0.0f;
+        const unsigned hi = bf16_rne_bits(w);
+        bits[t] = part == 0 ? hi : bf16_rne_bits(w - __uint_as_float(hi << 16));
+    }
+    out[x] = __uint_as_float((bits[0] & 0xffffu) | (bits[1] << 16));
+}
+
+extern "C" int nfe_decoder_pack_cross(const float* cross_w1, float lr_mul, float* packed_cross, nfe_stream_t stream) {
+    NFE_REQUIRE(cross_w1 && packed_cross, "nfe_decoder_pack_cross: null pointer");
+    hipLaunchKernelGGL(decoder_pack_cross_kernel, dim3(NFE_DECODER_CROSS_FLOATS / 256), dim3(256), 0, (hipStream_t)stream,
+                       cross_w1, lr_mul, packed_cross);
+    NFE_CHECK_LAUNCH("decoder_pack_cross_kernel");
+    return NFE_OK;
+}
+
 extern "C" int nfe_decoder_pack(const float* geo_w0, const float* geo_b0, const float* geo_w1, const float* geo_b1,
                                 const float* app_w0, const float* app_b0, const float* app_w1, const float* app_b1,
                                 float lr_mul, float* packed, nfe_stream_t stream) {

@@ -37,6 +37,7 @@ struct RenderK {
     unsigned* depth_minmax;        // ordered-uint {min, max}
     float density_noise;           // std of the Gaussian added to sigma (renderer.py:285-286), NOISE variants only
     const int* src_buf;            // DEPTH_BUFFER + NOISE: [N*M, S] which draw each merged sample is (k, or D + fine rank)
+    const float* dec_cross;        // CROSS variants: packed cross fragments (nfe_decoder_pack_cross)
 };
 
 // LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then per wave AFF_FLOATS of
@@ -47,6 +48,11 @@ constexpr int AFF_BSUM = 4 * 96;
 constexpr int XCHG_FLOATS = 32 * 32;
 constexpr int WAVE_LDS_FLOATS = AFF_FLOATS + XCHG_FLOATS;
 constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * WAVE_LDS_FLOATS) * 4;
+// CROSS variants (SegmentationOSGDecoder, triplane.py:192-230: sigma comes from the OTHER net's hidden layer): 8 more
+// split-bf16 layer-1 fragments behind the per-wave regions, geometry-head rows fed by the appearance head's hidden units.
+constexpr int LDS_CROSS = DEC_FLOATS + 4 * WAVE_LDS_FLOATS;
+constexpr int CROSS_WORDS = 8 * 64 * 4;
+constexpr int RENDER_LDS_BYTES_CROSS = RENDER_LDS_BYTES + CROSS_WORDS * 4;
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -501,6 +507,7 @@ __device__ __forceinline__ void split_hidden(const f32x16& a0, const f32x16& a1,
     }
 }
 
+template <bool CROSS = false>
 __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
                                               int lane, f32x16& og, f32x16& oa) {
     lane = launder(lane);
@@ -565,6 +572,14 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
         oa = NFE_MFMA_BF16(wh, hh, oa);
         oa = NFE_MFMA_BF16(wh, hl, oa);
         oa = NFE_MFMA_BF16(wl, hh, oa);
+        if (CROSS) {        // geometry-head rows that read the appearance head's hidden layer
+            const uint4* X = reinterpret_cast<const uint4*>(lds + LDS_CROSS) + lane;
+            Frag xh, xl;
+            xh.q = X[(2 * s) * 64]; xl.q = X[(2 * s + 1) * 64];
+            og = NFE_MFMA_BF16(xh, hh, og);
+            og = NFE_MFMA_BF16(xh, hl, og);
+            og = NFE_MFMA_BF16(xl, hh, og);
+        }
     }
     __builtin_amdgcn_sched_barrier(0);
 }
@@ -575,7 +590,7 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
 //   (seg starts on an even register so packed-fp32 pairs need no realigning moves)
 //   oa[r] = rgb channel 16h + r   (after the sigmoid clamp, triplane.py:269)
 // All 64 lanes must be active (quad broadcasts and the LDS exchange involve the whole wave).
-template <bool DUAL, bool SIGMA_ONLY, int MATH>
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool CROSS = false>
 __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const float* __restrict__ pa,
                                            int H, int W, const float* __restrict__ lds,
                                            const float* __restrict__ aff, float* __restrict__ xp,
@@ -609,7 +624,8 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
 #define NFE_MLP_PAIR 1
 #endif
     constexpr bool PAIR = NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3;
-    if (PAIR) mlp_pair_bf16(lds, fn, fd, lane, og, oa);
+    static_assert(!CROSS || (NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3), "the cross term lives in the paired split-bf16 decoder");
+    if (PAIR) mlp_pair_bf16<CROSS>(lds, fn, fd, lane, og, oa);
     else if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og);
     else mlp_bf16(lds, fn, 0, lane, og);
     if (!SIGMA_ONLY) {
@@ -631,6 +647,11 @@ __device__ __forceinline__ void stage_decoder(const float* __restrict__ dec, flo
     for (int i = threadIdx.x; i < DEC_B_G0 / 4; i += 256) reinterpret_cast<float4*>(lds)[i] = frag[i];
     const float4* bias = reinterpret_cast<const float4*>(dec + DEC_B_G0);
     for (int i = threadIdx.x; i < (DEC_FLOATS - DEC_B_G0) / 4; i += 256) reinterpret_cast<float4*>(lds + DEC_B_G0)[i] = bias[i];
+}
+
+__device__ __forceinline__ void stage_cross(const float* __restrict__ cross, float* lds) {
+    for (int i = threadIdx.x; i < CROSS_WORDS / 4; i += 256)
+        reinterpret_cast<float4*>(lds + LDS_CROSS)[i] = reinterpret_cast<const float4*>(cross)[i];
 }
 
 // Stage this wave's view affines into its LDS region, folding in the 1/3 of the mean over planes
@@ -665,10 +686,11 @@ __device__ __forceinline__ float sample_gaussian(unsigned long long seed, unsign
     return sqrtf(-2.0f * LN2 * log2_fast(u1)) * __builtin_amdgcn_cosf(u2);       // v_cos_f32 takes revolutions
 }
 
-template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false>
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_decoder<MATH>(P.dec, lds);
+    if (CROSS) stage_cross(P.dec_cross, lds);
     // wave id in an SGPR: everything derived from it (ray block, view, plane base) stays scalar
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
@@ -777,7 +799,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             // would pin >200 VGPRs per lane and spill.
             int opq;
             asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
-            eval_point<DUAL, SIGMA_ONLY, MATH>(pg, pa, P.H, P.W, lds + opq, aff + opq, xp + opq, gx, gy, gz, lane, og, oa);
+            eval_point<DUAL, SIGMA_ONLY, MATH, CROSS>(pg, pa, P.H, P.W, lds + opq, aff + opq, xp + opq, gx, gy, gz, lane, og, oa);
 
             if (NOISE) {
                 const unsigned draw = (P.depth_mode == DEPTH_BUFFER && P.src_buf) ? (unsigned)P.src_buf[ray * S + k] : (unsigned)k;
@@ -1019,12 +1041,14 @@ struct PointK {
     const float* coords; int N, Pn; float coord_scale;
     float* rgb; float* sigma; float* seg;
     float density_noise; unsigned long long seed;      // renderer.py:285-286 on points: Philox key (seed; point n*P+m, draw 0)
+    const float* dec_cross;
 };
 
-template <bool DUAL, int MATH>
+template <bool DUAL, int MATH, bool CROSS = false>
 __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_decoder<MATH>(P.dec, lds);
+    if (CROSS) stage_cross(P.dec_cross, lds);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     float* aff = lds + LDS_AFF + wave * WAVE_LDS_FLOATS;
@@ -1042,7 +1066,7 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
         const long long pt = (long long)n * P.Pn + m;
         const float* c = P.coords + pt * 3;
         f32x16 og, oa;
-        eval_point<DUAL, false, MATH>(P.planes_g + (long long)n * P.plane_view_stride,
+        eval_point<DUAL, false, MATH, CROSS>(P.planes_g + (long long)n * P.plane_view_stride,
                                 P.planes_a + (long long)n * P.plane_view_stride, P.H, P.W, lds, aff, xp,
                                 P.coord_scale * c[0], P.coord_scale * c[1], P.coord_scale * c[2], lane, og, oa);
         if (valid) {
@@ -1100,6 +1124,13 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
     const long long cap = (long long)num_cus() * blocks_per_cu;      // grid-stride beyond
     if (blocks > cap) blocks = cap;
     dim3 grid((unsigned)blocks);
+    if (P.dec_cross) {       // validated by nfe_render: one plane set, split-bf16 decoder, no density_noise; the coarse pass of a
+                             // two-pass render runs the full decoder too (sigma needs the appearance head's hidden layer)
+        allow_lds(render_kernel<false, false, NFE_MATH_BF16X3, false, true>, RENDER_LDS_BYTES_CROSS);
+        hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, true>), grid, dim3(256), RENDER_LDS_BYTES_CROSS, st, P);
+        NFE_CHECK_LAUNCH("render_kernel");
+        return NFE_OK;
+    }
     if (sigma_only) {
         if (dual) launch_render_math<true, true>(P, math, grid, st); else launch_render_math<false, true>(P, math, grid, st);
     } else {
@@ -1177,6 +1208,10 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.rgb = a->rgb; P.seg = a->seg; P.depth = a->depth; P.wsum = a->wsum; P.channels_first = a->channels_first;
     P.seed = a->seed; P.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device);
     P.density_noise = a->density_noise;
+    P.dec_cross = a->decoder_cross;
+    if (a->decoder_cross)
+        NFE_REQUIRE(a->planes_geo == a->planes_app && a->decoder_math == NFE_MATH_BF16X3 && a->density_noise == 0.0f,
+                    "nfe_render: decoder_cross (SegmentationOSGDecoder) needs one plane set, NFE_MATH_BF16X3 and density_noise == 0");
     const int mode = a->ray_start_per_ray ? DEPTH_PER_RAY : (a->disparity_space_sampling ? DEPTH_DISPARITY : DEPTH_STRATIFIED);
     const bool dual = a->planes_geo != a->planes_app;
     const int math = a->decoder_math;
@@ -1236,7 +1271,8 @@ extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app,
                                int64_t plane_view_stride, const float* geo_scale, const float* geo_shift,
                                const float* app_scale, const float* app_shift, const float* decoder_packed,
                                int decoder_math, const float* coords, int n_views, int n_points, float box_warp,
-                               float* rgb, float* sigma, float* seg, float density_noise, uint64_t seed, nfe_stream_t stream) {
+                               float* rgb, float* sigma, float* seg, float density_noise, uint64_t seed, const float* decoder_cross,
+                               nfe_stream_t stream) {
     NFE_REQUIRE(planes_geo && planes_app && decoder_packed && coords, "nfe_point_query: null input pointer");
     NFE_REQUIRE(rgb && sigma && seg, "nfe_point_query: null output pointer");
     NFE_REQUIRE(plane_h > 0 && plane_w > 0 && (long long)plane_h * plane_w <= (1ll << 25), "nfe_point_query: bad plane size %dx%d", plane_h, plane_w);
@@ -1250,14 +1286,19 @@ extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app,
     P.planes_g = planes_geo; P.planes_a = planes_app; P.plane_view_stride = plane_view_stride; P.H = plane_h; P.W = plane_w;
     P.aff[0] = geo_scale; P.aff[1] = geo_shift; P.aff[2] = app_scale; P.aff[3] = app_shift;
     P.dec = decoder_packed; P.coords = coords; P.N = n_views; P.Pn = n_points; P.coord_scale = 2.0f / box_warp;
-    P.rgb = rgb; P.sigma = sigma; P.seg = seg; P.density_noise = density_noise; P.seed = seed;
+    P.rgb = rgb; P.sigma = sigma; P.seg = seg; P.density_noise = density_noise; P.seed = seed; P.dec_cross = decoder_cross;
+    if (decoder_cross)
+        NFE_REQUIRE(planes_geo == planes_app && decoder_math == NFE_MATH_BF16X3, "nfe_point_query: decoder_cross needs one plane set and NFE_MATH_BF16X3");
     const long long total = (long long)n_views * ((n_points + 31) / 32);
     long long blocks = (total + 3) / 4;
     if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
     hipStream_t st = (hipStream_t)stream;
     const bool dual = planes_geo != planes_app;
     dim3 grid((unsigned)blocks), block(256);
-    if (decoder_math == NFE_MATH_FP32) {
+    if (decoder_cross) {
+        allow_lds(point_kernel<false, NFE_MATH_BF16X3, true>, RENDER_LDS_BYTES_CROSS);
+        hipLaunchKernelGGL((point_kernel<false, NFE_MATH_BF16X3, true>), grid, block, RENDER_LDS_BYTES_CROSS, st, P);
+    } else if (decoder_math == NFE_MATH_FP32) {
         if (dual) hipLaunchKernelGGL((point_kernel<true, NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);
         else hipLaunchKernelGGL((point_kernel<false, NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);
     } else {

@@ -152,9 +152,19 @@ def decoder_pack(geo_w0, geo_b0, geo_w1, geo_b1, app_w0, app_b0, app_w1, app_b1,
     return out
 
 
+def decoder_pack_cross(cross_w1, lr_mul=1.0):
+    """nfe_decoder_pack_cross: [16,64] geometry-head rows on the appearance head's hidden units (SegmentationOSGDecoder)."""
+    lib = _lib.load()
+    cross_w1 = _dev(cross_w1, "cross_w1", (16, 64))
+    out = torch.empty(_lib.NFE_DECODER_CROSS_FLOATS, device=cross_w1.device)
+    with torch.cuda.device(out.device):
+        _lib.check(lib.nfe_decoder_pack_cross(_ptr(cross_w1), float(lr_mul), _ptr(out), _stream()), "nfe_decoder_pack_cross")
+    return out
+
+
 def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dirs=None, cam2world=None,
            intrinsics=None, resolution=0, affines=None, u_coarse=None, u_fine=None, seed=0,
-           channels_first=False, taps=False, ray_limits=None, decoder_math=None):
+           channels_first=False, taps=False, ray_limits=None, decoder_math=None, decoder_cross=None):
     """nfe_render.  planes_* are packed [Np,3,H,W,32] (Np == N or 1); affines = 4x [N,96] or None.
 
     Returns (rgb, seg, depth, wsum[, taps]) with rgb [N,M,32] (or [N,32,M] if channels_first),
@@ -193,6 +203,10 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
         keep += affines
     a.decoder_packed = _dev(decoder_packed, "decoder_packed", (_lib.NFE_DECODER_PACKED_FLOATS,)).data_ptr()
     a.decoder_math = _math_mode(decoder_math)
+    if decoder_cross is not None:
+        decoder_cross = _dev(decoder_cross, "decoder_cross", (_lib.NFE_DECODER_CROSS_FLOATS,))
+        a.decoder_cross = decoder_cross.data_ptr()
+        keep.append(decoder_cross)
     a.n_views, a.n_rays = N, M
     if origins is not None:
         a.origins, a.dirs = origins.data_ptr(), dirs.data_ptr()
@@ -327,7 +341,8 @@ def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, dept
     return gg, ga
 
 
-def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affines=None, decoder_math=None, density_noise=0.0, seed=0):
+def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affines=None, decoder_math=None, density_noise=0.0, seed=0,
+                decoder_cross=None):
     """nfe_point_query: coords [N,P,3] -> dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15]).  density_noise > 0 adds
     N(0,1) * density_noise to sigma (renderer.py:285-286; Philox normals keyed by `seed` and the point index)."""
     lib = _lib.load()
@@ -351,6 +366,7 @@ def point_query(planes_geo, planes_app, decoder_packed, coords, box_warp, affine
     with torch.cuda.device(dev):
         _lib.check(lib.nfe_point_query(_ptr(planes_geo), _ptr(planes_app), H, W, stride, *[_ptr(t) for t in aff],
                                        _ptr(decoder_packed), _math_mode(decoder_math), _ptr(coords), N, P, float(box_warp),
-                                       _ptr(rgb), _ptr(sigma), _ptr(seg), float(density_noise), int(seed) & 0xFFFFFFFFFFFFFFFF, _stream()),
+                                       _ptr(rgb), _ptr(sigma), _ptr(seg), float(density_noise), int(seed) & 0xFFFFFFFFFFFFFFFF,
+                                       _ptr(_dev(decoder_cross, "decoder_cross", (_lib.NFE_DECODER_CROSS_FLOATS,)) if decoder_cross is not None else None), _stream()),
                    "nfe_point_query")
     return {"rgb": rgb, "sigma": sigma, "seg": seg}

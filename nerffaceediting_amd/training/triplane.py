@@ -91,21 +91,77 @@ class OSGDecoder(torch.nn.Module):
         raise NotImplementedError("the decoder is evaluated inside the fused kernels: use ImportanceRenderer.run_model(...)")
 
 
+class SegmentationOSGDecoder(torch.nn.Module):
+    """training/triplane.py:192-230 (the `disable_alignment` ablation): `net` 32 -> 64 -> 1 + 32 gives sigma and rgb, `seg_net`
+    32 -> 64 -> 15 the segmentation, both from the SAME (denorm) features.  For the fused kernels `seg_net` is the geometry
+    head (sigma row zero), `net` rows 1..32 the appearance head and `net` row 0 a cross term from the appearance head's hidden
+    layer into the sigma output (nfe_decoder_pack_cross)."""
+
+    def __init__(self, n_features, options):
+        super().__init__()
+        assert n_features == 32 and options["decoder_output_dim"] == 32 and options["decoder_seg_dim"] == 15
+        self.hidden_dim = 64
+        lr = options["decoder_lr_mul"]
+        self.lr_mul = lr
+        self.net = torch.nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr), torch.nn.Softplus(),
+                                       FullyConnectedLayer(self.hidden_dim, 1 + options["decoder_output_dim"], lr_multiplier=lr))
+        self.seg_net = torch.nn.Sequential(FullyConnectedLayer(n_features, self.hidden_dim, lr_multiplier=lr), torch.nn.Softplus(),
+                                           FullyConnectedLayer(self.hidden_dim, options["decoder_seg_dim"], lr_multiplier=lr))
+
+    def _params(self):
+        return [self.net[0].weight, self.net[0].bias, self.net[2].weight, self.net[2].bias,
+                self.seg_net[0].weight, self.seg_net[0].bias, self.seg_net[2].weight, self.seg_net[2].bias]
+
+    def heads(self):
+        nw0, nb0, nw2, nb2, sw0, sb0, sw2, sb2 = (p.detach() for p in self._params())
+        gw = torch.zeros(16, 64, device=nw2.device); gb = torch.zeros(16, device=nw2.device)
+        gw[1:], gb[1:], gb[:1] = sw2, sb2, nb2[:1]
+        return [sw0, sb0, gw, gb, nw0, nb0, nw2[1:].contiguous(), nb2[1:].contiguous()]
+
+    def cross(self):
+        x = torch.zeros(16, 64, device=self.net[2].weight.device)
+        x[:1] = self.net[2].weight.detach()[:1]
+        return x
+
+    def _refresh(self):
+        key = tuple((p.data_ptr(), p._version) for p in self._params())
+        if getattr(self, "_packed_key", None) != key:
+            self._packed = ops.decoder_pack(*self.heads(), lr_mul=self.lr_mul)
+            self._packed_cross = ops.decoder_pack_cross(self.cross(), lr_mul=self.lr_mul)
+            self._packed_key = key
+
+    def packed(self):
+        self._refresh()
+        return self._packed
+
+    def packed_cross(self):
+        self._refresh()
+        return self._packed_cross
+
+    def forward(self, sampled_norm_features, sampled_denorm_features, ray_directions):
+        raise NotImplementedError("the decoder is evaluated inside the fused kernels: use renderer.run_model(...) "
+                                  "or TriPlaneGenerator.sample(...)")
+
+
+def packed_cross_of(decoder):
+    """The cross-term blob of a decoder, or None (every decoder but SegmentationOSGDecoder)."""
+    fn = getattr(decoder, "packed_cross", None)
+    return fn() if fn is not None else None
+
+
 class TriPlaneGenerator(torch.nn.Module):
     def __init__(self, z_dim, c_dim, w_dim, img_resolution, img_channels, sr_num_fp16_res=0, mapping_kwargs={},
                  rendering_kwargs={}, sr_kwargs={}, disable_disentangle=False, disable_alignment=False, **synthesis_kwargs):
         super().__init__()
-        if disable_alignment:
-            raise NotImplementedError("disable_alignment (SegmentationOSGDecoder, triplane.py:48-51) is not built: its sigma and seg "
-                                      "come from two different hidden layers, the fused kernel has one geometry head")
+        assert not disable_alignment or disable_disentangle                                   # triplane.py:42
         self.z_dim, self.c_dim, self.w_dim = z_dim, c_dim, w_dim
         self.img_resolution, self.img_channels = img_resolution, img_channels
         # disable_disentangle (triplane.py:93,104-107,119): no normalisation, both decoder heads read the raw planes
-        self.disable_disentangle, self.disable_alignment = bool(disable_disentangle), False
+        self.disable_disentangle, self.disable_alignment = bool(disable_disentangle), bool(disable_alignment)
         self.init_args, self.init_kwargs = (), dict(                      # what persistence.persistent_class records
             z_dim=z_dim, c_dim=c_dim, w_dim=w_dim, img_resolution=img_resolution, img_channels=img_channels,
             sr_num_fp16_res=sr_num_fp16_res, mapping_kwargs=mapping_kwargs, rendering_kwargs=rendering_kwargs,
-            sr_kwargs=sr_kwargs, disable_disentangle=bool(disable_disentangle), disable_alignment=False, **synthesis_kwargs)
+            sr_kwargs=sr_kwargs, disable_disentangle=bool(disable_disentangle), disable_alignment=bool(disable_alignment), **synthesis_kwargs)
         self.renderer = DisentangledImportanceRenderer()
         self.ray_sampler = RaySampler()
         self.backbone = StyleGAN2Backbone(z_dim, c_dim, w_dim, img_resolution=256, img_channels=32 * 3,
@@ -113,8 +169,9 @@ class TriPlaneGenerator(torch.nn.Module):
         self.superresolution = _construct_class_by_name(class_name=rendering_kwargs["superresolution_module"], channels=32,
                                                         img_resolution=img_resolution, sr_num_fp16_res=sr_num_fp16_res,
                                                         sr_antialias=rendering_kwargs["sr_antialias"], **sr_kwargs)
-        self.decoder = DisentangledOSGDecoder(32, {"decoder_lr_mul": rendering_kwargs.get("decoder_lr_mul", 1),
-                                                   "decoder_output_dim": 32, "decoder_seg_dim": 15})
+        decoder_class = SegmentationOSGDecoder if disable_alignment else DisentangledOSGDecoder       # triplane.py:48-51
+        self.decoder = decoder_class(32, {"decoder_lr_mul": rendering_kwargs.get("decoder_lr_mul", 1),
+                                          "decoder_output_dim": 32, "decoder_seg_dim": 15})
         self.neural_rendering_resolution = 64
         self.rendering_kwargs = rendering_kwargs
         self._last_planes = None
@@ -206,7 +263,7 @@ class TriPlaneGenerator(torch.nn.Module):
             affines = tuple(torch.ones_like(a) if i % 2 == 0 else torch.zeros_like(a) for i, a in enumerate(affines))
         return ops.point_query(packed, packed, self.decoder.packed(), coordinates.to(torch.float32),
                                self.rendering_kwargs["box_warp"], affines=affines,
-                               decoder_math=self.renderer.decoder_math)
+                               decoder_math=self.renderer.decoder_math, decoder_cross=packed_cross_of(self.decoder))
 
     def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):
         ws = self.mapping(z, c, truncation_psi=truncation_psi, truncation_cutoff=truncation_cutoff, update_emas=update_emas)

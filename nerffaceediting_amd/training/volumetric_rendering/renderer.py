@@ -12,6 +12,12 @@ import torch
 from ... import ops
 
 
+def _cross(decoder):
+    """Cross-term blob of a SegmentationOSGDecoder (sigma from the other net's hidden layer); None for every other decoder."""
+    fn = getattr(decoder, "packed_cross", None)
+    return fn() if fn is not None else None
+
+
 def generate_planes():
     """Plane axes as in renderer.py:23-37 (kept for API compatibility; the projection p0=(x,y),
     p1=(x,z), p2=(z,x) these axes define is built into the kernel)."""
@@ -27,6 +33,8 @@ class _RenderWithPlaneGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, norm_planes, denorm_planes, renderer, decoder, ray_origins, ray_directions, options, jitter, seed, limits):
+        if _cross(decoder) is not None:
+            raise RuntimeError("plane gradients are not built for SegmentationOSGDecoder (disable_alignment)")
         same = norm_planes is denorm_planes
         pg, pa = renderer._pack_pair(norm_planes.detach(), norm_planes.detach() if same else denorm_planes.detach())
         out = ops.render(pg, pa, decoder.packed(), options, origins=ray_origins, dirs=ray_directions, u_coarse=jitter[0],
@@ -101,7 +109,7 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         pg, pa = self._pack_pair(norm_planes, denorm_planes)
         out = ops.render(pg, pa, decoder.packed(), rendering_options, origins=ray_origins, dirs=ray_directions,
                          u_coarse=u_c, u_fine=u_f, seed=self._seed(), ray_limits=limits, taps=self.keep_taps,
-                         decoder_math=self.decoder_math)
+                         decoder_math=self.decoder_math, decoder_cross=_cross(decoder))
         if self.keep_taps:
             self.last_taps = out[4]
         return out[0], out[1], out[2], out[3]
@@ -119,7 +127,7 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         out = ops.render(packed_planes, packed_planes, decoder.packed(), rendering_options, cam2world=cam2world,
                          intrinsics=intrinsics, resolution=resolution, affines=affines, u_coarse=u_c, u_fine=u_f,
                          seed=self._seed(), ray_limits=limits, channels_first=channels_first, taps=self.keep_taps,
-                         decoder_math=self.decoder_math)
+                         decoder_math=self.decoder_math, decoder_cross=_cross(decoder))
         if self.keep_taps:
             self.last_taps = out[4]
         return out[0], out[1], out[2], out[3]
@@ -131,7 +139,7 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         pg, pa = self._pack_pair(norm_planes, denorm_planes)
         seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if noise > 0 else 0
         return ops.point_query(pg, pa, decoder.packed(), sample_coordinates, options["box_warp"],
-                               decoder_math=self.decoder_math, density_noise=noise, seed=seed)
+                               decoder_math=self.decoder_math, density_noise=noise, seed=seed, decoder_cross=_cross(decoder))
 
 
 class ImportanceRenderer(DisentangledImportanceRenderer):

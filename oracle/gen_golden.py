@@ -226,6 +226,47 @@ def gen_legacy_renderer(seed=21, N=2, R=8, H=16, D=12, Ni=12):
     print("  wrote legacy_renderer.npz")
 
 
+def gen_segmentation_decoder(seed=31, N=2, R=8, H=16, D=12, Ni=12, P=300):
+    """The `disable_alignment` ablation: the reference renderer with the reference SegmentationOSGDecoder (triplane.py:192-230),
+    both plane arguments = the raw planes (triplane.py:119 with disable_disentangle), two-pass render + run_model."""
+    from training.triplane import SegmentationOSGDecoder
+    rng = np.random.RandomState(seed)
+    planes = smooth_planes(rng, N, H)
+    dec_np = orc.random_segmentation_decoder(seed + 1, bias_scale=0.3)
+    dec = SegmentationOSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32, "decoder_seg_dim": 15})
+    dec.load_state_dict({k: torch.from_numpy(v) for k, v in dec_np.items()})
+    dec.eval()
+    c2w, K = cams([(0.25, -0.1), (-0.35, 0.15)])
+    M = R * R
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, Ni).astype(np.float32)
+    opts = dict(depth_resolution=D, depth_resolution_importance=Ni, ray_start=2.25, ray_end=3.3, box_warp=1.0,
+                disparity_space_sampling=False, clamp_mode="softplus", white_back=False)
+    p5 = torch.from_numpy(planes).view(N, 3, 32, H, H)
+    o, d = RaySampler()(c2w, K, R)
+    rend = DisentangledImportanceRenderer()
+    with InjectRand([u_c, u_f]):
+        rgb, seg, depth, wsum = rend(p5, p5, dec, o, d, opts)
+    coords = ((rng.rand(N, P, 3) - 0.5) * 1.1).astype(np.float32)
+    pq = rend.run_model(p5, p5, dec, torch.from_numpy(coords), None, opts)
+    ref = dict(rgb=rgb.numpy(), seg=seg.numpy(), depth=depth.numpy(), wsum=wsum.numpy())
+    r = orc.render(p5.numpy(), p5.numpy(), dec_np, o.numpy(), d.numpy(), opts, u_c, u_f)
+    for k, v in zip(("rgb", "seg", "depth", "wsum"), r[:4]):
+        check(k, v, ref[k], 2e-5)
+    q = orc.run_model(p5.numpy(), p5.numpy(), dec_np, coords, opts)
+    for k, v in zip(("rgb", "sigma", "seg"), q):
+        check("pq." + k, v, pq[k].numpy(), 2e-5)
+    np.savez_compressed(
+        os.path.join(OUT, "segdecoder_render.npz"),
+        planes=planes, cam2world=c2w.numpy(), intrinsics=K.numpy(), R=R, u_coarse=u_c, u_fine=u_f, options=np.array(repr(opts)),
+        coords=coords,
+        **{"dec." + k: v for k, v in dec_np.items()},
+        **{"out." + k: v for k, v in ref.items()},
+        **{"pq." + k: pq[k].numpy() for k in ("rgb", "sigma", "seg")},
+        torch_version=np.array(torch.__version__))
+    print("  wrote segdecoder_render.npz")
+
+
 def gen_point_query(seed=7, N=2, H=16, P=500):
     rng = np.random.RandomState(seed)
     planes = smooth_planes(rng, N, H)
@@ -321,6 +362,7 @@ def main():
     gen_render_full_size("ffhq_render", seed=411, N=2, R=128, H=256, D=48, Ni=48, swap=True, stride=7, chunk=16384,
                          angles=((0.35, -0.15), (-0.3, 0.1)))
     gen_legacy_renderer()
+    gen_segmentation_decoder()
     print("point query:")
     gen_point_query()
     print("plane stats:")
@@ -338,6 +380,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "legacy_renderer":
         os.makedirs(OUT, exist_ok=True)
         gen_legacy_renderer()
+    elif len(sys.argv) > 1 and sys.argv[1] == "segmentation_decoder":
+        os.makedirs(OUT, exist_ok=True)
+        gen_segmentation_decoder()
     elif len(sys.argv) > 1 and sys.argv[1] == "ffhq_render":
         os.makedirs(OUT, exist_ok=True)
         gen_render_full_size("ffhq_render", seed=411, N=2, R=128, H=256, D=48, Ni=48, swap=True, stride=7, chunk=16384,

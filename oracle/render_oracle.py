@@ -271,13 +271,43 @@ def decoder_disentangled(f_norm, f_denorm, dec, lr_mul=1.0):
     return rgb.astype(F32), sigma.astype(F32), seg.astype(F32)
 
 
+def decoder_segmentation(f_denorm, dec, lr_mul=1.0):
+    """SegmentationOSGDecoder.forward, triplane.py:209-230 (the `disable_alignment` ablation): sigma and rgb from `net`,
+    seg from `seg_net`, BOTH on the denorm features.  dec = dict of net.{0,2}.{weight,bias}, seg_net.{0,2}.{weight,bias}."""
+    fd = f_denorm.mean(axis=1, dtype=F32)                                 # :211
+    N, S, C = fd.shape
+    h = softplus(fully_connected(fd.reshape(N * S, C), dec["net.0.weight"], dec["net.0.bias"], lr_mul))
+    x = fully_connected(h, dec["net.2.weight"], dec["net.2.bias"], lr_mul).reshape(N, S, -1)
+    with np.errstate(over="ignore"):
+        rgb = (F32(1) / (F32(1) + np.exp(-x[..., 1:]))) * F32(1 + 2 * 0.001) - F32(0.001)   # :219
+    sigma = x[..., 0:1]
+    h = softplus(fully_connected(fd.reshape(N * S, C), dec["seg_net.0.weight"], dec["seg_net.0.bias"], lr_mul))
+    seg = fully_connected(h, dec["seg_net.2.weight"], dec["seg_net.2.bias"], lr_mul).reshape(N, S, -1)
+    return rgb.astype(F32), sigma.astype(F32), seg.astype(F32)
+
+
+def random_segmentation_decoder(seed, bias_scale=0.0):
+    """Random SegmentationOSGDecoder parameters (state_dict names of the reference class)."""
+    rng = np.random.RandomState(seed)
+    dec = {}
+    for net, outs in (("net", 33), ("seg_net", 15)):
+        dec[f"{net}.0.weight"] = rng.randn(64, 32).astype(F32)
+        dec[f"{net}.0.bias"] = (rng.randn(64) * bias_scale).astype(F32)
+        dec[f"{net}.2.weight"] = rng.randn(outs, 64).astype(F32)
+        dec[f"{net}.2.bias"] = (rng.randn(outs) * bias_scale).astype(F32)
+    return dec
+
+
 def run_model(norm_planes, denorm_planes, dec, coords, options, noise_seed=0):
     """DisentangledImportanceRenderer.run_model, renderer.py:259-287.  density_noise (:285-286; absent from every shipped
     config, train.py:288-323): the reference's randn_like stream is torch's; here the normal of point (n, m) is the Philox
     draw the HIP library makes (density_noise_normals with ray = n*P + m, draw 0)."""
     fn = sample_from_planes(norm_planes, coords, options["box_warp"])
     fd = sample_from_planes(denorm_planes, coords, options["box_warp"])
-    rgb, sigma, seg = decoder_disentangled(fn, fd, dec, options.get("decoder_lr_mul", 1))
+    if "seg_net.0.weight" in dec:
+        rgb, sigma, seg = decoder_segmentation(fd, dec, options.get("decoder_lr_mul", 1))
+    else:
+        rgb, sigma, seg = decoder_disentangled(fn, fd, dec, options.get("decoder_lr_mul", 1))
     noise = F32(options.get("density_noise", 0) or 0)
     if noise > 0:
         N, P = coords.shape[:2]

@@ -136,3 +136,68 @@ def test_legacy_importance_renderer_and_osg_decoder(dev):
     pq = rend.run_model(t(z["planes"], dev), dec, t(z["coords"], dev), None, opts)
     assert set(pq) == {"rgb", "sigma"}
     assert max_abs(pq["rgb"].cpu().numpy(), z["pq_rgb"]) <= 3e-5 and max_abs(pq["sigma"].cpu().numpy(), z["pq_sigma"]) <= 3e-5
+
+
+def test_segmentation_decoder_ablation(dev):
+    """disable_alignment (triplane.py:48-51, 192-230): SegmentationOSGDecoder through the renderer's forward / run_model
+    against outputs of the reference renderer + reference decoder class; then the generator wiring."""
+    import ast
+    from nerffaceediting_amd.training.triplane import SegmentationOSGDecoder, TriPlaneGenerator
+    from nerffaceediting_amd.training.volumetric_rendering.ray_sampler import RaySampler
+    from nerffaceediting_amd.training.volumetric_rendering.renderer import DisentangledImportanceRenderer
+    z = load("segdecoder_render")
+    opts = ast.literal_eval(str(z["options"]))
+    dec = SegmentationOSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32, "decoder_seg_dim": 15})
+    dec.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("dec.")})     # the reference's names
+    dec = dec.to(dev)
+    p5 = t(z["planes"], dev).view(2, 3, 32, 16, 16)
+    o, d = RaySampler()(t(z["cam2world"], dev), t(z["intrinsics"], dev), int(z["R"]))
+    rend = DisentangledImportanceRenderer()
+    rend.inject_jitter(t(z["u_coarse"], dev), t(z["u_fine"], dev))
+    out = rend(p5, p5, dec, o, d, opts)
+    for k, v in zip(("rgb", "seg", "depth", "wsum"), out):
+        assert max_abs(v.cpu().numpy(), z["out." + k]) <= TOL, k
+    pq = rend.run_model(p5, p5, dec, t(z["coords"], dev), None, opts)
+    for k in ("rgb", "sigma", "seg"):
+        assert max_abs(pq[k].cpu().numpy(), z["pq." + k]) <= TOL, k
+    # single pass too (the coarse pass of the two-pass render above ran the full decoder)
+    o1 = dict(opts, depth_resolution_importance=0)
+    rend.inject_jitter(t(z["u_coarse"], dev))
+    got = rend(p5, p5, dec, o, d, o1)
+    want = orc.render(z["planes"].reshape(2, 3, 32, 16, 16), z["planes"].reshape(2, 3, 32, 16, 16),
+                      {k[4:]: z[k] for k in z.files if k.startswith("dec.")}, o.cpu().numpy(), d.cpu().numpy(), o1, z["u_coarse"])
+    for g, w in zip(got, want):
+        assert max_abs(g.cpu().numpy(), w) <= TOL
+    with pytest.raises(RuntimeError, match="decoder_cross"):           # two different plane sets are not this variant
+        rend.inject_jitter(t(z["u_coarse"], dev), t(z["u_fine"], dev))
+        rend(p5, p5 * 1.5, dec, o, d, opts)
+    with pytest.raises(RuntimeError, match="SegmentationOSGDecoder"):   # no plane gradients for the ablation decoder
+        rend(p5.clone().requires_grad_(True), p5, dec, o, d, opts)
+    # generator: disable_alignment needs disable_disentangle (triplane.py:42) and selects the decoder class (:48-51)
+    rk = dict(depth_resolution=8, depth_resolution_importance=8, ray_start=2.25, ray_end=3.3, box_warp=1, c_gen_conditioning_zero=False,
+              c_scale=1.0, superresolution_noise_mode="none", superresolution_module="training.superresolution.SuperresolutionHybrid8XDC",
+              sr_antialias=True, decoder_lr_mul=1, avg_camera_radius=2.7, avg_camera_pivot=[0, 0, 0.2])
+    with pytest.raises(AssertionError):
+        TriPlaneGenerator(512, 25, 512, 512, 3, rendering_kwargs=rk, disable_alignment=True, channel_base=2048, channel_max=16)
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+                          sr_kwargs=dict(channel_base=2048, channel_max=16, fused_modconv_default="inference_only"),
+                          disable_disentangle=True, disable_alignment=True, channel_base=2048, channel_max=16,
+                          fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None).to(dev).eval().requires_grad_(False)
+    assert isinstance(G.decoder, SegmentationOSGDecoder) and G.init_kwargs["disable_alignment"] is True
+    assert {"decoder.net.0.weight", "decoder.net.2.bias", "decoder.seg_net.0.weight", "decoder.seg_net.2.weight"} <= set(G.state_dict())
+    torch.manual_seed(0)
+    zl = torch.randn(1, 512, device=dev)
+    c = torch.cat([t(z["cam2world"][:1].reshape(1, 16), dev), t(z["intrinsics"][:1].reshape(1, 9), dev)], 1)
+    ws = G.mapping(zl, c)
+    uc, uf = torch.rand(1, 32 * 32, 8, device=dev), torch.rand(32 * 32, 8, device=dev)
+    G.renderer.inject_jitter(uc, uf)
+    img = G.synthesis(ws, c, neural_rendering_resolution=32, noise_mode="const")
+    assert img["image"].shape == (1, 3, 512, 512) and img["plane_mean"] is None
+    planes = G.backbone.synthesis(ws, noise_mode="const").view(1, 3, 32, 256, 256)
+    oo, dd = G.ray_sampler(c[:, :16].reshape(-1, 4, 4), c[:, 16:25].reshape(-1, 3, 3), 32)
+    G.renderer.inject_jitter(uc, uf)
+    feat, seg, _, _ = G.renderer(planes, planes, G.decoder, oo, dd, G.rendering_kwargs)
+    assert max_abs(img["image_seg"].cpu().numpy(), seg.permute(0, 2, 1).reshape(1, 15, 32, 32).cpu().numpy()) <= 1e-4
+    assert max_abs(img["image_raw"].cpu().numpy(), feat[..., :3].permute(0, 2, 1).reshape(1, 3, 32, 32).cpu().numpy()) <= 1e-4
+    sig = G.sample_mixed(t(z["coords"][:1], dev), None, ws, noise_mode="const")["sigma"]
+    assert torch.isfinite(sig).all()
