@@ -18,6 +18,8 @@
 // (networks_stylegan2.py:111-123) are applied once by prep_kernel.
 #include "nfe_common.h"
 
+#include <cstdlib>
+
 namespace nfe {
 
 // scaled decoder image in the workspace (floats)
@@ -392,6 +394,136 @@ __global__ __launch_bounds__(256, BWD_WAVES) void bwd_scatter_kernel(BwdK P) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// pass 3, sorted form: one wave = 8x8 neighbouring rays at ONE depth index.  Their 64 x 4 taps on a plane fall on
+// ~75 distinct texels (3.4x fewer than taps at 128^2 rays on 256^2 planes), so the wave sorts its 256 (texel, sample,
+// tap) keys per plane in LDS (bitonic), walks the sorted list summing weight * feature-gradient over each run of equal
+// texels, and issues ONE atomic row per run and plane set (lanes 0..31: geometry set, 32..63: appearance set).
+// The atomic unit - the bound of the direct form - sees 3.4x fewer operations.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int SORT_TILE_STRIDE = 65;
+constexpr unsigned KEY_INVALID = 0xFFFFFFFFu;
+
+__global__ __launch_bounds__(64) void bwd_scatter_sorted_kernel(BwdK P) {
+    __shared__ float tile[64 * SORT_TILE_STRIDE];       // [sample][0..31 geometry-set gradient, 32..63 appearance-set]
+    __shared__ unsigned keys[3 * 256];                  // per plane: texel << 8 | sample << 2 | tap
+    __shared__ float wtab[64 * 12];                     // tap weights [sample][plane*4 + tap]
+    const int lane = threadIdx.x;
+    const int n = blockIdx.z, kdepth = blockIdx.y, t = blockIdx.x;
+    int m; bool live = true;
+    if (P.R > 0 && (P.R & 7) == 0 && (long long)P.R * P.R == P.M) {       // 8x8 pixel tile
+        const int tiles_x = P.R >> 3;
+        m = ((t / tiles_x) * 8 + (lane >> 3)) * P.R + (t % tiles_x) * 8 + (lane & 7);
+    } else {
+        m = t * 64 + lane; live = m < P.M; m = min(m, P.M - 1);
+    }
+    const long long g = ((long long)n * P.M + m) * P.S + kdepth;
+    SampleGeo geo;
+    sample_geometry(P, n, m, P.depths[g], geo);
+    const float gsig = P.rec_sig[g], omega = P.rec_a[g];
+    const long long pv = (long long)n * P.plane_view_stride;
+    const long long gv = (long long)n * P.grad_view_stride;
+    const float* dec = P.dec;
+    const bool do_g = P.grad_g != nullptr, do_a = P.grad_a != nullptr && P.g_rgb != nullptr;
+    {
+        f32x2 f[16], df[16];
+        if (do_g) {
+            gather_set(P.planes_g + pv, geo, P.aff[0] ? P.aff[0] + n * 96 : nullptr, P.aff[1] ? P.aff[1] + n * 96 : nullptr, f);
+            f32x2 dout[8];
+            dout[0][0] = gsig;                                         // sigma = channel 0, seg = 1..15 (triplane.py:260-261)
+#pragma unroll
+            for (int c = 0; c < 15; ++c) dout[(1 + c) >> 1][(1 + c) & 1] = omega * cot_seg(P, n, m, c);
+            head_backward<16>(dec + BW_G0, dec + BB_G0, dec + BW_G1T, f, dout, df);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) df[c] = splat(0.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) tile[lane * SORT_TILE_STRIDE + c] = df[c >> 1][c & 1] * (1.0f / 3.0f);   // mean over planes, triplane.py:251
+        if (do_a) {
+            gather_set(P.planes_a + pv, geo, P.aff[2] ? P.aff[2] + n * 96 : nullptr, P.aff[3] ? P.aff[3] + n * 96 : nullptr, f);
+            f32x2 y[16];
+            head_forward<32>(dec + BW_A0, dec + BB_A0, dec + BW_A1T, dec + BB_A1, f, y);
+#pragma unroll
+            for (int c = 0; c < 32; ++c) {                             // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269)
+                const float sg = sigmoid_t(y[c >> 1][c & 1]);
+                y[c >> 1][c & 1] = omega * cot_rgb(P, n, m, c) * 1.002f * sg * (1.0f - sg);
+            }
+            head_backward<32>(dec + BW_A0, dec + BB_A0, dec + BW_A1T, f, y, df);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 16; ++c) df[c] = splat(0.0f);
+        }
+#pragma unroll
+        for (int c = 0; c < 32; ++c) tile[lane * SORT_TILE_STRIDE + 32 + c] = df[c >> 1][c & 1] * (1.0f / 3.0f);
+    }
+    const int plane_elems = P.H * P.W * 32;
+#pragma unroll
+    for (int q = 0; q < 12; ++q) {
+        const int p = q >> 2;
+        wtab[lane * 12 + q] = geo.w[q];
+        const unsigned texel = (unsigned)(geo.off[q] - p * plane_elems) >> 5;
+        keys[p * 256 + lane * 4 + (q & 3)] = (live && geo.w[q] != 0.0f) ? (texel << 8 | (unsigned)lane << 2 | (unsigned)(q & 3)) : KEY_INVALID;
+    }
+    __threadfence_block();
+    // bitonic sort of the three 256-key lists (ascending; invalid keys end up last); 128 pairs per list, 2 per lane
+    for (int k = 2; k <= 256; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                unsigned* a = keys + (r >> 1) * 256;
+                const int id = lane + 64 * (r & 1);
+                const int i = ((id & ~(j - 1)) << 1) | (id & (j - 1));
+                const unsigned x = a[i], y = a[i + j];
+                if ((x > y) == ((i & k) == 0)) { a[i] = y; a[i + j] = x; }
+            }
+            __threadfence_block();
+        }
+    // walk the sorted lists
+    const int ch = lane & 31, set = lane >> 5;
+    float* gbase = set ? (do_a ? P.grad_a + gv : nullptr) : (do_g ? P.grad_g + gv : nullptr);
+    const float* scale = P.aff[2 * set] ? P.aff[2 * set] + n * 96 : nullptr;
+#pragma unroll 1
+    for (int p = 0; p < 3; ++p) {
+        unsigned kreg[4]; float wreg[4]; int lastreg[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int idx = c * 64 + lane;
+            const unsigned kk = keys[p * 256 + idx];
+            const unsigned nxt = idx == 255 ? KEY_INVALID : keys[p * 256 + idx + 1];
+            kreg[c] = kk;
+            wreg[c] = kk != KEY_INVALID ? wtab[((kk >> 2) & 63) * 12 + p * 4 + (kk & 3)] : 0.0f;
+            lastreg[c] = (kk >> 8) != (nxt >> 8);
+        }
+        const float sc = scale ? scale[p * 32 + ch] : 1.0f;
+        float* base = gbase ? gbase + (long long)p * plane_elems + ch : nullptr;
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if ((unsigned)__builtin_amdgcn_readfirstlane((int)kreg[c]) == KEY_INVALID) break;          // lists are sorted: nothing valid from here on
+#pragma unroll 1
+            for (int i = 0; i < 64; i += 8) {
+                unsigned kk[8]; float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    kk[u] = (unsigned)__builtin_amdgcn_readlane((int)kreg[c], i + u);
+                    v[u] = tile[((kk[u] >> 2) & 63) * SORT_TILE_STRIDE + lane];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[c]), i + u));
+                    acc = fmaf(v[u], w, acc);
+                    if (__builtin_amdgcn_readlane(lastreg[c], i + u)) {
+                        if (base) unsafeAtomicAdd(base + (long long)(kk[u] >> 8) * 32, acc * sc);
+                        acc = 0.0f;
+                    }
+                }
+            }
+        }
+    }
+}
+
 static uint64_t align256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 
 }  // namespace nfe
@@ -462,7 +594,14 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     const long long rays = (long long)a->n_views * a->n_rays;
     hipLaunchKernelGGL(bwd_ray_kernel, dim3((unsigned)((rays + 255) / 256)), dim3(256), 0, st, P);
     NFE_CHECK_LAUNCH("bwd_ray_kernel");
-    hipLaunchKernelGGL(bwd_scatter_kernel, sgrid, dim3(256), 0, st, P);
-    NFE_CHECK_LAUNCH("bwd_scatter_kernel");
+    static const bool direct = [] { const char* e = getenv("NFE_BWD_SCATTER"); return e && e[0] == 'd'; }();     // A/B knob: "direct"
+    if (direct || (long long)a->plane_h * a->plane_w > (1ll << 24)) {      // sort keys carry a 24-bit texel index
+        hipLaunchKernelGGL(bwd_scatter_kernel, sgrid, dim3(256), 0, st, P);
+        NFE_CHECK_LAUNCH("bwd_scatter_kernel");
+    } else {
+        const dim3 tgrid((unsigned)((a->n_rays + 63) / 64), (unsigned)a->n_samples, (unsigned)a->n_views);
+        hipLaunchKernelGGL(bwd_scatter_sorted_kernel, tgrid, dim3(64), 0, st, P);
+        NFE_CHECK_LAUNCH("bwd_scatter_sorted_kernel");
+    }
     return NFE_OK;
 }
