@@ -16,6 +16,7 @@ Other workloads of SURVEY.md section 8(d) (never the default; same JSON contract
     --workload full     config 3: full synthesis (a1-a14), 8 views/GPU/step, 512^2 x 64 render, bf16 convs -> views/s
     --workload orbit    config 4: 512 (latent, camera) pairs sharded over the ranks (strong scaling), one all-gather
     --workload twopass  config 5: render core, D=96 + 96 importance samples, dual plane sets, 512^2 -> rays/s
+    --workload editstep plane-editing step: 128^2 x (48+48) dual-plane render + nfe_render_backward -> rays/s
 """
 import argparse
 import json
@@ -167,6 +168,51 @@ def extra_workload(args, torch, dist, dev, rank, world):
                               "traffic": None, "kernel": "sigma-only pass + importance_kernel + nfe::render_kernel<true,false>",
                               "kernel_ms": ms, "note": "logical gather bytes of all three passes / their total time (L2-resident planes)"})
 
+    if args.workload == "editstep":          # forward + backward of the renderer w.r.t. both plane sets, FFHQ rendering config
+        Re, Dc = 128, 48
+        seed = 1000 + rank
+        planes, dec_t, _, c2w_t, K_t, _, _, _ = synth_inputs(torch, dev, seed)
+        mean, std = ops.plane_stats(planes)
+        gs, gb, as_, ab = ops.make_affine(mean, std, mean.roll(1, 0).contiguous(), std.roll(1, 0).contiguous())
+        norm = ops.plane_pack(ops.plane_affine(planes, gs, gb))
+        denorm = ops.plane_pack(ops.plane_affine(planes, as_, ab))
+        names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
+                 "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+        heads = [dec_t[k] for k in names]
+        dec_packed = ops.decoder_pack(*heads)
+        opts = dict(depth_resolution=Dc, depth_resolution_importance=Dc, ray_start=2.25, ray_end=3.3, box_warp=1,
+                    disparity_space_sampling=False, clamp_mode="softplus")
+        Me = Re * Re
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        cots = tuple(torch.randn(VIEWS_PER_GPU, Me, c, generator=g).to(dev) for c in (32, 15, 1, 1))
+        ev = {}
+
+        def step(i):
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            out = ops.render(norm, denorm, dec_packed, opts, cam2world=c2w_t, intrinsics=K_t, resolution=Re, seed=seed + i, taps=True)
+            e[1].record()
+            ops.render_backward(norm, denorm, heads, 1.0, opts, out[4]["depths_all"], cots, cam2world=c2w_t, intrinsics=K_t, resolution=Re)
+            e[2].record()
+            ev[i] = e
+        dt = timed_steps(args, torch, dist, world, step)
+        timed = [ev[args.warmup + i] for i in range(args.steps)]
+        fwd_ms = sum(e[0].elapsed_time(e[1]) for e in timed) / args.steps
+        bwd_ms = sum(e[1].elapsed_time(e[2]) for e in timed) / args.steps
+        n_total = world * VIEWS_PER_GPU
+        S2 = 2 * Dc
+        bytes_sample = 2 * 2 * 1536 + 2 * 1536              # two gather passes over two plane sets + one scatter into two sets
+        ach = VIEWS_PER_GPU * Me * S2 * bytes_sample / (bwd_ms * 1e-3) / 1e9
+        return dict(base, metric="rays/s, plane-editing step: 128^2 x (48+48) dual-plane render forward + backward w.r.t. both plane sets",
+                    value=n_total * Me * args.steps / dt, unit="rays/s", ms_per_step=dt / args.steps * 1e3, scaling="weak", dtype="f32",
+                    config={"workload": "SURVEY 8(f)4 backward pass: 4 views/GPU/step, 128^2 rays, 48 + 48 samples, norm/denorm plane sets with "
+                                        "swapped statistics, random cotangents for rgb/seg/depth/wsum, gradients w.r.t. both plane sets",
+                            "views_per_step": n_total, "forward_ms": fwd_ms, "backward_ms": bwd_ms, "parallelism": f"views-dp{world}"},
+                    roofline={"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                              "traffic": None, "kernel": "nfe::bwd_eval_kernel + bwd_ray_kernel + bwd_scatter_sorted_kernel",
+                              "kernel_ms": bwd_ms, "note": "logical gather + scatter bytes of the backward (9216 B/sample) / its time; "
+                                                           "planes and gradients are L2 / Infinity-Cache resident"})
+
     conv_math = "bf16"
     G = full_generator(torch, dev, D, 0, conv_math)
     if args.workload == "full":              # config 3
@@ -236,7 +282,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["render", "full", "orbit", "twopass"], default="render")
+    ap.add_argument("--workload", choices=["render", "full", "orbit", "twopass", "editstep"], default="render")
     args = ap.parse_args()
 
     import torch

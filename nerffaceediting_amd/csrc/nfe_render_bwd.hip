@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, BWD_WAVES) void bwd_scatter_kernel(BwdK P) {
 // ------------------------------------------------------------------------------------------------------------
 // pass 3, sorted form: one wave = 8x8 neighbouring rays at ONE depth index.  Their 64 x 4 taps on a plane fall on
 // ~75 distinct texels (3.4x fewer than taps at 128^2 rays on 256^2 planes), so the wave sorts its 256 (texel, sample,
-// tap) keys per plane in LDS (bitonic), walks the sorted list summing weight * feature-gradient over each run of equal
+// tap) keys per plane (bitonic network in registers: 4 keys per lane, lane exchanges by ds_bpermute), walks the sorted list summing weight * feature-gradient over each run of equal
 // texels, and issues ONE atomic row per run and plane set (lanes 0..31: geometry set, 32..63: appearance set).
 // The atomic unit - the bound of the direct form - sees 3.4x fewer operations.
 // ------------------------------------------------------------------------------------------------------------
@@ -407,7 +407,6 @@ constexpr unsigned KEY_INVALID = 0xFFFFFFFFu;
 
 __global__ __launch_bounds__(64) void bwd_scatter_sorted_kernel(BwdK P) {
     __shared__ float tile[64 * SORT_TILE_STRIDE];       // [sample][0..31 geometry-set gradient, 32..63 appearance-set]
-    __shared__ unsigned keys[3 * 256];                  // per plane: texel << 8 | sample << 2 | tap
     __shared__ float wtab[64 * 12];                     // tap weights [sample][plane*4 + tap]
     const int lane = threadIdx.x;
     const int n = blockIdx.z, kdepth = blockIdx.y, t = blockIdx.x;
@@ -458,66 +457,88 @@ __global__ __launch_bounds__(64) void bwd_scatter_sorted_kernel(BwdK P) {
 #pragma unroll
         for (int c = 0; c < 32; ++c) tile[lane * SORT_TILE_STRIDE + 32 + c] = df[c >> 1][c & 1] * (1.0f / 3.0f);
     }
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 3      // timing experiment: decoder phase only
+    if (tile[lane] != 12345.678f) return;
+#endif
     const int plane_elems = P.H * P.W * 32;
+    unsigned key[3][4];                                 // element e = lane * 4 + r of each plane's list
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
         const int p = q >> 2;
         wtab[lane * 12 + q] = geo.w[q];
         const unsigned texel = (unsigned)(geo.off[q] - p * plane_elems) >> 5;
-        keys[p * 256 + lane * 4 + (q & 3)] = (live && geo.w[q] != 0.0f) ? (texel << 8 | (unsigned)lane << 2 | (unsigned)(q & 3)) : KEY_INVALID;
+        key[p][q & 3] = (live && geo.w[q] != 0.0f) ? (texel << 8 | (unsigned)lane << 2 | (unsigned)(q & 3)) : KEY_INVALID;
     }
     __threadfence_block();
-    // bitonic sort of the three 256-key lists (ascending; invalid keys end up last); 128 pairs per list, 2 per lane
-    for (int k = 2; k <= 256; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
+    // bitonic sort of the three 256-key lists in registers (ascending; invalid keys end up last): partners at distance
+    // 1, 2 are in the same lane, larger distances are lane ^ (distance / 4)
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                unsigned* a = keys + (r >> 1) * 256;
-                const int id = lane + 64 * (r & 1);
-                const int i = ((id & ~(j - 1)) << 1) | (id & (j - 1));
-                const unsigned x = a[i], y = a[i + j];
-                if ((x > y) == ((i & k) == 0)) { a[i] = y; a[i + j] = x; }
+    for (int k = 2; k <= 256; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 4) {
+                const int lj = j >> 2;
+                const bool keep_min = ((lane & lj) == 0) == ((lane & (k >> 2)) == 0);
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned other = (unsigned)__shfl_xor((int)key[p][r], lj);
+                        key[p][r] = keep_min ? min(key[p][r], other) : max(key[p][r], other);
+                    }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (r & j) continue;
+                    const bool up = k == 2 ? (r & 2) == 0 : (k == 4 ? (lane & 1) == 0 : (lane & (k >> 2)) == 0);
+#pragma unroll
+                    for (int p = 0; p < 3; ++p) {
+                        const unsigned lo = min(key[p][r], key[p][r | j]), hi = max(key[p][r], key[p][r | j]);
+                        key[p][r] = up ? lo : hi; key[p][r | j] = up ? hi : lo;
+                    }
+                }
             }
-            __threadfence_block();
         }
-    // walk the sorted lists
+    }
+    // walk the sorted lists: element e is register e & 3 of lane e >> 2
     const int ch = lane & 31, set = lane >> 5;
     float* gbase = set ? (do_a ? P.grad_a + gv : nullptr) : (do_g ? P.grad_g + gv : nullptr);
     const float* scale = P.aff[2 * set] ? P.aff[2 * set] + n * 96 : nullptr;
-#pragma unroll 1
-    for (int p = 0; p < 3; ++p) {
-        unsigned kreg[4]; float wreg[4]; int lastreg[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int idx = c * 64 + lane;
-            const unsigned kk = keys[p * 256 + idx];
-            const unsigned nxt = idx == 255 ? KEY_INVALID : keys[p * 256 + idx + 1];
-            kreg[c] = kk;
-            wreg[c] = kk != KEY_INVALID ? wtab[((kk >> 2) & 63) * 12 + p * 4 + (kk & 3)] : 0.0f;
-            lastreg[c] = (kk >> 8) != (nxt >> 8);
+    for (int p = 0; p < 3; ++p) {
+        float wreg[4]; int lastreg[4];
+        unsigned nxt0 = (unsigned)__shfl_down((int)key[p][0], 1);
+        if (lane == 63) nxt0 = KEY_INVALID;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const unsigned kk = key[p][r];
+            const unsigned nxt = r < 3 ? key[p][r < 3 ? r + 1 : 3] : nxt0;
+            wreg[r] = kk != KEY_INVALID ? wtab[((kk >> 2) & 63) * 12 + p * 4 + (kk & 3)] : 0.0f;
+            lastreg[r] = (kk >> 8) != (nxt >> 8);
         }
         const float sc = scale ? scale[p * 32 + ch] : 1.0f;
         float* base = gbase ? gbase + (long long)p * plane_elems + ch : nullptr;
         float acc = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if ((unsigned)__builtin_amdgcn_readfirstlane((int)kreg[c]) == KEY_INVALID) break;          // lists are sorted: nothing valid from here on
 #pragma unroll 1
-            for (int i = 0; i < 64; i += 8) {
-                unsigned kk[8]; float v[8];
+        for (int i = 0; i < 64; i += 2) {
+            if ((unsigned)__builtin_amdgcn_readlane((int)key[p][0], i) == KEY_INVALID) break;      // sorted: nothing valid from here on
+            unsigned kk[8]; float v[8];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    kk[u] = (unsigned)__builtin_amdgcn_readlane((int)kreg[c], i + u);
-                    v[u] = tile[((kk[u] >> 2) & 63) * SORT_TILE_STRIDE + lane];
-                }
+            for (int u = 0; u < 8; ++u) {
+                kk[u] = (unsigned)__builtin_amdgcn_readlane((int)key[p][u & 3], i + (u >> 2));
+                v[u] = tile[((kk[u] >> 2) & 63) * SORT_TILE_STRIDE + lane];
+            }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[c]), i + u));
-                    acc = fmaf(v[u], w, acc);
-                    if (__builtin_amdgcn_readlane(lastreg[c], i + u)) {
-                        if (base) unsafeAtomicAdd(base + (long long)(kk[u] >> 8) * 32, acc * sc);
-                        acc = 0.0f;
-                    }
+            for (int u = 0; u < 8; ++u) {
+                const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[u & 3]), i + (u >> 2)));
+                acc = fmaf(v[u], w, acc);
+                if (__builtin_amdgcn_readlane(lastreg[u & 3], i + (u >> 2))) {
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 4      // timing experiment: no atomics
+                    if (base) asm volatile("" :: "v"(acc * sc), "v"(kk[u]));
+#else
+                    if (base) unsafeAtomicAdd(base + (long long)(kk[u] >> 8) * 32, acc * sc);
+#endif
+                    acc = 0.0f;
                 }
             }
         }
