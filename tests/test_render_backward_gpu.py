@@ -99,11 +99,12 @@ def _random_case(seed, N, R, H, S, dev, affine=False):
     return planes, dec, c2w, K, o, d, depths, cot
 
 
-def test_backward_against_oracle_with_affines_and_camera_rays(dev):
+@pytest.mark.parametrize("R", [12, 16])            # 16: the 8x8-pixel tile mapping of the scatter kernel; 12: the linear one
+def test_backward_against_oracle_with_affines_and_camera_rays(R, dev):
     """Single-gather mode: raw planes + the four affines, rays generated from the cameras; gradients arrive w.r.t. the raw
     planes (chain rule through `scale`), both sets adding into ONE buffer."""
     from nerffaceediting_amd import ops
-    N, R, H, S = 2, 12, 24, 20
+    N, H, S = 2, 24, 20
     planes, dec, c2w, K, o, d, depths, cot = _random_case(77, N, R, H, S, dev)
     opts = dict(orc.FFHQ_OPTIONS, box_warp=1.0, white_back=True)
     norm5, den5, mean, std = orc.synthesis_planes(planes)
@@ -118,6 +119,39 @@ def test_backward_against_oracle_with_affines_and_camera_rays(dev):
                                     cam2world=t(c2w, dev), intrinsics=t(K, dev), resolution=R, affines=ops.make_affine(m_, s_))
     assert g is g_same
     assert rel_err(unpack(g), want) <= REL_TOL
+
+
+def test_backward_broadcast_planes(dev):
+    """One plane set rendered from several cameras (plane_view_stride 0): the gradients of all views add into one set."""
+    from nerffaceediting_amd import ops
+    N, R, H, S = 3, 16, 16, 10
+    planes, dec, c2w, K, o, d, depths, cot = _random_case(21, N, R, H, S, dev)
+    opts = dict(orc.FFHQ_OPTIONS, box_warp=1.0)
+    norm5, den5, _, _ = orc.synthesis_planes(planes[:1])
+    rep = lambda a: np.repeat(a, N, 0)
+    gn, gd = bwd.render_backward(rep(norm5), rep(den5), dec, o, d, depths, opts, cot["rgb"], cot["seg"], cot["depth"], cot["wsum"])
+    heads = [t(dec[k], dev) for k in NAMES]
+    cots = tuple(t(cot[k], dev) for k in ("rgb", "seg", "depth", "wsum"))
+    pn, pd = ops.plane_pack(t(norm5, dev)), ops.plane_pack(t(den5, dev))
+    gg, ga = ops.render_backward(pn, pd, heads, 1.0, opts, t(depths, dev), cots, cam2world=t(c2w, dev), intrinsics=t(K, dev), resolution=R)
+    assert gg.shape[0] == 1
+    assert rel_err(unpack(gg), gn.sum(0, keepdims=True)) <= REL_TOL
+    assert rel_err(unpack(ga), gd.sum(0, keepdims=True)) <= REL_TOL
+
+
+def test_direct_scatter_form():
+    """The one-atomic-row-per-tap scatter (planes beyond 2^24 texels; NFE_BWD_SCATTER=direct) against the same goldens.  The
+    switch is read once per process, so the cases run in a child interpreter."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NFE_BWD_SCATTER") == "direct":
+        pytest.skip("already the child run")
+    env = dict(os.environ, NFE_BWD_SCATTER="direct")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
+                        "reference_autograd or camera_rays"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_backward_finite_differences_larger_size(dev):
