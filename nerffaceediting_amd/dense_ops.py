@@ -26,6 +26,8 @@ def nchw_to_nhwc(x):
 
 
 def nhwc_to_nchw(x):
+    if x.requires_grad and torch.is_grad_enabled():      # part of an autograd graph (plane editing): a view keeps it differentiable
+        return x.permute(0, 3, 1, 2).contiguous()
     lib = _lib.load()
     x = _dev(x, "x", (None, None, None, None))
     N, H, W, C = x.shape

@@ -22,6 +22,10 @@ def compute_mean_var(planes):
 
 def normalize_plane(planes):
     """utils.py:152-155."""
+    if _in_graph(planes):                                    # differentiable form, statistics included, as in the reference
+        mean = planes.mean(dim=(-1, -2), keepdim=True)
+        var = torch.sqrt(planes.var(dim=(-1, -2), keepdim=True))
+        return (planes - mean) / (var + 1e-8), mean, var
     N, P, C, H, W = planes.shape
     mean, var = _stats5(planes)
     gs, gb, _, _ = ops.make_affine(mean.reshape(N, P * C, 1, 1), var.reshape(N, P * C, 1, 1))
@@ -29,8 +33,14 @@ def normalize_plane(planes):
     return out.reshape(N, P, C, H, W), mean, var
 
 
+def _in_graph(*ts):
+    return torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in ts)
+
+
 def denormalize_plane(planes, mean, var):
-    """utils.py:157-158."""
+    """utils.py:157-158.  With a leaf among the arguments (plane editing) the affine is a torch expression, so gradients reach it."""
+    if _in_graph(planes, mean, var):
+        return planes * var + mean
     N, P, C, H, W = planes.shape
     out = ops.plane_affine(planes.reshape(N, P * C, H, W), var.reshape(-1, P * C, 1, 1).contiguous(),
                            mean.reshape(-1, P * C, 1, 1).contiguous())

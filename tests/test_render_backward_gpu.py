@@ -137,6 +137,11 @@ def test_backward_broadcast_planes(dev):
     assert gg.shape[0] == 1
     assert rel_err(unpack(gg), gn.sum(0, keepdims=True)) <= REL_TOL
     assert rel_err(unpack(ga), gd.sum(0, keepdims=True)) <= REL_TOL
+    # image-layout cotangents ([N,32,M] / [N,15,M], the layout of render(..., channels_first=True))
+    cf = (cots[0].permute(0, 2, 1).contiguous(), cots[1].permute(0, 2, 1).contiguous(), cots[2], cots[3])
+    g2, a2 = ops.render_backward(pn, pd, heads, 1.0, opts, t(depths, dev), cf, cam2world=t(c2w, dev), intrinsics=t(K, dev), resolution=R,
+                                 channels_first=True)
+    assert rel_err(unpack(g2), gn.sum(0, keepdims=True)) <= REL_TOL and rel_err(unpack(a2), gd.sum(0, keepdims=True)) <= REL_TOL
 
 
 def test_direct_scatter_form():
