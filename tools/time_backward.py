@@ -1,6 +1,7 @@
 """Time nfe_render_backward (and the forward it differentiates) at plane-editing sizes.
     python tools/time_backward.py [N] [R] [D] [Di] [H]
 """
+import os
 import sys
 
 import numpy as np
@@ -30,6 +31,8 @@ def main():
     opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
     M = R * R
     cots = (torch.randn(N, M, 32, device=dev), torch.randn(N, M, 15, device=dev), torch.randn(N, M, 1, device=dev), torch.randn(N, M, 1, device=dev))
+    if os.environ.get("NO_RGB_COT"):          # geometry-only loss (seg / depth): the appearance head drops out of every kernel
+        cots = (None,) + cots[1:]
 
     def fwd():
         return ops.render(planes_n, planes_d, dec, opts, cam2world=c2w, intrinsics=K, resolution=R, seed=1, taps=True)
