@@ -44,6 +44,44 @@ def orbit_cameras(num_frames, device, lookat=(0, 0, 0.2), radius=2.7, pitch_rang
     return torch.cat(cs, 0)
 
 
+def interpolate_ws(ws_keyframes, w_frames=240, kind="cubic", wraps=2):
+    """gen_videos.py:103-113,135-136: the per-frame latents of an interpolation video.  ws_keyframes [K,num_ws,w_dim] ->
+    [K * w_frames, num_ws, w_dim]: frame f evaluates scipy's interp1d (cubic by default) of the keyframes tiled
+    2*wraps+1 times (so the curve is periodic) at f / w_frames."""
+    import scipy.interpolate
+    K = ws_keyframes.shape[0]
+    x = np.arange(-K * wraps, K * (wraps + 1))
+    y = np.tile(ws_keyframes.detach().cpu().numpy(), [wraps * 2 + 1, 1, 1])
+    interp = scipy.interpolate.interp1d(x, y, kind=kind, axis=0)
+    out = interp(np.arange(K * w_frames) / w_frames)
+    return torch.from_numpy(out).to(device=ws_keyframes.device, dtype=torch.float32)
+
+
+@torch.no_grad()
+def interpolation_video_frames(G, seeds, w_frames=240, kind="cubic", wraps=2, psi=1.0, truncation_cutoff=14, batch=4, gather=True,
+                               image_mode="image", **synthesis_kwargs):
+    """gen_videos.gen_interp_video (gen_videos.py:74-160) for a 1x1 grid, without the mp4 writer: keyframe latents from `seeds`
+    (mapped under the frontal conditioning camera, :95-98), cubic interpolation in w, one orbit camera per frame (:126-133),
+    frames rendered in batches and sharded over the ranks -> uint8 [F,512,512,3] (image_mode 'image' / 'image_raw')."""
+    dev = next(G.parameters()).device
+    zs = torch.cat([seed_to_z(s, G.z_dim, dev) for s in seeds], 0)
+    c2w = camera_utils.LookAtPoseSampler.sample(3.14 / 2, 3.14 / 2, torch.tensor([0, 0, 0.2], device=dev), radius=2.7, device=dev)
+    c_front = torch.cat([c2w.reshape(-1, 16), torch.tensor(FFHQ_INTRINSICS, device=dev).reshape(-1, 9)], 1).repeat(len(seeds), 1)
+    ws_key = G.mapping(zs, c_front, truncation_psi=psi, truncation_cutoff=truncation_cutoff)
+    ws = interpolate_ws(ws_key, w_frames, kind, wraps)
+    c = orbit_cameras(ws.shape[0], dev)
+    V = ws.shape[0]
+    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+    a, b = sharding.shard_range(V, rank, world)
+    frames = []
+    for i in range(a, b, batch):
+        j = min(b, i + batch)
+        out = G.synthesis(ws[i:j].contiguous(), c[i:j].contiguous(), noise_mode="const", **synthesis_kwargs)[image_mode]
+        frames.append(to_uint8(out))
+    local = torch.cat(frames, 0) if frames else torch.zeros((0, G.img_resolution, G.img_resolution, 3), dtype=torch.uint8, device=dev)
+    return sharding.all_gather_frames(local, V) if (gather and world > 1) else local
+
+
 def to_uint8(img):
     """gen_samples.py:177: (img.permute(0,2,3,1) * 127.5 + 128).clamp(0,255).uint8."""
     return (img.permute(0, 2, 3, 1) * 127.5 + 128).clamp(0, 255).to(torch.uint8)

@@ -221,6 +221,29 @@ def test_full_size_generator_forward():
     assert abs(float(out["image"].mean()) - float(z["image_mean"])) <= 1e-4
 
 
+def test_interpolation_video_frames(setup):
+    """gen_videos.gen_interp_video counterpart: keyframes from seeds, cubic interpolation in w, orbit cameras."""
+    from nerffaceediting_amd import apps
+    G, z, dev = setup
+    old = G.neural_rendering_resolution
+    G.neural_rendering_resolution = 32
+    try:
+        torch.manual_seed(3)
+        frames = apps.interpolation_video_frames(G, [0, 1], w_frames=2, batch=3)
+        assert frames.shape == (4, 512, 512, 3) and frames.dtype == torch.uint8
+        c = apps.orbit_cameras(4, dev)
+        zs = torch.cat([apps.seed_to_z(s, 512, dev) for s in (0, 1)], 0)
+        c2w = apps.camera_utils.LookAtPoseSampler.sample(3.14 / 2, 3.14 / 2, torch.tensor([0, 0, 0.2], device=dev), radius=2.7, device=dev)
+        c_front = torch.cat([c2w.reshape(-1, 16), torch.tensor(apps.FFHQ_INTRINSICS, device=dev).reshape(-1, 9)], 1).repeat(2, 1)
+        ws_key = G.mapping(zs, c_front, truncation_psi=1.0, truncation_cutoff=14)       # gen_videos.py:95-98
+        torch.manual_seed(3)
+        want = apps.to_uint8(G.synthesis(ws_key[:1], c[:1], noise_mode="const")["image"])
+        # frame 0 is keyframe 0 under orbit camera 0 (jitter differs per call: compare loosely, it is a 32^2 render)
+        assert float((frames[0].float() - want[0].float()).abs().mean()) < 6.0
+    finally:
+        G.neural_rendering_resolution = old
+
+
 def test_decode_is_differentiable_wrt_planes(setup):
     """Plane editing (utils.py:146-199): planes = encode(G, ws); norm/denorm as leaves; decode(); a loss on image_seg /
     image_raw / image_depth back-propagates to the planes.  Checked by a directional finite difference of decode() itself
