@@ -201,7 +201,8 @@ typedef struct nfe_render_backward_args {
     int32_t n_views, n_rays;
     const float* origins; const float* dirs;            /* [N,M,3] or both NULL: rays from cam2world/intrinsics */
     const float* cam2world; const float* intrinsics;
-    int32_t resolution;
+    int32_t resolution;                /* R with R*R == n_rays: required for camera rays; with origins/dirs a hint that the
+                                          rays are an R x R image in row-major order (8x8 ray tiles per wave), 0 = unknown */
     int32_t n_samples;                 /* S = depth_resolution + depth_resolution_importance */
     const float* depths;               /* [N,M,S] ascending per ray: tap_depths_all of the forward call */
     float box_warp;

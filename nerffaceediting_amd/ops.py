@@ -303,6 +303,8 @@ def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, dept
         origins = _dev(origins, "ray_origins", (N, M, 3))
         dirs = _dev(dirs, "ray_directions", (N, M, 3))
         a.origins, a.dirs = origins.data_ptr(), dirs.data_ptr()
+        r = int(round(M ** 0.5))                 # an r x r image in row-major order (RaySampler's order): lets the scatter kernel
+        a.resolution = int(resolution) if resolution else (r if r * r == M else 0)     # group 8x8 neighbouring rays per wave
     else:
         cam2world = _dev(cam2world, "cam2world_matrix", (N, 4, 4))
         intrinsics = _dev(intrinsics, "intrinsics", (N, 3, 3))
