@@ -506,7 +506,7 @@ __global__ __launch_bounds__(64) void bwd_scatter_sorted_kernel(BwdK P) {
     const float* scale = P.aff[2 * set] ? P.aff[2 * set] + n * 96 : nullptr;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        float wreg[4]; int lastreg[4];
+        float wreg[4]; unsigned wk[4];              // walk key: texel << 8 | sample << 2 | (1 if the run of this texel ends here)
         unsigned nxt0 = (unsigned)__shfl_down((int)key[p][0], 1);
         if (lane == 63) nxt0 = KEY_INVALID;
 #pragma unroll
@@ -514,7 +514,7 @@ __global__ __launch_bounds__(64) void bwd_scatter_sorted_kernel(BwdK P) {
             const unsigned kk = key[p][r];
             const unsigned nxt = r < 3 ? key[p][r < 3 ? r + 1 : 3] : nxt0;
             wreg[r] = kk != KEY_INVALID ? wtab[((kk >> 2) & 63) * 12 + p * 4 + (kk & 3)] : 0.0f;
-            lastreg[r] = (kk >> 8) != (nxt >> 8);
+            wk[r] = (kk & ~3u) | ((kk >> 8) != (nxt >> 8) ? 1u : 0u);
         }
         const float sc = scale ? scale[p * 32 + ch] : 1.0f;
         float* base = gbase ? gbase + (long long)p * plane_elems + ch : nullptr;
@@ -525,14 +525,14 @@ __global__ __launch_bounds__(64) void bwd_scatter_sorted_kernel(BwdK P) {
             unsigned kk[8]; float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
-                kk[u] = (unsigned)__builtin_amdgcn_readlane((int)key[p][u & 3], i + (u >> 2));
+                kk[u] = (unsigned)__builtin_amdgcn_readlane((int)wk[u & 3], i + (u >> 2));
                 v[u] = tile[((kk[u] >> 2) & 63) * SORT_TILE_STRIDE + lane];
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[u & 3]), i + (u >> 2)));
                 acc = fmaf(v[u], w, acc);
-                if (__builtin_amdgcn_readlane(lastreg[u & 3], i + (u >> 2))) {
+                if (kk[u] & 1u) {
 #if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 4      // timing experiment: no atomics
                     if (base) asm volatile("" :: "v"(acc * sc), "v"(kk[u]));
 #else
