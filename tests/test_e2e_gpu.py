@@ -290,3 +290,33 @@ def test_decode_is_differentiable_wrt_planes(setup):
                 assert abs(fd - an) <= 3e-2 * max(abs(an), 1.0), (which, fd, an)
     finally:
         G.neural_rendering_resolution, G.rendering_kwargs, G.renderer.decoder_math = old_res, old_kw, old_math
+
+
+def test_plane_optimisation_loop(setup):
+    """Geometry editing as an optimisation: make identity A render identity B's parsing map by optimising A's normalised
+    planes (appearance statistics untouched); then an appearance edit through the statistics only."""
+    from nerffaceediting_amd import editing, utils as U
+    G, z, dev = setup
+    ws, c = t(z["ws"], dev), t(z["c"], dev)
+    old_res, old_kw = G.neural_rendering_resolution, G.rendering_kwargs
+    G.neural_rendering_resolution = 32
+    G.rendering_kwargs = dict(old_kw, depth_resolution=16, depth_resolution_importance=16)
+    try:
+        with torch.no_grad():
+            planes = U.encode(G, ws, noise_mode="const")
+            norm, mean, var = U.normalize_plane(planes)
+            target = U.decode(G, ws[1:2], c[:1], norm[1:2], planes[1:2], noise_mode="const")
+            labels = target["image_seg"].argmax(1)
+        torch.manual_seed(0)
+        n2, m2, v2, losses = editing.optimize_planes(G, ws[:1], c[:1], norm[:1], mean[:1], var[:1],
+                                                     lambda out: editing.segmentation_loss(out["image_seg"], labels), steps=40, lr=0.05,
+                                                     noise_mode="const")
+        assert losses[-1] < 0.6 * losses[0], losses[::8]
+        assert torch.equal(m2, mean[:1]) and torch.equal(v2, var[:1]) and not torch.equal(n2, norm[:1])
+        raw_t = target["image_raw"]
+        _, m3, v3, l3 = editing.optimize_planes(G, ws[:1], c[:1], norm[:1], mean[:1], var[:1],
+                                                lambda out: (out["image_raw"] - raw_t).square().mean(), steps=25, lr=0.05,
+                                                optimize="stats", noise_mode="const")
+        assert l3[-1] < l3[0] and not torch.equal(m3, mean[:1])
+    finally:
+        G.neural_rendering_resolution, G.rendering_kwargs = old_res, old_kw
