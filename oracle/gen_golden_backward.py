@@ -102,6 +102,53 @@ def gen_case(tag, seed, N, R, H, D, Ni, angles, white_back=False, swap=False, bo
     print(f"  wrote backward_{tag}.npz")
 
 
+def gen_full_size(name="fullsize_backward", seed=911, N=1, R=128, H=256, D=48, Ni=48, n_keep=40000):
+    """The editing configuration at its real size (train.py:306-307: 128^2 rays, 48 + 48 samples, 256^2 planes, two plane sets
+    with different statistics) through the reference renderer under autograd.  Planes, decoder, jitter and cotangents are
+    regenerated from the seed by the test; the fixture keeps `n_keep` randomly chosen entries of each gradient and fp64
+    per-(plane, channel) sums of all of them."""
+    rng = np.random.RandomState(seed)
+    planes = smooth_planes(rng, N, H)
+    dec_np = orc.random_decoder(seed + 1, bias_scale=0.3)
+    dec_np["geo_net.2.bias"] = dec_np["geo_net.2.bias"].copy()
+    dec_np["geo_net.2.bias"][0] += np.float32(2.0)
+    c2w, K = cams([(0.3, -0.15)])
+    M = R * R
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, Ni).astype(np.float32)
+    cot = dict(rgb=rng.randn(N, M, 32).astype(np.float32), seg=rng.randn(N, M, 15).astype(np.float32),
+               depth=rng.randn(N, M, 1).astype(np.float32), wsum=rng.randn(N, M, 1).astype(np.float32))
+    new_mu = rng.randn(1, 96, 1, 1).astype(np.float32) * 0.5
+    new_sd = np.exp(rng.randn(1, 96, 1, 1).astype(np.float32) * 0.3)
+    opts = dict(depth_resolution=D, depth_resolution_importance=Ni, ray_start=2.25, ray_end=3.3, box_warp=1.0,
+                disparity_space_sampling=False, clamp_mode="softplus", white_back=False)
+    G = TriPlaneGenerator.__new__(TriPlaneGenerator)
+    with torch.no_grad():
+        norm, mean, std = TriPlaneGenerator.normalize_plane(G, torch.from_numpy(planes))
+        denorm = TriPlaneGenerator.denormalize_plane(G, norm, torch.from_numpy(new_mu), torch.from_numpy(new_sd))
+        o, d = RaySampler()(c2w, K, R)
+    norm5 = norm.reshape(N, 3, 32, H, H).clone().requires_grad_(True)
+    den5 = denorm.reshape(N, 3, 32, H, H).clone().requires_grad_(True)
+    rend = DisentangledImportanceRenderer()
+    dec = ref_decoder(dec_np).requires_grad_(False)
+    with InjectRand([u_c, u_f]):
+        outs = rend(norm5, den5, dec, o, d, opts)
+    loss = sum((v * torch.from_numpy(cot[k])).sum() for k, v in zip(("rgb", "seg", "depth", "wsum"), outs))
+    loss.backward()
+    g_norm, g_den = norm5.grad.numpy(), den5.grad.numpy()
+    idx = np.random.RandomState(seed + 7).choice(g_norm.size, n_keep, replace=False)
+    print(f"    max |grad_norm| {np.abs(g_norm).max():.3e}  max |grad_denorm| {np.abs(g_den).max():.3e}  wsum {float(outs[3].mean()):.3f}")
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"), seed=seed, N=N, R=R, H=H, D=D, Ni=Ni, cam2world=c2w.numpy(), intrinsics=K.numpy(),
+        options=np.array(repr(opts)), idx=idx.astype(np.int64),
+        grad_norm=g_norm.reshape(-1)[idx], grad_denorm=g_den.reshape(-1)[idx],
+        grad_norm_max=float(np.abs(g_norm).max()), grad_denorm_max=float(np.abs(g_den).max()),
+        grad_norm_sum=g_norm.astype(np.float64).sum(axis=(0, 3, 4)), grad_denorm_sum=g_den.astype(np.float64).sum(axis=(0, 3, 4)),
+        grad_norm_abs=np.abs(g_norm).astype(np.float64).sum(axis=(0, 3, 4)), grad_denorm_abs=np.abs(g_den).astype(np.float64).sum(axis=(0, 3, 4)),
+        rgb_mean=outs[0].detach().numpy().astype(np.float64).mean(axis=(0, 1)), torch_version=np.array(torch.__version__))
+    print(f"  wrote {name}.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     gen_case("single", 901, N=2, R=8, H=16, D=12, Ni=0, angles=[(0.3, -0.2), (-0.4, 0.1)])
@@ -111,4 +158,9 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "full_size":
+        os.makedirs(OUT, exist_ok=True)
+        gen_full_size()
+    else:
+        main()
+        gen_full_size()

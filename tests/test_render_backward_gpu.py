@@ -144,6 +144,52 @@ def test_backward_broadcast_planes(dev):
     assert rel_err(unpack(g2), gn.sum(0, keepdims=True)) <= REL_TOL and rel_err(unpack(a2), gd.sum(0, keepdims=True)) <= REL_TOL
 
 
+def test_backward_full_size_vs_reference_autograd(dev):
+    """The editing configuration at its real size (128^2 rays x 48+48 samples, 256^2 planes, two plane sets with different
+    statistics): forward + nfe_render_backward against gradients the reference produced under torch autograd.  Inputs are
+    regenerated from the fixture's seed (same numpy draws as oracle/gen_golden_backward.py gen_full_size); the fixture holds
+    40 000 entries of each gradient and fp64 per-(plane, channel) sums of all 6.3 M."""
+    import ast
+    from tests._golden import load
+    from nerffaceediting_amd import ops
+    z = load("fullsize_backward")
+    seed, N, R, H, D, Ni = (int(z[k]) for k in ("seed", "N", "R", "H", "D", "Ni"))
+    rng = np.random.RandomState(seed)
+    base = rng.randn(N, 96, H, H).astype(np.float32)                 # gen_golden.smooth_planes
+    mu = rng.randn(1, 96, 1, 1).astype(np.float32) * 0.7
+    sd = np.exp(rng.randn(1, 96, 1, 1).astype(np.float32) * 0.5)
+    planes = (base * sd + mu).astype(np.float32)
+    dec = orc.random_decoder(seed + 1, bias_scale=0.3)
+    dec["geo_net.2.bias"][0] += np.float32(2.0)
+    M = R * R
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, Ni).astype(np.float32)
+    cot = [rng.randn(N, M, 32).astype(np.float32), rng.randn(N, M, 15).astype(np.float32),
+           rng.randn(N, M, 1).astype(np.float32), rng.randn(N, M, 1).astype(np.float32)]
+    new_mu = rng.randn(1, 96, 1, 1).astype(np.float32) * 0.5
+    new_sd = np.exp(rng.randn(1, 96, 1, 1).astype(np.float32) * 0.3)
+    opts = ast.literal_eval(str(z["options"]))
+    p = t(planes, dev)
+    mean, std = ops.plane_stats(p)
+    normed = ((p - mean) / (std + 1e-8)).contiguous()
+    denormed = (normed * t(new_sd, dev) + t(new_mu, dev)).contiguous()
+    pn, pd = ops.plane_pack(normed), ops.plane_pack(denormed)
+    heads = [t(dec[k], dev) for k in NAMES]
+    kw = dict(cam2world=t(z["cam2world"], dev), intrinsics=t(z["intrinsics"], dev), resolution=R)
+    out = ops.render(pn, pd, ops.decoder_pack(*heads), opts, u_coarse=t(u_c, dev), u_fine=t(u_f, dev), taps=True, **kw)
+    assert float(np.abs(out[0].double().mean(dim=(0, 1)).cpu().numpy() - z["rgb_mean"]).max()) <= 2e-5
+    gg, ga = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], tuple(t(c, dev) for c in cot), **kw)
+    idx = torch.from_numpy(z["idx"]).to(dev)
+    for g, name in ((gg, "grad_norm"), (ga, "grad_denorm")):
+        g5 = g.permute(0, 1, 4, 2, 3).contiguous()                  # gather layout -> [N,3,32,H,W]
+        scale = float(z[name + "_max"])
+        err = float((g5.reshape(-1)[idx].cpu().double() - torch.from_numpy(z[name]).double()).abs().max())
+        sums = g5.double().sum(dim=(0, 3, 4)).cpu().numpy()
+        serr = float(np.abs(sums - z[name + "_sum"]).max()) / float(z[name + "_abs"].max())
+        print("full-size backward", name, "max-abs", err, "of", scale, " channel sums rel", serr)
+        assert err <= REL_TOL * scale and serr <= 1e-4
+
+
 def test_direct_scatter_form():
     """The one-atomic-row-per-tap scatter (planes beyond 2^24 texels; NFE_BWD_SCATTER=direct) against the same goldens.  The
     switch is read once per process, so the cases run in a child interpreter."""
