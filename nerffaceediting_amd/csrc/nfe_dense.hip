@@ -74,8 +74,18 @@ __global__ __launch_bounds__(256) void stats_nhwc_kernel(const float* __restrict
     const int rows_per = (hw + gridDim.z - 1) / gridDim.z;
     const int r0 = blockIdx.z * rows_per, r1 = min(hw, r0 + rows_per);
     double s = 0.0, ss = 0.0;
-    if (ch < c)
-        for (int r = r0 + sub; r < r1; r += 4) { const double v = x[((long long)n * hw + r) * c + ch]; s += v; ss += v * v; }
+    if (ch < c) {
+        const float* col = x + (long long)n * hw * c + ch;
+        int r = r0 + sub;
+        for (; r + 28 < r1; r += 32) {          // eight independent loads in flight per lane
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = col[(long long)(r + 4 * u) * c];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const double d = v[u]; s += d; ss += d * d; }
+        }
+        for (; r < r1; r += 4) { const double d = col[(long long)r * c]; s += d; ss += d * d; }
+    }
     __shared__ double sh[2][4][64];
     sh[0][sub][threadIdx.x & 63] = s; sh[1][sub][threadIdx.x & 63] = ss;
     __syncthreads();
@@ -922,7 +932,7 @@ extern "C" int nfe_plane_stats_nhwc(const float* x, int n, int hw, int c, float*
     hipStream_t st = (hipStream_t)stream;
     double* sums = (double*)scratch;
     if (hipMemsetAsync(sums, 0, (size_t)n * c * 2 * sizeof(double), st) != hipSuccess) return fail(NFE_ELAUNCH, "memset failed");
-    int split = hw / 256; if (split < 1) split = 1; if (split > 64) split = 64;
+    int split = hw / 128; if (split < 1) split = 1; if (split > 512) split = 512;       // >= 2 blocks per CU even for one view
     hipLaunchKernelGGL(stats_nhwc_kernel, dim3((c + 63) / 64, n, split), dim3(256), 0, st, x, hw, c, sums);
     hipLaunchKernelGGL(stats_finish_kernel, dim3((n * c + 255) / 256), dim3(256), 0, st, sums, n * c, hw, mean, std);
     NFE_CHECK_LAUNCH("stats_nhwc kernels");
