@@ -83,6 +83,12 @@ def test_module_interface_autograd(tag, dev):
     outs = rend(norm2, t(c["denorm_planes"], dev), dec, t(c["origins"], dev), t(c["dirs"], dev), opts)
     (outs[1] * t(c["cot"]["seg"], dev)).sum().backward()
     assert norm2.grad is not None and float(norm2.grad.abs().max()) > 0
+    # appearance-only editing: only denorm_planes is a leaf
+    den3 = t(c["denorm_planes"], dev).requires_grad_(True)
+    rend.inject_jitter(t(c["u_coarse"], dev), t(c["u_fine"], dev) if opts["depth_resolution_importance"] else None)
+    outs = rend(t(c["norm_planes"], dev), den3, dec, t(c["origins"], dev), t(c["dirs"], dev), opts)
+    sum((v * t(c["cot"][k], dev)).sum() for k, v in zip(("rgb", "seg", "depth", "wsum"), outs)).backward()
+    assert rel_err(den3.grad.cpu().numpy(), c["grad_denorm"]) <= REL_TOL
 
 
 def _random_case(seed, N, R, H, S, dev, affine=False):
