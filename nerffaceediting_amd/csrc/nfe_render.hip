@@ -38,6 +38,8 @@ struct RenderK {
     float density_noise;           // std of the Gaussian added to sigma (renderer.py:285-286), NOISE variants only
     const int* src_buf;            // DEPTH_BUFFER + NOISE: [N*M, S] which draw each merged sample is (k, or D + fine rank)
     const float* dec_cross;        // CROSS variants: packed cross fragments (nfe_decoder_pack_cross)
+    int seg_count;                 // SPLIT variants: depth segments per ray block (each marched by its own wave)
+    float* partials;               // SPLIT variants: [N*M, seg_count, PARTIAL_FLOATS] segment composites, see render_combine_kernel
 };
 
 // LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then per wave AFF_FLOATS of
@@ -48,6 +50,13 @@ constexpr int AFF_BSUM = 4 * 96;
 constexpr int XCHG_FLOATS = 32 * 32;
 constexpr int WAVE_LDS_FLOATS = AFF_FLOATS + XCHG_FLOATS;
 constexpr int RENDER_LDS_BYTES = (DEC_FLOATS + 4 * WAVE_LDS_FLOATS) * 4;
+// Depth-split launches (few rays: not enough ray blocks to fill the SIMDs): a ray block's S samples are cut into seg_count
+// contiguous segments marched by different waves; a segment starts at transmittance 1 and leaves (sum of w*rgb, sum of
+// w*seg, sum of w*t, sum of w, its transmittance) = 32 + 15 + 3 floats, composited in order by render_combine_kernel
+// (alpha compositing is associative: out = sum_s (prod_{s'<s} T_s') * partial_s).
+constexpr int PARTIAL_FLOATS = 52;
+constexpr int SPLIT_MAX_ITEMS = 2048;            // wave-items (ray block x segment) a split launch may have: 2 per SIMD
+constexpr int SPLIT_PARTIAL_BYTES = SPLIT_MAX_ITEMS * 32 * PARTIAL_FLOATS * 4;
 // CROSS variants (SegmentationOSGDecoder, triplane.py:192-230: sigma comes from the OTHER net's hidden layer): 8 more
 // split-bf16 layer-1 fragments behind the per-wave regions, geometry-head rows fed by the appearance head's hidden units.
 constexpr int LDS_CROSS = DEC_FLOATS + 4 * WAVE_LDS_FLOATS;
@@ -686,7 +695,7 @@ __device__ __forceinline__ float sample_gaussian(unsigned long long seed, unsign
     return sqrtf(-2.0f * LN2 * log2_fast(u1)) * __builtin_amdgcn_cosf(u2);       // v_cos_f32 takes revolutions
 }
 
-template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false>
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false, bool SPLIT = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_decoder<MATH>(P.dec, lds);
@@ -706,8 +715,11 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     int cur_view = -1;
     float tmin = INFINITY, tmax = -INFINITY;
 
+    const int nseg = SPLIT ? P.seg_count : 1;
 #pragma unroll 1
-    for (long long rb = (long long)blockIdx.x * 4 + wave; rb < total_rb; rb += n_waves) {
+    for (long long item = (long long)blockIdx.x * 4 + wave; item < total_rb * nseg; item += n_waves) {
+        const long long rb = SPLIT ? item / nseg : item;
+        const int seg = SPLIT ? (int)(item % nseg) : 0;
         const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
         if (n != cur_view) { stage_affine(P.aff, n, aff, lane); cur_view = n; }
 
@@ -763,8 +775,12 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
         for (int c = 0; c < 4; ++c) { acc_seg[c] = splat(0.0f); prev_seg[c] = splat(0.0f); }
         u32x4 rnd = {0, 0, 0, 0};
 
+        // samples [k0, k1) belong to this wave; a later segment first evaluates sample k0-1 (no compositing) to have the
+        // left end of its first mid-point interval
+        const int k0 = SPLIT ? (int)((long long)seg * S / nseg) : 0, k1 = SPLIT ? (int)((long long)(seg + 1) * S / nseg) : S;
+        const int kfirst = (SPLIT && k0 > 0) ? k0 - 1 : 0;
 #pragma unroll 1
-        for (int k = 0; k < S; ++k) {
+        for (int k = kfirst; k < k1; ++k) {
             float t;
             if (P.depth_mode == DEPTH_BUFFER) {
                 t = P.depth_buf[ray * S + k];
@@ -773,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                 if (P.u) {
                     u = P.u[ray * S + k];
                 } else {
-                    if ((k & 3) == 0)
+                    if ((k & 3) == 0 || (SPLIT && k == kfirst))
                         rnd = philox4x32_10((unsigned)ray, (unsigned)(k >> 2), 0u, 0u,
                                             (unsigned)seed, (unsigned)(seed >> 32));
                     unsigned bits = (k & 3) == 0 ? rnd.x : (k & 3) == 1 ? rnd.y : (k & 3) == 2 ? rnd.z : rnd.w;
@@ -805,7 +821,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                 const unsigned draw = (P.depth_mode == DEPTH_BUFFER && P.src_buf) ? (unsigned)P.src_buf[ray * S + k] : (unsigned)k;
                 og[0] = fmaf(P.density_noise, sample_gaussian(seed, (unsigned)ray, draw), og[0]);
             }
-            if (k > 0) {
+            if (k > kfirst) {
                 const float dlt = t - prev_t;
                 const float dens = softplus_f((prev_sig + og[0]) * 0.5f - 1.0f);
                 const float alpha = 1.0f - exp2_fast(-(dens * dlt) * LOG2E);
@@ -834,6 +850,23 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
         }
 
         // ---- outputs -------------------------------------------------------------------------
+        if (SPLIT) {
+            if (valid) {
+                float* pp = P.partials + (ray * nseg + seg) * PARTIAL_FLOATS;
+                if (!SIGMA_ONLY) {
+                    float4* o = reinterpret_cast<float4*>(pp + 16 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = make_float4(acc_rgb[2 * q][0], acc_rgb[2 * q][1], acc_rgb[2 * q + 1][0], acc_rgb[2 * q + 1][1]);
+                    const int ns = h ? 7 : 8;
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < ns) pp[32 + 8 * h + c] = acc_seg[c >> 1][c & 1];
+                }
+                if (h == 0) { pp[47] = acc_d; pp[48] = acc_w; pp[49] = T; }
+            }
+            continue;
+        }
         if (!SIGMA_ONLY && valid) {
             const float wb = P.white_back ? (1.0f - acc_w) : 0.0f;
             float rgbv[16], segv[8];
@@ -878,6 +911,46 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             atomicMin(P.depth_minmax + 0, f2ord(tmin));
             atomicMax(P.depth_minmax + 1, f2ord(tmax));
         }
+    }
+}
+
+
+// Composite the depth segments of a split launch in order (see PARTIAL_FLOATS) and finish exactly as the kernel's own
+// epilogue does; the coarse pass of a two-pass render (sigma_only) only needs its weights rescaled by the transmittance
+// in front of their segment.  One lane per (ray, output channel group): lanes 0..31 of a 64-lane group take rgb channel,
+// 32..46 seg channel, 47 depth + weight sum + the weights.
+__global__ __launch_bounds__(256) void render_combine_kernel(RenderK P, int sigma_only) {
+    const long long ray = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int c = threadIdx.x & 63;
+    if (ray >= (long long)P.N * P.M || c > 47) return;
+    const int nseg = P.seg_count, S = P.S;
+    const float* pp = P.partials + ray * nseg * PARTIAL_FLOATS;
+    const int n = (int)(ray / P.M), m = (int)(ray % P.M);
+    float T = 1.0f, acc = 0.0f, acc_d = 0.0f, acc_w = 0.0f;
+    for (int s = 0; s < nseg; ++s) {
+        const float* q = pp + s * PARTIAL_FLOATS;
+        if (c == 47) {
+            if (P.out_weights && T != 1.0f) {
+                const int k0 = (int)((long long)s * S / nseg), k1 = (int)((long long)(s + 1) * S / nseg);
+                for (int k = max(k0, 1); k < k1; ++k) P.out_weights[ray * (S - 1) + (k - 1)] *= T;
+            }
+            acc_d = fmaf(T, q[47], acc_d);
+        } else if (!sigma_only) {
+            acc = fmaf(T, q[c], acc);
+        }
+        acc_w = fmaf(T, q[48], acc_w);
+        T *= q[49];
+    }
+    if (sigma_only) return;
+    if (c < 32) {
+        const float wb = P.white_back ? (1.0f - acc_w) : 0.0f;
+        const float v = (acc + wb) * 2.0f - 1.0f;
+        if (P.channels_first) P.rgb[((long long)n * 32 + c) * P.M + m] = v; else P.rgb[ray * 32 + c] = v;
+    } else if (c < 47) {
+        if (P.channels_first) P.seg[((long long)n * 15 + (c - 32)) * P.M + m] = acc; else P.seg[ray * 15 + (c - 32)] = acc;
+    } else {
+        P.depth[ray] = acc_d / acc_w;
+        P.wsum[ray] = acc_w;
     }
 }
 
@@ -1131,6 +1204,34 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
         NFE_CHECK_LAUNCH("render_kernel");
         return NFE_OK;
     }
+    // Few ray blocks (e.g. one 128^2 view = 512 blocks on 1024 SIMDs): cut the march of each block into depth segments so
+    // that every SIMD gets about two waves; render_combine_kernel composites the segments.
+    static const bool allow_split = [] { const char* e = getenv("NFE_RENDER_SPLIT"); return !(e && e[0] == '0'); }();
+    int nseg = 1;
+    if (allow_split && P.partials && math == NFE_MATH_BF16X3 && P.density_noise == 0.0f && total_rb * 2 <= SPLIT_MAX_ITEMS && P.S >= 16) {
+        nseg = (int)(SPLIT_MAX_ITEMS / total_rb);
+        if (nseg > 8) nseg = 8;
+        if (nseg > P.S / 8) nseg = P.S / 8;
+    }
+    if (nseg >= 2) {
+        RenderK Q = P;
+        Q.seg_count = nseg;
+        long long sblocks = (total_rb * nseg + 3) / 4;
+        if (sblocks > cap) sblocks = cap;
+        dim3 sgrid((unsigned)sblocks);
+        if (sigma_only) {
+            if (dual) hipLaunchKernelGGL((render_kernel<true, true, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
+            else hipLaunchKernelGGL((render_kernel<false, true, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
+        } else {
+            if (dual) hipLaunchKernelGGL((render_kernel<true, false, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
+            else hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
+        }
+        NFE_CHECK_LAUNCH("render_kernel (split)");
+        const long long rays = (long long)P.N * P.M;
+        hipLaunchKernelGGL(render_combine_kernel, dim3((unsigned)((rays + 3) / 4)), dim3(256), 0, st, Q, sigma_only ? 1 : 0);
+        NFE_CHECK_LAUNCH("render_combine_kernel");
+        return NFE_OK;
+    }
     if (sigma_only) {
         if (dual) launch_render_math<true, true>(P, math, grid, st); else launch_render_math<false, true>(P, math, grid, st);
     } else {
@@ -1148,7 +1249,7 @@ using namespace nfe;
 
 extern "C" uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int D, int Di) {
     uint64_t nr = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0);
-    uint64_t b = 256;                                    // depth min/max words
+    uint64_t b = 256 + SPLIT_PARTIAL_BYTES;              // depth min/max words, segment composites of depth-split launches
     if (Di > 0) {
         b += align256(nr * (uint64_t)D * 4);             // coarse depths
         b += align256(nr * (uint64_t)(D - 1) * 4);       // coarse weights
@@ -1192,6 +1293,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     const uint64_t nr = (uint64_t)a->n_views * a->n_rays;
     char* ws = (char*)a->workspace;
     unsigned* minmax = (unsigned*)ws; ws += 256;
+    float* partials = (float*)ws; ws += SPLIT_PARTIAL_BYTES;
 
     RenderK P{};
     P.planes_g = a->planes_geo; P.planes_a = a->planes_app; P.plane_view_stride = a->plane_view_stride;
@@ -1209,6 +1311,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.seed = a->seed; P.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device);
     P.density_noise = a->density_noise;
     P.dec_cross = a->decoder_cross;
+    P.partials = a->decoder_cross ? nullptr : partials;
     if (a->decoder_cross)
         NFE_REQUIRE(a->planes_geo == a->planes_app && a->decoder_math == NFE_MATH_BF16X3 && a->density_noise == 0.0f,
                     "nfe_render: decoder_cross (SegmentationOSGDecoder) needs one plane set, NFE_MATH_BF16X3 and density_noise == 0");

@@ -304,3 +304,52 @@ def test_render_ffhq_config_dual_vs_reference(dev):
     rgb1 = ops.render(packed, packed, decp, opts, cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev), resolution=R,
                       affines=aff, u_coarse=_t(u_c, dev), u_fine=_t(u_f, dev))[0]
     assert max_abs(rgb1[:, idx].cpu().numpy(), z["rgb"]) <= TIGHT["bf16x3"]
+
+
+def test_depth_split_launches_match_unsplit(dev):
+    """Few-ray launches cut every ray block's march into depth segments marched by different waves (render_combine_kernel
+    composites them).  Same inputs, split on (this process) vs off (NFE_RENDER_SPLIT=0 is read once per process: child
+    interpreter): single pass and two-pass, one and two plane sets."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    import torch
+    from nerffaceediting_amd import ops
+    if os.environ.get("NFE_RENDER_SPLIT") == "0":
+        pytest.skip("this is the child run")
+    prog = r"""
+import sys, numpy as np, torch
+from nerffaceediting_amd import ops
+from oracle import render_oracle as orc
+dev = torch.device("cuda:0")
+rng = np.random.RandomState(4)
+t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(dev)
+names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias", "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+dec = orc.random_decoder(5, bias_scale=0.3); dec["geo_net.2.bias"][0] += np.float32(3.0)
+decp = ops.decoder_pack(*[t(dec[k]) for k in names])
+N, R, H = 2, 24, 32
+pa, pb = ops.plane_pack(t(rng.randn(N, 96, H, H))), ops.plane_pack(t(rng.randn(N, 96, H, H) * 0.7))
+c2w = np.concatenate([orc.lookat_pose(np.pi / 2 + 0.3 * i, np.pi / 2 - 0.1, [0, 0, 0.2], 2.7).reshape(1, 4, 4) for i in range(N)])
+K = np.repeat(orc.fov_to_intrinsics(18.837)[None], N, 0)
+outs = []
+for D, Di, wb in ((37, 0, False), (24, 24, True), (16, 40, False)):
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0, white_back=wb)
+    for second in (pa, pb):
+        r = ops.render(pa, second, decp, opts, cam2world=t(c2w), intrinsics=t(K), resolution=R, u_coarse=t(rng.rand(N, R * R, D)),
+                       u_fine=t(rng.rand(N * R * R, max(Di, 1))[:, :Di]) if Di else None, taps=True, channels_first=(D == 24))
+        outs += [x.cpu().numpy() for x in r[:4]] + [r[4]["depths_all"].cpu().numpy()] + ([r[4]["weights_coarse"].cpu().numpy()] if Di else [])
+np.savez(sys.argv[1], *outs)
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as td:
+        res = {}
+        for tag, env in (("split", dict(os.environ)), ("plain", dict(os.environ, NFE_RENDER_SPLIT="0"))):
+            out = os.path.join(td, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", prog, out], cwd=root, env=dict(env, PYTHONPATH=root), capture_output=True, text=True, timeout=600)
+            assert r.returncode == 0, r.stderr[-2000:]
+            z = np.load(out)
+            res[tag] = [z[k] for k in z.files]
+    assert len(res["split"]) == len(res["plain"]) > 20
+    for a, b in zip(res["split"], res["plain"]):
+        assert a.shape == b.shape and max_abs(a, b) <= 2e-5, max_abs(a, b)
