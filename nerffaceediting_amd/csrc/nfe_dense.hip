@@ -1072,12 +1072,22 @@ extern "C" uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c) 
 
 extern "C" int nfe_conv_accepts_split(int mode, int h, int w, int cin, int cout) { return conv3_eligible(mode, h, w, cin, cout) ? 1 : 0; }
 
-// Small 3x3 layers (at most one 16x16 tile per sample) split their K loop over this many workgroups.
-static int splitk_slices(int mode, int h, int w, int cin, int cout) {
-    const int lim = mode == NFE_CONV_1X1 ? 32 : 16;            // ToRGB has 9x less work per K-group: worth it up to 32^2
-    if (h > lim || w > lim || cout % 4 != 0) return 0;
+// Small 3x3 layers (at most one 16x16 tile per sample) split their K loop over this many workgroups.  So do 1x1 (ToRGB)
+// layers up to 128^2 whose weights do not fit the LDS-resident torgb_kernel (512 / 256 input channels) when the batch is too
+// small to fill the chip with (tile, M-block) workgroups alone: 73 us -> 15 us for the 64^2 x 512 -> 96 layer at batch 1.
+static int splitk_slices(int mode, int math, int n, int h, int w, int cin, int cout) {
+    if (cout % 4 != 0) return 0;
     const int G = (cin + 15) / 16;
-    return G >= 16 ? 8 : (G >= 8 ? 4 : 0);
+    const int ks = G >= 16 ? 8 : (G >= 8 ? 4 : 0);
+    const int lim = mode == NFE_CONV_1X1 ? 32 : 16;            // ToRGB has 9x less work per K-group: worth it up to 32^2
+    if (h <= lim && w <= lim) return ks;
+    if (mode == NFE_CONV_1X1 && h <= 128 && w <= 128) {
+        const int mb = (cout + 31) / 32, parts = math == NFE_CONV_BF16 ? 1 : 2;
+        const bool lds_resident = cin % 16 == 0 && (mb == 1 || mb == 3) && (long long)mb * (cin / 16) * parts * 1024 <= 64 * 1024;
+        const long long groups = (long long)n * ((h + 15) / 16) * ((w + 15) / 16) * mb;
+        if (!lds_resident && groups < 256) return ks;
+    }
+    return 0;
 }
 
 extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout) {
@@ -1086,7 +1096,7 @@ extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, in
     if (conv3_eligible(mode, h, w, cin, cout)) {
         const uint64_t elems = (uint64_t)n * h * w * cin;           // bf16 hi (+ lo) image of the modulated input
         fl += math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
-    } else if (const int ks = splitk_slices(mode, h, w, cin, cout)) {
+    } else if (const int ks = splitk_slices(mode, math, n, h, w, cin, cout)) {
         fl += (uint64_t)ks * n * (mode == NFE_CONV_3X3_UP2 ? (uint64_t)(2 * h + 1) * (2 * w + 1) : (uint64_t)h * w) * cout;   // partial sums
     }
     return fl;
@@ -1172,7 +1182,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     const int up = a->mode == NFE_CONV_3X3_UP2;
     const int gh = a->h + up, gw = a->w + up;
     dim3 grid(((gh + 15) / 16) * ((gw + 15) / 16), (a->cout + 31) / 32, a->n);
-    const int ks = a->out_planes ? 0 : splitk_slices(a->mode, a->h, a->w, a->cin, a->cout);
+    const int ks = a->out_planes ? 0 : splitk_slices(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout);
     if (ks && a->scratch && a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout)) {
         const long long slice = (long long)a->n * (up ? (long long)(2 * a->h + 1) * (2 * a->w + 1) : (long long)a->h * a->w) * a->cout;
         P.ksplit = ks; P.partial = a->scratch + (up ? slice : 0);      // after the transposed-conv scratch

@@ -29,8 +29,10 @@ c = apps.orbit_cameras(max(N, 2), dev)[:N]
 z = torch.randn(N, 512, device=dev)
 
 
-def timed(fn, reps=5):
-    fn(); torch.cuda.synchronize()
+def timed(fn, reps=10):
+    for _ in range(3):          # back-to-back warm-up: lets torch's caching allocator reach the pool size of overlapping calls
+        fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         out = fn()
