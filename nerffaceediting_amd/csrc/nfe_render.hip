@@ -929,15 +929,12 @@ __global__ __launch_bounds__(256) void render_combine_kernel(RenderK P, int sigm
     float T = 1.0f, acc = 0.0f, acc_d = 0.0f, acc_w = 0.0f;
     for (int s = 0; s < nseg; ++s) {
         const float* q = pp + s * PARTIAL_FLOATS;
-        if (c == 47) {
-            if (P.out_weights && T != 1.0f) {
-                const int k0 = (int)((long long)s * S / nseg), k1 = (int)((long long)(s + 1) * S / nseg);
-                for (int k = max(k0, 1); k < k1; ++k) P.out_weights[ray * (S - 1) + (k - 1)] *= T;
-            }
-            acc_d = fmaf(T, q[47], acc_d);
-        } else if (!sigma_only) {
-            acc = fmaf(T, q[c], acc);
+        if (P.out_weights && T != 1.0f) {            // weights of this segment: all 48 lanes of the ray share the rescale
+            const int k0 = (int)((long long)s * S / nseg), k1 = (int)((long long)(s + 1) * S / nseg);
+            for (int k = max(k0, 1) + c; k < k1; k += 48) P.out_weights[ray * (S - 1) + (k - 1)] *= T;
         }
+        if (c == 47) acc_d = fmaf(T, q[47], acc_d);
+        else if (!sigma_only) acc = fmaf(T, q[c], acc);
         acc_w = fmaf(T, q[48], acc_w);
         T *= q[49];
     }
