@@ -97,4 +97,29 @@ __device__ __forceinline__ Taps tap_geometry(int H, int W, float u, float v) {
     return t;
 }
 
+// One axis of the bilinear footprint: clamped tap coordinates, 1-D weights with out-of-range taps zeroed, and whether both
+// taps are inside.  The 2-D weights are separable ((vx ? ex : 0) * (vy ? ey : 0) == (vx && vy) ? ex * ey : 0), so on SQUARE
+// planes the three projections (x,y), (x,z), (z,x) of a sample share their axes: three axis computations instead of six.
+struct Axis { int c0, c1; float a0, a1; bool in; };
+__device__ __forceinline__ Axis axis_geometry(int size, float g) {
+    Axis a;
+    const float i = (g + 1.0f) * (0.5f * (float)size) - 0.5f;
+    const float f0 = floorf(i);
+    const float d = i - f0, e = 1.0f - d;
+    const int x0 = (int)fminf(fmaxf(f0, -2.0f), (float)(size + 1));
+    const int x1 = x0 + 1;
+    const bool v0 = (unsigned)x0 < (unsigned)size, v1 = (unsigned)x1 < (unsigned)size;
+    a.a0 = v0 ? e : 0.0f; a.a1 = v1 ? d : 0.0f;
+    a.c0 = min(max(x0, 0), size - 1); a.c1 = min(max(x1, 0), size - 1);
+    a.in = v0 && v1;
+    return a;
+}
+__device__ __forceinline__ Taps taps_from_axes(const Axis& u, const Axis& v) {      // u indexes W, v indexes H
+    Taps t;
+    t.xc0 = u.c0; t.xc1 = u.c1; t.yc0 = v.c0; t.yc1 = v.c1;
+    t.w[0] = u.a0 * v.a0; t.w[1] = u.a1 * v.a0; t.w[2] = u.a0 * v.a1; t.w[3] = u.a1 * v.a1;
+    t.wdef = (u.in && v.in) ? 0.0f : ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3])) - 1.0f;
+    return t;
+}
+
 }  // namespace nfe

@@ -216,6 +216,13 @@ __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, 
     offs[PL][0] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc0) * 128u; offs[PL][1] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc1) * 128u; \
     offs[PL][2] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc0) * 128u; offs[PL][3] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc1) * 128u;
 
+// SQUARE planes: the axes are shared between the projections (compile-time variant: a run-time branch here, with loads in
+// flight around it, produced run-dependent wrong results and is avoided on purpose).
+#define NFE_PIPE_GEOM_AX(PL, AU, AV)                                                                       \
+    tp[PL] = taps_from_axes(AU, AV);                                                                       \
+    offs[PL][0] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc0) * 128u; offs[PL][1] = (unsigned)(tp[PL].yc0 * W + tp[PL].xc1) * 128u; \
+    offs[PL][2] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc0) * 128u; offs[PL][3] = (unsigned)(tp[PL].yc1 * W + tp[PL].xc1) * 128u;
+
 // Two plane sets (norm_planes != normalised denorm_planes): twelve batches of one tap = 4 + 4 loads, two in flight.
 #define NFE_PIPE2_ISSUE_I(S, I)                                                                            \
     {                                                                                                      \
@@ -239,12 +246,14 @@ __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, 
         sa[2 * i_ + 1] = pk_fma(w2, f32x2{vg[S][4 + i_].z, vg[S][4 + i_].w}, sa[2 * i_ + 1]);              \
     }
 
+template <bool SQUARE>
 __device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ pg, const float* __restrict__ pa, int H, int W,
                                                       long long plane_elems, const float* __restrict__ aff, int lane,
                                                       float gx, float gy, float gz, f32x2 (&qn)[8], f32x2 (&qd)[8]) {
     Taps tp[3];
     unsigned offs[3][4];
-    NFE_PIPE_GEOM(0, gx, gy)
+    Axis ax_xw, ax_zh;
+    if (SQUARE) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) } else { NFE_PIPE_GEOM(0, gx, gy) }
     const int ll = launder(lane);
     const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
     const unsigned qoff_bytes = (unsigned)qoff * 4u;
@@ -254,7 +263,7 @@ __device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ 
 #pragma unroll
     for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); sa[c] = splat(0.0f); }
     NFE_PIPE2_ISSUE(0, 0, 0) NFE_PIPE2_ISSUE(1, 0, 1)
-    NFE_PIPE_GEOM(1, gx, gz)
+    if (SQUARE) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) } else { NFE_PIPE_GEOM(1, gx, gz) }
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 0, 2)
     __builtin_amdgcn_sched_barrier(0);
@@ -264,7 +273,7 @@ __device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ 
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 1, 1)
     plane_affine_acc<false, 0, true>(aff, qoff, tp[0], sg, qn, qd, sa);
-    NFE_PIPE_GEOM(2, gz, gx)
+    if (SQUARE) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_PIPE_GEOM(2, gz, gx) }
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 1, 2)
     __builtin_amdgcn_sched_barrier(0);
@@ -285,14 +294,15 @@ __device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ 
     plane_affine_acc<false, 2, true>(aff, qoff, tp[2], sg, qn, qd, sa);
 }
 
-template <bool SIGMA_ONLY>
+template <bool SIGMA_ONLY, bool SQUARE>
 __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, int H, int W, long long plane_elems,
                                                  const float* __restrict__ aff, int lane, float gx, float gy, float gz,
                                                  f32x2 (&qn)[8], f32x2 (&qd)[8]) {
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
     Taps tp[3];
     unsigned offs[3][4];
-    NFE_PIPE_GEOM(0, gx, gy)
+    Axis ax_xw, ax_zh;
+    if (SQUARE) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) } else { NFE_PIPE_GEOM(0, gx, gy) }
     const int ll = launder(lane);
     const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
     const unsigned qoff_bytes = (unsigned)qoff * 4u;
@@ -302,13 +312,14 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
 #pragma unroll
     for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
     NFE_PIPE_ISSUE(0, 0, 0) NFE_PIPE_ISSUE(1, 0, 2)
-    NFE_PIPE_GEOM(1, gx, gz)                       // the next plane's tap geometry runs under the loads in flight
+    // the next plane's tap geometry runs under the loads in flight
+    if (SQUARE) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) } else { NFE_PIPE_GEOM(1, gx, gz) }
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(0) NFE_PIPE_ISSUE(0, 1, 0)
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(1) NFE_PIPE_ISSUE(1, 1, 2)
     plane_affine_acc<SIGMA_ONLY, 0>(aff, qoff, tp[0], sg, qn, qd);
-    NFE_PIPE_GEOM(2, gz, gx)
+    if (SQUARE) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_PIPE_GEOM(2, gz, gx) }
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(0) NFE_PIPE_ISSUE(0, 2, 0)
     __builtin_amdgcn_sched_barrier(0);
@@ -599,7 +610,7 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
 //   (seg starts on an even register so packed-fp32 pairs need no realigning moves)
 //   oa[r] = rgb channel 16h + r   (after the sigmoid clamp, triplane.py:269)
 // All 64 lanes must be active (quad broadcasts and the LDS exchange involve the whole wave).
-template <bool DUAL, bool SIGMA_ONLY, int MATH, bool CROSS = false>
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool CROSS = false, bool SQUARE = false>
 __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const float* __restrict__ pa,
                                            int H, int W, const float* __restrict__ lds,
                                            const float* __restrict__ aff, float* __restrict__ xp,
@@ -619,8 +630,8 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
         }
     }
     const long long plane_elems = (long long)H * W * 32;
-    if (DUAL && !SIGMA_ONLY) gather_pipelined_dual(pg, pa, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
-    else gather_pipelined<SIGMA_ONLY>(pg, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
+    if (DUAL && !SIGMA_ONLY) gather_pipelined_dual<SQUARE>(pg, pa, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
+    else gather_pipelined<SIGMA_ONLY, SQUARE>(pg, H, W, plane_elems, aff, lane, gx, gy, gz, qn, qd);
     f32x2 fn[8], fd[8];          // own layout: channels 16h..16h+15 of this lane's point
     exchange_to_own(xp, lane, qn, fn);
     if (!SIGMA_ONLY) exchange_to_own(xp, lane, qd, fd);
@@ -695,7 +706,7 @@ __device__ __forceinline__ float sample_gaussian(unsigned long long seed, unsign
     return sqrtf(-2.0f * LN2 * log2_fast(u1)) * __builtin_amdgcn_cosf(u2);       // v_cos_f32 takes revolutions
 }
 
-template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false, bool SPLIT = false>
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false, bool SPLIT = false, bool SQUARE = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_decoder<MATH>(P.dec, lds);
@@ -815,7 +826,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             // would pin >200 VGPRs per lane and spill.
             int opq;
             asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
-            eval_point<DUAL, SIGMA_ONLY, MATH, CROSS>(pg, pa, P.H, P.W, lds + opq, aff + opq, xp + opq, gx, gy, gz, lane, og, oa);
+            eval_point<DUAL, SIGMA_ONLY, MATH, CROSS, SQUARE>(pg, pa, P.H, P.W, lds + opq, aff + opq, xp + opq, gx, gy, gz, lane, og, oa);
 
             if (NOISE) {
                 const unsigned draw = (P.depth_mode == DEPTH_BUFFER && P.src_buf) ? (unsigned)P.src_buf[ray * S + k] : (unsigned)k;
@@ -1179,6 +1190,8 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
     } else {
         if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+        else if (P.H == P.W && !DUAL)      // shared axis geometry: measured faster with one plane set (-2.5 %), not with two (+0.8 %)
+            hipLaunchKernelGGL((render_kernel<false, SIGMA_ONLY, NFE_MATH_BF16X3, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
     }
 }
@@ -1216,13 +1229,15 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
         long long sblocks = (total_rb * nseg + 3) / 4;
         if (sblocks > cap) sblocks = cap;
         dim3 sgrid((unsigned)sblocks);
+#define NFE_LAUNCH_SPLIT(DU, SG)                                                                                                   \
+        if (P.H == P.W && !(DU)) hipLaunchKernelGGL((render_kernel<false, SG, NFE_MATH_BF16X3, false, false, true, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q); \
+        else hipLaunchKernelGGL((render_kernel<DU, SG, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
         if (sigma_only) {
-            if (dual) hipLaunchKernelGGL((render_kernel<true, true, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
-            else hipLaunchKernelGGL((render_kernel<false, true, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
+            if (dual) { NFE_LAUNCH_SPLIT(true, true) } else { NFE_LAUNCH_SPLIT(false, true) }
         } else {
-            if (dual) hipLaunchKernelGGL((render_kernel<true, false, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
-            else hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
+            if (dual) { NFE_LAUNCH_SPLIT(true, false) } else { NFE_LAUNCH_SPLIT(false, false) }
         }
+#undef NFE_LAUNCH_SPLIT
         NFE_CHECK_LAUNCH("render_kernel (split)");
         const long long rays = (long long)P.N * P.M;
         hipLaunchKernelGGL(render_combine_kernel, dim3((unsigned)((rays + 3) / 4)), dim3(256), 0, st, Q, sigma_only ? 1 : 0);
