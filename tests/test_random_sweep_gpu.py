@@ -100,3 +100,37 @@ def test_backward_sweep(seed, dev):
     else:
         for got, want in ((gg, gn), (ga, gd)):
             assert float(np.abs(un(got) - want).max()) <= 1e-3 * float(np.abs(want).max()) + 1e-7, seed
+
+
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_pose_sweep_image_rays(two_pass, dev):
+    """Image rays generated in-kernel from 12 cameras (frontal to grazing yaw / pitch, near and far radii, narrow and wide
+    fields of view; many rays cross plane borders or miss the box) at 64^2 rays, against the C oracle fed with the oracle's
+    own RaySampler rays."""
+    from nerffaceediting_amd import ops
+    rng = np.random.RandomState(99)
+    poses = [(0.0, 0.0, 2.7, 18.837), (0.9, 0.0, 2.7, 18.837), (-1.3, 0.2, 2.7, 18.837), (0.3, 0.7, 2.7, 18.837),
+             (0.0, -0.8, 2.7, 18.837), (2.6, 0.1, 2.7, 18.837), (0.4, -0.2, 1.2, 30.0), (0.0, 0.0, 4.0, 12.0),
+             (1.57, 0.0, 2.2, 25.0), (-0.4, 0.5, 3.3, 18.837), (0.2, -0.1, 2.7, 45.0), (3.14, 0.0, 2.7, 18.837)]
+    N, R, H, D, Di = len(poses), 64, 64, 24, (24 if two_pass else 0)
+    c2w = np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2 + p, [0, 0, 0.2], r).reshape(1, 4, 4) for (y, p, r, f) in poses])
+    K = np.stack([orc.fov_to_intrinsics(f) for (y, p, r, f) in poses])
+    planes = (rng.randn(1, 96, H, H) * 1.1 + 0.1).astype(np.float32)
+    norm, den, _, _ = orc.synthesis_planes(planes)
+    dec = orc.random_decoder(5, bias_scale=0.3)
+    dec["geo_net.2.bias"][0] += np.float32(2.5)
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=0.6, ray_end=4.6, box_warp=1.0, clamp_mode="softplus")
+    u_c = rng.rand(N, R * R, D).astype(np.float32)
+    u_f = rng.rand(N * R * R, Di).astype(np.float32) if Di else None
+    o, d = orc.ray_sampler(c2w, K, R)
+    want = c_oracle.render(np.repeat(norm, N, 0), np.repeat(den, N, 0), dec, o, d, opts, u_c, u_f)
+    p = t(planes, dev)
+    mean, std = ops.plane_stats(p)
+    got = ops.render(ops.plane_pack(p), ops.plane_pack(p), ops.decoder_pack(*[t(dec[k], dev) for k in NAMES]), opts, cam2world=t(c2w, dev),
+                     intrinsics=t(K, dev), resolution=R, affines=[a.repeat(N, 1) for a in ops.make_affine(mean, std)],
+                     u_coarse=t(u_c, dev), u_fine=None if u_f is None else t(u_f, dev))
+    pts = o[:, :, None, :] + np.linspace(0.6, 4.6, 8)[None, None, :, None] * d[:, :, None, :]
+    outside = (np.abs(pts) > 0.5).any(-1).mean()
+    assert 0.3 < outside < 0.99                                                    # most samples are outside the box, some inside
+    for k, g, w in zip(("rgb", "seg", "depth", "wsum"), got, want):
+        assert max_abs(g.cpu().numpy(), w) <= 1e-3, k
