@@ -449,7 +449,10 @@ struct Conv3K {
     const unsigned short* xh; const unsigned short* xl; const uint4* packed; const float* dcoef; const float* noise;
     long long noise_n_stride; float noise_strength; const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp;
     float* out; float* scratch;
+    int c3_tiles;       // real tile count (grid.x is padded to a multiple of 8 for the XCD-aware order)
 };
+
+__host__ __device__ constexpr bool c3_xcd_order(int terms) { return terms == 3; }
 
 // WV waves per workgroup, each owning NBW image rows of 32 pixels: tile = 32 x (NBW * WV) pixels (ROWS rows).
 constexpr int C3_TW = 32, C3_PW = C3_TW + 2;
@@ -492,8 +495,20 @@ __global__ __launch_bounds__(64 * WV, (NBW * MBW > 8 ? 1 : ((STAGES * conv3_stag
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int gw = UP2 ? P.W + 1 : P.W;                       // tile grid: output pixels, or the extended input grid
     const int tiles_x = (gw + C3_TW - 1) / C3_TW;
-    const int ty0 = (blockIdx.x / tiles_x) * C3_TH, tx0 = (blockIdx.x % tiles_x) * C3_TW;
-    const int mb0 = blockIdx.y * MBW, n = blockIdx.z;
+    // XCD-aware order (split-bf16 variants): workgroups reach the 8 XCDs round-robin in dispatch order and every XCD has its own
+    // L2.  XCD x takes the tiles = x (mod 8) and walks the M-block groups of a tile back to back, so the tile's input patch is
+    // fetched into that L2 once instead of once per M-block group (the single-buffered split-bf16 stage cannot hide the longer
+    // fetch; measured -7 % on the SR head.  The double-buffered bf16 variants measured no gain and keep the plain order).
+    int tile_ = blockIdx.x, mbg_ = blockIdx.y;
+    if (c3_xcd_order(TERMS)) {
+        const int MBG = gridDim.y;
+        const int L = blockIdx.y * gridDim.x + blockIdx.x;
+        const int k_ = L >> 3;
+        tile_ = (k_ / MBG) * 8 + (L & 7); mbg_ = k_ % MBG;
+        if (tile_ >= P.c3_tiles) return;              // grid.x is padded to a multiple of 8
+    }
+    const int ty0 = (tile_ / tiles_x) * C3_TH, tx0 = (tile_ % tiles_x) * C3_TW;
+    const int mb0 = mbg_ * MBW, n = blockIdx.z;
     const int G = P.Cin >> 4;
 
     // this wave's share of the patch chunks: chunk c = wave + WV k; per-lane element offset of the pixel (or -1 = padding)
@@ -1055,8 +1070,9 @@ static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st
     }();
     (void)once;
     const unsigned tiles = ((mode_h + ROWS - 1) / ROWS) * ((mode_w + C3_TW - 1) / C3_TW);
-    dim3 grid(tiles, K.Cout / (32 * MBW), K.N);
-    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW>), grid, dim3(64 * WV), bytes, st, K);
+    Conv3K K2 = K; K2.c3_tiles = (int)tiles;
+    dim3 grid(c3_xcd_order(TERMS) ? (tiles + 7) / 8 * 8 : tiles, K.Cout / (32 * MBW), K.N);
+    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW>), grid, dim3(64 * WV), bytes, st, K2);
 }
 
 static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
