@@ -159,7 +159,9 @@ typedef struct nfe_render_args {
     const float* decoder_cross;        /* optional, from nfe_decoder_pack_cross (SegmentationOSGDecoder); NULL = none */
 } nfe_render_args;
 
-/* bytes of workspace nfe_render needs for these sizes */
+/* bytes of workspace nfe_render needs for these sizes: the depth min/max words, 13.6 MB for the segment composites of
+ * depth-split launches (few rays: every ray block's march is cut into segments marched by different waves), and with
+ * importance sampling the coarse depths / weights and the merged depths of every ray (density_noise: see above) */
 uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int depth_resolution,
                                     int depth_resolution_importance);
 int nfe_render(const nfe_render_args* args, nfe_stream_t stream);
