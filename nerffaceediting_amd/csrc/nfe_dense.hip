@@ -1185,6 +1185,11 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             else launch_conv3<3, 2, false, 2, 4, 4>(K, a->h, a->w, st);
         } else if (C3_MID && a->h >= 16 * C3_TALL_MIN_TILES && bf16) {   // 32 x 16 tiles on 4 waves (2 x 4 blocks per wave)
             launch_conv3<1, 2, false, 2, 4, 4>(K, a->h, a->w, st);
+        } else if (!bf16 && a->h >= 16 * C3_TALL_MIN_TILES &&
+                   (long long)((a->h + 15) / 16) * ((a->w + 31) / 32) * ((a->cout + 63) / 64) * a->n >= num_cus_dense()) {
+            // split-bf16: the 32 x 16 tile on FOUR waves (2 x 4 blocks per wave): the kernel is co-limited by LDS fragment reads,
+            // and a wave that owns four rows re-uses each weight fragment four times (0.5 instead of 0.67 reads per MFMA): +1.5 %
+            launch_conv3<3, 2, false, C3_STAGES_X3, 4, 4>(K, a->h, a->w, st);
         } else if (a->h >= 16 * C3_TALL_MIN_TILES &&           // 32 x 16 tiles (8 waves): half the weight bytes per MFMA - as long as
                    (long long)((a->h + 15) / 16) * ((a->w + 31) / 32) * ((a->cout + 63) / 64) * a->n >= num_cus_dense()) {   // they still fill the chip
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);
