@@ -16,6 +16,8 @@ Other workloads of SURVEY.md section 8(d) (never the default; same JSON contract
     --workload full     config 3: full synthesis (a1-a14), 8 views/GPU/step, 512^2 x 64 render, bf16 convs -> views/s
     --workload orbit    config 4: 512 (latent, camera) pairs sharded over the ranks (strong scaling), one all-gather
     --workload twopass  config 5: render core, D=96 + 96 importance samples, dual plane sets, 512^2 -> rays/s
+    --workload ffhq     the reference's own inference configuration (train.py:306-307): full synthesis, 128^2 x (48+48) render,
+                        fp32-grade (split-bf16) convs, 4 views/GPU/step -> views/s
     --workload editstep plane-editing step: 128^2 x (48+48) dual-plane render + nfe_render_backward -> rays/s
 """
 import argparse
@@ -213,10 +215,12 @@ def extra_workload(args, torch, dist, dev, rank, world):
                               "kernel_ms": bwd_ms, "note": "logical gather + scatter bytes of the backward (9216 B/sample) / its time; "
                                                            "planes and gradients are L2 / Infinity-Cache resident"})
 
-    conv_math = "bf16"
-    G = full_generator(torch, dev, D, 0, conv_math)
-    if args.workload == "full":              # config 3
-        NV = 8
+    ffhq = args.workload == "ffhq"
+    conv_math = "bf16x3" if ffhq else "bf16"
+    G = full_generator(torch, dev, 48 if ffhq else D, 48 if ffhq else 0, conv_math)
+    if args.workload in ("full", "ffhq"):    # config 3, or the FFHQ inference configuration
+        NV = 4 if ffhq else 8
+        Rn = 128 if ffhq else R
         g = torch.Generator(device="cpu").manual_seed(1000 + rank)
         z = torch.randn(NV, 512, generator=g).to(dev)
         c = apps.orbit_cameras(NV, dev)
@@ -229,7 +233,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
             wsi = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=14)
             e[0].record()
             G.stage_events = e
-            out = G.synthesis(wsi, c, neural_rendering_resolution=R, noise_mode="const")
+            out = G.synthesis(wsi, c, neural_rendering_resolution=Rn, noise_mode="const")
             e[3].record()
             ev[i] = e
             return out
@@ -243,10 +247,14 @@ def extra_workload(args, torch, dist, dev, rank, world):
         n_total = world * NV
         flops = GFLOP_DENSE_PER_VIEW * NV * 1e9
         ach = flops / (dense_ms * 1e-3) / 1e12
-        return dict(base, metric="512^2 views/s, full synthesis (mapping + backbone + 512^2 x 64 render + SR)",
-                    value=n_total * args.steps / dt, unit="views/s", ms_per_step=dt / args.steps * 1e3, scaling="weak", dtype="bf16",
-                    config={"workload": "BASELINE config 3: a1-a14, 8 views/GPU/step, neural render 512^2 x 64 -> antialias resize -> "
-                                        "SuperresolutionHybrid8XDC to 512^2, bf16 MFMA convs (fp32 accumulate), fp32 render",
+        what = ("FFHQ inference configuration (train.py:306-307): a1-a14, 4 views/GPU/step, neural render 128^2 x (48+48) -> "
+                "SuperresolutionHybrid8XDC to 512^2, split-bf16 (fp32-grade) MFMA convs, fp32 render") if ffhq else (
+                "BASELINE config 3: a1-a14, 8 views/GPU/step, neural render 512^2 x 64 -> antialias resize -> "
+                "SuperresolutionHybrid8XDC to 512^2, bf16 MFMA convs (fp32 accumulate), fp32 render")
+        return dict(base, metric="512^2 views/s, full synthesis (mapping + backbone + %s render + SR)" % ("128^2 x (48+48)" if ffhq else "512^2 x 64"),
+                    value=n_total * args.steps / dt, unit="views/s", ms_per_step=dt / args.steps * 1e3, scaling="weak",
+                    dtype="bf16x3" if ffhq else "bf16",
+                    config={"workload": what,
                             "views_per_step": n_total, "synthesis_ms": syn_ms, "stage_ms": stage, "parallelism": f"views-dp{world}"},
                     roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv3_kernel<*> + upfir/torgb (backbone + SR stages)",
@@ -282,7 +290,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["render", "full", "orbit", "twopass", "editstep"], default="render")
+    ap.add_argument("--workload", choices=["render", "full", "ffhq", "orbit", "twopass", "editstep"], default="render")
     args = ap.parse_args()
 
     import torch
