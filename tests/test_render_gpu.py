@@ -353,3 +353,42 @@ np.savez(sys.argv[1], *outs)
     assert len(res["split"]) == len(res["plain"]) > 20
     for a, b in zip(res["split"], res["plain"]):
         assert a.shape == b.shape and max_abs(a, b) <= 2e-5, max_abs(a, b)
+
+
+def test_outputs_do_not_depend_on_occupancy(dev):
+    """The same 512^2 x 64 launch with 1, 2 (default) and 4 workgroups per CU (NFE_RENDER_BLOCKS_PER_CU, read once per process:
+    child interpreters) must give bit-identical outputs: a build whose results depended on what else shared the CU (a
+    scheduling hazard) is caught here."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    prog = r"""
+import sys, hashlib, numpy as np, torch
+from nerffaceediting_amd import ops
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(3)
+N, R, H = 2, 512, 256
+raw = torch.randn(N, 96, H, H, generator=g).to(dev)
+mean, std = ops.plane_stats(raw)
+packed = ops.plane_pack(raw)
+shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+dec = ops.decoder_pack(*[(torch.randn(*s, generator=g) * (1.0 if len(s) == 2 else 0.2)).to(dev) for s in shapes])
+c2w = torch.eye(4).repeat(N, 1, 1); c2w[:, :3, 2] *= -1; c2w[:, 2, 3] = 2.7; c2w[1, 0, 3] = 0.3
+K = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]]).repeat(N, 1, 1)
+h = hashlib.sha256()
+for D, Di in ((64, 0), (24, 24)):
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    out = ops.render(packed, packed, dec, opts, cam2world=c2w.to(dev), intrinsics=K.to(dev), resolution=R, affines=ops.make_affine(mean, std), seed=5)
+    for t in out:
+        h.update(t.cpu().numpy().tobytes())
+print("HASH", h.hexdigest())
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hashes = {}
+    for b in ("1", "2", "4"):
+        env = dict(os.environ, NFE_RENDER_BLOCKS_PER_CU=b, PYTHONPATH=root)
+        r = subprocess.run([sys.executable, "-c", prog], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        hashes[b] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
+    assert hashes["1"] == hashes["2"] == hashes["4"], hashes
