@@ -374,8 +374,9 @@ mean, std = ops.plane_stats(raw)
 packed = ops.plane_pack(raw)
 shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
 dec = ops.decoder_pack(*[(torch.randn(*s, generator=g) * (1.0 if len(s) == 2 else 0.2)).to(dev) for s in shapes])
-c2w = torch.eye(4).repeat(N, 1, 1); c2w[:, :3, 2] *= -1; c2w[:, 2, 3] = 2.7; c2w[1, 0, 3] = 0.3
-K = torch.tensor([[4.2647, 0, 0.5], [0, 4.2647, 0.5], [0, 0, 1]]).repeat(N, 1, 1)
+from oracle import render_oracle as orc           # camera construction only
+c2w = torch.from_numpy(np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2 + p, [0, 0, 0.2], 2.7).reshape(1, 4, 4) for y, p in ((0.3, -0.2), (-0.9, 0.4))]))
+K = torch.from_numpy(np.repeat(orc.fov_to_intrinsics(18.837)[None], N, 0))      # rays that leave the planes at the image borders
 h = hashlib.sha256()
 for D, Di in ((64, 0), (24, 24)):
     opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
