@@ -38,6 +38,8 @@ struct RenderK {
     float density_noise;           // std of the Gaussian added to sigma (renderer.py:285-286), NOISE variants only
     const int* src_buf;            // DEPTH_BUFFER + NOISE: [N*M, S] which draw each merged sample is (k, or D + fine rank)
     const float* dec_cross;        // CROSS variants: packed cross fragments (nfe_decoder_pack_cross)
+    // EVAL variants (first pass of nfe_render_backward): per sample sigma and a = <2 g_rgb, rgb> + <g_seg, seg> instead of a march
+    const float* ev_g_rgb; const float* ev_g_seg; int ev_channels_first; float* ev_sig; float* ev_a;
     int seg_count;                 // SPLIT variants: depth segments per ray block (each marched by its own wave)
     float* partials;               // SPLIT variants: [N*M, seg_count, PARTIAL_FLOATS] segment composites, see render_combine_kernel
 };
@@ -706,7 +708,7 @@ __device__ __forceinline__ float sample_gaussian(unsigned long long seed, unsign
     return sqrtf(-2.0f * LN2 * log2_fast(u1)) * __builtin_amdgcn_cosf(u2);       // v_cos_f32 takes revolutions
 }
 
-template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false, bool SPLIT = false, bool SQUARE = false>
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false, bool SPLIT = false, bool SQUARE = false, bool EVAL = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_decoder<MATH>(P.dec, lds);
@@ -771,6 +773,17 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
         const float* pg = P.planes_g + (long long)n * P.plane_view_stride;
         const float* pa = P.planes_a + (long long)n * P.plane_view_stride;
 
+        float ev_cr[16], ev_cs[8];            // EVAL: this lane half's cotangents (2 * g_rgb[16h..], g_seg[8h..])
+        if (EVAL) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ev_cr[r] = P.ev_g_rgb ? 2.0f * (P.ev_channels_first ? P.ev_g_rgb[((long long)n * 32 + 16 * h + r) * P.M + m]
+                                                                      : P.ev_g_rgb[ray * 32 + 16 * h + r]) : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                ev_cs[c] = (P.ev_g_seg && 8 * h + c < 15) ? (P.ev_channels_first ? P.ev_g_seg[((long long)n * 15 + 8 * h + c) * P.M + m]
+                                                                                   : P.ev_g_seg[ray * 15 + 8 * h + c]) : 0.0f;
+        }
         // ---- depth schedule (sample_stratified, renderer.py:169-192) -------------------------
         float rs = P.ray_start, re = P.ray_end;
         if (P.depth_mode == DEPTH_PER_RAY) { rs = P.rs_ray[ray]; re = P.re_ray[ray]; }
@@ -789,7 +802,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
         // samples [k0, k1) belong to this wave; a later segment first evaluates sample k0-1 (no compositing) to have the
         // left end of its first mid-point interval
         const int k0 = SPLIT ? (int)((long long)seg * S / nseg) : 0, k1 = SPLIT ? (int)((long long)(seg + 1) * S / nseg) : S;
-        const int kfirst = (SPLIT && k0 > 0) ? k0 - 1 : 0;
+        const int kfirst = EVAL ? k0 : ((SPLIT && k0 > 0) ? k0 - 1 : 0);     // EVAL: samples are independent, nothing to prime
 #pragma unroll 1
         for (int k = kfirst; k < k1; ++k) {
             float t;
@@ -832,6 +845,16 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                 const unsigned draw = (P.depth_mode == DEPTH_BUFFER && P.src_buf) ? (unsigned)P.src_buf[ray * S + k] : (unsigned)k;
                 og[0] = fmaf(P.density_noise, sample_gaussian(seed, (unsigned)ray, draw), og[0]);
             }
+            if (EVAL) {
+                float a = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a = fmaf(ev_cr[r], oa[r], a);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) a = fmaf(ev_cs[c], og[2 + c], a);
+                a += __shfl_xor(a, 32);                                   // the two channel halves of the point
+                if (valid && h == 0) { P.ev_sig[ray * S + k] = og[0]; P.ev_a[ray * S + k] = a; }
+                continue;
+            }
             if (k > kfirst) {
                 const float dlt = t - prev_t;
                 const float dens = softplus_f((prev_sig + og[0]) * 0.5f - 1.0f);
@@ -861,6 +884,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
         }
 
         // ---- outputs -------------------------------------------------------------------------
+        if (EVAL) continue;
         if (SPLIT) {
             if (valid) {
                 float* pp = P.partials + (ray * nseg + seg) * PARTIAL_FLOATS;
@@ -1254,6 +1278,38 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
 }
 
 static uint64_t align256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
+
+// First pass of nfe_render_backward on the forward kernel's machinery (quad gather, split-bf16 MFMA decoder): sigma_i and
+// a_i = <2 g_rgb, rgb_i> + <g_seg, seg_i> of every sample of the sorted depth buffer.  Samples are independent, so the depth
+// segments of a ray block simply go to different waves when the launch is small.
+int render_eval_pass(const nfe_render_backward_args* a, const float* decoder_packed, float* rec_sig, float* rec_a, hipStream_t st) {
+    RenderK P{};
+    P.planes_g = a->planes_geo; P.planes_a = a->planes_app; P.plane_view_stride = a->plane_view_stride;
+    P.H = a->plane_h; P.W = a->plane_w;
+    P.aff[0] = a->geo_scale; P.aff[1] = a->geo_shift; P.aff[2] = a->app_scale; P.aff[3] = a->app_shift;
+    P.dec = decoder_packed;
+    P.N = a->n_views; P.M = a->n_rays;
+    P.R = (a->resolution > 0 && (long long)a->resolution * a->resolution == a->n_rays) ? a->resolution : 0;
+    P.tiled = (P.R > 0 && (P.R % 8) == 0) ? 1 : 0;
+    P.origins = a->origins; P.dirs = a->dirs; P.cam2world = a->cam2world; P.intrinsics = a->intrinsics;
+    P.S = a->n_samples; P.depth_mode = DEPTH_BUFFER; P.depth_buf = a->depths;
+    P.coord_scale = 2.0f / a->box_warp;
+    P.ev_g_rgb = a->grad_rgb; P.ev_g_seg = a->grad_seg; P.ev_channels_first = a->channels_first; P.ev_sig = rec_sig; P.ev_a = rec_a;
+    const long long total_rb = (long long)P.N * ((P.M + 31) / 32);
+    int nseg = (int)(SPLIT_MAX_ITEMS / total_rb);
+    if (nseg > 8) nseg = 8;
+    if (nseg > P.S / 8) nseg = P.S / 8;
+    if (nseg < 1) nseg = 1;
+    P.seg_count = nseg;
+    long long blocks = (total_rb * nseg + 3) / 4;
+    const long long cap = (long long)num_cus() * 2;
+    if (blocks > cap) blocks = cap;
+    const bool dual = a->planes_geo != a->planes_app;
+    if (dual) hipLaunchKernelGGL((render_kernel<true, false, NFE_MATH_BF16X3, false, false, true, false, true>), dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, st, P);
+    else hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, false, true, false, true>), dim3((unsigned)blocks), dim3(256), RENDER_LDS_BYTES, st, P);
+    NFE_CHECK_LAUNCH("render_kernel (eval)");
+    return NFE_OK;
+}
 
 }  // namespace nfe
 

@@ -553,7 +553,7 @@ using namespace nfe;
 
 extern "C" uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples) {
     const uint64_t ns = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0) * (uint64_t)(n_samples > 0 ? n_samples : 0);
-    return BWD_DEC_BYTES + 3 * align256(ns * 4);
+    return BWD_DEC_BYTES + 3 * align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4);
 }
 
 extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream_t stream) {
@@ -610,8 +610,18 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
 
     const long long per_view = (long long)a->n_rays * a->n_samples;
     const dim3 sgrid((unsigned)((per_view + 255) / 256), (unsigned)a->n_views);
-    hipLaunchKernelGGL(bwd_eval_kernel, sgrid, dim3(256), 0, st, P);
-    NFE_CHECK_LAUNCH("bwd_eval_kernel");
+    // pass 1: on the forward kernel's machinery (quad gather + split-bf16 MFMA decoder, nfe_render.hip) unless NFE_BWD_EVAL=valu
+    static const bool valu_eval = [] { const char* e = getenv("NFE_BWD_EVAL"); return e && e[0] == 'v'; }();
+    if (valu_eval || (long long)a->plane_h * a->plane_w > (1ll << 25)) {
+        hipLaunchKernelGGL(bwd_eval_kernel, sgrid, dim3(256), 0, st, P);
+        NFE_CHECK_LAUNCH("bwd_eval_kernel");
+    } else {
+        float* packed = (float*)((char*)P.rec_T + align256(ns * 4));
+        int rc = nfe_decoder_pack(a->geo_w0, a->geo_b0, a->geo_w1, a->geo_b1, a->app_w0, a->app_b0, a->app_w1, a->app_b1, a->lr_mul, packed, stream);
+        if (rc) return rc;
+        rc = render_eval_pass(a, packed, P.rec_sig, P.rec_a, st);
+        if (rc) return rc;
+    }
     const long long rays = (long long)a->n_views * a->n_rays;
     hipLaunchKernelGGL(bwd_ray_kernel, dim3((unsigned)((rays + 255) / 256)), dim3(256), 0, st, P);
     NFE_CHECK_LAUNCH("bwd_ray_kernel");
