@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NFE_ABI_VERSION 6
+#define NFE_ABI_VERSION 7
 
 #define NFE_OK 0
 #define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */
@@ -176,6 +176,15 @@ int nfe_point_query(const float* planes_geo, const float* planes_app, int plane_
                     int decoder_math, const float* coords, int n_views, int n_points, float box_warp,
                     float* rgb, float* sigma, float* seg, float density_noise, uint64_t seed,
                     const float* decoder_cross /* optional, see nfe_decoder_pack_cross */, nfe_stream_t stream);
+
+/* ---- a6 as a stand-alone module: DisentangledOSGDecoder.forward (triplane.py:249-270), OSGDecoder.forward (:178-190),
+ * SegmentationOSGDecoder.forward (:209-230) on caller-supplied sampled features.
+ * features_geo / features_app [N, n_planes, P, 32] (what sample_from_planes returns, renderer.py:55-65; the mean over the
+ * plane axis is taken here) -> rgb [N,P,32] (sigmoid clamp applied), sigma [N,P], seg [N,P,15].  features_app may equal
+ * features_geo (OSGDecoder; SegmentationOSGDecoder with decoder_cross).  decoder_packed / decoder_cross as in nfe_render_args. */
+int nfe_decoder_forward(const float* features_geo, const float* features_app, int n_views, int n_planes, int64_t n_points,
+                        const float* decoder_packed, int decoder_math, const float* decoder_cross,
+                        float* rgb, float* sigma, float* seg, nfe_stream_t stream);
 
 /* ---- backward of a5..a12 with respect to the plane sets ------------------------------------------
  * The vector-Jacobian product torch autograd computes for DisentangledImportanceRenderer.forward

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 6
+NFE_ABI_VERSION = 7
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_DECODER_CROSS_FLOATS = 2048
@@ -104,6 +104,7 @@ _SIGNATURES = {
     "nfe_plane_pack": (c_int, [FP, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_decoder_pack": (c_int, [FP] * 8 + [c_float, FP, c_void_p]),
     "nfe_decoder_pack_cross": (c_int, [FP, c_float, FP, c_void_p]),
+    "nfe_decoder_forward": (c_int, [FP, FP, c_int, c_int, c_int64, FP, c_int, FP, FP, FP, FP, c_void_p]),
     "nfe_render_workspace_bytes": (c_uint64, [c_int, c_int, c_int, c_int]),
     "nfe_render": (c_int, [POINTER(RenderArgs), c_void_p]),
     "nfe_render_backward_workspace_bytes": (c_uint64, [c_int, c_int, c_int]),

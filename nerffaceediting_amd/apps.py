@@ -107,18 +107,36 @@ def render_views(G, ws, c, batch=4, gather=True, **synthesis_kwargs):
     return sharding.all_gather_frames(local, V) if (gather and world > 1) else local
 
 
+def create_samples(N=256, voxel_origin=(0, 0, 0), cube_length=2.0, device=None):
+    """gen_samples.py:79-101, bit for bit: the N^3 query points of the shape sweep, [1, N^3, 3], z fastest.  The reference
+    divides the flat index as FLOATS (`overall_index.float() / N`), so only the z column sits on the lattice; the y and x
+    columns advance by 1/N and 1/N^2 of a voxel per point.  Reproduced as is, in fp32, since the extracted volume is defined
+    by these coordinates.  Returns (samples, voxel_origin, voxel_size) like the reference."""
+    import numpy as np
+    voxel_origin = np.array(voxel_origin) - cube_length / 2
+    voxel_size = cube_length / (N - 1)
+    idx = torch.arange(0, N ** 3, 1, dtype=torch.int64, device=device)
+    f = idx.float()
+    samples = torch.zeros(N ** 3, 3, device=device)
+    samples[:, 2] = idx % N
+    samples[:, 1] = (f / N) % N
+    samples[:, 0] = ((f / N) / N) % N
+    samples[:, 0] = (samples[:, 0] * voxel_size) + voxel_origin[2]
+    samples[:, 1] = (samples[:, 1] * voxel_size) + voxel_origin[1]
+    samples[:, 2] = (samples[:, 2] * voxel_size) + voxel_origin[0]
+    return samples.unsqueeze(0), voxel_origin, voxel_size
+
+
 @torch.no_grad()
 def extract_density(G, ws, shape_res=128, max_batch=1 << 20, cube_length=None, **synthesis_kwargs):
-    """gen_samples.py:79-101,186-205 shape extraction: sigma on a shape_res^3 grid -> [R,R,R].
-    The tri-planes are synthesised ONCE and reused for every chunk (the reference re-runs the backbone per chunk)."""
+    """gen_samples.py:186-203 shape extraction: sigma at the create_samples points -> [R,R,R] indexed [x,y,z] like the
+    reference's `sigmas.reshape((shape_res,)*3)`.  The tri-planes are synthesised ONCE and reused for every chunk (the
+    reference re-runs mapping + backbone per 10^6-point chunk)."""
     from . import ops
     from .training.triplane import packed_cross_of
-    L = cube_length if cube_length is not None else G.rendering_kwargs["box_warp"]
+    L = cube_length if cube_length is not None else G.rendering_kwargs["box_warp"] * 1
     R = shape_res
-    lin = torch.arange(R, device=ws.device, dtype=torch.float32)
-    idx = torch.arange(R ** 3, device=ws.device)
-    voxel = L / (R - 1)                                                       # create_samples, gen_samples.py:79-101
-    pts = torch.stack([(idx % R).float(), ((idx // R) % R).float(), ((idx // R) // R % R).float()], 1) * voxel - L / 2
+    pts, _, _ = create_samples(N=R, voxel_origin=[0, 0, 0], cube_length=L, device=ws.device)
     packed, mean, var = G._planes(ws, synthesis_kwargs)
     aff = ops.make_affine(mean, var)
     if G.disable_disentangle:                  # triplane.py:144-148: both heads read the raw planes
@@ -126,8 +144,20 @@ def extract_density(G, ws, shape_res=128, max_batch=1 << 20, cube_length=None, *
     out = torch.empty(R ** 3, device=ws.device)
     for s in range(0, R ** 3, max_batch):
         e = min(R ** 3, s + max_batch)
-        out[s:e] = ops.point_query(packed, packed, G.decoder.packed(), pts[None, s:e].contiguous(), G.rendering_kwargs["box_warp"],
+        out[s:e] = ops.point_query(packed, packed, G.decoder.packed(), pts[:, s:e].contiguous(), G.rendering_kwargs["box_warp"],
                                    affines=aff, decoder_math=G.renderer.decoder_math,
                                    decoder_cross=packed_cross_of(G.decoder))["sigma"].reshape(-1)
-    del lin
     return out.reshape(R, R, R)
+
+
+def density_to_volume(sigmas, pad_value=-1000.0):
+    """gen_samples.py:204-216: what is written to the .mrc / handed to marching cubes — flip axis 0 and overwrite a border of
+    int(30 * shape_res / 256) voxels on every face with -1000."""
+    R = sigmas.shape[0]
+    vol = torch.flip(sigmas, dims=(0,)).clone()
+    pad = int(30 * R / 256)
+    if pad > 0:
+        vol[:pad] = pad_value; vol[-pad:] = pad_value
+        vol[:, :pad] = pad_value; vol[:, -pad:] = pad_value
+        vol[:, :, :pad] = pad_value; vol[:, :, -pad:] = pad_value
+    return vol

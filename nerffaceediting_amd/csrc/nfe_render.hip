@@ -606,6 +606,37 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// The decoder proper (DisentangledOSGDecoder.forward after the mean over planes, triplane.py:254-270) on features that
+// are already in "own" layout: fn / fd = channels 16h..16h+15 of this lane's point of the geometry / appearance set.
+// Outputs as eval_point documents them.
+template <bool SIGMA_ONLY, int MATH, bool CROSS>
+__device__ __forceinline__ void decode_features(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
+                                                int lane, f32x16& og, f32x16& oa) {
+#ifdef NFE_ABLATE_MLP      // timing experiment only (tools/ablate.sh): no decoder
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { og[r] = fn[r >> 1][r & 1]; oa[r] = fd[r >> 1][r & 1]; }
+    return;
+#endif
+#ifndef NFE_MLP_PAIR
+#define NFE_MLP_PAIR 1
+#endif
+    constexpr bool PAIR = NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3;
+    static_assert(!CROSS || (NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3), "the cross term lives in the paired split-bf16 decoder");
+    if (PAIR) mlp_pair_bf16<CROSS>(lds, fn, fd, lane, og, oa);
+    else if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og);
+    else mlp_bf16(lds, fn, 0, lane, og);
+    if (!SIGMA_ONLY) {
+        if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa);
+        else if (!PAIR) mlp_bf16(lds, fd, 1, lane, oa);
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {    // oa carries log2(e): sigmoid(x) = 1/(1 + 2^-(x log2 e))
+            const f32x2 d = f32x2{exp2_fast(-oa[r]), exp2_fast(-oa[r + 1])} + splat(1.0f);
+            const f32x2 sg = pk_fma(f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])}, splat(1.002f), splat(-0.001f));
+            oa[r] = sg[0]; oa[r + 1] = sg[1];    // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269
+        }
+    }
+}
+
 // Evaluate the implicit model at one point per lane PAIR (lanes j and j+32 share a point; lane half
 // h holds channels [16h,16h+16) of every 32-vector).  Returns, for this lane:
 //   og[0] = sigma; og[2..] = seg channels (h=0: seg 0..7 in og[2..9]; h=1: seg 8..14 in og[2..8]); og[1] unused
@@ -637,29 +668,7 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
     f32x2 fn[8], fd[8];          // own layout: channels 16h..16h+15 of this lane's point
     exchange_to_own(xp, lane, qn, fn);
     if (!SIGMA_ONLY) exchange_to_own(xp, lane, qd, fd);
-#ifdef NFE_ABLATE_MLP      // timing experiment only (tools/ablate.sh): no decoder
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { og[r] = fn[r >> 1][r & 1]; oa[r] = fd[r >> 1][r & 1]; }
-    return;
-#endif
-#ifndef NFE_MLP_PAIR
-#define NFE_MLP_PAIR 1
-#endif
-    constexpr bool PAIR = NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3;
-    static_assert(!CROSS || (NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3), "the cross term lives in the paired split-bf16 decoder");
-    if (PAIR) mlp_pair_bf16<CROSS>(lds, fn, fd, lane, og, oa);
-    else if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og);
-    else mlp_bf16(lds, fn, 0, lane, og);
-    if (!SIGMA_ONLY) {
-        if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa);
-        else if (!PAIR) mlp_bf16(lds, fd, 1, lane, oa);
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {    // oa carries log2(e): sigmoid(x) = 1/(1 + 2^-(x log2 e))
-            const f32x2 d = f32x2{exp2_fast(-oa[r]), exp2_fast(-oa[r + 1])} + splat(1.0f);
-            const f32x2 sg = pk_fma(f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])}, splat(1.002f), splat(-0.001f));
-            oa[r] = sg[0]; oa[r + 1] = sg[1];    // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269
-        }
-    }
+    decode_features<SIGMA_ONLY, MATH, CROSS>(lds, fn, fd, lane, og, oa);
 }
 
 // Copy the decoder image for this math mode into LDS words [0, DEC_FLOATS): fragments then biases.
@@ -1188,6 +1197,66 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Decoder modules on caller-supplied sampled features (DisentangledOSGDecoder.forward, triplane.py:249-270;
+// OSGDecoder.forward :178-190; SegmentationOSGDecoder.forward :209-230): mean over the plane axis, then the two heads.
+// 32 points per wave step; lane (j, h) reads channels 16h..16h+15 of point j from every plane (64 contiguous bytes).
+// ------------------------------------------------------------------------------------------
+struct DecoderK {
+    const float* feat_g; const float* feat_a;       // [N, n_planes, Pn, 32]
+    int N, n_planes; long long Pn;
+    const float* dec; const float* dec_cross;
+    float* rgb; float* sigma; float* seg;
+};
+
+template <int MATH, bool CROSS = false>
+__global__ __launch_bounds__(256, 2) void decoder_kernel(DecoderK P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    stage_decoder<MATH>(P.dec, lds);
+    if (CROSS) stage_cross(P.dec_cross, lds);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    __syncthreads();
+    const long long blocks_per_view = (P.Pn + 31) >> 5;
+    const long long total = (long long)P.N * blocks_per_view;
+    const float inv_planes = 1.0f / (float)P.n_planes;
+    for (long long rb = (long long)blockIdx.x * 4 + wave; rb < total; rb += (long long)gridDim.x * 4) {
+        const int n = (int)(rb / blocks_per_view);
+        long long m = (rb % blocks_per_view) * 32 + j;
+        const bool valid = m < P.Pn;
+        m = m < P.Pn ? m : P.Pn - 1;
+        f32x2 fn[8], fd[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { fn[c] = splat(0.0f); fd[c] = splat(0.0f); }
+        for (int p = 0; p < P.n_planes; ++p) {
+            const long long off = (((long long)n * P.n_planes + p) * P.Pn + m) * 32 + 16 * h;
+            const float4* g = reinterpret_cast<const float4*>(P.feat_g + off);
+            const float4* a = reinterpret_cast<const float4*>(P.feat_a + off);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 x = g[q], y = a[q];
+                fn[2 * q] += f32x2{x.x, x.y}; fn[2 * q + 1] += f32x2{x.z, x.w};
+                fd[2 * q] += f32x2{y.x, y.y}; fd[2 * q + 1] += f32x2{y.z, y.w};
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { fn[c] = fn[c] * splat(inv_planes); fd[c] = fd[c] * splat(inv_planes); }
+        f32x16 og, oa;
+        decode_features<false, MATH, CROSS>(lds, fn, fd, lane, og, oa);
+        if (valid) {
+            const long long pt = (long long)n * P.Pn + m;
+            float4* o = reinterpret_cast<float4*>(P.rgb + pt * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = make_float4(oa[4 * q], oa[4 * q + 1], oa[4 * q + 2], oa[4 * q + 3]);
+            const int nseg = h ? 7 : 8;
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc)
+                if (cc < nseg) P.seg[pt * 15 + 8 * h + cc] = og[2 + cc];
+            if (h == 0) P.sigma[pt] = og[0];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
 static int num_cus() {
@@ -1346,7 +1415,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
                     "nfe_render: resolution^2 (%d^2) != n_rays (%d)", a->resolution, a->n_rays);
     }
     NFE_REQUIRE((a->ray_start_per_ray != nullptr) == (a->ray_end_per_ray != nullptr), "nfe_render: per-ray limits must come in pairs");
-    NFE_REQUIRE(!(a->ray_start_per_ray && a->disparity_space_sampling), "nfe_render: disparity sampling with per-ray limits is not supported");
+    NFE_REQUIRE(!(a->ray_start_per_ray && a->disparity_space_sampling), "nfe_render: disparity sampling with per-ray (auto) limits: the reference fails here too ([N,M,1] limits do not broadcast against [N,M,D,1] depths, renderer.py:174-181)");
     NFE_REQUIRE(a->box_warp > 0.0f, "nfe_render: box_warp must be positive");
     NFE_REQUIRE(a->decoder_math == NFE_MATH_BF16X3 || a->decoder_math == NFE_MATH_FP32, "nfe_render: unknown decoder_math %d", a->decoder_math);
     NFE_REQUIRE(a->rgb && a->seg && a->depth && a->wsum, "nfe_render: output pointers are null");
@@ -1477,5 +1546,35 @@ extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app,
         else hipLaunchKernelGGL((point_kernel<false, NFE_MATH_BF16X3>), grid, block, RENDER_LDS_BYTES, st, P);
     }
     NFE_CHECK_LAUNCH("point_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_decoder_forward(const float* features_geo, const float* features_app, int n_views, int n_planes, int64_t n_points,
+                                   const float* decoder_packed, int decoder_math, const float* decoder_cross,
+                                   float* rgb, float* sigma, float* seg, nfe_stream_t stream) {
+    NFE_REQUIRE(features_geo && features_app && decoder_packed, "nfe_decoder_forward: null input pointer");
+    NFE_REQUIRE(rgb && sigma && seg, "nfe_decoder_forward: null output pointer");
+    NFE_REQUIRE(n_views > 0 && n_planes > 0 && n_points >= 0, "nfe_decoder_forward: bad sizes N=%d planes=%d P=%lld", n_views, n_planes, (long long)n_points);
+    NFE_REQUIRE(decoder_math == NFE_MATH_BF16X3 || decoder_math == NFE_MATH_FP32, "nfe_decoder_forward: unknown decoder_math %d", decoder_math);
+    if (decoder_cross)
+        NFE_REQUIRE(features_geo == features_app && decoder_math == NFE_MATH_BF16X3, "nfe_decoder_forward: decoder_cross needs one feature set and NFE_MATH_BF16X3");
+    if (n_points == 0) return NFE_OK;
+    DecoderK P{};
+    P.feat_g = features_geo; P.feat_a = features_app; P.N = n_views; P.n_planes = n_planes; P.Pn = n_points;
+    P.dec = decoder_packed; P.dec_cross = decoder_cross; P.rgb = rgb; P.sigma = sigma; P.seg = seg;
+    const long long total = (long long)n_views * ((n_points + 31) / 32);
+    long long blocks = (total + 3) / 4;
+    if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((unsigned)blocks), block(256);
+    if (decoder_cross) {
+        allow_lds(decoder_kernel<NFE_MATH_BF16X3, true>, RENDER_LDS_BYTES_CROSS);
+        hipLaunchKernelGGL((decoder_kernel<NFE_MATH_BF16X3, true>), grid, block, RENDER_LDS_BYTES_CROSS, st, P);
+    } else if (decoder_math == NFE_MATH_FP32) {
+        hipLaunchKernelGGL((decoder_kernel<NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);
+    } else {
+        hipLaunchKernelGGL((decoder_kernel<NFE_MATH_BF16X3>), grid, block, RENDER_LDS_BYTES, st, P);
+    }
+    NFE_CHECK_LAUNCH("decoder_kernel");
     return NFE_OK;
 }

@@ -162,6 +162,28 @@ def decoder_pack_cross(cross_w1, lr_mul=1.0):
     return out
 
 
+def decoder_forward(features_geo, features_app, decoder_packed, decoder_math=None, decoder_cross=None):
+    """nfe_decoder_forward: sampled features [N,n_planes,P,32] (x2; the same tensor twice for a single-set decoder) ->
+    dict(rgb [N,P,32], sigma [N,P,1], seg [N,P,15]) — the decoders' own forward() (triplane.py:178-190, 209-230, 249-270)."""
+    lib = _lib.load()
+    features_geo = _dev(features_geo, "sampled_norm_features", (None, None, None, 32))
+    features_app = features_geo if features_app is features_geo else _dev(features_app, "sampled_denorm_features", tuple(features_geo.shape))
+    N, n_planes, P, _ = features_geo.shape
+    dev = features_geo.device
+    decoder_packed = _dev(decoder_packed, "decoder_packed", (_lib.NFE_DECODER_PACKED_FLOATS,))
+    if decoder_cross is not None:
+        decoder_cross = _dev(decoder_cross, "decoder_cross", (_lib.NFE_DECODER_CROSS_FLOATS,))
+    rgb = torch.empty(N, P, 32, device=dev)
+    sigma = torch.empty(N, P, 1, device=dev)
+    seg = torch.empty(N, P, 15, device=dev)
+    if N * P > 0:
+        with torch.cuda.device(dev):
+            _lib.check(lib.nfe_decoder_forward(_ptr(features_geo), _ptr(features_app), N, n_planes, P, _ptr(decoder_packed),
+                                               _math_mode(decoder_math), _ptr(decoder_cross), _ptr(rgb), _ptr(sigma), _ptr(seg),
+                                               _stream()), "nfe_decoder_forward")
+    return {"rgb": rgb, "sigma": sigma, "seg": seg}
+
+
 def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dirs=None, cam2world=None,
            intrinsics=None, resolution=0, affines=None, u_coarse=None, u_fine=None, seed=0,
            channels_first=False, taps=False, ray_limits=None, decoder_math=None, decoder_cross=None):

@@ -54,9 +54,12 @@ class DisentangledOSGDecoder(torch.nn.Module):
             self._packed_key = key
         return self._packed
 
+    decoder_math = None        # None -> split-bf16 MFMA; 'fp32' -> exact fp32 MFMA (as DisentangledImportanceRenderer.decoder_math)
+
     def forward(self, sampled_norm_features, sampled_denorm_features, ray_directions):
-        raise NotImplementedError("the decoder is evaluated inside the fused kernels: use renderer.run_model(...) "
-                                  "or TriPlaneGenerator.sample(...)")
+        """triplane.py:249-270: features [N,3,M,32] (x2) -> dict(rgb [N,M,32], sigma [N,M,1], seg [N,M,15]).  The renderer
+        never calls this (the decoder is evaluated inside the fused kernels); it serves callers that sample features themselves."""
+        return ops.decoder_forward(sampled_norm_features, sampled_denorm_features, self.packed(), decoder_math=self.decoder_math)
 
 
 class OSGDecoder(torch.nn.Module):
@@ -87,8 +90,12 @@ class OSGDecoder(torch.nn.Module):
             self._packed_key = key
         return self._packed
 
+    decoder_math = None
+
     def forward(self, sampled_features, ray_directions):
-        raise NotImplementedError("the decoder is evaluated inside the fused kernels: use ImportanceRenderer.run_model(...)")
+        """triplane.py:178-190: features [N,3,M,32] -> dict(rgb [N,M,32], sigma [N,M,1])."""
+        out = ops.decoder_forward(sampled_features, sampled_features, self.packed(), decoder_math=self.decoder_math)
+        return {"rgb": out["rgb"], "sigma": out["sigma"]}
 
 
 class SegmentationOSGDecoder(torch.nn.Module):
@@ -139,8 +146,8 @@ class SegmentationOSGDecoder(torch.nn.Module):
         return self._packed_cross
 
     def forward(self, sampled_norm_features, sampled_denorm_features, ray_directions):
-        raise NotImplementedError("the decoder is evaluated inside the fused kernels: use renderer.run_model(...) "
-                                  "or TriPlaneGenerator.sample(...)")
+        """triplane.py:209-230: both nets read the DENORM features (the norm features are ignored, as in the reference)."""
+        return ops.decoder_forward(sampled_denorm_features, sampled_denorm_features, self.packed(), decoder_cross=self.packed_cross())
 
 
 def packed_cross_of(decoder):
@@ -214,11 +221,9 @@ class TriPlaneGenerator(torch.nn.Module):
         R = neural_rendering_resolution
 
         if use_cached_backbone and self._last_planes is not None:
-            packed, mean, var = self._last_planes
+            packed, mean, var = self._cached_planes()
         else:
             packed, mean, var = self._planes(ws, synthesis_kwargs)
-        if cache_backbone:
-            self._last_planes = (packed, mean, var)
         stage_events = getattr(self, "stage_events", None)      # bench.py: [.., after backbone, after render, ..]
         if stage_events is not None:
             stage_events[1].record()
@@ -232,6 +237,8 @@ class TriPlaneGenerator(torch.nn.Module):
             else:
                 new_mean, new_var = planes_mean, planes_var
         affines = ops.make_affine(mean, var, new_mean, new_var)
+        if cache_backbone:
+            self._store_planes(packed, mean, var, affines if (new_mean is not None and not self.disable_disentangle) else None)
         if self.disable_disentangle:                # identity affines: sampled raw values go to both heads; no statistics returned
             affines = tuple(torch.ones_like(a) if i % 2 == 0 else torch.zeros_like(a) for i, a in enumerate(affines))
             mean = var = None
@@ -256,13 +263,42 @@ class TriPlaneGenerator(torch.nn.Module):
             "plane_var": var,
         }
 
+    # ---- backbone cache (triplane.py:88-89,109-110) -------------------------------------------------
+    # `_last_planes` is what the reference stores: the NCHW planes [N,96,H,W] AFTER an appearance override (so a later
+    # use_cached_backbone=True call keeps the overridden appearance and reports its statistics).  The gather-layout copy
+    # and its statistics live beside it, keyed on the tensor's identity: a caller that assigns its own tensor to
+    # `_last_planes` gets it re-packed on first use.
+    def _store_planes(self, packed, mean, var, override_affines):
+        N, _, H, W, _ = packed.shape
+        nchw = dense_ops.nhwc_to_nchw(packed.view(N * 3, H, W, 32)).view(N, 96, H, W)
+        if override_affines is not None:            # planes = denormalize_plane(norm_planes, mean', var'), triplane.py:98-103
+            _, _, a_scale, a_shift = override_affines
+            nchw = ops.plane_affine(nchw, a_scale.reshape(N, 96, 1, 1), a_shift.reshape(N, 96, 1, 1))
+            packed = ops.plane_pack(nchw)
+            mean, var = ops.plane_stats(nchw)
+        self._last_planes = nchw
+        self._last_packed = ((nchw.data_ptr(), nchw._version, tuple(nchw.shape)), packed, mean, var)
+
+    def _cached_planes(self):
+        p = self._last_planes
+        key = (p.data_ptr(), p._version, tuple(p.shape))
+        cached = getattr(self, "_last_packed", None)
+        if cached is None or cached[0] != key:
+            p4 = p.reshape(p.shape[0], 96, p.shape[-2], p.shape[-1]).to(torch.float32)
+            mean, var = ops.plane_stats(p4)
+            cached = self._last_packed = (key, ops.plane_pack(p4), mean, var)
+        return cached[1], cached[2], cached[3]
+
     def _sample_planes(self, ws, coordinates, synthesis_kwargs):
         packed, mean, var = self._planes(ws, synthesis_kwargs)
         affines = ops.make_affine(mean, var)
         if self.disable_disentangle:
             affines = tuple(torch.ones_like(a) if i % 2 == 0 else torch.zeros_like(a) for i, a in enumerate(affines))
+        # run_model receives self.rendering_kwargs (triplane.py:148,157), so density_noise applies here too (renderer.py:285-286)
+        noise = float(self.rendering_kwargs.get("density_noise", 0) or 0)
+        seed = int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item()) if noise > 0 else 0
         return ops.point_query(packed, packed, self.decoder.packed(), coordinates.to(torch.float32),
-                               self.rendering_kwargs["box_warp"], affines=affines,
+                               self.rendering_kwargs["box_warp"], affines=affines, density_noise=noise, seed=seed,
                                decoder_math=self.renderer.decoder_math, decoder_cross=packed_cross_of(self.decoder))
 
     def sample(self, coordinates, directions, z, c, truncation_psi=1, truncation_cutoff=None, update_emas=False, **synthesis_kwargs):

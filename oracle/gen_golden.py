@@ -161,6 +161,7 @@ def gen_render_full_size(name="fullsize_render", seed=401, N=1, R=512, H=256, D=
     the call's [min,max] of sampled depths, cannot bind a weighted mean of those depths).  Planes, decoder and jitter are
     regenerated from the seed by the tests; the fixture keeps every `stride`-th ray of the reference outputs.
       fullsize_render: BASELINE config-2 size, 512^2 rays x 64 samples, 256^2 planes, one view;
+      cfg5_render:     BASELINE config 5 (projector.py:33-34: 96 + 96 samples), 128^2 rays, two views, swapped statistics;
       ffhq_render:     the FFHQ rendering_kwargs (train.py:306-307: 128^2 rays, 48 + 48 samples), two views with
                        swapped appearance statistics (norm_planes != normalised denorm_planes: the editing path)."""
     rng = np.random.RandomState(seed)
@@ -267,6 +268,35 @@ def gen_segmentation_decoder(seed=31, N=2, R=8, H=16, D=12, Ni=12, P=300):
     print("  wrote segdecoder_render.npz")
 
 
+def gen_decoder_forward(seed=41, N=2, M=70):
+    """The three decoder modules called directly on sampled features [N,3,M,32] (triplane.py:178-190, 209-230, 249-270)."""
+    from training.triplane import OSGDecoder, SegmentationOSGDecoder
+    rng = np.random.RandomState(seed)
+    fn = (rng.randn(N, 3, M, 32) * 1.2).astype(np.float32)
+    fd = (rng.randn(N, 3, M, 32) * 0.9 + 0.2).astype(np.float32)
+    data = dict(features_norm=fn, features_denorm=fd)
+    dis = orc.random_decoder(seed + 1, bias_scale=0.3)
+    out = ref_decoder(dis)(torch.from_numpy(fn), torch.from_numpy(fd), None)
+    data.update({"dis." + k: v for k, v in dis.items()}, **{"dis.out." + k: v.numpy() for k, v in out.items()})
+    for k, v in zip(("rgb", "sigma", "seg"), orc.decoder_disentangled(fn, fd, dis)):
+        check("dis." + k, v, out[k].numpy(), 2e-5)
+    seg = orc.random_segmentation_decoder(seed + 2, bias_scale=0.3)
+    m = SegmentationOSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32, "decoder_seg_dim": 15})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in seg.items()})
+    out = m.eval()(torch.from_numpy(fn), torch.from_numpy(fd), None)
+    data.update({"seg." + k: v for k, v in seg.items()}, **{"seg.out." + k: v.numpy() for k, v in out.items()})
+    for k, v in zip(("rgb", "sigma", "seg"), orc.decoder_segmentation(fd, seg)):
+        check("seg." + k, v, out[k].numpy(), 2e-5)
+    w = {"net.0.weight": rng.randn(64, 32), "net.0.bias": rng.randn(64) * 0.3, "net.2.weight": rng.randn(33, 64), "net.2.bias": rng.randn(33) * 0.3}
+    w = {k: v.astype(np.float32) for k, v in w.items()}
+    m = OSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32})
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()})
+    out = m.eval()(torch.from_numpy(fd), None)
+    data.update({"osg." + k: v for k, v in w.items()}, **{"osg.out." + k: v.numpy() for k, v in out.items()})
+    np.savez_compressed(os.path.join(OUT, "decoder_forward.npz"), **data)
+    print("  wrote decoder_forward.npz")
+
+
 def gen_point_query(seed=7, N=2, H=16, P=500):
     rng = np.random.RandomState(seed)
     planes = smooth_planes(rng, N, H)
@@ -361,8 +391,11 @@ def main():
     gen_render_full_size()
     gen_render_full_size("ffhq_render", seed=411, N=2, R=128, H=256, D=48, Ni=48, swap=True, stride=7, chunk=16384,
                          angles=((0.35, -0.15), (-0.3, 0.1)))
+    gen_render_full_size("cfg5_render", seed=421, N=2, R=128, H=256, D=96, Ni=96, swap=True, stride=7, chunk=8192,
+                         angles=((0.3, -0.1), (-0.25, 0.15)))
     gen_legacy_renderer()
     gen_segmentation_decoder()
+    gen_decoder_forward()
     print("point query:")
     gen_point_query()
     print("plane stats:")
@@ -383,6 +416,14 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "segmentation_decoder":
         os.makedirs(OUT, exist_ok=True)
         gen_segmentation_decoder()
+    elif len(sys.argv) > 1 and sys.argv[1] == "decoder_forward":
+        os.makedirs(OUT, exist_ok=True)
+        gen_decoder_forward()
+    elif len(sys.argv) > 1 and sys.argv[1] == "cfg5_render":
+        # BASELINE config 5: 96 + 96 samples (projector.py:33-34), two plane sets with swapped statistics (utils.py:176 path)
+        os.makedirs(OUT, exist_ok=True)
+        gen_render_full_size("cfg5_render", seed=421, N=2, R=128, H=256, D=96, Ni=96, swap=True, stride=7, chunk=8192,
+                             angles=((0.3, -0.1), (-0.25, 0.15)))
     elif len(sys.argv) > 1 and sys.argv[1] == "ffhq_render":
         os.makedirs(OUT, exist_ok=True)
         gen_render_full_size("ffhq_render", seed=411, N=2, R=128, H=256, D=48, Ni=48, swap=True, stride=7, chunk=16384,

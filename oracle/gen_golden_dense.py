@@ -284,6 +284,111 @@ def gen_e2e_full():
     print("  wrote dense_e2e_full.npz")
 
 
+def gen_density_grid():
+    """gen_samples.py shape extraction (:79-101 create_samples, :186-214 the sigma sweep + flip + border trim) on the reduced
+    generator of gen_e2e: N=16 grid.  create_samples is the reference's own function (gen_samples.py imports `mrcfile`, absent
+    here and used only when a .mrc file is written: an empty placeholder module lets the import proceed); the sweep calls the
+    reference G.sample_mixed in chunks like gen_samples.py:197-201; flip + trim restate :205-216."""
+    import types
+    sys.modules.setdefault("mrcfile", types.ModuleType("mrcfile"))
+    import gen_samples as ref_gs
+    from training.triplane import TriPlaneGenerator
+    from oracle.dense_params import generator_params
+    rk = dict(E2E_KW["rendering_kwargs"])
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default="inference_only"),
+                          channel_base=E2E_KW["channel_base"], channel_max=E2E_KW["channel_max"],
+                          fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+    load(G, generator_params(51, E2E_KW["channel_base"], E2E_KW["channel_max"]))
+    e2e = np.load(os.path.join(OUT, "dense_e2e.npz"))
+    ws = t(e2e["ws"])[:1]
+    shape_res, max_batch = 16, 1500
+    samples, voxel_origin, voxel_size = ref_gs.create_samples(N=shape_res, voxel_origin=[0, 0, 0], cube_length=rk["box_warp"] * 1)
+    sigmas = torch.zeros((samples.shape[0], samples.shape[1], 1))
+    head = 0
+    while head < samples.shape[1]:
+        sigmas[:, head:head + max_batch] = G.sample_mixed(samples[:, head:head + max_batch], None, ws, noise_mode="const")["sigma"]
+        head += max_batch
+    grid = sigmas.reshape((shape_res, shape_res, shape_res)).numpy()
+    vol = np.flip(grid, 0).copy()
+    pad = int(30 * shape_res / 256)
+    vol[:pad] = vol[-pad:] = -1000
+    vol[:, :pad] = vol[:, -pad:] = -1000
+    vol[:, :, :pad] = vol[:, :, -pad:] = -1000
+    print(f"    reference sigma grid |max| {np.abs(grid).max():.3g}, voxel_size {voxel_size:.6f}, pad {pad}")
+    np.savez_compressed(os.path.join(OUT, "density_grid.npz"), samples=samples.numpy(), voxel_origin=np.asarray(voxel_origin, np.float64),
+                        voxel_size=float(voxel_size), shape_res=shape_res, max_batch=max_batch, sigma_grid=grid, sigma_volume=vol, pad=pad)
+    print("  wrote density_grid.npz")
+
+
+def _full_generator(rk):
+    from training.triplane import TriPlaneGenerator
+    from oracle.dense_params import generator_params
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default="inference_only"),
+                          channel_base=32768, channel_max=512, fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+    load(G, generator_params(71, 32768, 512))
+    assert sum(v.numel() for v in G.parameters()) == 30665223          # SURVEY.md section 8c
+    return G
+
+
+def gen_e2e_cfg1():
+    """BASELINE config 1 exactly: full-size generator forward(), N=1, 64^2 neural render, 48 + 48
+    samples, z = RandomState(0).randn(1,512), c = LookAtPoseSampler.sample(pi/2, pi/2, [0,0,0.2], radius=2.7) + FOV 18.837,
+    truncation_psi 1, noise_mode 'const'.  Jitter is regenerated from `u_seed` by the test."""
+    import math
+    from camera_utils import FOV_to_intrinsics, LookAtPoseSampler
+    from oracle.gen_golden import InjectRand
+    R, D, Di, u_seed = 64, 48, 48, 73
+    G = _full_generator(dict(E2E_KW["rendering_kwargs"], depth_resolution=D, depth_resolution_importance=Di))
+    z = t(np.random.RandomState(0).randn(1, 512))
+    c2w = LookAtPoseSampler.sample(math.pi / 2, math.pi / 2, torch.tensor([0, 0, 0.2]), radius=2.7)
+    c = torch.cat([c2w.reshape(1, 16), FOV_to_intrinsics(18.837).reshape(1, 9)], 1)
+    rng = np.random.RandomState(u_seed)
+    u_c = rng.rand(1, R * R, D).astype(np.float32)
+    u_f = rng.rand(R * R, Di).astype(np.float32)
+    with InjectRand([u_c, u_f]):
+        ref = G(z, c, neural_rendering_resolution=R, noise_mode="const")
+    data = dict(z=z.numpy(), c=c.numpy(), u_seed=u_seed, seed=71, R=R, D=D, Di=Di,
+                image_s4=ref["image"][:, :, 1::4, 2::4].numpy(), image_mean=float(ref["image"].double().mean()),
+                image_seg=ref["image_seg"].numpy(), image_raw=ref["image_raw"].numpy(), image_depth=ref["image_depth"].numpy(),
+                plane_mean=ref["plane_mean"].numpy(), plane_var=ref["plane_var"].numpy(), torch_version=np.array(torch.__version__))
+    for k in ("image", "image_seg", "image_raw", "image_depth"):
+        print(f"    reference {k:12s} |max| {float(ref[k].abs().max()):.3g}")
+    np.savez_compressed(os.path.join(OUT, "dense_e2e_cfg1.npz"), **data)
+    print("  wrote dense_e2e_cfg1.npz")
+
+
+def gen_e2e_cfg3():
+    """BASELINE config 3's data path at full size: synthesis() of the FFHQ-size generator at neural_rendering_resolution
+    512 with 64 samples (single pass), so the 32-channel 512^2 feature image goes through the antialiased 512 -> 128
+    down-resize into the SR head (superresolution.py:279-290).  One view (the reference materialises ~6.4 GB of gather
+    results per plane set at this size).  Jitter regenerated from `u_seed`; outputs stored strided + fp64 means."""
+    import math
+    from camera_utils import FOV_to_intrinsics, LookAtPoseSampler
+    from oracle.gen_golden import InjectRand
+    R, D, u_seed = 512, 64, 75
+    G = _full_generator(dict(E2E_KW["rendering_kwargs"], depth_resolution=D, depth_resolution_importance=0))
+    rng = np.random.RandomState(74)
+    z = t(rng.randn(1, 512))
+    c2w = LookAtPoseSampler.sample(math.pi / 2 - 0.3, math.pi / 2 - 0.1, torch.tensor([0, 0, 0.2]), radius=2.7)
+    c = torch.cat([c2w.reshape(1, 16), FOV_to_intrinsics(18.837).reshape(1, 9)], 1)
+    u_c = np.random.RandomState(u_seed).rand(1, R * R, D).astype(np.float32)
+    ws = G.mapping(z, c, truncation_psi=0.7, truncation_cutoff=14)
+    with InjectRand([u_c]):
+        ref = G.synthesis(ws, c, neural_rendering_resolution=R, noise_mode="const")
+    data = dict(z=z.numpy(), c=c.numpy(), ws=ws.numpy(), u_seed=u_seed, seed=71, R=R, D=D, Di=0,
+                image_s4=ref["image"][:, :, 1::4, 2::4].numpy(), image_raw_s3=ref["image_raw"][:, :, 1::3, 2::3].numpy(),
+                image_seg_s4=ref["image_seg"][:, :, 2::4, 1::4].numpy(), image_depth_s2=ref["image_depth"][:, :, ::2, 1::2].numpy(),
+                plane_mean=ref["plane_mean"].numpy(), plane_var=ref["plane_var"].numpy(), torch_version=np.array(torch.__version__))
+    for k in ("image", "image_seg", "image_raw", "image_depth"):
+        data[k + "_mean"] = ref[k].double().mean(dim=(0, 2, 3)).numpy()
+        data[k + "_absmax"] = float(ref[k].abs().max())
+        print(f"    reference {k:12s} |max| {float(ref[k].abs().max()):.3g}")
+    np.savez_compressed(os.path.join(OUT, "dense_e2e_cfg3.npz"), **data)
+    print("  wrote dense_e2e_cfg3.npz")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1] if len(sys.argv) > 1 else None         # e.g. `python oracle/gen_golden_dense.py synthesis_full`
@@ -297,6 +402,9 @@ if __name__ == "__main__":
     gen_sr()
     gen_e2e()
     gen_e2e_full()
+    gen_e2e_cfg1()
+    gen_e2e_cfg3()
+    gen_density_grid()
     gen_sr_variants()
     for f in sorted(os.listdir(OUT)):
         if f.startswith("dense_"):

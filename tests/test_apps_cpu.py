@@ -29,3 +29,18 @@ def test_seed_to_z_and_uint8_conversion():
     u8 = apps.to_uint8(img)
     assert u8.dtype == torch.uint8 and u8.shape == (1, 1, 5, 3)
     assert u8[0, 0, :, 0].tolist() == [0, 0, 128, 255, 255]               # gen_samples.py:177
+
+
+def test_create_samples_and_volume_match_reference():
+    """apps.create_samples against the reference's own create_samples (gen_samples.py:79-101, incl. its float-division
+    quirk on the x / y columns), and the flip + border trim of gen_samples.py:204-216."""
+    from tests._golden import load
+    z = load("density_grid")
+    R = int(z["shape_res"])
+    pts, origin, voxel = apps.create_samples(N=R, voxel_origin=[0, 0, 0], cube_length=1.0)
+    assert pts.shape == (1, R ** 3, 3) and np.array_equal(pts.numpy(), z["samples"])
+    assert np.allclose(origin, z["voxel_origin"]) and abs(voxel - float(z["voxel_size"])) < 1e-12
+    # z is the fastest axis and the only one on the lattice; x / y advance fractionally (the reference's float division)
+    assert abs(float(pts[0, 1, 2] - pts[0, 0, 2]) - voxel) < 1e-6 and 0 < float(pts[0, 1, 1] - pts[0, 0, 1]) < voxel
+    vol = apps.density_to_volume(torch.from_numpy(z["sigma_grid"]))
+    assert np.array_equal(vol.numpy(), z["sigma_volume"])

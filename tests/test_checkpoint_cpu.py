@@ -75,3 +75,16 @@ def test_vis_parsing_maps_matches_reference_formula():
         want = torch.where(lab == i, torch.tensor(col, dtype=torch.float32).view(1, 3, 1, 1).expand_as(want), want)
     assert torch.equal(img, want / 255.0 * 2 - 1)
     assert torch.equal(U.vis_parsing_maps(img, inverse=True), lab)
+
+
+def test_checkpoint_golden_record_is_current(tmp_path):
+    """tests/golden/checkpoint_e2e.json (what the GPU test trusts) == a fresh pickle -> legacy.load_network_pkl -> convert()
+    run on the reference class here."""
+    import json
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from oracle import gen_golden_checkpoint as gg
+    meta, digests = gg.converted_record(str(tmp_path))
+    with open(os.path.join(os.path.dirname(__file__), "golden", "checkpoint_e2e.json")) as f:
+        rec = json.load(f)
+    assert rec["converter_json"] == meta
+    assert rec["sha256"] == digests and len(digests) == 180

@@ -109,9 +109,28 @@ def test_render_views_and_density_grid(setup):
     oc = apps.orbit_cameras(8, dev)
     assert oc.shape == (8, 25) and float((oc[0] - oc[4]).abs().max()) > 1e-3
     sig = apps.extract_density(G, ws, shape_res=24, max_batch=5000, noise_mode="const")
-    want = G.sample_mixed(torch.tensor([[[-0.5, -0.5, -0.5], [0.5, 0.5, 0.5]]], device=dev), None, ws, noise_mode="const")["sigma"]
-    assert abs(float(sig[0, 0, 0]) - float(want[0, 0, 0])) <= 1e-5 and abs(float(sig[-1, -1, -1]) - float(want[0, 1, 0])) <= 1e-5
+    # off-diagonal probes: sig[i,j,k] is the density at the create_samples point of flat index (i*R + j)*R + k
+    pts, _, _ = apps.create_samples(N=24, cube_length=1.0, device=dev)
+    probe = torch.tensor([(1 * 24 + 2) * 24 + 3, (20 * 24 + 5) * 24 + 11, 0, 24 ** 3 - 1], device=dev)
+    want = G.sample_mixed(pts[:, probe].contiguous(), None, ws, noise_mode="const")["sigma"].reshape(-1)
+    got = torch.stack([sig[1, 2, 3], sig[20, 5, 11], sig[0, 0, 0], sig[-1, -1, -1]])
+    assert float((got - want).abs().max()) <= 1e-5
     del b
+
+
+def test_density_grid_vs_reference(setup):
+    """gen_samples.py's shape sweep (create_samples grid, chunked G.sample, reshape) on a 16^3 grid against the reference
+    generator's own sweep; then the flip + border trim that precedes the .mrc / marching-cubes export."""
+    from nerffaceediting_amd import apps
+    G, z, dev = setup
+    g = load("density_grid")
+    R = int(g["shape_res"])
+    sig = apps.extract_density(G, t(z["ws"], dev)[:1], shape_res=R, max_batch=int(g["max_batch"]), noise_mode="const")
+    assert sig.shape == (R, R, R)
+    e = err(sig, g["sigma_grid"])
+    print("density grid", e, float(np.abs(g["sigma_grid"]).max()))
+    assert e <= TOL
+    assert err(apps.density_to_volume(sig), g["sigma_volume"]) <= TOL
 
 
 def test_graphed_synthesis_matches_eager(setup):
@@ -219,6 +238,178 @@ def test_full_size_generator_forward():
     for k, e in errs.items():
         assert e <= TOL, (k, e)
     assert abs(float(out["image"].mean()) - float(z["image_mean"])) <= 1e-4
+
+
+def _full_generator(dev, seed, D, Di):
+    from nerffaceediting_amd.training.triplane import TriPlaneGenerator
+    rk = dict(RENDERING_KWARGS, depth_resolution=D, depth_resolution_importance=Di)
+    G = TriPlaneGenerator(512, 25, 512, 512, 3, sr_num_fp16_res=4, mapping_kwargs=dict(num_layers=2), rendering_kwargs=rk,
+                          sr_kwargs=dict(channel_base=32768, channel_max=512, fused_modconv_default="inference_only"),
+                          channel_base=32768, channel_max=512, fused_modconv_default="inference_only", num_fp16_res=0, conv_clamp=None)
+    sd = G.state_dict()
+    for k, v in generator_params(seed, 32768, 512).items():
+        assert tuple(sd[k].shape) == tuple(v.shape), k
+        sd[k] = v
+    G.load_state_dict(sd)
+    return G.to(dev).eval().requires_grad_(False)
+
+
+def test_full_size_generator_cfg1_exact():
+    """BASELINE config 1 exactly: the FFHQ-size generator through forward(), one latent
+    (RandomState(0)), frontal camera, 64^2 neural render x (48 + 48) samples, against the reference TriPlaneGenerator."""
+    dev = torch.device("cuda:0")
+    z = load("dense_e2e_cfg1")
+    R, D, Di = int(z["R"]), int(z["D"]), int(z["Di"])
+    assert (R, D, Di) == (64, 48, 48)
+    G = _full_generator(dev, int(z["seed"]), D, Di)
+    rng = np.random.RandomState(int(z["u_seed"]))                     # oracle/gen_golden_dense.py gen_e2e_cfg1
+    u_c = rng.rand(1, R * R, D).astype(np.float32)
+    u_f = rng.rand(R * R, Di).astype(np.float32)
+    assert np.array_equal(z["z"], np.random.RandomState(0).randn(1, 512).astype(np.float32))
+    G.renderer.inject_jitter(t(u_c, dev), t(u_f, dev))
+    out = G(t(z["z"], dev), t(z["c"], dev), neural_rendering_resolution=R, noise_mode="const")
+    errs = {"image": err(out["image"][:, :, 1::4, 2::4], z["image_s4"])}
+    for k in ("image_seg", "image_raw", "image_depth", "plane_mean", "plane_var"):
+        errs[k] = err(out[k], z[k])
+    print("cfg1 forward", errs)
+    for k, e in errs.items():
+        assert e <= TOL, (k, e)
+    assert abs(float(out["image"].double().mean()) - float(z["image_mean"])) <= 1e-4
+
+
+@pytest.mark.parametrize("conv_math", ["bf16x3", "bf16"])
+def test_full_size_synthesis_cfg3(conv_math):
+    """BASELINE config 3's data path at full size: synthesis() at neural_rendering_resolution 512 x 64 samples, so the 32-channel
+    512^2 feature image goes through the antialiased 512 -> 128 down-resize into the SR head (superresolution.py:279-290),
+    against the reference TriPlaneGenerator (one view).  bf16x3 (fp32-grade convs): the 1e-3 bar.  bf16 (the throughput mode
+    bench.py --workload full times): bounds relative to each output's magnitude, since plain-bf16 operands carry 2^-9
+    relative rounding through 13 + 6 conv layers."""
+    dev = torch.device("cuda:0")
+    z = load("dense_e2e_cfg3")
+    R, D = int(z["R"]), int(z["D"])
+    assert (R, D, int(z["Di"])) == (512, 64, 0)
+    G = _full_generator(dev, int(z["seed"]), D, 0)
+    G.backbone.synthesis.conv_math = conv_math
+    G.superresolution.conv_math = conv_math
+    u_c = np.random.RandomState(int(z["u_seed"])).rand(1, R * R, D).astype(np.float32)
+    ws = G.mapping(t(z["z"], dev), t(z["c"], dev), truncation_psi=0.7, truncation_cutoff=14)
+    assert err(ws, z["ws"]) <= 1e-4
+    G.renderer.inject_jitter(t(u_c, dev))
+    out = G.synthesis(t(z["ws"], dev), t(z["c"], dev), neural_rendering_resolution=R, noise_mode="const")
+    assert out["image"].shape == (1, 3, 512, 512) and out["image_raw"].shape == (1, 3, R, R) and out["image_seg"].shape == (1, 15, R, R)
+    errs = {"image": err(out["image"][:, :, 1::4, 2::4], z["image_s4"]),
+            "image_raw": err(out["image_raw"][:, :, 1::3, 2::3], z["image_raw_s3"]),
+            "image_seg": err(out["image_seg"][:, :, 2::4, 1::4], z["image_seg_s4"]),
+            "image_depth": err(out["image_depth"][:, :, ::2, 1::2], z["image_depth_s2"])}
+    means = {k: float(np.abs(out[k].double().mean(dim=(0, 2, 3)).cpu().numpy() - z[k + "_mean"]).max())
+             for k in ("image", "image_raw", "image_seg", "image_depth")}
+    print("cfg3 synthesis", conv_math, errs, "channel means", means)
+    if conv_math == "bf16x3":
+        for k, e in errs.items():
+            assert e <= TOL, (k, e)
+        for k, e in means.items():
+            assert e <= 1e-4, (k, e)
+        assert err(out["plane_mean"], z["plane_mean"]) <= TOL and err(out["plane_var"], z["plane_var"]) <= TOL
+    else:
+        for k, e in errs.items():
+            assert e <= 0.05 * max(float(z[k + "_absmax"]), 1.0), (k, e)
+        for k, e in means.items():
+            assert e <= 0.01 * max(float(z[k + "_absmax"]), 1.0), (k, e)
+
+
+def test_converted_checkpoint_renders_reference_outputs(tmp_path):
+    """f1 end to end: reference pickle -> tools/convert_checkpoint.convert() (run in the build container; its .json and the
+    SHA-256 of every tensor it wrote are the fixture checkpoint_e2e.json) -> checkpoint.load_generator() -> synthesis() ->
+    outputs captured from the reference generator (dense_e2e.npz).  The tensors are regenerated from the seed and proven
+    identical to the converter's output by the hashes before they are written in the converter's format."""
+    import hashlib
+    import json
+    import os
+    from nerffaceediting_amd.checkpoint import load_generator
+    from nerffaceediting_amd.training.triplane import TriPlaneGenerator
+    dev = torch.device("cuda:0")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "checkpoint_e2e.json")) as f:
+        rec = json.load(f)
+    meta = rec["converter_json"]
+    state = {k: v.numpy() for k, v in generator_params(int(rec["seed"]), int(rec["channel_base"]), int(rec["channel_max"])).items()}
+    skeleton = TriPlaneGenerator(*meta["init_args"], **meta["init_kwargs"]).state_dict()      # resample_filter buffers: constants
+    for k, v in skeleton.items():
+        state.setdefault(k, v.numpy())
+    assert sorted(state) == sorted(rec["sha256"])
+
+    def digest(a):
+        a = np.ascontiguousarray(a)
+        return hashlib.sha256(str(a.dtype).encode() + str(a.shape).encode() + a.tobytes()).hexdigest()
+    for k, v in state.items():
+        assert digest(v) == rec["sha256"][k], k
+    prefix = str(tmp_path / "converted")
+    np.savez(prefix + ".npz", **state)
+    with open(prefix + ".json", "w") as f:
+        json.dump(meta, f)
+    G = load_generator(prefix, device=dev)
+    assert G.neural_rendering_resolution == 32 and G.rendering_kwargs["depth_resolution_importance"] == 12
+    z = load("dense_e2e")
+    G.renderer.inject_jitter(t(z["u_coarse"], dev), t(z["u_fine"], dev))
+    out = G(t(z["z"], dev), t(z["c"], dev), truncation_psi=0.7, truncation_cutoff=14, noise_mode="const")     # R = 32 from the checkpoint
+    errs = {"image": err(out["image"][:, :, ::4, ::4], z["plain.image_s4"])}
+    for k in ("image_seg", "image_raw", "image_depth", "plane_mean", "plane_var"):
+        errs[k] = err(out[k], z["plain." + k])
+    print("converted checkpoint", errs)
+    for k, e in errs.items():
+        assert e <= TOL, (k, e)
+
+
+def test_last_planes_contract(setup):
+    """`_last_planes` is the reference's NCHW tensor (triplane.py:88-89,110): cached AFTER an appearance override, so a later
+    use_cached_backbone call keeps the overridden appearance and reports its statistics; a caller may assign its own tensor."""
+    G, z, dev = setup
+    R = int(z["R"])
+    ws, c = t(z["ws"], dev), t(z["c"], dev)
+    uc, uf = t(z["u_coarse"], dev), t(z["u_fine"], dev)
+    try:
+        G.renderer.inject_jitter(uc, uf)
+        a = G.synthesis(ws, c, neural_rendering_resolution=R, noise_mode="const", cache_backbone=True, planes_mean=1, planes_var=0)
+        lp = G._last_planes
+        assert isinstance(lp, torch.Tensor) and lp.shape == (2, 96, 256, 256)
+        assert err(a["image_raw"], z["swap.image_raw"]) <= TOL
+        # the cached planes are the DENORMALISED ones: their statistics are the override's (mean of identity 1, std of identity 0)
+        m, s = G.compute_mean_var(lp)
+        assert err(m, np.repeat(z["plain.plane_mean"][1:2], 2, 0)) <= 1e-3 and err(s, np.repeat(z["plain.plane_var"][0:1], 2, 0)) <= 1e-3
+        G.renderer.inject_jitter(uc, uf)
+        b = G.synthesis(torch.zeros_like(ws), c, use_cached_backbone=True, noise_mode="const")      # no override now: appearance is kept
+        assert err(b["image_raw"], z["swap.image_raw"]) <= TOL
+        assert err(b["plane_mean"], m.cpu().numpy()) <= 1e-5
+        # a caller-assigned tensor (5-D view, as utils.encode returns) is honoured
+        planes = G.backbone.synthesis(ws, noise_mode="const")
+        G._last_planes = planes.view(2, 3, 32, 256, 256)
+        G.renderer.inject_jitter(uc, uf)
+        d = G.synthesis(torch.zeros_like(ws), c, use_cached_backbone=True, noise_mode="const")
+        assert err(d["image_raw"], z["plain.image_raw"]) <= TOL and err(d["plane_mean"], z["plain.plane_mean"]) <= 1e-4
+    finally:
+        G._last_planes = None
+
+
+def test_sample_passes_density_noise(setup):
+    """sample()/sample_mixed() hand self.rendering_kwargs to run_model (triplane.py:148,157), so `density_noise` perturbs
+    sigma there too (renderer.py:285-286): sigma moves by N(0,1) * density_noise, rgb and seg do not."""
+    G, z, dev = setup
+    ws, coords = t(z["ws"], dev), t(z["sample.coords"], dev)
+    old = G.rendering_kwargs
+    try:
+        G.rendering_kwargs = dict(old, density_noise=0.5)
+        torch.manual_seed(11)
+        a = G.sample_mixed(coords, None, ws, noise_mode="const")
+        torch.manual_seed(11)
+        b = G.sample_mixed(coords, None, ws, noise_mode="const")
+        torch.manual_seed(12)
+        c2 = G.sample_mixed(coords, None, ws, noise_mode="const")
+    finally:
+        G.rendering_kwargs = old
+    assert torch.equal(a["sigma"], b["sigma"]) and not torch.equal(a["sigma"], c2["sigma"])
+    for k in ("rgb", "seg"):
+        assert err(a[k], z["sample." + k]) <= TOL
+    dz = (a["sigma"].cpu().double() - torch.from_numpy(z["sample.sigma"]).double()).flatten() / 0.5
+    assert abs(float(dz.mean())) < 0.2 and 0.8 < float(dz.std()) < 1.2, (float(dz.mean()), float(dz.std()))
 
 
 def test_interpolation_video_frames(setup):

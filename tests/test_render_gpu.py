@@ -263,13 +263,18 @@ def test_render_full_size_vs_reference(math, dev):
     assert abs(float(wsum.double().mean()) - float(z["wsum_mean"])) <= 1e-5
 
 
-def test_render_ffhq_config_dual_vs_reference(dev):
-    """The FFHQ rendering_kwargs (128^2 rays, 48 coarse + 48 importance samples) with swapped appearance statistics (two plane
-    sets: the editing path through renderer(norm_planes, denorm_planes, ...)) against the reference renderer."""
+@pytest.mark.parametrize("math", MATHS)
+@pytest.mark.parametrize("name", ["ffhq_render", "cfg5_render"])
+def test_render_two_pass_dual_vs_reference(name, math, dev):
+    """Two-pass renders at real sizes with swapped appearance statistics (two plane sets: the editing path through
+    renderer(norm_planes, denorm_planes, ...), utils.py:176) against the reference renderer:
+      ffhq_render - the FFHQ rendering_kwargs (train.py:306-307): 128^2 rays, 48 coarse + 48 importance samples;
+      cfg5_render - BASELINE config 5 (projector.py:33-34): 128^2 rays, 96 + 96 samples (192-entry sort / merge / depth buffer).
+    Both the DUAL-gather form and the single-gather form (raw planes + affines), both decoder math modes."""
     import ast
     import torch
     from nerffaceediting_amd import ops
-    z = load("ffhq_render")
+    z = load(name)
     seed, N, R, H, D, Ni, stride = (int(z[k]) for k in ("seed", "N", "R", "H", "D", "Ni", "stride"))
     rng = np.random.RandomState(seed)
     base = rng.randn(N, 96, H, H).astype(np.float32)                 # gen_golden.smooth_planes
@@ -280,6 +285,7 @@ def test_render_ffhq_config_dual_vs_reference(dev):
     u_c = rng.rand(N, R * R, D).astype(np.float32)
     u_f = rng.rand(N * R * R, Ni).astype(np.float32)
     opts = ast.literal_eval(str(z["options"]))
+    assert (opts["depth_resolution"], opts["depth_resolution_importance"]) == (D, Ni)
     p = _t(planes, dev)
     mean, std = ops.plane_stats(p)
     # explicit norm / denorm plane sets, as utils.decode() hands them to the renderer
@@ -288,22 +294,24 @@ def test_render_ffhq_config_dual_vs_reference(dev):
     names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
              "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
     decp = ops.decoder_pack(*[_t(dec[k], dev) for k in names])
-    rgb, seg, depth, wsum = ops.render(ops.plane_pack(normed.contiguous()), ops.plane_pack(denormed.contiguous()), decp, opts,
-                                       cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev), resolution=R,
-                                       u_coarse=_t(u_c, dev), u_fine=_t(u_f, dev))[:4]
+    cam = dict(cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev), resolution=R,
+               u_coarse=_t(u_c, dev), u_fine=_t(u_f, dev), decoder_math=math)
     idx = torch.arange(0, R * R, stride, device=dev)
-    errs = {"rgb": max_abs(rgb[:, idx].cpu().numpy(), z["rgb"]), "seg": max_abs(seg[:, idx].cpu().numpy(), z["seg"]),
-            "depth": max_abs(depth[:, idx].cpu().numpy(), z["depth"]), "wsum": max_abs(wsum[:, idx].cpu().numpy(), z["wsum"])}
-    print("ffhq dual", errs)
-    for k, e in errs.items():
-        assert e <= TIGHT["bf16x3"] or (k == "depth" and e <= TOL), (k, e)
-    assert max_abs(rgb.double().mean(dim=(0, 1)).cpu().numpy(), z["rgb_mean"]) <= 2e-5
-    # the single-gather form of the same render (raw planes + affines) agrees with the two-plane-set form
     aff = ops.make_affine(mean, std, mean.flip(0).contiguous(), std.flip(0).contiguous())
     packed = ops.plane_pack(p)
-    rgb1 = ops.render(packed, packed, decp, opts, cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev), resolution=R,
-                      affines=aff, u_coarse=_t(u_c, dev), u_fine=_t(u_f, dev))[0]
-    assert max_abs(rgb1[:, idx].cpu().numpy(), z["rgb"]) <= TIGHT["bf16x3"]
+    forms = {"dual": (ops.plane_pack(normed.contiguous()), ops.plane_pack(denormed.contiguous()), None),
+             "single": (packed, packed, aff)}            # the single-gather form of the same render (raw planes + affines)
+    for form, (pg, pa, af) in forms.items():
+        rgb, seg, depth, wsum, tap = ops.render(pg, pa, decp, opts, affines=af, taps=True, **cam)
+        errs = {"rgb": max_abs(rgb[:, idx].cpu().numpy(), z["rgb"]), "seg": max_abs(seg[:, idx].cpu().numpy(), z["seg"]),
+                "depth": max_abs(depth[:, idx].cpu().numpy(), z["depth"]), "wsum": max_abs(wsum[:, idx].cpu().numpy(), z["wsum"])}
+        print(name, form, math, errs)
+        for k, e in errs.items():
+            assert e <= TIGHT[math] or (k == "depth" and e <= TOL), (form, k, e)
+        assert max_abs(rgb.double().mean(dim=(0, 1)).cpu().numpy(), z["rgb_mean"]) <= 2e-5
+        assert abs(float(wsum.double().mean()) - float(z["wsum_mean"])) <= 2e-5
+        da = tap["depths_all"]
+        assert da.shape == (N, R * R, D + Ni) and bool((da[..., 1:] >= da[..., :-1]).all()), "merged depths must be sorted"
 
 
 def test_depth_split_launches_match_unsplit(dev):
@@ -356,9 +364,11 @@ np.savez(sys.argv[1], *outs)
 
 
 def test_outputs_do_not_depend_on_occupancy(dev):
-    """The same 512^2 x 64 launch with 1, 2 (default) and 4 workgroups per CU (NFE_RENDER_BLOCKS_PER_CU, read once per process:
+    """The same launches with 1, 2 (default), 3 and 4 workgroups per CU (NFE_RENDER_BLOCKS_PER_CU, read once per process:
     child interpreters) must give bit-identical outputs: a build whose results depended on what else shared the CU (a
-    scheduling hazard) is caught here."""
+    scheduling hazard) is caught here.  Covered kernel variants: square planes / one set (SQUARE),
+    non-square planes (run-time axis geometry), two plane sets (DUAL), single pass 512^2 x 64, two-pass 24+24 and 96+96
+    (sigma-only pass + importance_kernel + depth-buffer pass), exact-fp32 decoder."""
     import hashlib
     import os
     import subprocess
@@ -372,24 +382,38 @@ N, R, H = 2, 512, 256
 raw = torch.randn(N, 96, H, H, generator=g).to(dev)
 mean, std = ops.plane_stats(raw)
 packed = ops.plane_pack(raw)
+aff = ops.make_affine(mean, std)
+packed2 = ops.plane_pack((raw * 0.8 + 0.1).contiguous())                  # a second plane set (DUAL kernels)
+rawr = torch.randn(N, 96, 192, 320, generator=g).to(dev)                   # non-square planes
+packedr = ops.plane_pack(rawr)
+affr = ops.make_affine(*ops.plane_stats(rawr))
 shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
 dec = ops.decoder_pack(*[(torch.randn(*s, generator=g) * (1.0 if len(s) == 2 else 0.2)).to(dev) for s in shapes])
 from oracle import render_oracle as orc           # camera construction only
 c2w = torch.from_numpy(np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2 + p, [0, 0, 0.2], 2.7).reshape(1, 4, 4) for y, p in ((0.3, -0.2), (-0.9, 0.4))]))
 K = torch.from_numpy(np.repeat(orc.fov_to_intrinsics(18.837)[None], N, 0))      # rays that leave the planes at the image borders
 h = hashlib.sha256()
-for D, Di in ((64, 0), (24, 24)):
+cases = [(packed, packed, aff, 512, 64, 0, None), (packed, packed, aff, 512, 24, 24, None),
+         (packedr, packedr, affr, 512, 64, 0, None), (packedr, packedr, affr, 256, 24, 24, None),
+         (packed, packed2, None, 512, 64, 0, None), (packed, packed2, None, 256, 96, 96, None),
+         (packed, packed, aff, 256, 96, 96, None), (packed, packed, aff, 256, 48, 48, "fp32"), (packed, packed2, None, 256, 32, 0, "fp32")]
+for pg, pa, af, R, D, Di, math in cases:
     opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
-    out = ops.render(packed, packed, dec, opts, cam2world=c2w.to(dev), intrinsics=K.to(dev), resolution=R, affines=ops.make_affine(mean, std), seed=5)
+    out = ops.render(pg, pa, dec, opts, cam2world=c2w.to(dev), intrinsics=K.to(dev), resolution=R, affines=af, seed=5, decoder_math=math)
+    hh = hashlib.sha256()
     for t in out:
-        h.update(t.cpu().numpy().tobytes())
+        hh.update(t.cpu().numpy().tobytes())
+    print("CASE", R, D, Di, math, tuple(pg.shape[2:4]), pg is pa, hh.hexdigest()[:16])
+    h.update(hh.digest())
 print("HASH", h.hexdigest())
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     hashes = {}
-    for b in ("1", "2", "4"):
+    detail = {}
+    for b in ("1", "2", "3", "4"):
         env = dict(os.environ, NFE_RENDER_BLOCKS_PER_CU=b, PYTHONPATH=root)
-        r = subprocess.run([sys.executable, "-c", prog], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", prog], cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         hashes[b] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
-    assert hashes["1"] == hashes["2"] == hashes["4"], hashes
+        detail[b] = [l for l in r.stdout.splitlines() if l.startswith("CASE")]
+    assert hashes["1"] == hashes["2"] == hashes["3"] == hashes["4"], detail

@@ -61,6 +61,41 @@ def test_run_model_signature(dev):
         assert max_abs(out[k].cpu().numpy(), z["out." + k]) <= TOL, k
 
 
+@pytest.mark.parametrize("math", [None, "fp32"])
+def test_decoder_modules_forward(math, dev):
+    """The decoder modules called directly on sampled features [N,3,M,32], as ordinary nn.Module.forward()s
+    (triplane.py:178-190, 209-230, 249-270), against outputs of the reference classes."""
+    from nerffaceediting_amd.training.triplane import OSGDecoder, SegmentationOSGDecoder
+    z = load("decoder_forward")
+    fn, fd = t(z["features_norm"], dev), t(z["features_denorm"], dev)
+    tol = 5e-5 if math == "fp32" else 3e-4
+    sub = lambda pre: {k[len(pre):]: torch.from_numpy(z[k]) for k in z.files if k.startswith(pre) and ".out." not in k}
+    dis = make_decoder({k: v.numpy() for k, v in sub("dis.").items()}, dev)
+    dis.decoder_math = math
+    out = dis(fn, fd, None)
+    assert out["rgb"].shape == (2, 70, 32) and out["sigma"].shape == (2, 70, 1) and out["seg"].shape == (2, 70, 15)
+    for k in ("rgb", "sigma", "seg"):
+        assert max_abs(out[k].cpu().numpy(), z["dis.out." + k]) <= tol, ("dis", k)
+    osg = OSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32})
+    osg.load_state_dict(sub("osg."))
+    osg = osg.to(dev)
+    osg.decoder_math = math
+    out = osg(fd, None)
+    assert sorted(out) == ["rgb", "sigma"]
+    for k in ("rgb", "sigma"):
+        assert max_abs(out[k].cpu().numpy(), z["osg.out." + k]) <= tol, ("osg", k)
+    if math is None:                                      # the cross-term decoder exists in split-bf16 only
+        seg = SegmentationOSGDecoder(32, {"decoder_lr_mul": 1, "decoder_output_dim": 32, "decoder_seg_dim": 15})
+        seg.load_state_dict(sub("seg."))
+        out = seg.to(dev)(fn, fd, None)
+        for k in ("rgb", "sigma", "seg"):
+            assert max_abs(out[k].cpu().numpy(), z["seg.out." + k]) <= tol, ("seg", k)
+    # ragged / empty point counts
+    out = dis(fn[:, :, :33].contiguous(), fd[:, :, :33].contiguous(), None)
+    assert max_abs(out["seg"].cpu().numpy(), z["dis.out.seg"][:, :33]) <= tol
+    assert dis(fn[:, :, :0].contiguous(), fd[:, :, :0].contiguous(), None)["rgb"].shape == (2, 0, 32)
+
+
 def test_camera_utils_match_reference_goldens(dev):
     import math
     from nerffaceediting_amd import camera_utils as cu
