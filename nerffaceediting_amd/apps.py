@@ -70,16 +70,7 @@ def interpolation_video_frames(G, seeds, w_frames=240, kind="cubic", wraps=2, ps
     ws_key = G.mapping(zs, c_front, truncation_psi=psi, truncation_cutoff=truncation_cutoff)
     ws = interpolate_ws(ws_key, w_frames, kind, wraps)
     c = orbit_cameras(ws.shape[0], dev)
-    V = ws.shape[0]
-    rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
-    a, b = sharding.shard_range(V, rank, world)
-    frames = []
-    for i in range(a, b, batch):
-        j = min(b, i + batch)
-        out = G.synthesis(ws[i:j].contiguous(), c[i:j].contiguous(), noise_mode="const", **synthesis_kwargs)[image_mode]
-        frames.append(to_uint8(out))
-    local = torch.cat(frames, 0) if frames else torch.zeros((0, G.img_resolution, G.img_resolution, 3), dtype=torch.uint8, device=dev)
-    return sharding.all_gather_frames(local, V) if (gather and world > 1) else local
+    return render_views(G, ws, c, batch=batch, gather=gather, uint8=True, image_mode=image_mode, noise_mode="const", **synthesis_kwargs)
 
 
 def to_uint8(img):
@@ -88,22 +79,37 @@ def to_uint8(img):
 
 
 @torch.no_grad()
-def render_views(G, ws, c, batch=4, gather=True, **synthesis_kwargs):
-    """Render V independent (ws[v], c[v]) pairs -> frames [V,3,H,W] (fp32, in view order on every rank).
+def render_views(G, ws, c, batch=4, gather=True, uint8=False, image_mode="image", overlap=True, **synthesis_kwargs):
+    """Render V independent (ws[v], c[v]) pairs -> frames in view order on every rank: fp32 [V,3,H,W], or with
+    uint8=True the gen_samples.py:177 conversion [V,H,W,3] (4x fewer bytes on the wire).
 
-    ws [V,num_ws,w_dim] (or [1,...] broadcast: one identity, many cameras, as utils.render_video does),
-    c [V,25].  Under torch.distributed each rank renders a contiguous block of views
-    (sharding.shard_range) and frames are all-gathered once; without it everything runs locally."""
+    ws [V,num_ws,w_dim] (or [1,...] broadcast: one identity, many cameras, as utils.render_video does), c [V,25].
+    Under torch.distributed each rank renders its contiguous block of views (sharding.shard_range) `batch` frames at a
+    time and the frames are exchanged chunk by chunk (sharding.ChunkedFrameGather): the all-gather of chunk k runs on the
+    backend's stream under the rendering of chunk k+1 (overlap=False: one all-gather at the end).  gather=False returns
+    this rank's block only."""
     V = c.shape[0]
     if ws.shape[0] == 1 and V > 1:
         ws = ws.expand(V, -1, -1)
+    dev = c.device
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
+
+    def frames_of(i, j):
+        if j <= i:
+            shape = (0, G.img_resolution, G.img_resolution, 3) if uint8 else (0, 3, G.img_resolution, G.img_resolution)
+            return torch.zeros(shape, dtype=torch.uint8 if uint8 else torch.float32, device=dev)
+        img = G.synthesis(ws[i:j].contiguous(), c[i:j].contiguous(), **synthesis_kwargs)[image_mode]
+        return to_uint8(img) if uint8 else img
+    if gather and world > 1 and overlap:
+        res = G.img_resolution if image_mode == "image" else G.neural_rendering_resolution
+        shape = (res, res, 3) if uint8 else (3, res, res)
+        gat = sharding.ChunkedFrameGather(V, batch, shape, torch.uint8 if uint8 else torch.float32, dev)
+        for k in range(gat.rounds()):
+            gat.submit(k, frames_of(*gat.local_slice(k)))
+        return gat.finish()
     a, b = sharding.shard_range(V, rank, world)
-    frames = []
-    for i in range(a, b, batch):
-        j = min(b, i + batch)
-        frames.append(G.synthesis(ws[i:j].contiguous(), c[i:j].contiguous(), **synthesis_kwargs)["image"])
-    local = torch.cat(frames, 0) if frames else c.new_zeros((0, 3, G.img_resolution, G.img_resolution))
+    frames = [frames_of(i, min(b, i + batch)) for i in range(a, b, batch)]
+    local = torch.cat(frames, 0) if frames else frames_of(0, 0)
     return sharding.all_gather_frames(local, V) if (gather and world > 1) else local
 
 

@@ -9,6 +9,12 @@
 // (:288-300).  See DESIGN.md §4 for the lane mapping and the MFMA operand layouts.
 #include "nfe_common.h"
 
+#ifdef NFE_SQUARE_RUNTIME
+#define NFE_SQUARE_RT 1
+#else
+#define NFE_SQUARE_RT 0
+#endif
+
 namespace nfe {
 
 // ------------------------------------------------------------------------------------------
@@ -304,6 +310,10 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     Taps tp[3];
     unsigned offs[3][4];
     Axis ax_xw, ax_zh;
+#ifdef NFE_SQUARE_RUNTIME      // experiment only (tools/repro_square_branch.sh): the run-time form of the SQUARE variant, DESIGN.md section 10
+    const bool SQ_RT = (H == W);
+#define SQUARE SQ_RT
+#endif
     if (SQUARE) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) } else { NFE_PIPE_GEOM(0, gx, gy) }
     const int ll = launder(lane);
     const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
@@ -332,6 +342,9 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(1)
     plane_affine_acc<SIGMA_ONLY, 2>(aff, qoff, tp[2], sg, qn, qd);
+#ifdef NFE_SQUARE_RUNTIME
+#undef SQUARE
+#endif
 }
 
 // Exchange tile: row = point (0..31), 8 granules of 4 channels per row, granule g of row r stored at position
@@ -1283,7 +1296,7 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
     } else {
         if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
-        else if (P.H == P.W && !DUAL)      // shared axis geometry: measured faster with one plane set (-2.5 %), not with two (+0.8 %)
+        else if (P.H == P.W && !DUAL && !NFE_SQUARE_RT)      // shared axis geometry: measured faster with one plane set (-2.5 %), not with two (+0.8 %)
             hipLaunchKernelGGL((render_kernel<false, SIGMA_ONLY, NFE_MATH_BF16X3, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
     }
@@ -1323,7 +1336,7 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
         if (sblocks > cap) sblocks = cap;
         dim3 sgrid((unsigned)sblocks);
 #define NFE_LAUNCH_SPLIT(DU, SG)                                                                                                   \
-        if (P.H == P.W && !(DU)) hipLaunchKernelGGL((render_kernel<false, SG, NFE_MATH_BF16X3, false, false, true, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q); \
+        if (P.H == P.W && !(DU) && !NFE_SQUARE_RT) hipLaunchKernelGGL((render_kernel<false, SG, NFE_MATH_BF16X3, false, false, true, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q); \
         else hipLaunchKernelGGL((render_kernel<DU, SG, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
         if (sigma_only) {
             if (dual) { NFE_LAUNCH_SPLIT(true, true) } else { NFE_LAUNCH_SPLIT(false, true) }

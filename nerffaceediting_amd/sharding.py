@@ -51,3 +51,75 @@ def all_gather_frames_async(local_frames, n_views, group=None):
     out = block.new_empty((world * per,) + tuple(block.shape[1:]))
     work = dist.all_gather_into_tensor(out, block.contiguous(), group=group, async_op=True)
     return work, out[:n_views]
+
+
+class ChunkedFrameGather:
+    """The exchange of a sharded job done chunk by chunk, overlapped with rendering ("one all_gather per
+    chunk, overlapped with rendering").  Every rank owns the contiguous block shard_range(n_views, rank, world) and renders
+    it `chunk` frames at a time; after round k it calls submit(k, frames_of_round_k) and goes on rendering round k+1 while
+    the collective of round k runs on the backend's stream (RCCL over xGMI under 'nccl').  At most `max_in_flight`
+    collectives are outstanding; a retired round is copied from its staging buffer [world, chunk, ...] to its final rows
+    of the result [n_views, ...] (rank r's round k lands at start_r + k*chunk).  Ragged blocks (short or empty last
+    rounds, empty ranks) are padded inside the staging buffer only.  finish() drains and returns the result.
+
+    All ranks must call submit() for the same rounds in the same order: rounds() gives that count (from the longest
+    block), and a rank whose block is exhausted submits an empty tensor.
+    """
+
+    def __init__(self, n_views, chunk, frame_shape, dtype, device, group=None, max_in_flight=2):
+        self.n_views, self.chunk, self.group = int(n_views), int(chunk), group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.rank = dist.get_rank(group) if self.active else 0
+        self.frame_shape, self.dtype, self.device = tuple(frame_shape), dtype, device
+        self.spans = [shard_range(self.n_views, r, self.world) for r in range(self.world)]
+        self.out = torch.empty((self.n_views,) + self.frame_shape, dtype=dtype, device=device)
+        self.max_in_flight = max(1, int(max_in_flight))
+        self.pending = []                      # (work, round, staging)
+        self.free = []                         # staging buffers to reuse
+
+    def rounds(self):
+        longest = max(b - a for a, b in self.spans)
+        return -(-longest // self.chunk)
+
+    def local_slice(self, k):
+        """[start, stop) of the frames this rank renders in round k (may be empty)."""
+        a, b = self.spans[self.rank]
+        s = min(a + k * self.chunk, b)
+        return s, min(s + self.chunk, b)
+
+    def _retire(self, entry):
+        work, k, staging = entry
+        if work is not None:
+            work.wait()
+        for r, (a, b) in enumerate(self.spans):
+            s = min(a + k * self.chunk, b)
+            e = min(s + self.chunk, b)
+            if e > s:
+                self.out[s:e].copy_(staging[r, :e - s])
+        self.free.append(staging)
+
+    def submit(self, k, frames):
+        s, e = self.local_slice(k)
+        assert frames.shape[0] == e - s and tuple(frames.shape[1:]) == self.frame_shape and frames.dtype == self.dtype, \
+            (tuple(frames.shape), (e - s,) + self.frame_shape)
+        if not self.active:
+            if e > s:
+                self.out[s:e].copy_(frames)
+            return
+        while len(self.pending) >= self.max_in_flight:
+            self._retire(self.pending.pop(0))
+        staging = self.free.pop() if self.free else torch.empty((self.world, self.chunk) + self.frame_shape, dtype=self.dtype, device=self.device)
+        block = frames
+        if e - s < self.chunk:                 # ragged tail / exhausted block: pad to the common chunk size
+            block = frames.new_zeros((self.chunk,) + self.frame_shape)
+            if e > s:
+                block[:e - s].copy_(frames)
+        work = dist.all_gather_into_tensor(staging.view((self.world * self.chunk,) + self.frame_shape), block.contiguous(),
+                                           group=self.group, async_op=True)
+        self.pending.append((work, k, staging))
+
+    def finish(self):
+        while self.pending:
+            self._retire(self.pending.pop(0))
+        return self.out

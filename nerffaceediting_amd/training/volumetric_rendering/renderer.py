@@ -69,6 +69,7 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         self.last_taps = None
         self.decoder_math = None          # None -> split-bf16 MFMA; 'fp32' -> exact fp32 MFMA
         self.seed_tensor = None
+        self._pack_cache = []
 
     # -- parity hook ---------------------------------------------------------------------------------
     def inject_jitter(self, u_coarse, u_fine=None):
@@ -88,12 +89,24 @@ class DisentangledImportanceRenderer(torch.nn.Module):
             return self.seed_tensor
         return int(torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).item())
 
-    @staticmethod
-    def _pack_pair(norm_planes, denorm_planes):
-        pg = ops.plane_pack(norm_planes)
+    def _packed(self, planes):
+        """Gather-layout copy of an NCHW plane tensor, cached on the tensor's identity (storage pointer, in-place version
+        counter, shape): an orbit over fixed planes (utils.py:78-80 calls the renderer once per frame with the same two
+        tensors) re-packs nothing; an optimiser step bumps `_version` and invalidates the entry.  Two entries: norm + denorm.
+        Each entry keeps its source tensor alive, so the allocator cannot hand the same address to different data."""
+        key = (planes.data_ptr(), planes._version, tuple(planes.shape), tuple(planes.stride()), planes.device)
+        for k, _, v in self._pack_cache:
+            if k == key:
+                return v
+        v = ops.plane_pack(planes)
+        self._pack_cache = [(key, planes, v)] + self._pack_cache[:1]
+        return v
+
+    def _pack_pair(self, norm_planes, denorm_planes):
+        pg = self._packed(norm_planes)
         same = (norm_planes is denorm_planes) or (norm_planes.data_ptr() == denorm_planes.data_ptr()
                                                  and norm_planes.shape == denorm_planes.shape)
-        return pg, (pg if same else ops.plane_pack(denorm_planes))
+        return pg, (pg if same else self._packed(denorm_planes))
 
     # -- reference interface -------------------------------------------------------------------------
     def forward(self, norm_planes, denorm_planes, decoder, ray_origins, ray_directions, rendering_options):
