@@ -302,6 +302,13 @@ __device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ 
     plane_affine_acc<false, 2, true>(aff, qoff, tp[2], sg, qn, qd, sa);
 }
 
+// experiment helper (NFE_SQUARE_RUNTIME == 6): `H == W` as an integer in an SGPR, opaque to the optimiser
+__device__ __forceinline__ int sq_flag_scc(int H, int W) {
+    int f;
+    asm volatile("s_cmp_eq_u32 %1, %2\n\ts_cselect_b32 %0, 1, 0" : "=s"(f) : "s"(H), "s"(W) : "scc");
+    return f;
+}
+
 template <bool SIGMA_ONLY, bool SQUARE>
 __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, int H, int W, long long plane_elems,
                                                  const float* __restrict__ aff, int lane, float gx, float gy, float gz,
@@ -310,11 +317,28 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     Taps tp[3];
     unsigned offs[3][4];
     Axis ax_xw, ax_zh;
-#ifdef NFE_SQUARE_RUNTIME      // experiment only (tools/repro_square_branch.sh): the run-time form of the SQUARE variant, DESIGN.md section 10
+    // Experiment switch (profiles/experiments/r02_square_branch.md; never defined in the shipped build): decide SQUARE at run time.
+    //   1: `H == W` as the compiler lowers it (lane mask in an SGPR pair, s_and_b64 vcc, exec, mask + s_cbranch_vccz): branch
+    //      direction is unreliable when two waves share a SIMD -> run-dependent wrong pixels;
+    //   6: the condition re-made by s_cmp at every site (s_cbranch_scc): stable;   10: as 1, but both arms compute the square
+    //      geometry: stable, i.e. the failure of 1 is the branch going the wrong way, not corrupted data.
+#ifdef NFE_SQUARE_RUNTIME
     const bool SQ_RT = (H == W);
-#define SQUARE SQ_RT
+#if NFE_SQUARE_RUNTIME == 6
+#define SQUARE_AT(i) (sq_flag_scc(H, W) != 0)
+#else
+#define SQUARE_AT(i) SQ_RT
 #endif
-    if (SQUARE) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) } else { NFE_PIPE_GEOM(0, gx, gy) }
+#else
+#define SQUARE_AT(i) SQUARE
+#endif
+#if defined(NFE_SQUARE_RUNTIME) && NFE_SQUARE_RUNTIME == 10
+#define NFE_ELSE_GEOM(PL, U, V, AU, AV) asm volatile("; else arm " #PL); NFE_PIPE_GEOM_AX(PL, AU, AV)
+#else
+#define NFE_ELSE_GEOM(PL, U, V, AU, AV) NFE_PIPE_GEOM(PL, U, V)
+#endif
+    if (SQUARE_AT(0)) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) }
+    else { ax_xw = axis_geometry(W, gx); NFE_ELSE_GEOM(0, gx, gy, ax_xw, axis_geometry(H, gy)) }
     const int ll = launder(lane);
     const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
     const unsigned qoff_bytes = (unsigned)qoff * 4u;
@@ -325,13 +349,14 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
     NFE_PIPE_ISSUE(0, 0, 0) NFE_PIPE_ISSUE(1, 0, 2)
     // the next plane's tap geometry runs under the loads in flight
-    if (SQUARE) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) } else { NFE_PIPE_GEOM(1, gx, gz) }
+    if (SQUARE_AT(1)) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) }
+    else { ax_zh = axis_geometry(H, gz); NFE_ELSE_GEOM(1, gx, gz, ax_xw, ax_zh) }
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(0) NFE_PIPE_ISSUE(0, 1, 0)
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(1) NFE_PIPE_ISSUE(1, 1, 2)
     plane_affine_acc<SIGMA_ONLY, 0>(aff, qoff, tp[0], sg, qn, qd);
-    if (SQUARE) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_PIPE_GEOM(2, gz, gx) }
+    if (SQUARE_AT(2)) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_ELSE_GEOM(2, gz, gx, ax_zh, ax_xw) }
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(0) NFE_PIPE_ISSUE(0, 2, 0)
     __builtin_amdgcn_sched_barrier(0);
@@ -342,9 +367,8 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(1)
     plane_affine_acc<SIGMA_ONLY, 2>(aff, qoff, tp[2], sg, qn, qd);
-#ifdef NFE_SQUARE_RUNTIME
-#undef SQUARE
-#endif
+#undef SQUARE_AT
+#undef NFE_ELSE_GEOM
 }
 
 // Exchange tile: row = point (0..31), 8 granules of 4 channels per row, granule g of row r stored at position

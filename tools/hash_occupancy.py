@@ -33,6 +33,8 @@ cases = [(packed, packed, aff, 512, 64, 0, None), (packed, packed, aff, 512, 24,
          (packedr, packedr, affr, 512, 64, 0, None), (packedr, packedr, affr, 256, 24, 24, None),
          (packed, packed2, None, 512, 64, 0, None), (packed, packed2, None, 256, 96, 96, None),
          (packed, packed, aff, 256, 96, 96, None), (packed, packed, aff, 256, 48, 48, "fp32"), (packed, packed2, None, 256, 32, 0, "fp32")]
+if os.environ.get("HASH_SQUARE_ONLY"):          # experimental builds that hard-wire the square path must not see other planes
+    cases = [c for c in cases if c[0] is packed and c[1] is packed and c[6] is None]
 for pg, pa, af, R, D, Di, math in cases:
     opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
     hs = set()
