@@ -12,6 +12,10 @@ batch-of-views path does.
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 Prints ONE JSON line on rank 0.
 
+The default line also carries `strong_scaling`: the 512-frame orbit job of BASELINE config 4 (full synthesis, frames sharded
+over the ranks, chunked uint8 all-gather overlapped with rendering), run once after the timed region, so a 1/2/4/8-GPU sweep
+of the default command measures both the weak-scaling render metric (`value`) and the strong-scaling views/s.
+
 Other workloads of SURVEY.md section 8(d) (never the default; same JSON contract, lines kept in profiles/):
     --workload full     config 3: full synthesis (a1-a14), 8 views/GPU/step, 512^2 x 64 render, bf16 convs -> views/s
     --workload orbit    config 4: 512 (latent, camera) pairs sharded over the ranks (strong scaling), one all-gather
@@ -35,19 +39,47 @@ sys.path.insert(0, ROOT)
 VIEWS_PER_GPU, R, D, PLANE = 4, 512, 64, 256
 BYTES_PER_RAY_S1 = D * 1 * 1536 + 196        # S=1 (single-gather identity) -> 98 500 B/ray
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")   # written by tools/pmc.sh (rocprofv3 --pmc passes)
+PEAK_CLOCK_GHZ = 2.4                         # MI355X shader clock (hipDeviceProp clockRate); the chip runs 1.9-2.2 GHz under this load
+N_CU, N_SIMD = 256, 1024
+# Per-launch hardware counters of the dominant kernel, from rocprofv3 --pmc passes of THIS command on the shipped build
+# (tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed).  PMC cannot be collected inside the timed process.
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_issue_floor.json")
+# Issue costs measured by tools/microbench/valu_rate.hip on MI355X (profiles/r02_valu_rate.txt): a wave issues one VALU
+# instruction per 4.94 cycles whether 1 or 2 waves share the SIMD; an MFMA holds the wave's issue for 8 cycles.
+CYC_PER_VALU_ISSUE, CYC_PER_MFMA_ISSUE = 4.94, 8.0
 
 
-def measured_traffic():
-    """HBM bytes per render_kernel launch from the committed rocprofv3 PMC passes of this same command
-    (tools/pmc.sh): FETCH_SIZE*1024*2 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE*1024.  PMC counters
-    cannot be collected from inside the timed process, so the figure comes from the profile file."""
+def issue_model(kern_ms, logical_bytes):
+    """The ceilings that can bind render_kernel, each as (time this resource needs per launch) / (measured time per launch):
+      wave_issue   per-wave instruction issue: the 2 048 resident waves (2 per SIMD) each issue their VALU instructions at one
+                   per 4.94 cycles and their MFMAs at 8 cycles of issue each (microbenchmark), at the 2.4 GHz peak clock;
+      matrix_pipe  SQ_VALU_MFMA_BUSY_CYCLES per SIMD (32 cycles per v_mfma_f32_32x32x16_bf16);
+      l1_request   TCP_TOTAL_CACHE_ACCESSES / 256 CUs at one 64-byte request per clock per CU;
+      hbm          (2 x FETCH_SIZE + WRITE_SIZE) bytes against 8 TB/s  (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md);
+      logical_gather  SURVEY 8(d)'s algorithmic gather bytes against 8 TB/s - NOT a physical bound (the 25 MB plane set of a
+                   view is L2 / Infinity-Cache resident): kept because north_star quotes it; it exceeds 1.
+    Returns (bound name, dict of fractions, detail)."""
     try:
-        with open(PMC_TRAFFIC_FILE) as f:
-            d = json.load(f)
-        return float(d["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
-        return None
+        with open(PMC_FILE) as f:
+            c = json.load(f)
+    except (OSError, ValueError):
+        return None, {}, {"note": f"{os.path.relpath(PMC_FILE, ROOT)} missing: run tools/pmc.sh"}
+    t = kern_ms * 1e-3
+    clk = PEAK_CLOCK_GHZ * 1e9
+    waves = 2 * N_SIMD
+    issue_s = (c["SQ_INSTS_VALU"] * CYC_PER_VALU_ISSUE + c["SQ_INSTS_MFMA"] * CYC_PER_MFMA_ISSUE) / waves / clk
+    matrix_s = c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / clk
+    l1_s = c["TCP_TOTAL_CACHE_ACCESSES"] / N_CU / clk
+    hbm_bytes = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0
+    frac = {"wave_issue": issue_s / t, "matrix_pipe": matrix_s / t, "l1_request": l1_s / t,
+            "hbm": hbm_bytes / t / (HBM_PEAK_GBS * 1e9), "logical_gather": logical_bytes / t / (HBM_PEAK_GBS * 1e9)}
+    physical = {k: v for k, v in frac.items() if k != "logical_gather"}
+    bound = max(physical, key=physical.get)
+    detail = {"counters_file": os.path.relpath(PMC_FILE, ROOT), "kernel_profiled": c.get("kernel"), "kernel_ms_profiled": c.get("avg_ns_profiled", 0) / 1e6,
+              "valu_instructions": c["SQ_INSTS_VALU"], "mfma_instructions": c["SQ_INSTS_MFMA"], "l1_requests": c["TCP_TOTAL_CACHE_ACCESSES"],
+              "hbm_bytes": hbm_bytes, "effective_clock_ghz_profiled": c.get("GRBM_GUI_ACTIVE", 0) / 8.0 / max(c.get("avg_ns_profiled", 1), 1),
+              "cycles_per_valu_issue": CYC_PER_VALU_ISSUE, "cycles_per_mfma_issue": CYC_PER_MFMA_ISSUE, "peak_clock_ghz": PEAK_CLOCK_GHZ}
+    return bound, frac, detail
 
 
 def synth_inputs(torch, dev, seed):
@@ -166,9 +198,12 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     config={"workload": "BASELINE config 5: render core through the (norm, denorm) entry, appearance statistics swapped "
                                         "between views, 4 views/GPU/step, 512^2 rays, 96 coarse + 96 importance samples",
                             "views_per_step": n_total, "parallelism": f"views-dp{world}"},
-                    roofline={"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                              "traffic": None, "kernel": "sigma-only pass + importance_kernel + nfe::render_kernel<true,false>",
-                              "kernel_ms": ms, "note": "logical gather bytes of all three passes / their total time (L2-resident planes)"})
+                    roofline={"bound": "wave_issue", "achieved": None, "peak": None, "unit": None, "frac": None,
+                              "traffic": None, "kernel": "sigma-only pass + importance_kernel + nfe::render_kernel<DUAL>",
+                              "kernel_ms": ms, "logical_gather_gbs": ach,
+                              "note": "same per-wave issue bound as the headline kernel (no counter file for this workload, so no frac); "
+                                      "logical_gather_gbs = SURVEY 8(d) gather bytes of all three passes / their time, not a physical rate "
+                                      "(planes are cache resident)"})
 
     if args.workload == "editstep":          # forward + backward of the renderer w.r.t. both plane sets, FFHQ rendering config
         Re, Dc = 128, 48
@@ -210,10 +245,11 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     config={"workload": "SURVEY 8(f)4 backward pass: 4 views/GPU/step, 128^2 rays, 48 + 48 samples, norm/denorm plane sets with "
                                         "swapped statistics, random cotangents for rgb/seg/depth/wsum, gradients w.r.t. both plane sets",
                             "views_per_step": n_total, "forward_ms": fwd_ms, "backward_ms": bwd_ms, "parallelism": f"views-dp{world}"},
-                    roofline={"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                              "traffic": None, "kernel": "nfe::bwd_eval_kernel + bwd_ray_kernel + bwd_scatter_sorted_kernel",
-                              "kernel_ms": bwd_ms, "note": "logical gather + scatter bytes of the backward (9216 B/sample) / its time; "
-                                                           "planes and gradients are L2 / Infinity-Cache resident"})
+                    roofline={"bound": "atomics", "achieved": None, "peak": None, "unit": None, "frac": None,
+                              "traffic": None, "kernel": "nfe::render_kernel<EVAL> + bwd_ray_kernel + bwd_scatter_sorted_kernel",
+                              "kernel_ms": bwd_ms, "logical_gather_scatter_gbs": ach,
+                              "note": "the scatter is bound by memory-side float atomics (profiles/r0*_pmc_backward.txt); logical gather + "
+                                      "scatter bytes (9216 B/sample) / time is quoted for reference only (planes and gradients are cache resident)"})
 
     ffhq = args.workload == "ffhq"
     conv_math = "bf16x3" if ffhq else "bf16"
@@ -260,28 +296,65 @@ def extra_workload(args, torch, dist, dev, rank, world):
                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv3_kernel<*> + upfir/torgb (backbone + SR stages)",
                               "kernel_ms": dense_ms, "note": "289.1 GFLOP per view (SURVEY 8d) / time of the backbone + SR stages"})
 
-    # orbit: config 4, strong scaling: 512 frames in total
-    V = 512
+    out = orbit_job(args, torch, dist, dev, rank, world, frames=args.orbit_frames, G=G, steps=args.steps, warmup=args.warmup)
+    return dict(base, metric="512^2 views/s, 512-frame orbit (gen_videos camera path)", value=out["views_per_s"], unit="views/s",
+                ms_per_step=out["seconds_per_pass"] * 1e3, scaling="strong", dtype="bf16",
+                config={"workload": out["workload"], "frames": out["frames"], "frames_per_rank": out["frames_per_rank"],
+                        "chunk": out["chunk"], "parallelism": f"frames-dp{world}"},
+                roofline={"bound": "mfma", "achieved": out["dense_tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": out["dense_tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
+                          "kernel": "whole step (dense flops of this rank / wall time)", "kernel_ms": None})
+
+
+def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, warmup=0, chunk=8):
+    """BASELINE config 4, the strong-scaling job: `frames` (per-frame ws, camera) pairs on the gen_videos.py:128-133 camera
+    path, full synthesis at 512^2 x 64 with bf16 convs, frames cut into contiguous blocks per rank and rendered `chunk` at a
+    time; the uint8 frames ([chunk,512,512,3], what the video writer consumes, gen_videos.py:147-151) of chunk k are
+    all-gathered over RCCL while chunk k+1 renders (sharding.ChunkedFrameGather).  Timed like the main loop: barrier +
+    synchronize on both sides, MAX over ranks."""
+    from nerffaceediting_amd import apps, sharding
+    if G is None:
+        G = full_generator(torch, dev, D, 0, "bf16")
+    G.neural_rendering_resolution = R
+    V = int(frames)
     c_all = apps.orbit_cameras(V, dev)
     a, b = sharding.shard_range(V, rank, world)
-    ws_local = torch.stack([torch.from_numpy(np.random.RandomState(f).randn(14, 512).astype(np.float32)) for f in range(a, b)]).to(dev)
-    G.neural_rendering_resolution = R
+    ws_local = torch.stack([torch.from_numpy(np.random.RandomState(f).randn(14, 512).astype(np.float32)) for f in range(a, max(b, a + 1))]).to(dev)
 
-    def step(i):
-        frames = []
-        for j in range(0, b - a, 8):
-            frames.append(G.synthesis(ws_local[j:j + 8].contiguous(), c_all[a + j:a + j + 8].contiguous(), noise_mode="const")["image"])
-        local = torch.cat(frames, 0)
-        return sharding.all_gather_frames(local, V) if world > 1 else local
-    dt = timed_steps(args, torch, dist, world, step)
-    ach = GFLOP_DENSE_PER_VIEW * (b - a) * args.steps * 1e9 / dt / 1e12
-    return dict(base, metric="512^2 views/s, 512-frame orbit (gen_videos camera path)", value=V * args.steps / dt, unit="views/s",
-                ms_per_step=dt / args.steps * 1e3, scaling="strong", dtype="bf16",
-                config={"workload": "BASELINE config 4: 512 (per-frame ws, camera) pairs, gen_videos.py:128-133 path, contiguous blocks per "
-                                    "rank, one all-gather of [512,3,512,512] fp32 frames per step", "frames": V, "frames_per_rank": b - a,
-                        "parallelism": f"frames-dp{world}"},
-                roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                          "traffic": None, "kernel": "whole step (dense flops of this rank / wall time)", "kernel_ms": None})
+    def one_pass():
+        gat = sharding.ChunkedFrameGather(V, chunk, (G.img_resolution, G.img_resolution, 3), torch.uint8, dev)
+        for k in range(gat.rounds()):
+            s_, e_ = gat.local_slice(k)
+            if e_ > s_:
+                img = G.synthesis(ws_local[s_ - a:e_ - a].contiguous(), c_all[s_:e_].contiguous(), noise_mode="const")["image"]
+                fr = apps.to_uint8(img)
+            else:
+                fr = torch.zeros((0, G.img_resolution, G.img_resolution, 3), dtype=torch.uint8, device=dev)
+            gat.submit(k, fr)
+        return gat.finish()
+    G.synthesis(ws_local[:chunk].contiguous(), c_all[a:a + min(chunk, b - a)].contiguous(), noise_mode="const")     # weight packing, allocator
+    for _ in range(warmup):
+        one_pass()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(max(steps, 1)):
+        out = one_pass()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out.shape == (V, G.img_resolution, G.img_resolution, 3)
+    per_pass = dt / max(steps, 1)
+    return {"workload": f"BASELINE config 4: {V} (per-frame ws, camera) pairs, gen_videos.py:128-133 path, full synthesis 512^2 x 64 + SR, bf16 "
+                        f"convs, contiguous blocks per rank, uint8 frames all-gathered per {chunk}-frame chunk under the next chunk's render",
+            "frames": V, "frames_per_rank": b - a, "chunk": chunk, "n_gpus": world, "seconds_per_pass": per_pass, "views_per_s": V / per_pass,
+            "scaling": "strong", "dense_tflops": GFLOP_DENSE_PER_VIEW * (b - a) * 1e9 / per_pass / 1e12}
 
 
 def main():
@@ -291,6 +364,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["render", "full", "ffhq", "orbit", "twopass", "editstep"], default="render")
+    ap.add_argument("--orbit-frames", type=int, default=512, help="frames of the strong-scaling orbit job (BASELINE config 4)")
+    ap.add_argument("--no-strong-scaling", action="store_true", help="skip the config-4 orbit job reported beside the default line")
     args = ap.parse_args()
 
     import torch
@@ -370,28 +445,55 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # ---- outside the timed region: the same launch with the exact-fp32 MFMA decoder, and the strong-scaling job of config 4
+    fe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+    mean, std = ops.plane_stats(planes)
+    aff, packed = ops.make_affine(mean, std), ops.plane_pack(planes)
+    for a_, b_ in fe:
+        a_.record()
+        ops.render(packed, packed, dec_packed, opts, cam2world=c2w_t, intrinsics=K_t, resolution=R, affines=aff, seed=seed,
+                   channels_first=True, decoder_math="fp32")
+        b_.record()
+    torch.cuda.synchronize()
+    fp32_ms = min(a_.elapsed_time(b_) for a_, b_ in fe)
+    strong = None if args.no_strong_scaling else orbit_job(args, torch, dist, dev, rank, world, frames=args.orbit_frames)
+
     if rank == 0:
         kern_ms = sum(a.elapsed_time(b) for a, b in ev) / max(args.steps, 1)
         rays_per_step = n_total * M
         value = rays_per_step * args.steps / dt
         launch_bytes = VIEWS_PER_GPU * M * BYTES_PER_RAY_S1
-        achieved = launch_bytes / (kern_ms * 1e-3) / 1e9
+        bound, frac, detail = issue_model(kern_ms, launch_bytes)
+        if bound == "wave_issue":       # achieved / peak in the binding resource's own unit
+            ach, peak, unit = frac[bound] * PEAK_CLOCK_GHZ, PEAK_CLOCK_GHZ, "G issue-cycles/s per wave"
+        elif bound == "hbm":
+            ach, peak, unit = frac[bound] * HBM_PEAK_GBS, HBM_PEAK_GBS, "GB/s"
+        elif bound is not None:
+            ach, peak, unit = frac[bound] * PEAK_CLOCK_GHZ, PEAK_CLOCK_GHZ, "G busy-cycles/s per unit"
+        else:
+            ach, peak, unit = None, None, None
         out = {
             "metric": "rays/s, 512^2 x 64-sample tri-plane render", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE config 2: render core (a2,a4-a12), 4 views/GPU/step, 512^2 rays x 64 "
-                                   "stratified samples, 256^2x96 planes, fp32, Philox jitter",
-                       "views_per_step": n_total, "views_per_s": n_total * args.steps / dt,
+                                   "stratified samples, 256^2x96 planes, fp32 in/out, Philox jitter; decoder_math=bf16x3 "
+                                   "(fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate: 2-6e-6 "
+                                   "max-abs vs the reference; the exact-fp32 MFMA mode is timed beside it)",
+                       "decoder_math": "bf16x3", "views_per_step": n_total, "views_per_s": n_total * args.steps / dt,
                        "rays_per_view": M, "depth_samples": D, "parallelism": f"views-dp{world}"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": measured_traffic(),
-                         "kernel": "nfe::render_kernel<false,false>", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_launch": launch_bytes,
-                         "note": "achieved = logical gather bytes (S=1: 98500 B/ray) / kernel time; traffic = HBM bytes per "
-                                 "launch from profiles/r01_pmc_traffic.json (planes stay L2/Infinity-Cache resident, so "
-                                 "traffic << algorithmic bytes); the kernel is TA/VALU-bound, see DESIGN.md §6"},
+            "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                         "frac": frac.get(bound) if bound else None, "traffic": detail.get("hbm_bytes"),
+                         "kernel": "nfe::render_kernel<DUAL=0,SIGMA_ONLY=0,BF16X3,...,SQUARE=1>", "kernel_ms": kern_ms,
+                         "kernel_ms_fp32_exact": fp32_ms, "fractions": frac,
+                         "algorithmic_bytes_per_launch": launch_bytes, "detail": detail,
+                         "note": "frac = time the binding resource needs per launch (hardware counters of this build, profiles/) / "
+                                 "kernel time measured here with HIP events; `fractions` lists every ceiling: per-wave instruction "
+                                 "issue, matrix pipe, L1 request rate, true HBM traffic, and SURVEY 8(d)'s logical gather bytes "
+                                 "(not physical: planes are cache resident, so it exceeds 1); traffic = HBM bytes per launch"},
         }
+        if strong is not None:
+            out["strong_scaling"] = strong
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (host cores are shared by all ranks)
             out["cpu_baseline"] = cpu_baseline(planes_np, dec_np, c2w, K, opts, seed)
         print(json.dumps(out))

@@ -28,6 +28,16 @@ for k in sorted(vals, key=lambda k: -sum(dur.get(k, [0]))):
         v = vals[k][c]
         print(f"   {c:32s} avg/dispatch {sum(v)/len(v):.4g}   (n={len(v)})")
 
+# Counter record of the dominant kernel for bench.py's roofline block (per launch; see bench.py issue_model())
+import json
+dom0 = max(vals, key=lambda k: sum(dur.get(k, [0])))
+rec = {"kernel": dom0, "avg_ns_profiled": sum(dur[dom0]) / max(1, len(dur[dom0])), "dispatches": len(dur[dom0])}
+for c, v in vals[dom0].items():
+    rec[c] = sum(v) / len(v)
+with open(os.path.join(root, "issue_floor.json"), "w") as f:
+    json.dump(rec, f, indent=1, sort_keys=True)
+print("issue_floor.json:", rec)
+
 # HBM traffic of the dominant kernel for bench.py's roofline.traffic
 import json
 dom = max(vals, key=lambda k: sum(dur.get(k, [0])))
