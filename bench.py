@@ -39,22 +39,26 @@ sys.path.insert(0, ROOT)
 VIEWS_PER_GPU, R, D, PLANE = 4, 512, 64, 256
 BYTES_PER_RAY_S1 = D * 1 * 1536 + 196        # S=1 (single-gather identity) -> 98 500 B/ray
 HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
-PEAK_CLOCK_GHZ = 2.4                         # MI355X shader clock (hipDeviceProp clockRate); the chip runs 1.9-2.2 GHz under this load
+PEAK_CLOCK_GHZ = 2.4                         # MI355X shader clock (hipDeviceProp clockRate); the chip holds 1.9-2.2 GHz under this load
 N_CU, N_SIMD = 256, 1024
 # Per-launch hardware counters of the dominant kernel, from rocprofv3 --pmc passes of THIS command on the shipped build
-# (tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed).  PMC cannot be collected inside the timed process.
+# (tools/r02_profile.sh: tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed).  PMC cannot be collected
+# inside the timed process.
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_issue_floor.json")
-# Issue costs measured by tools/microbench/valu_rate.hip on MI355X (profiles/r02_valu_rate.txt): a wave issues one VALU
-# instruction per 4.94 cycles whether 1 or 2 waves share the SIMD; an MFMA holds the wave's issue for 8 cycles.
-CYC_PER_VALU_ISSUE, CYC_PER_MFMA_ISSUE = 4.94, 8.0
 
 
-def issue_model(kern_ms, logical_bytes):
-    """The ceilings that can bind render_kernel, each as (time this resource needs per launch) / (measured time per launch):
-      wave_issue   per-wave instruction issue: the 2 048 resident waves (2 per SIMD) each issue their VALU instructions at one
-                   per 4.94 cycles and their MFMAs at 8 cycles of issue each (microbenchmark), at the 2.4 GHz peak clock;
+def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD):
+    """The ceilings that can bind render_kernel, each as (cycles this resource is busy per launch) / (kernel cycles), with the
+    kernel cycles = the kernel time measured HERE x the effective shader clock of the profiled run (GRBM_GUI_ACTIVE / 8 XCDs /
+    profiled kernel time; SQ_* counters are quad-cycles, MI355X_MICROARCH.md):
+      wave_issue   share of a wave's life spent issuing instructions: SQ_ACTIVE_INST_ANY x 4 / resident waves (the grid is
+                   persistent: 2 workgroups x 4 waves per CU live for the whole launch).  The rest is issue stalls on
+                   dependencies / busy pipes (SQ_WAIT_INST_ANY) and s_waitcnt (SQ_WAIT_ANY), which two waves per SIMD - all
+                   that 256 VGPRs allow - cannot hide.  tools/microbench/valu_rate.hip (profiles/r02_valu_rate.txt): a wave
+                   issues at most one VALU instruction per 4.9 cycles, alone or beside a second wave;
       matrix_pipe  SQ_VALU_MFMA_BUSY_CYCLES per SIMD (32 cycles per v_mfma_f32_32x32x16_bf16);
       l1_request   TCP_TOTAL_CACHE_ACCESSES / 256 CUs at one 64-byte request per clock per CU;
+      ta_busy      TA_TA_BUSY per CU (texture-addresser busy cycles);
       hbm          (2 x FETCH_SIZE + WRITE_SIZE) bytes against 8 TB/s  (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md);
       logical_gather  SURVEY 8(d)'s algorithmic gather bytes against 8 TB/s - NOT a physical bound (the 25 MB plane set of a
                    view is L2 / Infinity-Cache resident): kept because north_star quotes it; it exceeds 1.
@@ -63,22 +67,24 @@ def issue_model(kern_ms, logical_bytes):
         with open(PMC_FILE) as f:
             c = json.load(f)
     except (OSError, ValueError):
-        return None, {}, {"note": f"{os.path.relpath(PMC_FILE, ROOT)} missing: run tools/pmc.sh"}
+        return None, {}, {"note": f"{os.path.relpath(PMC_FILE, ROOT)} missing: run tools/r02_profile.sh"}
     t = kern_ms * 1e-3
-    clk = PEAK_CLOCK_GHZ * 1e9
-    waves = 2 * N_SIMD
-    issue_s = (c["SQ_INSTS_VALU"] * CYC_PER_VALU_ISSUE + c["SQ_INSTS_MFMA"] * CYC_PER_MFMA_ISSUE) / waves / clk
-    matrix_s = c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / clk
-    l1_s = c["TCP_TOTAL_CACHE_ACCESSES"] / N_CU / clk
+    clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["avg_ns_profiled"] * 1e-9)          # effective shader clock of the profiled launches, Hz
+    cycles = t * clk
     hbm_bytes = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0
-    frac = {"wave_issue": issue_s / t, "matrix_pipe": matrix_s / t, "l1_request": l1_s / t,
+    frac = {"wave_issue": c["SQ_ACTIVE_INST_ANY"] * 4.0 / resident_waves / cycles,
+            "matrix_pipe": c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / cycles,
+            "l1_request": c["TCP_TOTAL_CACHE_ACCESSES"] / N_CU / cycles,
+            "ta_busy": c["TA_TA_BUSY"] / N_CU / cycles,
             "hbm": hbm_bytes / t / (HBM_PEAK_GBS * 1e9), "logical_gather": logical_bytes / t / (HBM_PEAK_GBS * 1e9)}
     physical = {k: v for k, v in frac.items() if k != "logical_gather"}
     bound = max(physical, key=physical.get)
-    detail = {"counters_file": os.path.relpath(PMC_FILE, ROOT), "kernel_profiled": c.get("kernel"), "kernel_ms_profiled": c.get("avg_ns_profiled", 0) / 1e6,
-              "valu_instructions": c["SQ_INSTS_VALU"], "mfma_instructions": c["SQ_INSTS_MFMA"], "l1_requests": c["TCP_TOTAL_CACHE_ACCESSES"],
-              "hbm_bytes": hbm_bytes, "effective_clock_ghz_profiled": c.get("GRBM_GUI_ACTIVE", 0) / 8.0 / max(c.get("avg_ns_profiled", 1), 1),
-              "cycles_per_valu_issue": CYC_PER_VALU_ISSUE, "cycles_per_mfma_issue": CYC_PER_MFMA_ISSUE, "peak_clock_ghz": PEAK_CLOCK_GHZ}
+    detail = {"counters_file": os.path.relpath(PMC_FILE, ROOT), "kernel_profiled": c.get("kernel"), "kernel_ms_profiled": c["avg_ns_profiled"] / 1e6,
+              "effective_clock_ghz": clk / 1e9, "valu_instructions": c["SQ_INSTS_VALU"], "mfma_instructions": c["SQ_INSTS_MFMA"],
+              "l1_requests": c["TCP_TOTAL_CACHE_ACCESSES"], "hbm_bytes": hbm_bytes,
+              "wave_life_split": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                                  "waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
+              "l2_hit_rate": c["TCC_HIT"] / max(c["TCC_HIT"] + c["TCC_MISS"], 1.0)}
     return bound, frac, detail
 
 
@@ -464,12 +470,10 @@ def main():
         value = rays_per_step * args.steps / dt
         launch_bytes = VIEWS_PER_GPU * M * BYTES_PER_RAY_S1
         bound, frac, detail = issue_model(kern_ms, launch_bytes)
-        if bound == "wave_issue":       # achieved / peak in the binding resource's own unit
-            ach, peak, unit = frac[bound] * PEAK_CLOCK_GHZ, PEAK_CLOCK_GHZ, "G issue-cycles/s per wave"
-        elif bound == "hbm":
+        if bound == "hbm":              # achieved / peak in the binding resource's own unit
             ach, peak, unit = frac[bound] * HBM_PEAK_GBS, HBM_PEAK_GBS, "GB/s"
-        elif bound is not None:
-            ach, peak, unit = frac[bound] * PEAK_CLOCK_GHZ, PEAK_CLOCK_GHZ, "G busy-cycles/s per unit"
+        elif bound is not None:         # busy cycles per second of the binding unit (wave issue port, matrix pipe, L1, TA)
+            ach, peak, unit = frac[bound] * detail["effective_clock_ghz"], detail["effective_clock_ghz"], "G busy-cycles/s per unit"
         else:
             ach, peak, unit = None, None, None
         out = {
@@ -487,10 +491,12 @@ def main():
                          "kernel": "nfe::render_kernel<DUAL=0,SIGMA_ONLY=0,BF16X3,...,SQUARE=1>", "kernel_ms": kern_ms,
                          "kernel_ms_fp32_exact": fp32_ms, "fractions": frac,
                          "algorithmic_bytes_per_launch": launch_bytes, "detail": detail,
-                         "note": "frac = time the binding resource needs per launch (hardware counters of this build, profiles/) / "
-                                 "kernel time measured here with HIP events; `fractions` lists every ceiling: per-wave instruction "
-                                 "issue, matrix pipe, L1 request rate, true HBM traffic, and SURVEY 8(d)'s logical gather bytes "
-                                 "(not physical: planes are cache resident, so it exceeds 1); traffic = HBM bytes per launch"},
+                         "note": "frac = busy cycles of the binding resource per launch (hardware counters of this build, profiles/) / "
+                                 "kernel cycles (kernel time measured here with HIP events x effective clock); `fractions` lists every "
+                                 "ceiling: per-wave instruction issue, matrix pipe, L1 request rate, TA, true HBM traffic, and SURVEY "
+                                 "8(d)'s logical gather bytes (not physical: planes are cache resident, so it exceeds 1); no unit is "
+                                 "saturated: the kernel is latency-bound at the 2 waves per SIMD its 256 VGPRs allow (DESIGN.md 6); "
+                                 "traffic = HBM bytes per launch"},
         }
         if strong is not None:
             out["strong_scaling"] = strong

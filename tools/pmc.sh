@@ -3,7 +3,7 @@
 # beyond --kernel-trace).  Usage: tools/pmc.sh <outdir-under-gpurun_out> [bench args...]
 set -u
 OUT=gpurun_out/${1:-pmc}; shift || true
-ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline}
+ARGS=${@:---steps 3 --warmup 1 --no-cpu-baseline --no-strong-scaling}
 PROG=${PMC_PROG:-bench.py}          # PMC_PROG=tools/time_full.py tools/pmc.sh out 4 128 48 48 bf16x3
 export TMPDIR=/tmp
 mkdir -p $OUT

@@ -30,7 +30,9 @@ for k in sorted(vals, key=lambda k: -sum(dur.get(k, [0]))):
 
 # Counter record of the dominant kernel for bench.py's roofline block (per launch; see bench.py issue_model())
 import json
-dom0 = max(vals, key=lambda k: sum(dur.get(k, [0])))
+pat = os.environ.get("PMC_KERNEL")             # substring of the kernel name to report (default: the kernel with most GPU time)
+cands = [k for k in vals if (pat in k)] if pat else list(vals)
+dom0 = max(cands or list(vals), key=lambda k: sum(dur.get(k, [0])))
 rec = {"kernel": dom0, "avg_ns_profiled": sum(dur[dom0]) / max(1, len(dur[dom0])), "dispatches": len(dur[dom0])}
 for c, v in vals[dom0].items():
     rec[c] = sum(v) / len(v)
@@ -40,7 +42,7 @@ print("issue_floor.json:", rec)
 
 # HBM traffic of the dominant kernel for bench.py's roofline.traffic
 import json
-dom = max(vals, key=lambda k: sum(dur.get(k, [0])))
+dom = dom0
 v = vals[dom]
 if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
     fetch = sum(v["FETCH_SIZE"]) / len(v["FETCH_SIZE"]) * 1024.0
