@@ -450,6 +450,8 @@ struct Conv3K {
     long long noise_n_stride; float noise_strength; const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp;
     float* out; float* scratch;
     int c3_tiles;       // real tile count (grid.x is padded to a multiple of 8 for the XCD-aware order)
+    int ksplit;         // > 1: blockIdx.z = n * ksplit + ks; this workgroup sums K-groups [ks*G/ksplit, (ks+1)*G/ksplit) and writes
+    float* partial;     //      raw partial sums [ksplit][N,H,W,Cout] that splitk_reduce_kernel adds in slice order (+ epilogue)
 };
 
 __host__ __device__ constexpr bool c3_xcd_order(int terms) { return terms == 3; }
@@ -480,7 +482,7 @@ constexpr int conv3_stage_bytes() { return (MBW * 9 + C3Tile<ROWS>::B_CHUNKS) * 
 // 32 x 16 pixels on four waves, ONE wave per SIMD with 256 accumulator registers - half the LDS reads and half the
 // L1->LDS bytes per MFMA of the small tiles.
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
-__global__ __launch_bounds__(64 * WV, (NBW * MBW > 8 ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
+__global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && WV == 8)) ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
     constexpr int NACC = UP2 ? 4 : 1;
     constexpr int A_CHUNKS = MBW * 9 * PARTS;
@@ -508,8 +510,11 @@ __global__ __launch_bounds__(64 * WV, (NBW * MBW > 8 ? 1 : ((STAGES * conv3_stag
         if (tile_ >= P.c3_tiles) return;              // grid.x is padded to a multiple of 8
     }
     const int ty0 = (tile_ / tiles_x) * C3_TH, tx0 = (tile_ % tiles_x) * C3_TW;
-    const int mb0 = mbg_ * MBW, n = blockIdx.z;
-    const int G = P.Cin >> 4;
+    const int KS = (!UP2 && P.ksplit > 1) ? P.ksplit : 1;
+    const int mb0 = mbg_ * MBW, n = blockIdx.z / KS, ks = blockIdx.z % KS;
+    const int G_all = P.Cin >> 4;
+    const int g_per = (G_all + KS - 1) / KS, g_base = ks * g_per;
+    const int G = min(G_all, g_base + g_per) - g_base;        // K-groups of this workgroup: g_base + [0, G)
 
     // this wave's share of the patch chunks: chunk c = wave + WV k; per-lane element offset of the pixel (or -1 = padding)
     long long boff[B_PER_WAVE];
@@ -540,7 +545,7 @@ __global__ __launch_bounds__(64 * WV, (NBW * MBW > 8 ? 1 : ((STAGES * conv3_stag
         // weights: chunk (m, t, part) <- packed[((mb0+m)*G + g)*18 + t*2 + part]
         for (int c = wave; c < A_CHUNKS; c += WV) {
             const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
-            const uint4* src = P.packed + (((long long)(mb0 + m) * G + g) * 18 + t * 2 + part) * 64 + lane;
+            const uint4* src = P.packed + (((long long)(mb0 + m) * G_all + g_base + g) * 18 + t * 2 + part) * 64 + lane;
             lds_dma16(src, base + c * 1024);
         }
 #pragma unroll
@@ -550,7 +555,7 @@ __global__ __launch_bounds__(64 * WV, (NBW * MBW > 8 ? 1 : ((STAGES * conv3_stag
 #pragma unroll
                 for (int part = 0; part < PARTS; ++part) {
                     const unsigned short* xs = part ? P.xl : P.xh;
-                    const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + 16 * g) : (const void*)nfe_zero16;
+                    const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + 16 * (g_base + g)) : (const void*)nfe_zero16;
                     lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
                 }
             }
@@ -632,6 +637,16 @@ __global__ __launch_bounds__(64 * WV, (NBW * MBW > 8 ? 1 : ((STAGES * conv3_stag
             continue;
         }
         if (y >= P.H || x >= P.W) continue;
+        if (KS > 1) {                                   // raw partial sums of this K slice; the epilogue runs in splitk_reduce_kernel
+            float* dst = P.partial + ((((long long)ks * P.N + n) * P.H + y) * P.W + x) * P.Cout + 32 * mb0 + 4 * h;
+#pragma unroll
+            for (int m = 0; m < MBW; ++m)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    *reinterpret_cast<float4*>(dst + 32 * m + 8 * qq) = make_float4(acc[0][m][nb][4 * qq], acc[0][m][nb][4 * qq + 1],
+                                                                                      acc[0][m][nb][4 * qq + 2], acc[0][m][nb][4 * qq + 3]);
+            continue;
+        }
         const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
 #pragma unroll
         for (int m = 0; m < MBW; ++m)
@@ -1061,6 +1076,8 @@ static int num_cus_dense() {
 #ifndef C3_TALL_MIN_TILES
 #define C3_TALL_MIN_TILES 4          // use the 8-wave 32x16 tile from 64 rows up
 #endif
+static int x3_knob() { static const int k = [] { const char* e = getenv("NFE_C3_X3"); return e ? atoi(e) : 0; }(); return k; }
+
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st) {
     constexpr int ROWS = NBW * WV;
@@ -1071,13 +1088,27 @@ static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st
     (void)once;
     const unsigned tiles = ((mode_h + ROWS - 1) / ROWS) * ((mode_w + C3_TW - 1) / C3_TW);
     Conv3K K2 = K; K2.c3_tiles = (int)tiles;
-    dim3 grid(c3_xcd_order(TERMS) ? (tiles + 7) / 8 * 8 : tiles, K.Cout / (32 * MBW), K.N);
+    dim3 grid(c3_xcd_order(TERMS) ? (tiles + 7) / 8 * 8 : tiles, K.Cout / (32 * MBW), K.N * (K.ksplit > 1 ? K.ksplit : 1));
     hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW>), grid, dim3(64 * WV), bytes, st, K2);
 }
 
 static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
     if (cin % 16 != 0 || w < 32 || h < 8) return false;
     return mode == NFE_CONV_3X3 ? cout % 64 == 0 : (mode == NFE_CONV_3X3_UP2 && cout % 32 == 0);
+}
+
+// Plain 3x3 layers on the LDS-DMA path with too few (tile, M-block group, sample) workgroups to fill the chip twice (32^2 / 64^2
+// layers at small batch): split the K loop over 2 or 4 workgroups, each keeping at least 8 K-groups; partial sums go through
+// splitk_reduce_kernel (deterministic slice order).  0 = no split.
+static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout) {
+    static const bool off = [] { const char* e = getenv("NFE_C3_KSPLIT"); return e && e[0] == '0'; }();
+    if (off || mode != NFE_CONV_3X3 || !conv3_eligible(mode, h, w, cin, cout)) return 0;
+    const int rows = (h >= 16 * C3_TALL_MIN_TILES && (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense()) ? 16 : 8;
+    const long long wgs = (long long)((h + rows - 1) / rows) * ((w + 31) / 32) * (cout / 64) * n;
+    const int G = cin / 16;
+    int ks = 1;
+    while (ks < 4 && wgs * ks < 2LL * num_cus_dense() && G / (ks * 2) >= 8) ks *= 2;
+    return ks > 1 ? ks : 0;
 }
 
 extern "C" uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c) {
@@ -1112,6 +1143,7 @@ extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, in
     if (conv3_eligible(mode, h, w, cin, cout)) {
         const uint64_t elems = (uint64_t)n * h * w * cin;           // bf16 hi (+ lo) image of the modulated input
         fl += math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
+        fl += (uint64_t)conv3_ksplit(mode, n, h, w, cin, cout) * n * h * w * cout;      // split-K partial sums
     } else if (const int ks = splitk_slices(mode, math, n, h, w, cin, cout)) {
         fl += (uint64_t)ks * n * (mode == NFE_CONV_3X3_UP2 ? (uint64_t)(2 * h + 1) * (2 * w + 1) : (uint64_t)h * w) * cout;   // partial sums
     }
@@ -1173,8 +1205,17 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         K.Cin = a->cin; K.Cout = a->cout; K.lrelu = a->lrelu; K.act_gain = a->act_gain; K.clamp = a->clamp; K.out = a->out; K.scratch = a->scratch;
         const int ext = up2 ? 1 : 0;
         const bool bf16 = a->math == NFE_CONV_BF16;
+        const int c3ks = conv3_ksplit(a->mode, a->n, a->h, a->w, a->cin, a->cout);
+        if (c3ks) {
+            K.ksplit = c3ks;
+            K.partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);       // behind the (possibly unused) split-image area
+        }
         if (up2) {
+            static const int up_knob = [] { const char* e = getenv("NFE_C3_UP"); return e ? atoi(e) : 0; }();   // tuning experiments
             if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext, st);
+            else if (up_knob == 1) launch_conv3<3, 1, true, 2, 4>(K, a->h + ext, a->w + ext, st);              // double-buffered
+            else if (up_knob == 2 && a->h >= 32) launch_conv3<3, 1, true, 1, 8>(K, a->h + ext, a->w + ext, st); // 8 waves: 32 x 16 tile
+            else if (up_knob == 3 && a->h >= 32) launch_conv3<3, 1, true, 2, 8>(K, a->h + ext, a->w + ext, st);
             else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext, st);
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
@@ -1185,6 +1226,10 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             else launch_conv3<3, 2, false, 2, 4, 4>(K, a->h, a->w, st);
         } else if (C3_MID && a->h >= 16 * C3_TALL_MIN_TILES && bf16) {   // 32 x 16 tiles on 4 waves (2 x 4 blocks per wave)
             launch_conv3<1, 2, false, 2, 4, 4>(K, a->h, a->w, st);
+        } else if (!bf16 && x3_knob() == 1 && a->h >= 16) {
+            launch_conv3<3, 2, false, 2, 8>(K, a->h, a->w, st);          // experiment: 32 x 16 tile on 8 waves, double-buffered, 1 WG/CU
+        } else if (!bf16 && x3_knob() == 2 && a->h >= 16) {
+            launch_conv3<3, 2, false, 2, 4, 4>(K, a->h, a->w, st);       // experiment: 32 x 16 tile on 4 waves, double-buffered, 1 WG/CU
         } else if (!bf16 && a->h >= 16 * C3_TALL_MIN_TILES &&
                    (long long)((a->h + 15) / 16) * ((a->w + 31) / 32) * ((a->cout + 63) / 64) * a->n >= num_cus_dense()) {
             // split-bf16: the 32 x 16 tile on FOUR waves (2 x 4 blocks per wave): the kernel is co-limited by LDS fragment reads,
@@ -1197,6 +1242,11 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         } else {
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 4>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, C3_STAGES_X3, 4>(K, a->h, a->w, st);
+        }
+        if (c3ks) {
+            const long long slice = (long long)a->n * a->h * a->w * a->cout;
+            P.ksplit = c3ks; P.partial = K.partial;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, 0);
         }
         NFE_CHECK_LAUNCH("conv3 kernels");
         return split_tail();
