@@ -47,6 +47,22 @@ def denormalize_plane(planes, mean, var):
     return out.reshape(N, P, C, H, W)
 
 
+class _NotDifferentiableImage(torch.autograd.Function):
+    """The super-resolution head runs on raw-pointer HIP ops, outside autograd.  When the planes are being optimised, `image`
+    is tied to the graph through this node so that a loss term on it fails loudly in backward() instead of silently
+    contributing a zero plane gradient (the reference's utils.decode back-propagates through the SR head)."""
+
+    @staticmethod
+    def forward(ctx, image, anchor):
+        return image.view_as(image)
+
+    @staticmethod
+    def backward(ctx, grad):
+        raise RuntimeError("decode(): out['image'] is not differentiable with respect to the planes in this package (the SR head "
+                           "runs outside autograd): build the editing loss on image_raw / image_seg / image_depth, or detach "
+                           "out['image'] explicitly")
+
+
 def encode(G, ws, **synthesis_kwargs):
     """utils.py:160-163: ws -> planes (N,3,32,256,256)."""
     planes = G.backbone.synthesis(ws, **synthesis_kwargs)
@@ -69,7 +85,10 @@ def decode(G, ws, cam, norm_planes, denorm_planes, **synthesis_kwargs):
         ws = ws.expand(N, -1, -1).contiguous()
     sr = G.superresolution.forward_nhwc(rgb, feat, ws, noise_mode=G.rendering_kwargs["superresolution_noise_mode"],
                                         **{k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"})
-    return {"image_raw": dense_ops.nhwc_to_nchw(rgb), "image": dense_ops.nhwc_to_nchw(sr),
+    image = dense_ops.nhwc_to_nchw(sr)
+    if torch.is_grad_enabled() and feature_samples.requires_grad:
+        image = _NotDifferentiableImage.apply(image, feature_samples)
+    return {"image_raw": dense_ops.nhwc_to_nchw(rgb), "image": image,
             "image_depth": depth_samples.permute(0, 2, 1).reshape(N, 1, R, R),
             "image_seg": dense_ops.nhwc_to_nchw(seg_samples.view(N, R, R, 15))}
 

@@ -460,7 +460,10 @@ def test_decode_is_differentiable_wrt_planes(setup):
             return sum((out[k] * tgt[k]).sum() for k in tgt), out
         n1, d1 = norm.clone().requires_grad_(True), denorm.clone().requires_grad_(True)
         loss, out = loss_of(n1, d1)
-        assert out["image"].shape == (1, 3, 512, 512) and not out["image"].requires_grad      # the SR image is outside the graph
+        assert out["image"].shape == (1, 3, 512, 512)
+        with pytest.raises(RuntimeError, match="not differentiable"):       # the SR image is outside the graph, and says so
+            out["image"].sum().backward(retain_graph=True)
+        n1.grad = d1.grad = None
         loss.backward()
         assert n1.grad is not None and d1.grad is not None and torch.isfinite(n1.grad).all() and float(n1.grad.abs().max()) > 0
         # the usual editing loop: only norm_planes is a leaf, the appearance planes are re-derived from it every step
