@@ -148,8 +148,19 @@ def full_generator(torch, dev, D, Di, conv_math):
     return G
 
 
-def timed_steps(args, torch, dist, world, step):
-    """W untimed + exactly K timed steps between barrier + synchronize; MAX over ranks."""
+def timed_steps(args, torch, dist, world, step, n_streams=1):
+    """W untimed + exactly K timed steps between barrier + synchronize; MAX over ranks.  n_streams > 1: consecutive steps are
+    issued on alternating HIP streams (every step still runs completely inside the timed region: both synchronize calls wait
+    for all streams), so the latency-bound render of one batch overlaps the convolutions of the next."""
+    if n_streams > 1:
+        ring = [torch.cuda.Stream() for _ in range(n_streams)]
+        for s_ in ring:
+            s_.wait_stream(torch.cuda.current_stream())
+        inner = step
+
+        def step(i):                      # noqa: F811
+            with torch.cuda.stream(ring[i % n_streams]):
+                return inner(i)
     for i in range(args.warmup):
         step(i)
     if world > 1:
@@ -279,7 +290,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
             e[3].record()
             ev[i] = e
             return out
-        dt = timed_steps(args, torch, dist, world, step)
+        dt = timed_steps(args, torch, dist, world, step, n_streams=args.streams)
         G.stage_events = None
         timed = [ev[args.warmup + i] for i in range(args.steps)]
         avg = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in timed) / args.steps
@@ -297,7 +308,10 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     value=n_total * args.steps / dt, unit="views/s", ms_per_step=dt / args.steps * 1e3, scaling="weak",
                     dtype="bf16x3" if ffhq else "bf16",
                     config={"workload": what,
-                            "views_per_step": n_total, "synthesis_ms": syn_ms, "stage_ms": stage, "parallelism": f"views-dp{world}"},
+                            "views_per_step": n_total, "synthesis_ms": syn_ms, "stage_ms": stage, "streams": args.streams,
+                            "stage_ms_note": "HIP-event times on the step's own stream; with streams > 1 consecutive steps overlap, so the "
+                                             "stages of one step are stretched by the other stream's work (use --streams 1 for stage times)",
+                            "parallelism": f"views-dp{world}"},
                     roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv3_kernel<*> + upfir/torgb (backbone + SR stages)",
                               "kernel_ms": dense_ms, "note": "289.1 GFLOP per view (SURVEY 8d) / time of the backbone + SR stages"})
@@ -327,16 +341,18 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
     a, b = sharding.shard_range(V, rank, world)
     ws_local = torch.stack([torch.from_numpy(np.random.RandomState(f).randn(14, 512).astype(np.float32)) for f in range(a, max(b, a + 1))]).to(dev)
 
+    def chunk_frames(s_, e_):
+        if e_ <= s_:
+            return torch.zeros((0, G.img_resolution, G.img_resolution, 3), dtype=torch.uint8, device=dev)
+        img = G.synthesis(ws_local[s_ - a:e_ - a].contiguous(), c_all[s_:e_].contiguous(), noise_mode="const")["image"]
+        return apps.to_uint8(img)
+
     def one_pass():
         gat = sharding.ChunkedFrameGather(V, chunk, (G.img_resolution, G.img_resolution, 3), torch.uint8, dev)
+        ring = apps.StreamRing(dev, getattr(args, "streams", 2))       # chunks alternate between two HIP streams
         for k in range(gat.rounds()):
-            s_, e_ = gat.local_slice(k)
-            if e_ > s_:
-                img = G.synthesis(ws_local[s_ - a:e_ - a].contiguous(), c_all[s_:e_].contiguous(), noise_mode="const")["image"]
-                fr = apps.to_uint8(img)
-            else:
-                fr = torch.zeros((0, G.img_resolution, G.img_resolution, 3), dtype=torch.uint8, device=dev)
-            gat.submit(k, fr)
+            sl = gat.local_slice(k)
+            gat.submit(k, ring.take(*ring.run(lambda: chunk_frames(*sl))))
         return gat.finish()
     G.synthesis(ws_local[:chunk].contiguous(), c_all[a:a + min(chunk, b - a)].contiguous(), noise_mode="const")     # weight packing, allocator
     for _ in range(warmup):
@@ -370,6 +386,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["render", "full", "ffhq", "orbit", "twopass", "editstep"], default="render")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the full-synthesis workloads alternate their batches on")
     ap.add_argument("--orbit-frames", type=int, default=512, help="frames of the strong-scaling orbit job (BASELINE config 4)")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the config-4 orbit job reported beside the default line")
     args = ap.parse_args()

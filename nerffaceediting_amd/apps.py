@@ -78,8 +78,45 @@ def to_uint8(img):
     return (img.permute(0, 2, 3, 1) * 127.5 + 128).clamp(0, 255).to(torch.uint8)
 
 
+class StreamRing:
+    """Issue consecutive batches on alternating HIP streams: the latency-bound volume render of one batch then overlaps the
+    MFMA-bound convolutions of the next (measured +8 % views/s on the FFHQ configuration, tools/time_streams.py).
+    run(fn) executes fn() on the next stream of the ring and returns (result, event); the consumer stream calls
+    take(result, event) before touching the result (stream-ordered wait, no host sync)."""
+
+    def __init__(self, device, n_streams=2):
+        self.main = torch.cuda.current_stream(device)
+        self.streams = [torch.cuda.Stream(device) for _ in range(n_streams)] if n_streams > 1 else []
+        for s in self.streams:
+            s.wait_stream(self.main)          # everything already queued (weights, inputs) is visible to the ring
+        self.i = 0
+
+    def run(self, fn):
+        if not self.streams:
+            return fn(), None
+        s = self.streams[self.i % len(self.streams)]
+        self.i += 1
+        with torch.cuda.stream(s):
+            out = fn()
+            ev = torch.cuda.Event()
+            ev.record(s)
+        return out, ev
+
+    def take(self, out, ev):
+        if ev is not None:
+            self.main.wait_event(ev)
+            for t in (out.values() if isinstance(out, dict) else [out]):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(self.main)
+        return out
+
+    def drain(self):
+        for s in self.streams:
+            self.main.wait_stream(s)
+
+
 @torch.no_grad()
-def render_views(G, ws, c, batch=4, gather=True, uint8=False, image_mode="image", overlap=True, **synthesis_kwargs):
+def render_views(G, ws, c, batch=4, gather=True, uint8=False, image_mode="image", overlap=True, streams=2, **synthesis_kwargs):
     """Render V independent (ws[v], c[v]) pairs -> frames in view order on every rank: fp32 [V,3,H,W], or with
     uint8=True the gen_samples.py:177 conversion [V,H,W,3] (4x fewer bytes on the wire).
 
@@ -100,15 +137,17 @@ def render_views(G, ws, c, batch=4, gather=True, uint8=False, image_mode="image"
             return torch.zeros(shape, dtype=torch.uint8 if uint8 else torch.float32, device=dev)
         img = G.synthesis(ws[i:j].contiguous(), c[i:j].contiguous(), **synthesis_kwargs)[image_mode]
         return to_uint8(img) if uint8 else img
+    ring = StreamRing(dev, streams)
     if gather and world > 1 and overlap:
         res = G.img_resolution if image_mode == "image" else G.neural_rendering_resolution
         shape = (res, res, 3) if uint8 else (3, res, res)
         gat = sharding.ChunkedFrameGather(V, batch, shape, torch.uint8 if uint8 else torch.float32, dev)
         for k in range(gat.rounds()):
-            gat.submit(k, frames_of(*gat.local_slice(k)))
+            sl = gat.local_slice(k)
+            gat.submit(k, ring.take(*ring.run(lambda: frames_of(*sl))))
         return gat.finish()
     a, b = sharding.shard_range(V, rank, world)
-    frames = [frames_of(i, min(b, i + batch)) for i in range(a, b, batch)]
+    frames = [ring.take(*ring.run(lambda i=i: frames_of(i, min(b, i + batch)))) for i in range(a, b, batch)]
     local = torch.cat(frames, 0) if frames else frames_of(0, 0)
     return sharding.all_gather_frames(local, V) if (gather and world > 1) else local
 

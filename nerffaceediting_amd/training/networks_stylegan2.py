@@ -20,8 +20,16 @@ def _pack_cached(module, weight):
     key = (weight.data_ptr(), weight._version, tuple(weight.shape))
     if getattr(module, "_packed_key", None) != key:
         module._packed = dense_ops.conv_pack(weight.detach())
+        _publish()
         module._packed_key = key
     return module._packed
+
+
+def _publish():
+    """A cached device buffer is about to become visible to every later call, possibly on another HIP stream (apps.StreamRing):
+    finish the kernels that fill it first.  Happens once per parameter version; skipped while a hipGraph is being captured."""
+    if not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().synchronize()
 
 
 class FullyConnectedLayer(torch.nn.Module):
@@ -227,6 +235,7 @@ class SynthesisBlock(torch.nn.Module):
             const = getattr(self, "_const_nhwc", None)
             if const is None or self._const_key != (self.const.data_ptr(), self.const._version):
                 self._const_nhwc = self.const.detach().permute(1, 2, 0).contiguous()
+                _publish()
                 self._const_key = (self.const.data_ptr(), self.const._version)
             x = self._const_nhwc.unsqueeze(0).repeat(ws.shape[0], 1, 1, 1)
             x = self.conv1.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0])

@@ -9,7 +9,7 @@ import importlib
 import torch
 
 from .. import dense_ops, ops
-from .networks_stylegan2 import FullyConnectedLayer, Generator as StyleGAN2Backbone
+from .networks_stylegan2 import FullyConnectedLayer, Generator as StyleGAN2Backbone, _publish
 from .volumetric_rendering.ray_sampler import RaySampler
 from .volumetric_rendering.renderer import DisentangledImportanceRenderer
 
@@ -51,6 +51,7 @@ class DisentangledOSGDecoder(torch.nn.Module):
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_packed_key", None) != key:
             self._packed = ops.decoder_pack(*[p.detach() for p in ps], lr_mul=self.lr_mul)
+            _publish()
             self._packed_key = key
         return self._packed
 
@@ -87,6 +88,7 @@ class OSGDecoder(torch.nn.Module):
         key = tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_packed_key", None) != key:
             self._packed = ops.decoder_pack(*self.heads(), lr_mul=self.lr_mul)
+            _publish()
             self._packed_key = key
         return self._packed
 
@@ -135,6 +137,7 @@ class SegmentationOSGDecoder(torch.nn.Module):
         if getattr(self, "_packed_key", None) != key:
             self._packed = ops.decoder_pack(*self.heads(), lr_mul=self.lr_mul)
             self._packed_cross = ops.decoder_pack_cross(self.cross(), lr_mul=self.lr_mul)
+            _publish()
             self._packed_key = key
 
     def packed(self):

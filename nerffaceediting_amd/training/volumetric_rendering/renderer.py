@@ -99,6 +99,8 @@ class DisentangledImportanceRenderer(torch.nn.Module):
             if k == key:
                 return v
         v = ops.plane_pack(planes)
+        if not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream().synchronize()         # cached for later calls, possibly on another stream (apps.StreamRing)
         self._pack_cache = [(key, planes, v)] + self._pack_cache[:1]
         return v
 
