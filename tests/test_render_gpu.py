@@ -366,7 +366,7 @@ np.savez(sys.argv[1], *outs)
 def test_outputs_do_not_depend_on_occupancy(dev):
     """The same launches with 1, 2 (default), 3 and 4 workgroups per CU (NFE_RENDER_BLOCKS_PER_CU, read once per process:
     child interpreters) must give bit-identical outputs: a build whose results depended on what else shared the CU (a
-    scheduling hazard) is caught here.  Covered kernel variants: square planes / one set (SQUARE),
+    scheduling hazard such as the misbehaving uniform branch of profiles/experiments/r02_square_branch.md) is caught here.  Covered kernel variants: square planes / one set (SQUARE),
     non-square planes (run-time axis geometry), two plane sets (DUAL), single pass 512^2 x 64, two-pass 24+24 and 96+96
     (sigma-only pass + importance_kernel + depth-buffer pass), exact-fp32 decoder."""
     import hashlib
