@@ -116,7 +116,20 @@ typedef struct nfe_conv_args {
                                      `out` may be NULL (the fp32 output is then not written) */
     const float* x_split;         /* in: such an image of this layer's modulated input (written by the producer with this
                                      layer's styles); `x` may then be NULL.  Needs the fast path (scratch as above). */
+    /* Fused ToRGB: the image path of SynthesisBlock.forward (networks_stylegan2.py:450-457: y = torgb(x, w); img =
+     * upsample2d(img) + y) evaluated in this layer's epilogue, in fp32, on the activation while it is still in registers
+     * (the M-block groups of a pixel leave partial sums; a small kernel adds them in order, then bias, clamp, skip).  Only
+     * where nfe_conv_fuses_rgb() says so; `out` may then be NULL (the fp32 activation is not written at all). */
+    const float* rgb_weight;      /* [rgb_channels, Cout] ToRGBLayer.weight (1x1), or NULL = no fusion */
+    const float* rgb_styles;      /* [N, Cout] ToRGB styles, already times weight_gain (ToRGBLayer.forward :353-354) */
+    const float* rgb_bias;        /* [rgb_channels] */
+    const float* rgb_skip;        /* previous-resolution image [N,H/2,W/2,rgb_channels] or NULL */
+    float* rgb_out;               /* [N,H,W,rgb_channels] */
+    int32_t rgb_channels;         /* 1..4 */
+    float rgb_clamp;              /* conv_clamp of the ToRGB layer, < 0 = none */
 } nfe_conv_args;
+/* 1 if a NFE_CONV_3X3 call of these sizes evaluates rgb_* in its epilogue (LDS-DMA path, no split-K, rgb_channels <= 4) */
+int nfe_conv_fuses_rgb(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels);
 int nfe_modulated_conv(const nfe_conv_args* args, nfe_stream_t stream);
 /* floats of a bf16 hi(+lo) activation image [n,h,w,c] (hi only for NFE_CONV_BF16) */
 uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c);

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 7
+NFE_ABI_VERSION = 8
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_DECODER_CROSS_FLOATS = 2048
@@ -75,6 +75,7 @@ class ConvArgs(ctypes.Structure):
         ("lrelu", c_int32), ("act_gain", c_float), ("clamp", c_float),
         ("skip", FP), ("out_planes", c_int32), ("out", FP), ("scratch", FP), ("scratch_floats", c_uint64),
         ("next_styles", FP), ("next_split", FP), ("x_split", FP),
+        ("rgb_weight", FP), ("rgb_styles", FP), ("rgb_bias", FP), ("rgb_skip", FP), ("rgb_out", FP), ("rgb_channels", c_int32), ("rgb_clamp", c_float),
     ]
 
 
@@ -126,6 +127,7 @@ _SIGNATURES = {
     "nfe_conv_scratch_floats": (c_uint64, [c_int] * 7),
     "nfe_conv_split_floats": (c_uint64, [c_int] * 5),
     "nfe_conv_accepts_split": (c_int, [c_int] * 5),
+    "nfe_conv_fuses_rgb": (c_int, [c_int] * 8),
     "nfe_resize_bilinear": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
                                 FP, FP, FP, c_float, c_uint64, FP, c_void_p]),

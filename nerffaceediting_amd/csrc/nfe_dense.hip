@@ -450,6 +450,7 @@ struct Conv3K {
     long long noise_n_stride; float noise_strength; const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp;
     float* out; float* scratch;
     int c3_tiles;       // real tile count (grid.x is padded to a multiple of 8 for the XCD-aware order)
+    const float* rgb_w; const float* rgb_s; float* rgb_partial; int rgb_c;     // fused ToRGB (plain 3x3, no split-K): see rgb_combine_kernel
     int ksplit;         // > 1: blockIdx.z = n * ksplit + ks; this workgroup sums K-groups [ks*G/ksplit, (ks+1)*G/ksplit) and writes
     float* partial;     //      raw partial sums [ksplit][N,H,W,Cout] that splitk_reduce_kernel adds in slice order (+ epilogue)
 };
@@ -615,6 +616,16 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
     }
 
     // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of pixel (row, j) ----
+    const bool fuse_rgb = !UP2 && P.rgb_w != nullptr;
+    float* wmod = reinterpret_cast<float*>(lds);       // [rgb_c][32 * MBW]: ToRGB weight x style of this workgroup's channels
+    if (fuse_rgb) {
+        __syncthreads();                               // every wave is done with the last K-group's fragments
+        for (int i = tid; i < P.rgb_c * 32 * MBW; i += 64 * WV) {
+            const int c = i / (32 * MBW), ch = 32 * mb0 + i % (32 * MBW);
+            wmod[i] = P.rgb_w[(long long)c * P.Cout + ch] * P.rgb_s[(long long)n * P.Cout + ch];
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int y = ty0 + NBW * wave + nb, x = tx0 + j;
@@ -648,6 +659,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
             continue;
         }
         const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
+        float rgb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int m = 0; m < MBW; ++m)
 #pragma unroll
@@ -660,8 +672,48 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                 v.y = epilogue_act(acc[0][m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
                 v.z = epilogue_act(acc[0][m][nb][4 * qq + 2] * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
                 v.w = epilogue_act(acc[0][m][nb][4 * qq + 3] * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-                *reinterpret_cast<float4*>(P.out + (((long long)n * P.H + y) * P.W + x) * P.Cout + o0) = v;
+                if (P.out) *reinterpret_cast<float4*>(P.out + (((long long)n * P.H + y) * P.W + x) * P.Cout + o0) = v;
+                if (fuse_rgb) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (c < P.rgb_c) {
+                            const float4 wq = *reinterpret_cast<const float4*>(wmod + c * 32 * MBW + 32 * m + 8 * qq + 4 * h);
+                            rgb[c] = fmaf(v.x, wq.x, fmaf(v.y, wq.y, fmaf(v.z, wq.z, fmaf(v.w, wq.w, rgb[c]))));
+                        }
+                }
             }
+        if (fuse_rgb) {                                // the two lane halves hold complementary channels of pixel (y, x)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rgb[c] += __shfl_xor(rgb[c], 32);
+            if (h == 0)
+                *reinterpret_cast<float4*>(P.rgb_partial + ((((long long)mbg_ * P.N + n) * P.H + y) * P.W + x) * 4) = make_float4(rgb[0], rgb[1], rgb[2], rgb[3]);
+        }
+    }
+}
+
+// Fused ToRGB, second half: add the M-block-group partial sums of every pixel in group order, then what torgb's own epilogue
+// does (bias, clamp; networks_stylegan2.py:353-357) and the skip path img = upsample2d(img) + y (:453-456).
+__global__ __launch_bounds__(256) void rgb_combine_kernel(const float* __restrict__ partial, int groups, int N, int H, int W, int C,
+                                                          const float* __restrict__ bias, float clamp, const float* __restrict__ skip,
+                                                          float* __restrict__ out) {
+    const long long npix = (long long)N * H * W;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+        float4 s = reinterpret_cast<const float4*>(partial)[i];
+        for (int g = 1; g < groups; ++g) {
+            const float4 t = reinterpret_cast<const float4*>(partial)[i + g * npix];
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        float v[4] = {s.x, s.y, s.z, s.w};
+        const int n = (int)(i / ((long long)H * W)); const long long yx = i % ((long long)H * W);
+        const int y = (int)(yx / W), x = (int)(yx % W);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < C) v[c] = epilogue_act(v[c] + bias[c], 0, 1.0f, clamp);
+        if (skip) {
+            const float4 sk = skip_up2(skip, n, H >> 1, W >> 1, C, y, x, 0);
+            v[0] += sk.x; v[1] += sk.y; v[2] += sk.z; v[3] += sk.w;
+        }
+        for (int c = 0; c < C; ++c) out[i * C + c] = v[c];
     }
 }
 
@@ -1111,6 +1163,12 @@ static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout) {
     return ks > 1 ? ks : 0;
 }
 
+extern "C" int nfe_conv_fuses_rgb(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels) {
+    (void)math;
+    if (mode != NFE_CONV_3X3 || rgb_channels < 1 || rgb_channels > 4 || cout > 256 || C3_BIG) return 0;
+    return conv3_eligible(mode, h, w, cin, cout) && conv3_ksplit(mode, n, h, w, cin, cout) == 0 ? 1 : 0;
+}
+
 extern "C" uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c) {
     if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return 0;
     const uint64_t elems = (uint64_t)n * h * w * c;
@@ -1144,6 +1202,7 @@ extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, in
         const uint64_t elems = (uint64_t)n * h * w * cin;           // bf16 hi (+ lo) image of the modulated input
         fl += math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
         fl += (uint64_t)conv3_ksplit(mode, n, h, w, cin, cout) * n * h * w * cout;      // split-K partial sums
+        if (nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, 3)) fl += (uint64_t)(cout / 64) * n * h * w * 4;   // fused-ToRGB partial sums
     } else if (const int ks = splitk_slices(mode, math, n, h, w, cin, cout)) {
         fl += (uint64_t)ks * n * (mode == NFE_CONV_3X3_UP2 ? (uint64_t)(2 * h + 1) * (2 * w + 1) : (uint64_t)h * w) * cout;   // partial sums
     }
@@ -1155,7 +1214,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a->struct_size == sizeof(nfe_conv_args), "nfe_modulated_conv: struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(nfe_conv_args));
     NFE_REQUIRE(a->mode >= 0 && a->mode <= 2, "nfe_modulated_conv: unknown mode %d", a->mode);
     NFE_REQUIRE(a->math == NFE_CONV_BF16X3 || a->math == NFE_CONV_BF16, "nfe_modulated_conv: unknown math %d", a->math);
-    NFE_REQUIRE((a->x || a->x_split) && a->styles && a->packed && a->bias && (a->out || a->next_split), "nfe_modulated_conv: null pointer");
+    NFE_REQUIRE((a->x || a->x_split) && a->styles && a->packed && a->bias && (a->out || a->next_split || a->rgb_weight), "nfe_modulated_conv: null pointer");
     NFE_REQUIRE(!a->next_split || (a->next_styles && a->mode != NFE_CONV_1X1), "nfe_modulated_conv: next_split needs next_styles and a 3x3 mode");
     NFE_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->cin > 0 && a->cout > 0 && a->cin % 4 == 0, "nfe_modulated_conv: bad sizes n=%d h=%d w=%d cin=%d cout=%d", a->n, a->h, a->w, a->cin, a->cout);
     NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || (a->scratch && a->cout % 4 == 0 && a->scratch_floats >= (uint64_t)a->n * (2 * a->h + 1) * (2 * a->w + 1) * a->cout),
@@ -1188,7 +1247,14 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
                       a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout);
     NFE_REQUIRE(!a->x_split || fast, "nfe_modulated_conv: x_split needs the fast path (eligible sizes and nfe_conv_scratch_floats() of scratch)");
     NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || a->out || a->next_split, "nfe_modulated_conv: no output requested");
-    NFE_REQUIRE(a->mode == NFE_CONV_3X3_UP2 || a->out, "nfe_modulated_conv: `out` may only be NULL on up-sampling layers with next_split");
+    const bool fuse_rgb = a->rgb_weight != nullptr;
+    if (fuse_rgb) {
+        NFE_REQUIRE(a->rgb_styles && a->rgb_bias && a->rgb_out, "nfe_modulated_conv: rgb_weight needs rgb_styles, rgb_bias and rgb_out");
+        NFE_REQUIRE(fast && nfe_conv_fuses_rgb(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout, a->rgb_channels),
+                    "nfe_modulated_conv: this layer cannot evaluate ToRGB in its epilogue (ask nfe_conv_fuses_rgb first)");
+        NFE_REQUIRE(!a->rgb_skip || (a->h % 2 == 0 && a->w % 2 == 0), "nfe_modulated_conv: rgb_skip needs even sizes");
+    }
+    NFE_REQUIRE(a->mode == NFE_CONV_3X3_UP2 || a->out || fuse_rgb, "nfe_modulated_conv: `out` may only be NULL on up-sampling layers with next_split or with a fused ToRGB");
     if (fast) {
         // fast path: modulate + split once, then the LDS-DMA implicit GEMM
         const bool up2 = a->mode == NFE_CONV_3X3_UP2;
@@ -1206,6 +1272,10 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         const int ext = up2 ? 1 : 0;
         const bool bf16 = a->math == NFE_CONV_BF16;
         const int c3ks = conv3_ksplit(a->mode, a->n, a->h, a->w, a->cin, a->cout);
+        if (fuse_rgb) {
+            K.rgb_w = a->rgb_weight; K.rgb_s = a->rgb_styles; K.rgb_c = a->rgb_channels;
+            K.rgb_partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);   // behind the split-image area (no split-K here)
+        }
         if (c3ks) {
             K.ksplit = c3ks;
             K.partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);       // behind the (possibly unused) split-image area
@@ -1248,6 +1318,9 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             P.ksplit = c3ks; P.partial = K.partial;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, 0);
         }
+        if (fuse_rgb)
+            hipLaunchKernelGGL(rgb_combine_kernel, dim3(grid1d((long long)a->n * a->h * a->w, 256, 1 << 14)), dim3(256), 0, st, K.rgb_partial,
+                               a->cout / 64, a->n, a->h, a->w, a->rgb_channels, a->rgb_bias, a->rgb_clamp, a->rgb_skip, a->rgb_out);
         NFE_CHECK_LAUNCH("conv3 kernels");
         return split_tail();
     }

@@ -184,11 +184,20 @@ def can_chain(mode, math, n, h, w, cin, cout):
     return bool(_lib.load().nfe_conv_accepts_split(int(mode), h, w, cin, cout))
 
 
+def fuses_rgb(mode, math, n, h, w, cin, cout, rgb_channels):
+    """True if a 3x3 layer of these sizes can evaluate the block's ToRGB in its epilogue (nfe_conv_fuses_rgb)."""
+    if not FAST_PATH:
+        return False
+    return bool(_lib.load().nfe_conv_fuses_rgb(int(mode), MATH[math], n, h, w, cin, cout, rgb_channels))
+
+
 def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, noise_strength=0.0, lrelu=True,
-                   act_gain=1.0, clamp=None, skip=None, out_planes=False, math=None, next_styles=None, want_out=True):
+                   act_gain=1.0, clamp=None, skip=None, out_planes=False, math=None, next_styles=None, want_out=True, rgb=None):
     """nfe_modulated_conv.  x [N,H,W,Cin] NHWC (or a SplitImage of the modulated input) -> [N,Ho,Wo,Cout]
     (or [N,3,Ho,Wo,32] if out_planes).  With next_styles [N,Cout] also returns the SplitImage for the consuming
-    3x3 layer: (out, split); out is None if want_out is False (up-sampling layers only)."""
+    3x3 layer: (out, split); out is None if want_out is False (up-sampling layers only).
+    rgb = (weight [C,Cout], styles [N,Cout], bias [C], skip [N,H/2,W/2,C] or None, clamp): the block's ToRGB evaluated in
+    this layer's epilogue (only where fuses_rgb() is true) -> returns (out or None, rgb_image [N,H,W,C])."""
     lib = _lib.load()
     a = _lib.ConvArgs()
     a.struct_size = ctypes.sizeof(_lib.ConvArgs)
@@ -223,7 +232,18 @@ def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, 
         skip = _dev(skip, "skip", (N, H // 2, W // 2, cout)); a.skip = skip.data_ptr()
     a.out_planes = int(bool(out_planes))
     out = None
-    if want_out or next_styles is None:
+    rgb_out = None
+    if rgb is not None:
+        rw, rs, rb, rskip, rclamp = rgb
+        C = rw.shape[0]
+        rw = _dev(rw.reshape(C, cout), "rgb_weight", (C, cout)); rs = _dev(rs, "rgb_styles", (N, cout)); rb = _dev(rb, "rgb_bias", (C,))
+        rgb_out = torch.empty(N, Ho, Wo, C, device=dev)
+        a.rgb_weight, a.rgb_styles, a.rgb_bias, a.rgb_out, a.rgb_channels = rw.data_ptr(), rs.data_ptr(), rb.data_ptr(), rgb_out.data_ptr(), C
+        a.rgb_clamp = -1.0 if rclamp is None else float(rclamp)
+        if rskip is not None:
+            rskip = _dev(rskip, "rgb_skip", (N, H // 2, W // 2, C)); a.rgb_skip = rskip.data_ptr()
+        keep += [rw, rs, rb, rskip, rgb_out]
+    if want_out or (next_styles is None and rgb is None):
         out = torch.empty((N, 3, Ho, Wo, 32) if out_planes else (N, Ho, Wo, cout), device=dev)
         a.out = out.data_ptr()
     split = None
@@ -238,6 +258,8 @@ def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, 
         a.scratch, a.scratch_floats = scratch.data_ptr(), n_scratch
     keep += [dcoef, noise, bias, skip, scratch, next_styles, split]
     _call(dev, lambda: lib.nfe_modulated_conv(ctypes.byref(a), _stream()), "nfe_modulated_conv")
+    if rgb is not None:
+        return out, rgb_out
     return out if next_styles is None else (out, split)
 
 

@@ -123,7 +123,7 @@ class SynthesisLayer(torch.nn.Module):
             self._ns, self._ns_key = float(self.noise_strength.detach()), key
         return self._ns
 
-    def forward_nhwc(self, x, w, noise_mode="random", gain=1, conv_math=None, styles=None, next_styles=None, want_out=True, dcoef=None):
+    def forward_nhwc(self, x, w, noise_mode="random", gain=1, conv_math=None, styles=None, next_styles=None, want_out=True, dcoef=None, rgb=None):
         """x: NHWC tensor, or a dense_ops.SplitImage made by the producing layer with this layer's `styles`.  With
         next_styles (the styles of the 3x3 layer consuming the output) returns (out, SplitImage).  styles / dcoef may
         come precomputed (batch_styles: one launch for a whole network)."""
@@ -145,7 +145,7 @@ class SynthesisLayer(torch.nn.Module):
         clamp = self.conv_clamp * gain if self.conv_clamp is not None else None
         return dense_ops.modulated_conv(x, styles, packed, self.out_channels, mode, self.bias.detach(), dcoef=dcoef, noise=noise,
                                         noise_strength=strength, lrelu=True, act_gain=self.act_gain * gain, clamp=clamp,
-                                        math=conv_math, next_styles=next_styles, want_out=want_out)
+                                        math=conv_math, next_styles=next_styles, want_out=want_out, rgb=rgb)
 
     def forward(self, x, w, noise_mode="random", fused_modconv=True, gain=1):
         return dense_ops.nhwc_to_nchw(self.forward_nhwc(dense_ops.nchw_to_nhwc(x), w, noise_mode=noise_mode, gain=gain))
@@ -226,8 +226,17 @@ class SynthesisBlock(torch.nn.Module):
         self.torgb = ToRGBLayer(out_channels, img_channels, w_dim=w_dim, conv_clamp=conv_clamp)
         self.num_torgb += 1
 
-    def forward_nhwc(self, x, img, ws, noise_mode="random", out_planes=False, conv_math=None, pre=None, **_ignored):
-        """pre: (styles, dcoefs) of this block's layers when the caller batched them for the whole network."""
+    def _fused_rgb(self, x_shape, img, st, out_planes, conv_math):
+        """Arguments for evaluating this block's ToRGB inside conv1's epilogue, or None where conv1 cannot (out_planes, wide
+        images, layers off the LDS-DMA path or with split-K)."""
+        N, r, c1, co = x_shape[0], self.resolution, self.conv1.in_channels, self.conv1.out_channels
+        if out_planes or self.img_channels > 4 or not dense_ops.fuses_rgb(_lib.NFE_CONV_3X3, conv_math, N, r, r, c1, co, self.img_channels):
+            return None
+        return (self.torgb.weight.detach(), st[-1], self.torgb.bias.detach(), img, self.torgb.conv_clamp)
+
+    def forward_nhwc(self, x, img, ws, noise_mode="random", out_planes=False, conv_math=None, pre=None, want_x=True, **_ignored):
+        """pre: (styles, dcoefs) of this block's layers when the caller batched them for the whole network.  want_x=False
+        (last block of a network): the activation itself is not returned, and not written where ToRGB runs fused."""
         assert ws.shape[1:] == (self.num_conv + self.num_torgb, self.w_dim), f"wrong ws shape {list(ws.shape)}"   # :419
         ws = ws.to(torch.float32)
         st, dc = pre if pre is not None else batch_styles(block_layers(self), ws, range(ws.shape[1]))
@@ -245,6 +254,10 @@ class SynthesisBlock(torch.nn.Module):
                 # conv0's FIR epilogue writes conv1's modulated bf16 input directly: no fp32 round trip between them
                 _, xs = self.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0],
                                                 next_styles=st[1], want_out=False)
+                fused = self._fused_rgb(ws.shape, img, st, out_planes, conv_math)
+                if fused is not None:           # conv1 + ToRGB + skip in one pass over the activation
+                    return self.conv1.forward_nhwc(xs, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1],
+                                                   rgb=fused, want_out=want_x)
                 x = self.conv1.forward_nhwc(xs, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1])
             else:
                 x = self.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0])

@@ -65,7 +65,7 @@ class _TwoBlockSR(torch.nn.Module):
         ws = ws.to(torch.float32)
         st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2])   # all six in one launch
         x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]))
-        x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[3:], dc[3:]))
+        x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[3:], dc[3:]), want_x=False)
         return rgb
 
     def forward(self, rgb, x, ws, **block_kwargs):
@@ -149,7 +149,7 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
         ws = ws.to(torch.float32)
         st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2])   # all six in one launch
         x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]))
-        x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[3:], dc[3:]))
+        x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[3:], dc[3:]), want_x=False)
         return rgb
 
     def forward(self, rgb, x, ws, **block_kwargs):
