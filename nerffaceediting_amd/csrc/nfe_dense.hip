@@ -496,7 +496,12 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int gw = UP2 ? P.W + 1 : P.W;                       // tile grid: output pixels, or the extended input grid
+    // Tile grid: output pixels, or the (H+1) x (W+1) extended input grid of the transposed conv.  EDGE mode (W a multiple of
+    // the tile width): the extra column x = W is not tiled (a 32-wide tile for one column); the right-most tile of every tile
+    // row computes it as ONE extra N-block on wave 0 (lane = tile row): that column only sees input column W-1 through the
+    // three kw = 2 taps, i.e. phases (a, b = 0), and its B fragments are column 32 of the patch the tile has staged anyway.
+    const bool edge_mode = UP2 && (P.W % C3_TW) == 0;
+    const int gw = UP2 ? (edge_mode ? P.W : P.W + 1) : P.W;
     const int tiles_x = (gw + C3_TW - 1) / C3_TW;
     // XCD-aware order (split-bf16 variants): workgroups reach the 8 XCDs round-robin in dispatch order and every XCD has its own
     // L2.  XCD x takes the tiles = x (mod 8) and walks the M-block groups of a tile back to back, so the tile's input patch is
@@ -540,6 +545,21 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
             const int pp = (NBW * wave + rr) * C3_PW + j + cc;
             brd[rr][cc] = (2 * pp + (h ^ ((pp >> 3) & 1))) * 16;
         }
+
+    const bool edge_tile = edge_mode && tx0 + C3_TW == P.W;
+    int brde[2];                                               // patch offsets of the edge column for dy = 0, 1 (lane j = tile row j)
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy) {
+        const int pp = (min(j, C3_TH - 1) + dy) * C3_PW + C3_TW;
+        brde[dy] = (2 * pp + (h ^ ((pp >> 3) & 1))) * 16;
+    }
+    f32x16 acce[UP2 ? 2 : 1][MBW];                             // edge column, phases a = 0, 1 (b = 0)
+#pragma unroll
+    for (int a = 0; a < (UP2 ? 2 : 1); ++a)
+#pragma unroll
+        for (int m = 0; m < MBW; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acce[a][m][r] = 0.0f;
 
     auto issue = [&](int g, int stage) {
         unsigned char* base = lds + stage * STAGE_BYTES;
@@ -611,11 +631,41 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                     }
                 }
             }
+            if (UP2 && kw == 2 && edge_tile && wave == 0) {   // wave-uniform
+                Frag8 bh, bl;
+                const int dy = 1 - (kh >> 1);
+                bh.q = *reinterpret_cast<const uint4*>(ldsB + brde[dy]);
+                if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brde[dy]);
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bh.v, acce[kh & 1][m], 0, 0, 0);
+                    if (TERMS == 3) {
+                        acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bl.v, acce[kh & 1][m], 0, 0, 0);
+                        acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m].v, bh.v, acce[kh & 1][m], 0, 0, 0);
+                    }
+                }
+            }
         }
         stage = stage + 1 == STAGES ? 0 : stage + 1;
     }
 
     // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of pixel (row, j) ----
+    if (UP2 && edge_tile && wave == 0 && j < C3_TH && ty0 + j <= P.H) {           // edge column: T[2y + a][2W], a = 0, 1
+        const int TH2 = 2 * P.H + 1, TW2 = 2 * P.W + 1, y = ty0 + j;
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            const int Y = 2 * y + a;
+            if (Y >= TH2) continue;
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) {
+                float* dst = P.scratch + (((long long)n * TH2 + Y) * TW2 + (TW2 - 1)) * P.Cout + 32 * (mb0 + m) + 4 * h;
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq)
+                    *reinterpret_cast<float4*>(dst + 8 * qq) = make_float4(acce[UP2 ? a : 0][m][4 * qq], acce[UP2 ? a : 0][m][4 * qq + 1],
+                                                                            acce[UP2 ? a : 0][m][4 * qq + 2], acce[UP2 ? a : 0][m][4 * qq + 3]);
+            }
+        }
+    }
     const bool fuse_rgb = !UP2 && P.rgb_w != nullptr;
     float* wmod = reinterpret_cast<float*>(lds);       // [rgb_c][32 * MBW]: ToRGB weight x style of this workgroup's channels
     if (fuse_rgb) {
@@ -1282,11 +1332,12 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         }
         if (up2) {
             static const int up_knob = [] { const char* e = getenv("NFE_C3_UP"); return e ? atoi(e) : 0; }();   // tuning experiments
-            if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext, st);
-            else if (up_knob == 1) launch_conv3<3, 1, true, 2, 4>(K, a->h + ext, a->w + ext, st);              // double-buffered
-            else if (up_knob == 2 && a->h >= 32) launch_conv3<3, 1, true, 1, 8>(K, a->h + ext, a->w + ext, st); // 8 waves: 32 x 16 tile
-            else if (up_knob == 3 && a->h >= 32) launch_conv3<3, 1, true, 2, 8>(K, a->h + ext, a->w + ext, st);
-            else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext, st);
+            const int ext_w = (a->w % C3_TW) == 0 ? 0 : ext;       // EDGE mode: the extra column rides on the right-most tiles
+            if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext_w, st);
+            else if (up_knob == 1) launch_conv3<3, 1, true, 2, 4>(K, a->h + ext, a->w + ext_w, st);              // double-buffered
+            else if (up_knob == 2 && a->h >= 32) launch_conv3<3, 1, true, 1, 8>(K, a->h + ext, a->w + ext_w, st); // 8 waves: 32 x 16 tile
+            else if (up_knob == 3 && a->h >= 32) launch_conv3<3, 1, true, 2, 8>(K, a->h + ext, a->w + ext_w, st);
+            else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext_w, st);
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
         } else if (C3_BIG && a->cout % 128 == 0 && a->h >= 16 &&
