@@ -100,15 +100,28 @@ __device__ __forceinline__ float softplus_log2(float y) {
 // canonicalising v_max before the real one)
 __device__ __forceinline__ float relu_bits(float y) { return __int_as_float(max(__float_as_int(y), 0)); }
 
-// softplus_log2 over a whole accumulator as max(y,0) + log2(1 + 2^-|y|): no overflow, so torch's threshold
-// select (y > 20 -> y, where the two agree to fp32 rounding) needs no compare/select pair; -|y| is a free
-// source modifier and the two adds run packed (v_pk_add_f32).
+// min(y, 126.0f) as one integer min on the bit pattern (negative floats are negative ints and stay; fminf costs a canonicalising
+// v_max before the v_min)
+__device__ __forceinline__ float min126_bits(float y) { return __int_as_float(min(__float_as_int(y), 0x42fc0000)); }
+
+// softplus_log2 over a whole accumulator as log2(1 + 2^min(y, 126)): 3.5 instructions per value (v_min, v_exp, half a
+// v_pk_add, v_log) against 4 for the max(y,0) + log2(1 + 2^-|y|) form.  min(y, 126) keeps 2^y finite (torch's threshold select
+// y > 20 -> y is reproduced by the arithmetic itself: log2(1 + 2^y) == y to fp32 rounding from y = 25 up); for y << 0 the sum
+// 1 + 2^y rounds exactly as 1 + 2^-|y| did in the old form, so the two agree to an ulp everywhere.
+#ifndef NFE_SOFTPLUS_MINFORM
+#define NFE_SOFTPLUS_MINFORM 1
+#endif
 __device__ __forceinline__ void softplus_log2_x16(f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
+#if NFE_SOFTPLUS_MINFORM
+        const f32x2 e = f32x2{exp2_fast(min126_bits(a[r])), exp2_fast(min126_bits(a[r + 1]))} + splat(1.0f);
+        a[r] = log2_fast(e[0]); a[r + 1] = log2_fast(e[1]);
+#else
         const f32x2 e = f32x2{exp2_fast(-__builtin_fabsf(a[r])), exp2_fast(-__builtin_fabsf(a[r + 1]))} + splat(1.0f);
         const f32x2 l = f32x2{log2_fast(e[0]), log2_fast(e[1])} + f32x2{relu_bits(a[r]), relu_bits(a[r + 1])};
         a[r] = l[0]; a[r + 1] = l[1];
+#endif
     }
 }
 
@@ -901,13 +914,16 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                 if (valid && h == 0) { P.ev_sig[ray * S + k] = og[0]; P.ev_a[ray * S + k] = a; }
                 continue;
             }
-            if (k > kfirst) {
-                const float dlt = t - prev_t;
+            {   // Branch-free: the first sample of a march (or of a depth segment) composites with a zero-length interval, i.e.
+                // alpha = 0, w = 0, T unchanged (1 + 1e-10 == 1 in fp32), every accumulator += 0.  A uniform `if (k > kfirst)`
+                // here made every loop-carried accumulator a phi and cost ~57 register copies per step at the back edge.
+                const bool first = k == kfirst;
+                const float dlt = t - (first ? t : prev_t);
                 const float dens = softplus_f((prev_sig + og[0]) * 0.5f - 1.0f);
                 const float alpha = 1.0f - exp2_fast(-(dens * dlt) * LOG2E);
                 const float w = alpha * T;
                 T = T * (1.0f - alpha + 1e-10f);
-                if (P.out_weights && valid && h == 0) P.out_weights[ray * (S - 1) + (k - 1)] = w;
+                if (P.out_weights && valid && h == 0 && !first) P.out_weights[ray * (S - 1) + (k - 1)] = w;
                 if (!SIGMA_ONLY) {
                     const f32x2 wh = splat(w * 0.5f);      // w * (a + b)/2 == (w/2) * (a + b), exactly
 #pragma unroll
