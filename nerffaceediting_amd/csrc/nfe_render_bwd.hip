@@ -47,6 +47,7 @@ struct BwdK {
     const float* g_rgb; const float* g_seg; const float* g_depth; const float* g_wsum; int channels_first;
     float* grad_g; float* grad_a; long long grad_view_stride;
     float* rec_sig; float* rec_a; float* rec_T;      // [N*M*S] each: (sigma, a, T) then (dL/dsigma, omega, -)
+    const uint4* bfrag;                // split-bf16 MFMA fragments of the decoder and its transposes (bwd_frag_kernel), or null
 };
 
 struct PrepK { const float* w[8]; float lr_mul; float* out; };
@@ -396,6 +397,207 @@ __global__ __launch_bounds__(256, BWD_WAVES) void bwd_scatter_kernel(BwdK P) {
 
 
 // ------------------------------------------------------------------------------------------------------------
+// Decoder forward + backward of the scatter pass on MFMA (v_mfma_f32_32x32x16_bf16, split-bf16: hi*hi + hi*lo + lo*hi,
+// fp32-grade like the forward kernel).  The wave's 64 samples are two N-blocks of 32; lane = sample on the way
+// in (that is how the gather leaves the features), lane (j, h) = (sample 32b + j, k-half h) inside the GEMMs.
+//   F0  pre = W0 f + b0            A = W0 (2 M-blocks, K = 32 channels: 2 k-steps)            both heads
+//   F1  y   = W1 softplus(pre) + b1 (appearance head only: its forward output enters the sigmoid derivative)
+//   DH  dh  = W1^T dout            A = W1^T (rows = hidden units in pre's accumulator layout)
+//       dpre = dh * sigmoid(pre)   elementwise, accumulator layout
+//   DF  df  = W0^T dpre            A = W0^T (rows permuted so that register r of lane (j,h) is channel 16h + r)
+// B operands never move between lanes after the first step: an accumulator IS the next B operand once the K order of the next
+// A fragments is chosen to match ("hidden unit held by (M-block, register, half)" = "k index the lane supplies"), as in the
+// forward kernel.  Only F0's B operand has to be made from the lane = sample layout: channels 16s..16s+7 (Y) and 16s+8..16s+15
+// (X) of a k-step are swapped between the lane halves by v_permlane32_swap: Y becomes N-block 0's operand, X N-block 1's.
+// Fragment image (bwd_frag_kernel, 52 fragments of 64 lanes x 8 bf16, hi and lo parts):
+// ------------------------------------------------------------------------------------------------------------
+constexpr int BF_F0 = 0;      // + ((head*2 + mblk)*2 + s)*2 + part
+constexpr int BF_F1A = 16;    // + s*2 + part
+constexpr int BF_DHG = 24;    // + mblk*2 + part
+constexpr int BF_DHA = 28;    // + (mblk*2 + s)*2 + part
+constexpr int BF_DF = 36;     // + (head*4 + s)*2 + part
+constexpr int BF_COUNT = 52;
+constexpr int BWD_FRAG_BYTES = BF_COUNT * 64 * 16;
+
+typedef __bf16 bwd_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bwd_bf16x2 __attribute__((ext_vector_type(2)));
+union BFrag { bwd_bf16x8 v; uint4 q; unsigned u[4]; };
+
+__device__ __forceinline__ int bf_hidden_of(int s, int h, int e) { const int r = 8 * (s & 1) + e; return 32 * (s >> 1) + (r & 3) + 8 * (r >> 2) + 4 * h; }
+__device__ __forceinline__ int bf_channel_of_row(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+
+__global__ void bwd_frag_kernel(const float* __restrict__ dec, unsigned* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= BF_COUNT * 64 * 4) return;
+    const int w = idx & 3, lane = (idx >> 2) & 63, frag = idx >> 8;
+    const int i = lane & 31, h = lane >> 5, part = frag & 1;
+    unsigned bits[2];
+    for (int k = 0; k < 2; ++k) {
+        const int e = 2 * w + k;
+        float v;
+        if (frag < BF_F1A) {
+            const int q = frag >> 1, s = q & 1, mblk = (q >> 1) & 1, head = q >> 2;
+            v = dec[(head ? BW_A0 : BW_G0) + (32 * mblk + i) * 32 + 16 * s + 8 * h + e];
+        } else if (frag < BF_DHG) {
+            const int s = (frag - BF_F1A) >> 1;
+            v = dec[BW_A1T + bf_hidden_of(s, h, e) * 32 + bf_channel_of_row(i)];
+        } else if (frag < BF_DHA) {
+            const int mblk = (frag - BF_DHG) >> 1;
+            v = dec[BW_G1T + (32 * mblk + i) * 16 + 8 * h + e];
+        } else if (frag < BF_DF) {
+            const int q = (frag - BF_DHA) >> 1, s = q & 1, mblk = q >> 1;
+            v = dec[BW_A1T + (32 * mblk + i) * 32 + 16 * h + 8 * s + e];
+        } else {
+            const int q = (frag - BF_DF) >> 1, s = q & 3, head = q >> 2;
+            v = dec[(head ? BW_A0 : BW_G0) + bf_hidden_of(s, h, e) * 32 + bf_channel_of_row(i)];
+        }
+        bwd_bf16x2 ph = {(__bf16)v, (__bf16)0.0f};
+        const unsigned hi = *reinterpret_cast<unsigned*>(&ph) & 0xffffu;
+        bwd_bf16x2 pl = {(__bf16)(v - __uint_as_float(hi << 16)), (__bf16)0.0f};
+        bits[k] = part == 0 ? hi : (*reinterpret_cast<unsigned*>(&pl) & 0xffffu);
+    }
+    out[idx] = bits[0] | (bits[1] << 16);
+}
+
+// fp32 pair -> packed bf16 hi word and lo word (hi = top 16 bits, lo = bf16(x - hi))
+__device__ __forceinline__ void bsplit(float a, float b, unsigned& hi, unsigned& lo) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+    bwd_bf16x2 p = {(__bf16)(a - __uint_as_float(ua & 0xffff0000u)), (__bf16)(b - __uint_as_float(ub & 0xffff0000u))};
+    lo = *reinterpret_cast<unsigned*>(&p);
+}
+__device__ __forceinline__ f32x16 mfma3(const BFrag& ah, const BFrag& al, const BFrag& bh, const BFrag& bl, f32x16 c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, c, 0, 0, 0);
+    return c;
+}
+// accumulator registers 8*(s&1) .. +7 -> B operand (hi, lo)
+__device__ __forceinline__ void acc_operand(const f32x16& a, int s1, BFrag& bh, BFrag& bl) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) bsplit(a[8 * s1 + 2 * w], a[8 * s1 + 2 * w + 1], bh.u[w], bl.u[w]);
+}
+
+// One head for both N-blocks.  f: this lane's sample, 32 channels (lane = sample).  dout_of(b, r, acc y or nullptr) supplies the
+// cotangent of the head's outputs in B-operand order.  Result: tile[(32b + j) * stride + col0 + 16h + r] = df / 3.
+template <bool APP, typename DoutGeo, typename DoutApp>
+__device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const float* __restrict__ dec, const f32x2 (&f)[16], int lane,
+                                          float* __restrict__ tile, int stride, int col0, DoutGeo dout_geo, DoutApp dout_app) {
+    const int j = lane & 31, h = lane >> 5;
+    const int head = APP ? 1 : 0;
+    const float* b0 = dec + (APP ? BB_A0 : BB_G0);
+    // ---- B operands of F0 for both N-blocks: word w of k-step s holds channels 16s + 2w, +1 (Y) / 16s + 8 + 2w, +1 (X)
+    BFrag bh[2][2], bl[2][2];                       // [block][k-step]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            unsigned yh, yl, xh, xl;
+            bsplit(f[8 * s + w][0], f[8 * s + w][1], yh, yl);
+            bsplit(f[8 * s + 4 + w][0], f[8 * s + 4 + w][1], xh, xl);
+            auto sh = __builtin_amdgcn_permlane32_swap(yh, xh, false, false);
+            auto sl = __builtin_amdgcn_permlane32_swap(yl, xl, false, false);
+            bh[0][s].u[w] = sh[0]; bh[1][s].u[w] = sh[1];
+            bl[0][s].u[w] = sl[0]; bl[1][s].u[w] = sl[1];
+        }
+#pragma unroll 1
+    for (int b = 0; b < 2; ++b) {
+        {   // the fragment loads are loop invariant: hoisted, all 52 of them would sit in registers (208 VGPRs) for the whole kernel
+            unsigned long long fp = reinterpret_cast<unsigned long long>(F);
+            asm volatile("" : "+v"(fp));
+            F = reinterpret_cast<const uint4*>(fp);
+        }
+        // ---- F0: pre-activations of the 64 hidden units (2 M-blocks), bias first
+        f32x16 pre[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(b0 + 32 * mb + 8 * q + 4 * h);
+                pre[mb][4 * q] = bb.x; pre[mb][4 * q + 1] = bb.y; pre[mb][4 * q + 2] = bb.z; pre[mb][4 * q + 3] = bb.w;
+            }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                BFrag ah, al;
+                ah.q = F[(BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 0) * 64]; al.q = F[(BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 1) * 64];
+                pre[mb] = mfma3(ah, al, b == 0 ? bh[0][s] : bh[1][s], b == 0 ? bl[0][s] : bl[1][s], pre[mb]);
+            }
+        f32x16 dh[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dh[mb][r] = 0.0f;
+        if (APP) {
+            // ---- F1: y = W1 softplus(pre) + b1, register r = channel 16h + r
+            f32x16 y;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bb = *reinterpret_cast<const float4*>(dec + BB_A1 + 16 * h + 4 * q);
+                y[4 * q] = bb.x; y[4 * q + 1] = bb.y; y[4 * q + 2] = bb.z; y[4 * q + 3] = bb.w;
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f32x16 hv;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) hv[8 * (s & 1) + r] = softplus_t(pre[s >> 1][8 * (s & 1) + r]);
+                BFrag hh, hl, ah, al;
+                acc_operand(hv, s & 1, hh, hl);
+                ah.q = F[(BF_F1A + s * 2 + 0) * 64]; al.q = F[(BF_F1A + s * 2 + 1) * 64];
+                y = mfma3(ah, al, hh, hl, y);
+            }
+            dout_app(b, y);                                       // y[r] <- cotangent of app output channel 16h + r
+            // ---- DH: dh = W1^T dout, K = 32 outputs: k-step s = registers 8s..8s+7
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                BFrag dhh, dhl;
+                acc_operand(y, s, dhh, dhl);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    BFrag ah, al;
+                    ah.q = F[(BF_DHA + (mb * 2 + s) * 2 + 0) * 64]; al.q = F[(BF_DHA + (mb * 2 + s) * 2 + 1) * 64];
+                    dh[mb] = mfma3(ah, al, dhh, dhl, dh[mb]);
+                }
+            }
+        } else {
+            // ---- DH, geometry head: K = 16 outputs (sigma, 15 seg): the lane supplies outputs 8h .. 8h+7
+            float d[8];
+            dout_geo(b, d);
+            BFrag dhh, dhl;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) bsplit(d[2 * w], d[2 * w + 1], dhh.u[w], dhl.u[w]);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                BFrag ah, al;
+                ah.q = F[(BF_DHG + mb * 2 + 0) * 64]; al.q = F[(BF_DHG + mb * 2 + 1) * 64];
+                dh[mb] = mfma3(ah, al, dhh, dhl, dh[mb]);
+            }
+        }
+        // ---- dpre = dh * softplus'(pre), then DF: df = W0^T dpre (K = 64 hidden units: 4 k-steps)
+        f32x16 df;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) df[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            f32x16 dp;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float p = pre[s >> 1][8 * (s & 1) + r];
+                dp[8 * (s & 1) + r] = dh[s >> 1][8 * (s & 1) + r] * (p > 20.0f ? 1.0f : sigmoid_t(p));
+            }
+            BFrag ph, pl, ah, al;
+            acc_operand(dp, s & 1, ph, pl);
+            ah.q = F[(BF_DF + (head * 4 + s) * 2 + 0) * 64]; al.q = F[(BF_DF + (head * 4 + s) * 2 + 1) * 64];
+            df = mfma3(ah, al, ph, pl, df);
+        }
+        float* row = tile + (32 * b + j) * stride + col0 + 16 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) row[r] = df[r] * (1.0f / 3.0f);          // mean over planes, triplane.py:251
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // pass 3, sorted form: one wave = 8x8 neighbouring rays at ONE depth index.  Their 64 x 4 taps on a plane fall on
 // ~75 distinct texels (3.4x fewer than taps at 128^2 rays on 256^2 planes), so the wave sorts its 256 (texel, sample,
 // tap) keys per plane (bitonic network in registers: 4 keys per lane, lane exchanges by ds_bpermute), walks the sorted list summing weight * feature-gradient over each run of equal
@@ -405,7 +607,8 @@ __global__ __launch_bounds__(256, BWD_WAVES) void bwd_scatter_kernel(BwdK P) {
 constexpr int SORT_TILE_STRIDE = 65;
 constexpr unsigned KEY_INVALID = 0xFFFFFFFFu;
 
-__global__ __launch_bounds__(64) void bwd_scatter_sorted_kernel(BwdK P) {
+template <bool MFMA>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_scatter_sorted_kernel(BwdK P) {   // 256 registers
     __shared__ float tile[64 * SORT_TILE_STRIDE];       // [sample][0..31 geometry-set gradient, 32..63 appearance-set]
     __shared__ float wtab[64 * 12];                     // tap weights [sample][plane*4 + tap]
     const int lane = threadIdx.x;
@@ -425,7 +628,46 @@ __global__ __launch_bounds__(64) void bwd_scatter_sorted_kernel(BwdK P) {
     const long long gv = (long long)n * P.grad_view_stride;
     const float* dec = P.dec;
     const bool do_g = P.grad_g != nullptr, do_a = P.grad_a != nullptr && P.g_rgb != nullptr;
-    {
+    if (MFMA) {       // decoder forward + backward on the matrix cores (head_mfma): 64 samples = two N-blocks of 32
+        const uint4* F = P.bfrag + lane;
+        const int jj = lane & 31, hh = lane >> 5;
+        f32x2 f[16];
+        if (do_g) {
+            gather_set(P.planes_g + pv, geo, P.aff[0] ? P.aff[0] + n * 96 : nullptr, P.aff[1] ? P.aff[1] + n * 96 : nullptr, f);
+            head_mfma<false>(F, dec, f, lane, tile, SORT_TILE_STRIDE, 0,
+                             [&](int b, float (&d)[8]) {          // outputs 8h..8h+7 of sample 32b + j: sigma = 0, seg = 1..15 (triplane.py:260-261)
+                                 const int src = 32 * b + jj;
+                                 const float gs = __shfl(gsig, src), om = __shfl(omega, src);
+                                 const int mm = __shfl(m, src);
+#pragma unroll
+                                 for (int e = 0; e < 8; ++e) {
+                                     const int o = 8 * hh + e;
+                                     d[e] = o == 0 ? gs : om * cot_seg(P, n, mm, o - 1);
+                                 }
+                             },
+                             [](int, f32x16&) {});
+        } else {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) tile[lane * SORT_TILE_STRIDE + c] = 0.0f;
+        }
+        if (do_a) {
+            gather_set(P.planes_a + pv, geo, P.aff[2] ? P.aff[2] + n * 96 : nullptr, P.aff[3] ? P.aff[3] + n * 96 : nullptr, f);
+            head_mfma<true>(F, dec, f, lane, tile, SORT_TILE_STRIDE, 32, [](int, float (&)[8]) {},
+                            [&](int b, f32x16& y) {               // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269), channel 16h + r
+                                const int src = 32 * b + jj;
+                                const float om = __shfl(omega, src);
+                                const int mm = __shfl(m, src);
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const float sg = sigmoid_t(y[r]);
+                                    y[r] = om * cot_rgb(P, n, mm, 16 * hh + r) * 1.002f * sg * (1.0f - sg);
+                                }
+                            });
+        } else {
+#pragma unroll
+            for (int c = 0; c < 32; ++c) tile[lane * SORT_TILE_STRIDE + 32 + c] = 0.0f;
+        }
+    } else {
         f32x2 f[16], df[16];
         if (do_g) {
             gather_set(P.planes_g + pv, geo, P.aff[0] ? P.aff[0] + n * 96 : nullptr, P.aff[1] ? P.aff[1] + n * 96 : nullptr, f);
@@ -553,7 +795,7 @@ using namespace nfe;
 
 extern "C" uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples) {
     const uint64_t ns = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0) * (uint64_t)(n_samples > 0 ? n_samples : 0);
-    return BWD_DEC_BYTES + 3 * align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4);
+    return BWD_DEC_BYTES + 3 * align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES);
 }
 
 extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream_t stream) {
@@ -631,7 +873,15 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
         NFE_CHECK_LAUNCH("bwd_scatter_kernel");
     } else {
         const dim3 tgrid((unsigned)((a->n_rays + 63) / 64), (unsigned)a->n_samples, (unsigned)a->n_views);
-        hipLaunchKernelGGL(bwd_scatter_sorted_kernel, tgrid, dim3(64), 0, st, P);
+        static const bool valu_dec = [] { const char* e = getenv("NFE_BWD_DECODER"); return e && e[0] == 'v'; }();      // A/B knob: "valu"
+        if (valu_dec) {
+            hipLaunchKernelGGL(bwd_scatter_sorted_kernel<false>, tgrid, dim3(64), 0, st, P);
+        } else {
+            unsigned* frags = (unsigned*)((char*)P.rec_T + align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4));
+            hipLaunchKernelGGL(bwd_frag_kernel, dim3((BF_COUNT * 64 * 4 + 255) / 256), dim3(256), 0, st, dec, frags);
+            P.bfrag = reinterpret_cast<const uint4*>(frags);
+            hipLaunchKernelGGL(bwd_scatter_sorted_kernel<true>, tgrid, dim3(64), 0, st, P);
+        }
         NFE_CHECK_LAUNCH("bwd_scatter_sorted_kernel");
     }
     return NFE_OK;
