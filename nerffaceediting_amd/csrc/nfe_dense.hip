@@ -1178,8 +1178,6 @@ static int num_cus_dense() {
 #ifndef C3_TALL_MIN_TILES
 #define C3_TALL_MIN_TILES 4          // use the 8-wave 32x16 tile from 64 rows up
 #endif
-static int x3_knob() { static const int k = [] { const char* e = getenv("NFE_C3_X3"); return e ? atoi(e) : 0; }(); return k; }
-
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st) {
     constexpr int ROWS = NBW * WV;
@@ -1347,10 +1345,6 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             else launch_conv3<3, 2, false, 2, 4, 4>(K, a->h, a->w, st);
         } else if (C3_MID && a->h >= 16 * C3_TALL_MIN_TILES && bf16) {   // 32 x 16 tiles on 4 waves (2 x 4 blocks per wave)
             launch_conv3<1, 2, false, 2, 4, 4>(K, a->h, a->w, st);
-        } else if (!bf16 && x3_knob() == 1 && a->h >= 16) {
-            launch_conv3<3, 2, false, 2, 8>(K, a->h, a->w, st);          // experiment: 32 x 16 tile on 8 waves, double-buffered, 1 WG/CU
-        } else if (!bf16 && x3_knob() == 2 && a->h >= 16) {
-            launch_conv3<3, 2, false, 2, 4, 4>(K, a->h, a->w, st);       // experiment: 32 x 16 tile on 4 waves, double-buffered, 1 WG/CU
         } else if (!bf16 && a->h >= 16 * C3_TALL_MIN_TILES &&
                    (long long)((a->h + 15) / 16) * ((a->w + 31) / 32) * ((a->cout + 63) / 64) * a->n >= num_cus_dense()) {
             // split-bf16: the 32 x 16 tile on FOUR waves (2 x 4 blocks per wave): the kernel is co-limited by LDS fragment reads,
