@@ -444,6 +444,12 @@ __global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict_
 }
 
 __device__ uint4 nfe_zero16[4];                                  // source of the zero padding for LDS-DMA
+#ifdef C3_PROFILE      // diagnostic build only (tools/c3_profile.py): shader cycles summed over all waves of all conv3 launches
+__device__ unsigned long long c3_prof[4];                        // {load phase, compute phase, epilogue, waves}
+#define C3_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#else
+#define C3_STAMP(var)
+#endif
 
 struct Conv3K {
     const unsigned short* xh; const unsigned short* xl; const uint4* packed; const float* dcoef; const float* noise;
@@ -593,16 +599,21 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][m][nb][r] = 0.0f;
 
+#ifdef C3_PROFILE
+    unsigned long long prof_load = 0, prof_comp = 0;
+#endif
     for (int pre = 0; pre < STAGES - 1; ++pre)
         if (pre < G) issue(pre, pre);
     int stage = 0;
     for (int g = 0; g < G; ++g) {
+        C3_STAMP(ts0);
         if (STAGES == 1) { __syncthreads(); issue(g, 0); }
         // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
         if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
         __syncthreads();
         if (STAGES >= 2 && g + STAGES - 1 < G) issue(g + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);
+        C3_STAMP(ts1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
         const unsigned char* ldsB = base + A_CHUNKS * 1024;
@@ -647,7 +658,13 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
             }
         }
         stage = stage + 1 == STAGES ? 0 : stage + 1;
+#ifdef C3_PROFILE
+        { C3_STAMP(ts2); prof_load += ts1 - ts0; prof_comp += ts2 - ts1; }
+#endif
     }
+#ifdef C3_PROFILE
+    C3_STAMP(ts_ep0);
+#endif
 
     // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of pixel (row, j) ----
     if (UP2 && edge_tile && wave == 0 && j < C3_TH && ty0 + j <= P.H) {           // edge column: T[2y + a][2W], a = 0, 1
@@ -668,18 +685,22 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
     }
     const bool fuse_rgb = !UP2 && P.rgb_w != nullptr;
     float* wmod = reinterpret_cast<float*>(lds);       // [rgb_c][32 * MBW]: ToRGB weight x style of this workgroup's channels
+    // per-wave 32 px x 32 channel tile (row stride 36 floats) behind wmod: the activation goes through it so that every store
+    // instruction writes 8 pixels x 128 contiguous bytes (full lines) instead of 64 separate 16-byte pieces
+    constexpr int ST_STRIDE = 36;
+    float* stile = reinterpret_cast<float*>(lds) + 4 * 32 * MBW + wave * (32 * ST_STRIDE);
+    if (!UP2 && KS == 1) __syncthreads();              // every wave is done with the last K-group's fragments: LDS is free
     if (fuse_rgb) {
-        __syncthreads();                               // every wave is done with the last K-group's fragments
         for (int i = tid; i < P.rgb_c * 32 * MBW; i += 64 * WV) {
             const int c = i / (32 * MBW), ch = 32 * mb0 + i % (32 * MBW);
             wmod[i] = P.rgb_w[(long long)c * P.Cout + ch] * P.rgb_s[(long long)n * P.Cout + ch];
         }
         __syncthreads();
     }
+    if (UP2) {
 #pragma unroll
-    for (int nb = 0; nb < NBW; ++nb) {
-        const int y = ty0 + NBW * wave + nb, x = tx0 + j;
-        if (UP2) {
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int y = ty0 + NBW * wave + nb, x = tx0 + j;
             if (y > P.H || x > P.W) continue;
             const int TH2 = 2 * P.H + 1, TW2 = 2 * P.W + 1;
 #pragma unroll
@@ -695,10 +716,12 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                                                                                 acc[a][m][nb][4 * qq + 2], acc[a][m][nb][4 * qq + 3]);
                 }
             }
-            continue;
         }
-        if (y >= P.H || x >= P.W) continue;
-        if (KS > 1) {                                   // raw partial sums of this K slice; the epilogue runs in splitk_reduce_kernel
+    } else if (KS > 1) {                                // raw partial sums of this K slice; the epilogue runs in splitk_reduce_kernel
+#pragma unroll
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int y = ty0 + NBW * wave + nb, x = tx0 + j;
+            if (y >= P.H || x >= P.W) continue;
             float* dst = P.partial + ((((long long)ks * P.N + n) * P.H + y) * P.W + x) * P.Cout + 32 * mb0 + 4 * h;
 #pragma unroll
             for (int m = 0; m < MBW; ++m)
@@ -706,39 +729,81 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                 for (int qq = 0; qq < 4; ++qq)
                     *reinterpret_cast<float4*>(dst + 32 * m + 8 * qq) = make_float4(acc[0][m][nb][4 * qq], acc[0][m][nb][4 * qq + 1],
                                                                                       acc[0][m][nb][4 * qq + 2], acc[0][m][nb][4 * qq + 3]);
-            continue;
         }
-        const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
-        float rgb[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    } else {
+        // Per-channel epilogue constants and the noise values are loaded up front, one M-block at a time: inside the store loop
+        // every such load sits behind the previous store (the pointers may alias), which made the epilogue a chain of ~32 exposed
+        // L2 round trips per wave, 20-30 % of the wave's life (tools/c3_profile.py).
+        float nzv[NBW], rgb[NBW][4];
 #pragma unroll
-        for (int m = 0; m < MBW; ++m)
+        for (int nb = 0; nb < NBW; ++nb) {
+            const int y = min(ty0 + NBW * wave + nb, P.H - 1), x = min(tx0 + j, P.W - 1);
+            nzv[nb] = P.noise ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) rgb[nb][c] = 0.0f;
+        }
+#pragma unroll
+        for (int m = 0; m < MBW; ++m) {
+            float4 dq[4], bq[4];
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 const int o0 = 32 * (mb0 + m) + 8 * qq + 4 * h;
-                const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + o0) : make_float4(1, 1, 1, 1);
-                const float4 b = *reinterpret_cast<const float4*>(P.bias + o0);
-                float4 v;
-                v.x = epilogue_act(acc[0][m][nb][4 * qq + 0] * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
-                v.y = epilogue_act(acc[0][m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
-                v.z = epilogue_act(acc[0][m][nb][4 * qq + 2] * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
-                v.w = epilogue_act(acc[0][m][nb][4 * qq + 3] * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-                if (P.out) *reinterpret_cast<float4*>(P.out + (((long long)n * P.H + y) * P.W + x) * P.Cout + o0) = v;
-                if (fuse_rgb) {
+                dq[qq] = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + o0) : make_float4(1, 1, 1, 1);
+                bq[qq] = *reinterpret_cast<const float4*>(P.bias + o0);
+            }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (c < P.rgb_c) {
-                            const float4 wq = *reinterpret_cast<const float4*>(wmod + c * 32 * MBW + 32 * m + 8 * qq + 4 * h);
-                            rgb[c] = fmaf(v.x, wq.x, fmaf(v.y, wq.y, fmaf(v.z, wq.z, fmaf(v.w, wq.w, rgb[c]))));
-                        }
+            for (int nb = 0; nb < NBW; ++nb) {
+                const int y = ty0 + NBW * wave + nb;
+                if (y >= P.H) continue;                 // wave-uniform; lanes beyond the image width compute along and are masked at the store
+                const float nz = nzv[nb];
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const int o0 = 32 * (mb0 + m) + 8 * qq + 4 * h;
+                    const float4 d = dq[qq], b = bq[qq];
+                    float4 v;
+                    v.x = epilogue_act(acc[0][m][nb][4 * qq + 0] * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+                    v.y = epilogue_act(acc[0][m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+                    v.z = epilogue_act(acc[0][m][nb][4 * qq + 2] * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+                    v.w = epilogue_act(acc[0][m][nb][4 * qq + 3] * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+                    if (P.out) *reinterpret_cast<float4*>(stile + j * ST_STRIDE + 8 * qq + 4 * h) = v;
+                    if (fuse_rgb) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (c < P.rgb_c) {
+                                const float4 wq = *reinterpret_cast<const float4*>(wmod + c * 32 * MBW + 32 * m + 8 * qq + 4 * h);
+                                rgb[nb][c] = fmaf(v.x, wq.x, fmaf(v.y, wq.y, fmaf(v.z, wq.z, fmaf(v.w, wq.w, rgb[nb][c]))));
+                            }
+                    }
+                }
+                if (P.out) {            // same-wave LDS operations execute in order: no barrier between the writes above and these reads
+                    float* orow = P.out + (((long long)n * P.H + y) * P.W + tx0) * P.Cout + 32 * (mb0 + m);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {
+                        const int p = 8 * it + (lane >> 3), c = lane & 7;
+                        const float4 v = *reinterpret_cast<const float4*>(stile + p * ST_STRIDE + 4 * c);
+                        if (tx0 + p < P.W) *reinterpret_cast<float4*>(orow + (long long)p * P.Cout + 4 * c) = v;
+                    }
                 }
             }
+        }
         if (fuse_rgb) {                                // the two lane halves hold complementary channels of pixel (y, x)
 #pragma unroll
-            for (int c = 0; c < 4; ++c) rgb[c] += __shfl_xor(rgb[c], 32);
-            if (h == 0)
-                *reinterpret_cast<float4*>(P.rgb_partial + ((((long long)mbg_ * P.N + n) * P.H + y) * P.W + x) * 4) = make_float4(rgb[0], rgb[1], rgb[2], rgb[3]);
+            for (int nb = 0; nb < NBW; ++nb) {
+                const int y = ty0 + NBW * wave + nb, x = tx0 + j;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) rgb[nb][c] += __shfl_xor(rgb[nb][c], 32);
+                if (h == 0 && y < P.H && x < P.W)
+                    *reinterpret_cast<float4*>(P.rgb_partial + ((((long long)mbg_ * P.N + n) * P.H + y) * P.W + x) * 4) =
+                        make_float4(rgb[nb][0], rgb[nb][1], rgb[nb][2], rgb[nb][3]);
+            }
         }
     }
+#ifdef C3_PROFILE
+    if (lane == 0) {
+        C3_STAMP(ts_ep1);
+        atomicAdd(&c3_prof[0], prof_load); atomicAdd(&c3_prof[1], prof_comp); atomicAdd(&c3_prof[2], ts_ep1 - ts_ep0); atomicAdd(&c3_prof[3], 1ull);
+    }
+#endif
 }
 
 // Fused ToRGB, second half: add the M-block-group partial sums of every pixel in group order, then what torgb's own epilogue
@@ -1329,12 +1394,9 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             K.partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);       // behind the (possibly unused) split-image area
         }
         if (up2) {
-            static const int up_knob = [] { const char* e = getenv("NFE_C3_UP"); return e ? atoi(e) : 0; }();   // tuning experiments
+            // (round 2 measured, without gain: a double-buffered stage (C3_STAGES_X3_UP = 2) and the 32 x 16 tile on 8 waves: DESIGN.md 5)
             const int ext_w = (a->w % C3_TW) == 0 ? 0 : ext;       // EDGE mode: the extra column rides on the right-most tiles
             if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext_w, st);
-            else if (up_knob == 1) launch_conv3<3, 1, true, 2, 4>(K, a->h + ext, a->w + ext_w, st);              // double-buffered
-            else if (up_knob == 2 && a->h >= 32) launch_conv3<3, 1, true, 1, 8>(K, a->h + ext, a->w + ext_w, st); // 8 waves: 32 x 16 tile
-            else if (up_knob == 3 && a->h >= 32) launch_conv3<3, 1, true, 2, 8>(K, a->h + ext, a->w + ext_w, st);
             else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext_w, st);
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
@@ -1413,3 +1475,11 @@ extern "C" int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, 
     NFE_CHECK_LAUNCH("resize_kernel");
     return NFE_OK;
 }
+
+#ifdef C3_PROFILE
+extern "C" int nfe_debug_c3_profile(unsigned long long* out4, int reset) {
+    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(nfe::c3_prof), 32) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(nfe::c3_prof), z, 32) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
