@@ -253,6 +253,46 @@ def test_torgb_fast_paths_match_generic(shape, math, dev):
     assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
 
 
+@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("shape,C,want_x", [((2, 64, 64, 64, 128), 3, True), ((1, 96, 128, 32, 256), 3, False), ((3, 32, 32, 128, 64), 4, True),
+                                            ((2, 40, 72, 48, 128), 1, False)])
+def test_fused_torgb_matches_separate_layers(shape, C, want_x, math, dev):
+    """nfe_conv_args.rgb_*: the block's ToRGB (1x1 modulated conv without demodulation, bias, clamp) and the skip path
+    img = upsample2d(img) + y (networks_stylegan2.py:450-457) evaluated in conv1's epilogue == conv1 followed by the ToRGB layer;
+    with want_x False the fp32 activation is not produced at all.  Includes ragged tiles (40 x 72) and 2 / 4 M-block groups."""
+    from nerffaceediting_amd import _lib, dense_ops as D
+    N, H, W, cin, cout = shape
+    g = torch.Generator(device="cpu").manual_seed(23)
+    x = torch.randn(N, H, W, cin, generator=g).to(dev)
+    styles = (torch.randn(N, cin, generator=g) * 0.5 + 1.0).to(dev)
+    weight = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    bias = torch.randn(cout, generator=g).to(dev)
+    noise = torch.randn(H, W, generator=g).to(dev)
+    rw = torch.randn(C, cout, 1, 1, generator=g).to(dev)
+    rs = (torch.randn(N, cout, generator=g) * 0.05).to(dev)
+    rb = torch.randn(C, generator=g).to(dev)
+    skip = torch.randn(N, H // 2, W // 2, C, generator=g).to(dev)
+    packed, wsq = D.conv_pack(weight)
+    dcoef = D.conv_demod(styles, wsq)
+    kw = dict(bias=bias, dcoef=dcoef, noise=noise, noise_strength=0.3, lrelu=True, act_gain=2 ** 0.5, clamp=256.0, math=math)
+    assert D.fuses_rgb(_lib.NFE_CONV_3X3, math, N, H, W, cin, cout, C)
+    out, rgb = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_3X3, rgb=(rw, rs, rb, skip, 256.0), want_out=want_x, **kw)
+    ref_x = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_3X3, **kw)
+    assert (out is not None) == want_x
+    if want_x:
+        assert torch.equal(out, ref_x)
+    xr = ref_x.double() * rs.double()[:, None, None, :]                                # fp64 restatement of the ToRGB layer on ref_x
+    y = torch.einsum("nhwc,oc->nhwo", xr, rw.double().reshape(C, cout)) + rb.double()
+    y = y.clamp(-256, 256)
+    up = torch.nn.functional.conv_transpose2d(skip.double().permute(0, 3, 1, 2).reshape(N * C, 1, H // 2, W // 2),
+                                              (torch.outer(torch.tensor([1., 3., 3., 1.]), torch.tensor([1., 3., 3., 1.])).double() / 16)[None, None].to(dev),
+                                              stride=2, padding=1).reshape(N, C, H, W).permute(0, 2, 3, 1)
+    ref = y + up
+    assert rgb.shape == (N, H, W, C)
+    assert float((rgb.double() - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1.0)
+    assert not D.fuses_rgb(_lib.NFE_CONV_3X3, math, N, 8, 8, cin, cout, C) and not D.fuses_rgb(_lib.NFE_CONV_3X3, math, N, H, W, cin, cout, 96)
+
+
 @pytest.mark.parametrize("tag", ["SuperresolutionHybrid8X.64", "SuperresolutionHybrid4X.64", "SuperresolutionHybrid4X.128",
                                  "SuperresolutionHybrid2X.96", "SuperresolutionHybridDeepfp32.64"])
 def test_superresolution_variants(tag, dev):

@@ -118,6 +118,29 @@ def test_render_views_and_density_grid(setup):
     del b
 
 
+def test_stream_ring_matches_single_stream(setup):
+    """apps.render_views on two alternating HIP streams (StreamRing) == the same batches on one stream, bit for bit (same Philox
+    keys: the seeds are drawn from torch's CPU generator in call order), uint8 conversion included."""
+    from nerffaceediting_amd import apps
+    G, z, dev = setup
+    ws = t(z["ws"], dev)[:1]
+    c = apps.orbit_cameras(5, dev)
+    old = G.neural_rendering_resolution
+    G.neural_rendering_resolution = 32
+    try:
+        outs = []
+        for streams in (1, 2, 3):
+            torch.manual_seed(9)
+            outs.append(apps.render_views(G, ws, c, batch=2, streams=streams, noise_mode="const"))
+        torch.manual_seed(9)
+        u8 = apps.render_views(G, ws, c, batch=2, streams=2, uint8=True, noise_mode="const")
+    finally:
+        G.neural_rendering_resolution = old
+    assert outs[0].shape == (5, 3, 512, 512)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert torch.equal(u8, apps.to_uint8(outs[0]))
+
+
 def test_density_grid_vs_reference(setup):
     """gen_samples.py's shape sweep (create_samples grid, chunked G.sample, reshape) on a 16^3 grid against the reference
     generator's own sweep; then the flip + border trim that precedes the .mrc / marching-cubes export."""
