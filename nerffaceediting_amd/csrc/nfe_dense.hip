@@ -522,7 +522,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         if (tile_ >= P.c3_tiles) return;              // grid.x is padded to a multiple of 8
     }
     const int ty0 = (tile_ / tiles_x) * C3_TH, tx0 = (tile_ % tiles_x) * C3_TW;
-    const int KS = (!UP2 && P.ksplit > 1) ? P.ksplit : 1;
+    const int KS = P.ksplit > 1 ? P.ksplit : 1;
     const int mb0 = mbg_ * MBW, n = blockIdx.z / KS, ks = blockIdx.z % KS;
     const int G_all = P.Cin >> 4;
     const int g_per = (G_all + KS - 1) / KS, g_base = ks * g_per;
@@ -675,7 +675,8 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
             if (Y >= TH2) continue;
 #pragma unroll
             for (int m = 0; m < MBW; ++m) {
-                float* dst = P.scratch + (((long long)n * TH2 + Y) * TW2 + (TW2 - 1)) * P.Cout + 32 * (mb0 + m) + 4 * h;
+                float* dst = (KS > 1 ? P.partial + (long long)ks * P.N * TH2 * TW2 * P.Cout : P.scratch) +
+                             (((long long)n * TH2 + Y) * TW2 + (TW2 - 1)) * P.Cout + 32 * (mb0 + m) + 4 * h;
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq)
                     *reinterpret_cast<float4*>(dst + 8 * qq) = make_float4(acce[UP2 ? a : 0][m][4 * qq], acce[UP2 ? a : 0][m][4 * qq + 1],
@@ -709,7 +710,8 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                 if (Y >= TH2 || X >= TW2) continue;
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) {
-                    float* dst = P.scratch + (((long long)n * TH2 + Y) * TW2 + X) * P.Cout + 32 * (mb0 + m) + 4 * h;
+                    float* dst = (KS > 1 ? P.partial + (long long)ks * P.N * TH2 * TW2 * P.Cout : P.scratch) +
+                                 (((long long)n * TH2 + Y) * TW2 + X) * P.Cout + 32 * (mb0 + m) + 4 * h;
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq)
                         *reinterpret_cast<float4*>(dst + 8 * qq) = make_float4(acc[a][m][nb][4 * qq], acc[a][m][nb][4 * qq + 1],
@@ -1267,10 +1269,18 @@ static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
 // splitk_reduce_kernel (deterministic slice order).  0 = no split.
 static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout) {
     static const bool off = [] { const char* e = getenv("NFE_C3_KSPLIT"); return e && e[0] == '0'; }();
-    if (off || mode != NFE_CONV_3X3 || !conv3_eligible(mode, h, w, cin, cout)) return 0;
+    if (off || mode == NFE_CONV_1X1 || !conv3_eligible(mode, h, w, cin, cout)) return 0;
+    const int G = cin / 16;
+    if (mode == NFE_CONV_3X3_UP2) {            // the kernel and the reduce pass support it (NFE_C3_KSPLIT_UP=1), measured without gain at
+        static const bool on = [] { const char* e = getenv("NFE_C3_KSPLIT_UP"); return e && e[0] == '1'; }();      // batch 1 and 4: off
+        if (!on) return 0;
+        const long long wgs = (long long)((h + 1 + 7) / 8) * ((w % 32 == 0 ? w : w + 1 + 31) / 32) * (cout / 32) * n;
+        int ks = 1;
+        while (ks < 4 && wgs * ks < 4LL * num_cus_dense() && G / (ks * 2) >= 4) ks *= 2;
+        return ks > 1 ? ks : 0;
+    }
     const int rows = (h >= 16 * C3_TALL_MIN_TILES && (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense()) ? 16 : 8;
     const long long wgs = (long long)((h + rows - 1) / rows) * ((w + 31) / 32) * (cout / 64) * n;
-    const int G = cin / 16;
     int ks = 1;
     while (ks < 4 && wgs * ks < 2LL * num_cus_dense() && G / (ks * 2) >= 8) ks *= 2;
     return ks > 1 ? ks : 0;
@@ -1314,7 +1324,8 @@ extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, in
     if (conv3_eligible(mode, h, w, cin, cout)) {
         const uint64_t elems = (uint64_t)n * h * w * cin;           // bf16 hi (+ lo) image of the modulated input
         fl += math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
-        fl += (uint64_t)conv3_ksplit(mode, n, h, w, cin, cout) * n * h * w * cout;      // split-K partial sums
+        fl += (uint64_t)conv3_ksplit(mode, n, h, w, cin, cout) * n *
+              (mode == NFE_CONV_3X3_UP2 ? (uint64_t)(2 * h + 1) * (2 * w + 1) : (uint64_t)h * w) * cout;          // split-K partial sums
         if (nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, 3)) fl += (uint64_t)(cout / 64) * n * h * w * 4;   // fused-ToRGB partial sums
     } else if (const int ks = splitk_slices(mode, math, n, h, w, cin, cout)) {
         fl += (uint64_t)ks * n * (mode == NFE_CONV_3X3_UP2 ? (uint64_t)(2 * h + 1) * (2 * w + 1) : (uint64_t)h * w) * cout;   // partial sums
@@ -1393,11 +1404,18 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             K.ksplit = c3ks;
             K.partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);       // behind the (possibly unused) split-image area
         }
+        auto reduce_up = [&]() {                    // slices of the transposed-conv result -> a->scratch, in order, before the FIR
+            if (!(c3ks && up2)) return;
+            const long long slice = (long long)a->n * (2 * a->h + 1) * (2 * a->w + 1) * a->cout;
+            P.ksplit = c3ks; P.partial = K.partial;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, 1);
+        };
         if (up2) {
             // (round 2 measured, without gain: a double-buffered stage (C3_STAGES_X3_UP = 2) and the 32 x 16 tile on 8 waves: DESIGN.md 5)
             const int ext_w = (a->w % C3_TW) == 0 ? 0 : ext;       // EDGE mode: the extra column rides on the right-most tiles
             if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext_w, st);
             else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext_w, st);
+            reduce_up();
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
         } else if (C3_BIG && a->cout % 128 == 0 && a->h >= 16 &&
@@ -1420,7 +1438,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 4>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, C3_STAGES_X3, 4>(K, a->h, a->w, st);
         }
-        if (c3ks) {
+        if (c3ks && !up2) {
             const long long slice = (long long)a->n * a->h * a->w * a->cout;
             P.ksplit = c3ks; P.partial = K.partial;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, 0);
