@@ -73,36 +73,16 @@ __device__ __forceinline__ u32x4 philox4x32_10(unsigned c0, unsigned c1, unsigne
 }
 __device__ __forceinline__ float u01(unsigned bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
 
-// Bilinear tap geometry of one sample on one plane: F.grid_sample(bilinear, zeros, align_corners=False),
-// renderer.py:64, unnormalised as ATen's CPU kernel does.  Clamped coordinates are always addressable;
-// out-of-range taps carry weight 0.
 struct Taps { int xc0, xc1, yc0, yc1; float w[4]; float wdef; };   // wdef = (sum of weights) - 1, exactly 0 when all 4 taps are inside
 
-__device__ __forceinline__ Taps tap_geometry(int H, int W, float u, float v) {
-    Taps t;
-    const float ix = (u + 1.0f) * (0.5f * (float)W) - 0.5f;
-    const float iy = (v + 1.0f) * (0.5f * (float)H) - 0.5f;
-    const float x0f = floorf(ix), y0f = floorf(iy);
-    const float dx = ix - x0f, dy = iy - y0f, ex = 1.0f - dx, ey = 1.0f - dy;
-    const int x0 = (int)fminf(fmaxf(x0f, -2.0f), (float)(W + 1));
-    const int y0 = (int)fminf(fmaxf(y0f, -2.0f), (float)(H + 1));
-    const int x1 = x0 + 1, y1 = y0 + 1;
-    const bool vx0 = (unsigned)x0 < (unsigned)W, vx1 = (unsigned)x1 < (unsigned)W;
-    const bool vy0 = (unsigned)y0 < (unsigned)H, vy1 = (unsigned)y1 < (unsigned)H;
-    t.w[0] = (vx0 && vy0) ? ex * ey : 0.0f;
-    t.w[1] = (vx1 && vy0) ? dx * ey : 0.0f;
-    t.w[2] = (vx0 && vy1) ? ex * dy : 0.0f;
-    t.w[3] = (vx1 && vy1) ? dx * dy : 0.0f;
-    t.xc0 = min(max(x0, 0), W - 1); t.xc1 = min(max(x1, 0), W - 1);
-    t.yc0 = min(max(y0, 0), H - 1); t.yc1 = min(max(y1, 0), H - 1);
-    t.wdef = (vx0 && vx1 && vy0 && vy1) ? 0.0f : ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3])) - 1.0f;
-    return t;
-}
-
 // One axis of the bilinear footprint: clamped tap coordinates, 1-D weights with out-of-range taps zeroed, and whether both
-// taps are inside.  The 2-D weights are separable ((vx ? ex : 0) * (vy ? ey : 0) == (vx && vy) ? ex * ey : 0), so on SQUARE
-// planes the three projections (x,y), (x,z), (z,x) of a sample share their axes: three axis computations instead of six.
-struct Axis { int c0, c1; float a0, a1; bool in; };
+// taps are inside (as 1.0 / 0.0).  The 2-D weights are separable ((vx ? ex : 0) * (vy ? ey : 0) == (vx && vy) ? ex * ey : 0,
+// bit for bit: the factors are in [0, 1]), so on SQUARE planes the three projections (x,y), (x,z), (z,x) of a sample share
+// their axes: three axis computations instead of six.
+// Every per-lane condition here is consumed by the v_cndmask that follows its v_cmp; none is combined with another one.  The
+// combined form `(vx && vy) ? w : 0` compiles to v_cmp -> SGPR pair, s_and_b64 vcc, v_cndmask, and that SALU step has returned
+// a stale mask for lanes 48-63 in a 256-register kernel at two waves per SIMD (profiles/experiments/r02_lane_mask.md).
+struct Axis { int c0, c1; float a0, a1; float in; };
 __device__ __forceinline__ Axis axis_geometry(int size, float g) {
     Axis a;
     const float i = (g + 1.0f) * (0.5f * (float)size) - 0.5f;
@@ -110,18 +90,23 @@ __device__ __forceinline__ Axis axis_geometry(int size, float g) {
     const float d = i - f0, e = 1.0f - d;
     const int x0 = (int)fminf(fmaxf(f0, -2.0f), (float)(size + 1));
     const int x1 = x0 + 1;
-    const bool v0 = (unsigned)x0 < (unsigned)size, v1 = (unsigned)x1 < (unsigned)size;
-    a.a0 = v0 ? e : 0.0f; a.a1 = v1 ? d : 0.0f;
+    a.a0 = (unsigned)x0 < (unsigned)size ? e : 0.0f;
+    a.a1 = (unsigned)x1 < (unsigned)size ? d : 0.0f;
     a.c0 = min(max(x0, 0), size - 1); a.c1 = min(max(x1, 0), size - 1);
-    a.in = v0 && v1;
+    a.in = (unsigned)x0 < (unsigned)(size - 1) ? 1.0f : 0.0f;           // 0 <= x0 and x0 + 1 < size
     return a;
 }
 __device__ __forceinline__ Taps taps_from_axes(const Axis& u, const Axis& v) {      // u indexes W, v indexes H
     Taps t;
     t.xc0 = u.c0; t.xc1 = u.c1; t.yc0 = v.c0; t.yc1 = v.c1;
     t.w[0] = u.a0 * v.a0; t.w[1] = u.a1 * v.a0; t.w[2] = u.a0 * v.a1; t.w[3] = u.a1 * v.a1;
-    t.wdef = (u.in && v.in) ? 0.0f : ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3])) - 1.0f;
+    t.wdef = u.in * v.in != 0.0f ? 0.0f : ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3])) - 1.0f;
     return t;
+}
+// Bilinear tap geometry of one sample on one plane: F.grid_sample(bilinear, zeros, align_corners=False), renderer.py:64,
+// unnormalised as ATen's CPU kernel does.  Clamped coordinates are always addressable; out-of-range taps carry weight 0.
+__device__ __forceinline__ Taps tap_geometry(int H, int W, float u, float v) {
+    return taps_from_axes(axis_geometry(W, u), axis_geometry(H, v));
 }
 
 }  // namespace nfe

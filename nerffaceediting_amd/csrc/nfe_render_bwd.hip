@@ -48,6 +48,9 @@ struct BwdK {
     float* grad_g; float* grad_a; long long grad_view_stride;
     float* rec_sig; float* rec_a; float* rec_T;      // [N*M*S] each: (sigma, a, T) then (dL/dsigma, omega, -)
     const uint4* bfrag;                // split-bf16 MFMA fragments of the decoder and its transposes (bwd_frag_kernel), or null
+    // binned scatter (one chunk of views x 64-ray tiles): feature gradients, bin records and their sorted list
+    float* df; uint2* rec_key; float4* rec_w; uint2* binrank; unsigned* counts; unsigned* offsets; uint2* list_key; float4* list_w;
+    int n0, t0, t_count, bins_x, bins_y;      // chunk origin (view, ray tile), ray tiles per view in the chunk, plane tiles
 };
 
 struct PrepK { const float* w[8]; float lr_mul; float* out; };
@@ -133,7 +136,11 @@ __device__ __forceinline__ void gather_set(const float* __restrict__ planes, con
         float wsum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 5      // timing experiment: every tap reads the same texel row (no gather traffic)
+            const float4* tx = reinterpret_cast<const float4*>(planes + (g.off[4 * p + k] & 0));
+#else
             const float4* tx = reinterpret_cast<const float4*>(planes + g.off[4 * p + k]);
+#endif
             const f32x2 w = splat(g.w[4 * p + k]);
             wsum += g.w[4 * p + k];
 #pragma unroll
@@ -341,11 +348,11 @@ __device__ __forceinline__ void scatter_set(float* __restrict__ tile, const f32x
             const int off = __shfl(geo.off[k], src);
             const float w = __shfl(geo.w[k], src);
 #if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 1      // timing experiments only: plain stores / no memory operation
-            if (alive && w != 0.0f) grad[off + ch] = v * w * sc[k >> 2];
+            if ((alive ? w : 0.0f) != 0.0f) grad[off + ch] = v * w * sc[k >> 2];
 #elif defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 2
-            if (alive && w != 0.0f) asm volatile("" :: "v"(v * w * sc[k >> 2]), "v"(off));
+            if ((alive ? w : 0.0f) != 0.0f) asm volatile("" :: "v"(v * w * sc[k >> 2]), "v"(off));
 #else
-            if (alive && w != 0.0f) unsafeAtomicAdd(grad + off + ch, v * w * sc[k >> 2]);
+            if ((alive ? w : 0.0f) != 0.0f) unsafeAtomicAdd(grad + off + ch, v * w * sc[k >> 2]);
 #endif
         }
     }
@@ -606,13 +613,19 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 // ------------------------------------------------------------------------------------------------------------
 constexpr int SORT_TILE_STRIDE = 65;
 constexpr unsigned KEY_INVALID = 0xFFFFFFFFu;
+constexpr int BIN_SHIFT = 3, BIN_MASK = 7, BIN_TEXELS = 9;       // plane tiles of the binned form: 8 x 8 texels + the far taps' row/column
+constexpr int BIN_SEGMENT = 1024;                                // records per workgroup before a bin is split (at most BIN_SPLIT ways)
+constexpr int BIN_SPLIT = 4;
+constexpr int BIN_BATCH = 16;                                    // records (256-byte row loads) a wave keeps in flight
+constexpr uint64_t BWD_CHUNK_SAMPLES = 1ull << 23;               // 2 GiB of feature gradients per chunk
+constexpr uint64_t BWD_MAX_BINS = 1ull << 19;
 
-template <bool MFMA>
+template <bool MFMA, bool BINNED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_scatter_sorted_kernel(BwdK P) {   // 256 registers
     __shared__ float tile[64 * SORT_TILE_STRIDE];       // [sample][0..31 geometry-set gradient, 32..63 appearance-set]
-    __shared__ float wtab[64 * 12];                     // tap weights [sample][plane*4 + tap]
+    __shared__ float wtab[BINNED ? 1 : 64 * 12];        // tap weights [sample][plane*4 + tap]
     const int lane = threadIdx.x;
-    const int n = blockIdx.z, kdepth = blockIdx.y, t = blockIdx.x;
+    const int n = blockIdx.z + (BINNED ? P.n0 : 0), kdepth = blockIdx.y, t = blockIdx.x + (BINNED ? P.t0 : 0);
     int m; bool live = true;
     if (P.R > 0 && (P.R & 7) == 0 && (long long)P.R * P.R == P.M) {       // 8x8 pixel tile
         const int tiles_x = P.R >> 3;
@@ -702,6 +715,64 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 3      // timing experiment: decoder phase only
     if (tile[lane] != 12345.678f) return;
 #endif
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 6      // timing experiment: gather + decoder only
+    if (BINNED) { if (tile[lane] != 12345.678f) return; }
+#endif
+    if (BINNED) {       // feature gradients to the chunk buffer, one bin record per (sample, plane); bwd_accumulate_kernel adds them up
+        __builtin_amdgcn_wave_barrier();
+        const unsigned wave = ((unsigned)blockIdx.z * (unsigned)P.t_count + blockIdx.x) * (unsigned)P.S + (unsigned)kdepth;
+        float* dst = P.df + (size_t)wave * 4096 + lane;
+#pragma unroll 8
+        for (int sidx = 0; sidx < 64; ++sidx) dst[sidx * 64] = tile[sidx * SORT_TILE_STRIDE + lane];
+        const unsigned idx = wave * 64 + (unsigned)lane;
+        const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
+        float ro[3], rd[3];                 // tap geometry again (cheaper than 24 registers kept across the decoder)
+        ray_of(P, n, m, ro, rd);
+        const float tt = P.depths[g];
+        const float cx = P.coord_scale * fmaf(tt, rd[0], ro[0]), cy = P.coord_scale * fmaf(tt, rd[1], ro[1]), cz = P.coord_scale * fmaf(tt, rd[2], ro[2]);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const Taps tp = tap_geometry(P.H, P.W, p == 2 ? cz : cx, p == 0 ? cy : (p == 1 ? cz : cx));      // as sample_geometry
+            const int x0 = tp.xc0, x1 = tp.xc1, y0 = tp.yc0, y1 = tp.yc1;
+            // (one compare per decision, no lane masks combined on the scalar unit: profiles/experiments/r02_lane_mask.md)
+            const bool any = (live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
+            const unsigned bin = any ? ((unsigned)blockIdx.z * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
+                                     : KEY_INVALID;
+            // rank inside the bin: one returning atomic per distinct bin of the wave.  The loop condition is made with scalar
+            // compares on purpose: the lane-mask form (v_cmp -> vcc, s_cbranch_vccz) of a uniform branch is not reliable in a
+            // 256-register kernel at two waves per SIMD (profiles/experiments/r02_square_branch.md; it went the wrong way here too)
+            unsigned rank = 0;
+            const unsigned long long have = __ballot(any);
+            unsigned todo_lo = (unsigned)have, todo_hi = (unsigned)(have >> 32);
+            for (;;) {
+                todo_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_lo); todo_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_hi);
+                asm volatile("" : "+s"(todo_lo), "+s"(todo_hi));
+                if ((todo_lo | todo_hi) == 0u) break;
+                const int leader = todo_lo ? __builtin_ctz(todo_lo) : 32 + __builtin_ctz(todo_hi);
+                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                const unsigned long long same = __ballot(bin == b);          // b is a live record's bin, dead lanes hold KEY_INVALID
+                unsigned base = 0;
+                if (lane == leader) base = atomicAdd(P.counts + b, (unsigned)__popcll(same));
+                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
+                if (bin == b) rank = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+                todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
+            }
+            const size_t slot = (size_t)p * ((size_t)gridDim.z * P.t_count * P.S * 64) + idx;
+            P.binrank[slot] = make_uint2(bin, rank);
+            if (any) {
+                // The accumulate pass adds the four taps of a record at local texels l0, l0 + 1, l0 + row, l0 + row + 1 with plain
+                // read-modify-writes, so they must be four different texels.  Where clamping makes two taps the same texel (x1 == x0
+                // at a plane edge: one of the pair is out of range and carries weight 0) their weights are folded into the first.
+                const int sx = x1 - x0, sy = y1 - y0;
+                float w0 = tp.w[0], w1 = tp.w[1], w2 = tp.w[2], w3 = tp.w[3];
+                if (sx == 0) { w0 += w1; w2 += w3; w1 = 0.0f; w3 = 0.0f; }
+                if (sy == 0) { w0 += w2; w1 += w3; w2 = 0.0f; w3 = 0.0f; }
+                P.rec_key[slot] = make_uint2(idx, (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK)));
+                P.rec_w[slot] = make_float4(w0, w1, w2, w3);
+            }
+        }
+        return;
+    }
     const int plane_elems = P.H * P.W * 32;
     unsigned key[3][4];                                 // element e = lane * 4 + r of each plane's list
 #pragma unroll
@@ -709,7 +780,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const int p = q >> 2;
         wtab[lane * 12 + q] = geo.w[q];
         const unsigned texel = (unsigned)(geo.off[q] - p * plane_elems) >> 5;
-        key[p][q & 3] = (live && geo.w[q] != 0.0f) ? (texel << 8 | (unsigned)lane << 2 | (unsigned)(q & 3)) : KEY_INVALID;
+        key[p][q & 3] = (live ? geo.w[q] : 0.0f) != 0.0f ? (texel << 8 | (unsigned)lane << 2 | (unsigned)(q & 3)) : KEY_INVALID;
     }
     __threadfence_block();
     // bitonic sort of the three 256-key lists in registers (ascending; invalid keys end up last): partners at distance
@@ -787,7 +858,158 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// pass 3, binned form (default).  The memory-side float atomics bound the sorted form (4.6 M atomic texel rows per 1.6 M
+// samples); here ONE WAVE owns an 8 x 8 texel tile of one plane of one view and adds every tap that lands on it into its own
+// LDS tile (both plane sets: 9 x 9 texels x 64 channels = 20 KiB, seven waves per CU) with plain read-modify-writes - LDS
+// executes a wave's operations in order and nobody else writes the tile; ds_add_f32 is not an option: measured at one lane per
+// 12 cycles (768 cycles per wave instruction, tools/microbench/valu_rate.hip) - then adds the tile to the gradient planes once.
+//   bwd_scatter_sorted_kernel<MFMA, BINNED>  decoder backward per sample -> df[sample][64] (256 B rows) + per (sample, plane) a
+//                                            record (sample, four tile-local texels, 4 weights), its bin and its rank in the bin
+//                                            (one returning atomic per distinct bin of a wave)
+//   bwd_bin_scan_kernel                      exclusive scan of the bin counts
+//   bwd_bin_fill_kernel                      records to their sorted position
+//   bwd_accumulate_kernel                    one wave per (bin, segment): 64 records at a time (one per lane), then per record
+//                                            one 256-byte row load (lane = channel of both sets, 16 in flight) and 4 LDS updates
+// Work is cut into chunks (whole views, or ray tiles of one view) so that df stays within BWD_CHUNK_SAMPLES * 256 B.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void bwd_bin_scan_kernel(const unsigned* __restrict__ counts, unsigned* __restrict__ offsets, int nbins) {
+    __shared__ unsigned part[1024];
+    const int per = (nbins + 1023) / 1024;
+    const int b0 = threadIdx.x * per, b1 = min(b0 + per, nbins);
+    unsigned sum = 0;
+    for (int b = b0; b < b1; ++b) sum += counts[b];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const unsigned v = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    unsigned run = part[threadIdx.x] - sum;
+    for (int b = b0; b < b1; ++b) { offsets[b] = run; run += counts[b]; }
+}
+
+__global__ __launch_bounds__(256) void bwd_bin_fill_kernel(BwdK P, unsigned long long slots) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= slots) return;
+    const uint2 br = P.binrank[i];
+    if (br.x == KEY_INVALID) return;
+    const unsigned pos = P.offsets[br.x] + br.y;
+    P.list_key[pos] = P.rec_key[i];
+    P.list_w[pos] = P.rec_w[i];
+}
+
+__global__ __launch_bounds__(64) void bwd_accumulate_kernel(BwdK P) {
+    __shared__ float acc[BIN_TEXELS * BIN_TEXELS * 64];      // [texel][channel of both sets]; this wave is the only writer: no LDS atomics
+    const unsigned bin = blockIdx.x;                         // (ds_add_f32 runs at one lane per 12 cycles on gfx950, profiles/r02_valu_rate.txt)
+    const unsigned count = P.counts[bin];
+    const unsigned seg_len = max((unsigned)BIN_SEGMENT, (count + gridDim.y - 1) / gridDim.y);
+    const unsigned seg0 = blockIdx.y * seg_len;
+    if (seg0 >= count) return;
+    const unsigned seg1 = min(seg0 + seg_len, count);
+    const int lane = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < BIN_TEXELS * BIN_TEXELS; ++i) acc[i * 64 + lane] = 0.0f;
+    const unsigned first = P.offsets[bin] + seg0, last = P.offsets[bin] + seg1;
+    const float* __restrict__ df = P.df + lane;
+    float* accl = acc + lane;
+    // 64 records at a time, one per lane (lanes past the end: the last record with zero weights); per record one 256-byte row
+    // load, lane = channel.  Two-deep pipeline: the next 64 records and the next 16 rows are in flight while 16 rows are added.
+    auto load_keys = [&](unsigned r0, uint2& key, float4& wq) {
+        const bool in = r0 + (unsigned)lane < last;
+        key = P.list_key[in ? r0 + (unsigned)lane : last - 1];
+        wq = P.list_w[in ? r0 + (unsigned)lane : last - 1];
+        if (!in) wq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    uint2 key; float4 wq;
+    load_keys(first, key, wq);
+    for (unsigned r0 = first; r0 < last; r0 += 64) {
+        uint2 nkey; float4 nwq;
+        load_keys(min(r0 + 64, last - 1), nkey, nwq);
+        float va[BIN_BATCH], vb[BIN_BATCH];      // ping-pong (no copies: a register move would wait for the load it copies)
+        auto fetch = [&](float (&v)[BIN_BATCH], int i0) {
+#pragma unroll
+            for (int u = 0; u < BIN_BATCH; ++u) v[u] = df[(size_t)(unsigned)__builtin_amdgcn_readlane((int)key.x, i0 + u) * 64];
+        };
+        auto add = [&](const float (&v)[BIN_BATCH], int i0) {
+#pragma unroll
+            for (int u = 0; u < BIN_BATCH; ++u) {
+                const int i = i0 + u;
+                float* a = accl + ((unsigned)__builtin_amdgcn_readlane((int)key.y, i) << 6);
+                const float w0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wq.x), i));
+                const float w1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wq.y), i));
+                const float w2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wq.z), i));
+                const float w3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wq.w), i));
+                const float c0 = a[0], c1 = a[64], c2 = a[BIN_TEXELS * 64], c3 = a[BIN_TEXELS * 64 + 64];      // four different texels
+                a[0] = fmaf(w0, v[u], c0);
+                a[64] = fmaf(w1, v[u], c1);
+                a[BIN_TEXELS * 64] = fmaf(w2, v[u], c2);
+                a[BIN_TEXELS * 64 + 64] = fmaf(w3, v[u], c3);
+            }
+        };
+        static_assert(BIN_BATCH == 16, "the 64 records of a group are four batches");
+        const int cnt = (int)min(64u, last - r0);
+        fetch(va, 0);
+        if (cnt > 16) fetch(vb, 16);
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads ahead of the batch they overlap with
+        add(va, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 32) fetch(va, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 16) add(vb, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 48) fetch(vb, 48);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 32) add(va, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 48) add(vb, 48);
+        key = nkey; wq = nwq;
+    }
+    // tile -> gradient planes: lanes 0..31 the geometry set, 32..63 the appearance set, one 128-byte row each per atomic
+    const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
+    const unsigned vp = bin / bins_per_plane, tb = bin - vp * bins_per_plane;
+    const int n = P.n0 + (int)(vp / 3), p = (int)(vp % 3);
+    const int ty = (int)(tb / P.bins_x), tx = (int)(tb - ty * P.bins_x);
+    const int ch = lane & 31, set = lane >> 5;
+    float* g = set ? ((P.grad_a && P.g_rgb) ? P.grad_a : nullptr) : P.grad_g;
+    const float* scale = P.aff[2 * set] ? P.aff[2 * set] + n * 96 : nullptr;
+    const float sc = scale ? scale[p * 32 + ch] : 1.0f;
+    if (g) g += (long long)n * P.grad_view_stride + (long long)p * P.H * P.W * 32 + ch;
+#pragma unroll 1
+    for (int ly = 0; ly < BIN_TEXELS; ++ly) {
+        const int y = (ty << BIN_SHIFT) + ly;
+        if (y >= P.H) break;
+#pragma unroll
+        for (int lx = 0; lx < BIN_TEXELS; ++lx) {
+            const int x = (tx << BIN_SHIFT) + lx;
+            if (x >= P.W) break;
+            const float v = g ? acc[((ly * BIN_TEXELS + lx) << 6) + lane] : 0.0f;
+            if (v != 0.0f) unsafeAtomicAdd(g + ((long long)y * P.W + x) * 32, v * sc);
+        }
+    }
+}
+
 static uint64_t align256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
+
+// Chunking of the binned scatter: sample slots (64 per wave, whole 64-ray tiles x all depths) of the largest chunk
+static uint64_t chunk_limit() {
+    static const uint64_t v = [] { const char* e = getenv("NFE_BWD_CHUNK"); const long long x = e ? atoll(e) : 0; return x > 0 ? (uint64_t)x : BWD_CHUNK_SAMPLES; }();
+    return v;
+}
+static uint64_t chunk_slots(int n_views, int n_rays, int n_samples) {
+    if (n_views <= 0 || n_rays <= 0 || n_samples <= 0) return 0;
+    const uint64_t tiles = ((uint64_t)n_rays + 63) / 64, per_tile = 64ull * (uint64_t)n_samples, per_view = tiles * per_tile;
+    const uint64_t cap = chunk_limit() > per_tile ? chunk_limit() : per_tile;
+    if (per_view >= cap) return (cap / per_tile) * per_tile;                            // ray tiles of one view
+    const uint64_t views = cap / per_view < (uint64_t)n_views ? cap / per_view : (uint64_t)n_views;
+    return views * per_view;
+}
+// df rows + (key, weights) records and their sorted copy + (bin, rank) + counts and offsets
+static uint64_t binned_bytes(uint64_t slots) {
+    return align256(slots * 256) + 2 * (align256(slots * 3 * 8) + align256(slots * 3 * 16)) + align256(slots * 3 * 8) + 2 * align256(BWD_MAX_BINS * 4);
+}
 
 }  // namespace nfe
 
@@ -795,7 +1017,8 @@ using namespace nfe;
 
 extern "C" uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples) {
     const uint64_t ns = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0) * (uint64_t)(n_samples > 0 ? n_samples : 0);
-    return BWD_DEC_BYTES + 3 * align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES);
+    return BWD_DEC_BYTES + 3 * align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES) +
+           binned_bytes(chunk_slots(n_views, n_rays, n_samples));
 }
 
 extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream_t stream) {
@@ -867,22 +1090,61 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     const long long rays = (long long)a->n_views * a->n_rays;
     hipLaunchKernelGGL(bwd_ray_kernel, dim3((unsigned)((rays + 255) / 256)), dim3(256), 0, st, P);
     NFE_CHECK_LAUNCH("bwd_ray_kernel");
-    static const bool direct = [] { const char* e = getenv("NFE_BWD_SCATTER"); return e && e[0] == 'd'; }();     // A/B knob: "direct"
-    if (direct || (long long)a->plane_h * a->plane_w > (1ll << 24)) {      // sort keys carry a 24-bit texel index
+    static const char scatter_mode = [] { const char* e = getenv("NFE_BWD_SCATTER"); return e ? e[0] : 'b'; }();     // A/B knob: "direct", "sorted", default binned
+    static const bool valu_dec = [] { const char* e = getenv("NFE_BWD_DECODER"); return e && e[0] == 'v'; }();      // A/B knob: "valu"
+    unsigned* frags = (unsigned*)((char*)P.rec_T + align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4));
+    if (scatter_mode == 'd' || (long long)a->plane_h * a->plane_w > (1ll << 24)) {      // sort keys carry a 24-bit texel index
         hipLaunchKernelGGL(bwd_scatter_kernel, sgrid, dim3(256), 0, st, P);
         NFE_CHECK_LAUNCH("bwd_scatter_kernel");
-    } else {
-        const dim3 tgrid((unsigned)((a->n_rays + 63) / 64), (unsigned)a->n_samples, (unsigned)a->n_views);
-        static const bool valu_dec = [] { const char* e = getenv("NFE_BWD_DECODER"); return e && e[0] == 'v'; }();      // A/B knob: "valu"
-        if (valu_dec) {
-            hipLaunchKernelGGL(bwd_scatter_sorted_kernel<false>, tgrid, dim3(64), 0, st, P);
-        } else {
-            unsigned* frags = (unsigned*)((char*)P.rec_T + align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4));
-            hipLaunchKernelGGL(bwd_frag_kernel, dim3((BF_COUNT * 64 * 4 + 255) / 256), dim3(256), 0, st, dec, frags);
-            P.bfrag = reinterpret_cast<const uint4*>(frags);
-            hipLaunchKernelGGL(bwd_scatter_sorted_kernel<true>, tgrid, dim3(64), 0, st, P);
-        }
+        return NFE_OK;
+    }
+    if (!valu_dec) {
+        hipLaunchKernelGGL(bwd_frag_kernel, dim3((BF_COUNT * 64 * 4 + 255) / 256), dim3(256), 0, st, dec, frags);
+        P.bfrag = reinterpret_cast<const uint4*>(frags);
+    }
+    const unsigned ray_tiles = (unsigned)((a->n_rays + 63) / 64);
+    P.bins_x = (a->plane_w + BIN_MASK) >> BIN_SHIFT; P.bins_y = (a->plane_h + BIN_MASK) >> BIN_SHIFT;
+    const uint64_t bins_per_view = 3ull * P.bins_x * P.bins_y;
+    if (scatter_mode == 's' || bins_per_view > BWD_MAX_BINS) {
+        const dim3 tgrid(ray_tiles, (unsigned)a->n_samples, (unsigned)a->n_views);
+        if (valu_dec) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<false, false>), tgrid, dim3(64), 0, st, P);
+        else hipLaunchKernelGGL((bwd_scatter_sorted_kernel<true, false>), tgrid, dim3(64), 0, st, P);
         NFE_CHECK_LAUNCH("bwd_scatter_sorted_kernel");
+        return NFE_OK;
+    }
+    // binned form, chunk by chunk
+    const uint64_t slots_max = chunk_slots(a->n_views, a->n_rays, a->n_samples);
+    char* bw = (char*)frags + align256(BWD_FRAG_BYTES);
+    P.df = (float*)bw; bw += align256(slots_max * 256);
+    P.rec_key = (uint2*)bw; bw += align256(slots_max * 3 * 8);
+    P.list_key = (uint2*)bw; bw += align256(slots_max * 3 * 8);
+    P.rec_w = (float4*)bw; bw += align256(slots_max * 3 * 16);
+    P.list_w = (float4*)bw; bw += align256(slots_max * 3 * 16);
+    P.binrank = (uint2*)bw; bw += align256(slots_max * 3 * 8);
+    P.counts = (unsigned*)bw; bw += align256(BWD_MAX_BINS * 4);
+    P.offsets = (unsigned*)bw;
+    const uint64_t per_tile = 64ull * (uint64_t)a->n_samples, view_slots = (uint64_t)ray_tiles * per_tile;
+    unsigned views_per_chunk = 1, tiles_per_chunk = ray_tiles;
+    if (view_slots >= slots_max) tiles_per_chunk = (unsigned)(slots_max / per_tile);
+    else views_per_chunk = (unsigned)(slots_max / view_slots);
+    while ((uint64_t)views_per_chunk * bins_per_view > BWD_MAX_BINS) --views_per_chunk;
+    for (unsigned n0 = 0; n0 < (unsigned)a->n_views; n0 += views_per_chunk) {
+        const unsigned nv = min(views_per_chunk, (unsigned)a->n_views - n0);
+        for (unsigned t0 = 0; t0 < ray_tiles; t0 += tiles_per_chunk) {
+            const unsigned nt = min(tiles_per_chunk, ray_tiles - t0);
+            P.n0 = (int)n0; P.t0 = (int)t0; P.t_count = (int)nt;
+            const unsigned nbins = nv * (unsigned)bins_per_view;
+            const unsigned long long slots = (unsigned long long)nv * nt * per_tile;
+            if (hipMemsetAsync(P.counts, 0, (size_t)nbins * 4, st) != hipSuccess) return fail(NFE_ELAUNCH, "nfe_render_backward: hipMemsetAsync failed");
+            const dim3 tgrid(nt, (unsigned)a->n_samples, nv);
+            if (valu_dec) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<false, true>), tgrid, dim3(64), 0, st, P);
+            else hipLaunchKernelGGL((bwd_scatter_sorted_kernel<true, true>), tgrid, dim3(64), 0, st, P);
+            NFE_CHECK_LAUNCH("bwd_scatter_sorted_kernel<binned>");
+            hipLaunchKernelGGL(bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, P.counts, P.offsets, (int)nbins);
+            hipLaunchKernelGGL(bwd_bin_fill_kernel, dim3((unsigned)((slots * 3 + 255) / 256)), dim3(256), 0, st, P, slots * 3);
+            hipLaunchKernelGGL(bwd_accumulate_kernel, dim3(nbins, BIN_SPLIT), dim3(64), 0, st, P);
+            NFE_CHECK_LAUNCH("bwd_accumulate_kernel");
+        }
     }
     return NFE_OK;
 }

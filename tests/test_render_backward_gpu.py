@@ -196,19 +196,52 @@ def test_backward_full_size_vs_reference_autograd(dev):
         assert err <= REL_TOL * scale and serr <= 1e-4
 
 
-def test_direct_scatter_form():
-    """The one-atomic-row-per-tap scatter (planes beyond 2^24 texels; NFE_BWD_SCATTER=direct) against the same goldens.  The
-    switch is read once per process, so the cases run in a child interpreter."""
+@pytest.mark.parametrize("env", [{"NFE_BWD_SCATTER": "direct"}, {"NFE_BWD_SCATTER": "sorted"}, {"NFE_BWD_CHUNK": "30000"},
+                                 {"NFE_BWD_CHUNK": "400000", "NFE_BWD_DECODER": "valu"}],
+                         ids=["direct", "sorted", "binned_ray_chunks", "binned_view_chunks_valu"])
+def test_other_scatter_forms(env):
+    """The default scatter is the binned form in one chunk.  Same goldens for: the one-atomic-row-per-tap form (planes beyond 2^24
+    texels), the sorted-run form (planes whose 8 x 8 tiling exceeds the bin table), the binned form cut into chunks of ray tiles
+    and of whole views, and the fp32 VALU decoder.  The switches are read once per process, so the cases run in a child interpreter."""
     import os
     import subprocess
     import sys
-    if os.environ.get("NFE_BWD_SCATTER") == "direct":
+    if os.environ.get("NFE_BWD_CHILD") == "1":
         pytest.skip("already the child run")
-    env = dict(os.environ, NFE_BWD_SCATTER="direct")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", os.path.abspath(__file__), "-k",
-                        "reference_autograd or camera_rays"], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+                        "reference_autograd or camera_rays or broadcast"], cwd=root, env=dict(os.environ, NFE_BWD_CHILD="1", **env),
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_backward_is_repeatable(dev):
+    """Six launches of the editing-size backward give the same gradients up to the order of the float adds (1e-6 of the largest
+    entry).  Guards the binned scatter's record stream: a lane-mask hazard once zeroed single tap weights of lanes 48-63 in
+    a handful of waves per launch (profiles/experiments/r02_lane_mask.md), which moved gradients by percents from run to run."""
+    from nerffaceediting_amd import ops
+    N, R, D, Di, H = 2, 128, 48, 48, 256
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pn = torch.randn(N, 3, H, H, 32, generator=g).to(dev)
+    pd = (torch.randn(N, 3, H, H, 32, generator=g) * 1.3 + 0.2).to(dev)
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+    heads = [torch.randn(*s, generator=g).to(dev) * (1.0 if len(s) == 2 else 0.2) for s in shapes]
+    heads[3][0] += 2.0
+    c2w = np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2, [0, 0, 0.2], 2.7).reshape(1, 4, 4) for y in (-0.4, 0.4)])
+    K = np.stack([orc.fov_to_intrinsics(18.837)] * N)
+    kw = dict(cam2world=t(c2w.astype(np.float32), dev), intrinsics=t(K.astype(np.float32), dev), resolution=R)
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    cots = tuple(torch.randn(N, R * R, c, generator=g).to(dev) for c in (32, 15, 1, 1))
+    out = ops.render(pn, pd, ops.decoder_pack(*heads), opts, seed=1, taps=True, **kw)
+    runs = []
+    for _ in range(6):
+        gg, ga = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, **kw)
+        runs.append((gg.clone(), ga.clone()))
+    for k in (0, 1):
+        scale = float(runs[0][k].abs().max())
+        assert scale > 0
+        for r in runs[1:]:
+            assert float((r[k] - runs[0][k]).abs().max()) <= 1e-6 * scale
 
 
 def test_backward_finite_differences_larger_size(dev):

@@ -19,12 +19,13 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-enum Mode { FMA = 0, PK_FMA, EXP, MOV_DPP, SWIZZLE, MFMA_ONLY, MFMA_FMA8, MFMA_FMA4, MFMA_PK4, FMA_EXP_MIX, PK_MUL, CVT_PK, PERM, LDS_READ128, N_MODES };
+enum Mode { FMA = 0, PK_FMA, EXP, MOV_DPP, SWIZZLE, MFMA_ONLY, MFMA_FMA8, MFMA_FMA4, MFMA_PK4, FMA_EXP_MIX, PK_MUL, CVT_PK, PERM, LDS_READ128, LDS_ADD_F32, LDS_ADD_U32, LDS_RMW_F32, N_MODES };
 static const char* mode_name[N_MODES] = {"v_fma_f32", "v_pk_fma_f32", "v_exp_f32", "v_mov_b32 dpp quad_perm", "ds_swizzle_b32",
                                          "mfma_32x32x16_bf16 alone", "mfma + 8 v_fma_f32", "mfma + 4 v_fma_f32", "mfma + 4 v_pk_fma_f32",
-                                         "6 v_fma + 2 v_exp", "v_pk_mul_f32", "v_cvt_pk_bf16_f32", "v_perm_b32", "ds_read_b128"};
+                                         "6 v_fma + 2 v_exp", "v_pk_mul_f32", "v_cvt_pk_bf16_f32", "v_perm_b32", "ds_read_b128",
+                                         "ds_add_f32 (64 banks)", "ds_add_u32 (64 banks)", "ds_read_b32+add+ds_write_b32"};
 // instructions counted per loop iteration (the "unit" whose cycles are reported)
-static const int per_iter[N_MODES] = {64, 64, 64, 64, 64, 16, 16 * 9, 16 * 5, 16 * 5, 64, 64, 64, 64, 32};
+static const int per_iter[N_MODES] = {64, 64, 64, 64, 64, 16, 16 * 9, 16 * 5, 16 * 5, 64, 64, 64, 64, 32, 32, 32, 32};
 
 template <int MODE>
 __global__ __launch_bounds__(1024) void rate(float* out, int iters, unsigned long long* cycles) {
@@ -108,6 +109,25 @@ __global__ __launch_bounds__(1024) void rate(float* out, int iters, unsigned lon
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)");
             }
+        } else if (MODE == LDS_ADD_F32 || MODE == LDS_ADD_U32) {
+            // lane = consecutive dword (conflict-free), rows differ per instruction and per wave
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const unsigned addr = (unsigned)(size_t)(lds + ((threadIdx.x >> 6) & 3) * 1024 + (i & 15) * 64 + (threadIdx.x & 63));
+                if (MODE == LDS_ADD_F32) asm volatile("ds_add_f32 %0, %1" :: "v"(addr), "v"(a[i & 15]) : "memory");
+                else asm volatile("ds_add_u32 %0, %1" :: "v"(addr), "v"(u) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)");
+        } else if (MODE == LDS_RMW_F32) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                const unsigned addr = (unsigned)(size_t)(lds + ((threadIdx.x >> 6) & 3) * 1024 + (i & 15) * 64 + (threadIdx.x & 63));
+                float t;
+                asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(t) : "v"(addr) : "memory");
+                t += a[i & 15];
+                asm volatile("ds_write_b32 %0, %1" :: "v"(addr), "v"(t) : "memory");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)");
         } else {
             // 16 MFMAs per iteration on two accumulators, with k VALU fillers after each
 #pragma unroll
@@ -181,6 +201,9 @@ int main() {
     run<CVT_PK>(cus, out, dcyc);
     run<PERM>(cus, out, dcyc);
     run<LDS_READ128>(cus, out, dcyc);
+    run<LDS_ADD_F32>(cus, out, dcyc);
+    run<LDS_ADD_U32>(cus, out, dcyc);
+    run<LDS_RMW_F32>(cus, out, dcyc);
     run<MFMA_ONLY>(cus, out, dcyc);
     run<MFMA_FMA4>(cus, out, dcyc);
     run<MFMA_FMA8>(cus, out, dcyc);
