@@ -611,7 +611,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 // texels, and issues ONE atomic row per run and plane set (lanes 0..31: geometry set, 32..63: appearance set).
 // The atomic unit - the bound of the direct form - sees 3.4x fewer operations.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int SORT_TILE_STRIDE = 65;
+constexpr int SORT_TILE_STRIDE = 68;      // floats per sample row: rows stay 16-byte aligned (the gather exchange uses ds_*_b128)
 constexpr unsigned KEY_INVALID = 0xFFFFFFFFu;
 constexpr int BIN_SHIFT = 3, BIN_MASK = 7, BIN_TEXELS = 9;       // plane tiles of the binned form: 8 x 8 texels + the far taps' row/column
 constexpr int BIN_SEGMENT = 1024;                                // records per workgroup before a bin is split (at most BIN_SPLIT ways)
@@ -620,9 +620,85 @@ constexpr int BIN_BATCH = 16;                                    // records (256
 constexpr uint64_t BWD_CHUNK_SAMPLES = 1ull << 23;               // 2 GiB of feature gradients per chunk
 constexpr uint64_t BWD_MAX_BINS = 1ull << 19;
 
+// Both plane sets of the wave's 64 samples, gathered with EIGHT LANES PER TEXEL ROW (lane = (sample within a group of 8, 4
+// channels)): a 16-byte load instruction covers 8 rows of 128 contiguous bytes instead of 64 rows, which is what the texture
+// path is priced by (the lane = sample form of gather_set spends more than half of this kernel there).  Tap offsets and weights
+// live in the lane = sample layout and are fetched by ds_bpermute.  Results go through the tile: row = sample, columns 0..31 the
+// geometry set, 32..63 the appearance set, already scaled by 1/3; same operation order per channel as gather_set.
+// "pointer is not null" as an integer in an SGPR, opaque to the optimiser: branches on it are s_cmp + s_cbranch_scc, never the
+// lane-mask form (s_and_b64 vcc, exec, mask; s_cbranch_vccz) that has gone the wrong way in 256-register kernels at two waves
+// per SIMD (profiles/experiments/r02_square_branch.md, r02_lane_mask.md)
+__device__ __forceinline__ int sgpr_nonnull(const void* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    int f;
+    asm volatile("s_cmp_lg_u64 %1, 0\n\ts_cselect_b32 %0, 1, 0" : "=s"(f) : "s"(v) : "scc");
+    return f;
+}
+
+template <bool DO_G, bool DO_A>
+__device__ __forceinline__ void gather_pair_coop(const BwdK& P, int n, const SampleGeo& geo, int lane, float* tile) {
+    const int s8 = lane >> 3, c4 = (lane & 7) * 4;
+    const long long pv = (long long)n * P.plane_view_stride;
+    const float* pg = P.planes_g + pv + c4;
+    const float* pa = P.planes_a + pv + c4;
+    float4 sc[2][3], sh[2][3];
+#pragma unroll
+    for (int set = 0; set < 2; ++set)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            sc[set][p] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+            sh[set][p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+    for (int set = 0; set < 2; ++set)
+        if (sgpr_nonnull(P.aff[2 * set]) != 0) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                sc[set][p] = *reinterpret_cast<const float4*>(P.aff[2 * set] + n * 96 + p * 32 + c4);
+                sh[set][p] = *reinterpret_cast<const float4*>(P.aff[2 * set + 1] + n * 96 + p * 32 + c4);
+            }
+        }
+    auto fma4 = [](float w, const float4& v, const float4& a) { return make_float4(fmaf(w, v.x, a.x), fmaf(w, v.y, a.y), fmaf(w, v.z, a.z), fmaf(w, v.w, a.w)); };
+    auto affine = [](const float4& s, const float4& c, float wsum, const float4& h, const float4& f) {
+        return make_float4(f.x + fmaf(s.x, c.x, wsum * h.x), f.y + fmaf(s.y, c.y, wsum * h.y), f.z + fmaf(s.z, c.z, wsum * h.z), f.w + fmaf(s.w, c.w, wsum * h.w));
+    };
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+        const int src = 8 * i + s8;
+        float4 fg = make_float4(0.0f, 0.0f, 0.0f, 0.0f), fa = fg;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            float4 sg = make_float4(0.0f, 0.0f, 0.0f, 0.0f), sa = sg;
+            float wsum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int off = __shfl(geo.off[4 * p + k], src);
+                const float w = __shfl(geo.w[4 * p + k], src);
+                wsum += w;
+                if (DO_G) sg = fma4(w, *reinterpret_cast<const float4*>(pg + off), sg);
+                if (DO_A) sa = fma4(w, *reinterpret_cast<const float4*>(pa + off), sa);
+            }
+            fg = affine(sg, sc[0][p], wsum, sh[0][p], fg);
+            fa = affine(sa, sc[1][p], wsum, sh[1][p], fa);
+        }
+        const float third = 1.0f / 3.0f;        // mean over planes, triplane.py:251
+        *reinterpret_cast<float4*>(tile + src * SORT_TILE_STRIDE + c4) = make_float4(fg.x * third, fg.y * third, fg.z * third, fg.w * third);
+        *reinterpret_cast<float4*>(tile + src * SORT_TILE_STRIDE + 32 + c4) = make_float4(fa.x * third, fa.y * third, fa.z * third, fa.w * third);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+// this lane's sample (lane = sample) back from the tile
+__device__ __forceinline__ void tile_row(const float* tile, int lane, int col0, f32x2 (&f)[16]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(tile + lane * SORT_TILE_STRIDE + col0 + 4 * q);
+        f[2 * q] = f32x2{v.x, v.y}; f[2 * q + 1] = f32x2{v.z, v.w};
+    }
+}
+
 template <bool MFMA, bool BINNED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_scatter_sorted_kernel(BwdK P) {   // 256 registers
-    __shared__ float tile[64 * SORT_TILE_STRIDE];       // [sample][0..31 geometry-set gradient, 32..63 appearance-set]
+    __shared__ __attribute__((aligned(16))) float tile[64 * SORT_TILE_STRIDE];       // [sample][0..31 geometry-set gradient, 32..63 appearance-set]
     __shared__ float wtab[BINNED ? 1 : 64 * 12];        // tap weights [sample][plane*4 + tap]
     const int lane = threadIdx.x;
     const int n = blockIdx.z + (BINNED ? P.n0 : 0), kdepth = blockIdx.y, t = blockIdx.x + (BINNED ? P.t0 : 0);
@@ -645,8 +721,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const uint4* F = P.bfrag + lane;
         const int jj = lane & 31, hh = lane >> 5;
         f32x2 f[16];
+        const int sets = sgpr_nonnull(P.grad_g) | (sgpr_nonnull(P.grad_a) & sgpr_nonnull(P.g_rgb)) << 1;
+        if (sets == 3) gather_pair_coop<true, true>(P, n, geo, lane, tile);          // (no run-time switch inside the pipelined loop)
+        else if (sets == 1) gather_pair_coop<true, false>(P, n, geo, lane, tile);
+        else gather_pair_coop<false, true>(P, n, geo, lane, tile);
         if (do_g) {
-            gather_set(P.planes_g + pv, geo, P.aff[0] ? P.aff[0] + n * 96 : nullptr, P.aff[1] ? P.aff[1] + n * 96 : nullptr, f);
+            tile_row(tile, lane, 0, f);
             head_mfma<false>(F, dec, f, lane, tile, SORT_TILE_STRIDE, 0,
                              [&](int b, float (&d)[8]) {          // outputs 8h..8h+7 of sample 32b + j: sigma = 0, seg = 1..15 (triplane.py:260-261)
                                  const int src = 32 * b + jj;
@@ -664,7 +744,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int c = 0; c < 32; ++c) tile[lane * SORT_TILE_STRIDE + c] = 0.0f;
         }
         if (do_a) {
-            gather_set(P.planes_a + pv, geo, P.aff[2] ? P.aff[2] + n * 96 : nullptr, P.aff[3] ? P.aff[3] + n * 96 : nullptr, f);
+            tile_row(tile, lane, 32, f);
             head_mfma<true>(F, dec, f, lane, tile, SORT_TILE_STRIDE, 32, [](int, float (&)[8]) {},
                             [&](int b, f32x16& y) {               // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269), channel 16h + r
                                 const int src = 32 * b + jj;
