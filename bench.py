@@ -262,10 +262,17 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     config={"workload": "SURVEY 8(f)4 backward pass: 4 views/GPU/step, 128^2 rays, 48 + 48 samples, norm/denorm plane sets with "
                                         "swapped statistics, random cotangents for rgb/seg/depth/wsum, gradients w.r.t. both plane sets",
                             "views_per_step": n_total, "forward_ms": fwd_ms, "backward_ms": bwd_ms, "parallelism": f"views-dp{world}"},
-                    roofline={"bound": "atomics", "achieved": None, "peak": None, "unit": None, "frac": None,
-                              "traffic": None, "kernel": "nfe::render_kernel<EVAL> + bwd_ray_kernel + bwd_scatter_sorted_kernel",
+                    roofline={"bound": "hbm", "achieved": None, "peak": None, "unit": None, "frac": None,
+                              "traffic": None,
+                              "kernel": "nfe::render_kernel<EVAL> + bwd_ray_kernel + bwd_scatter_sorted_kernel<MFMA,BINNED> + bwd_bin_fill_kernel + "
+                                        "bwd_accumulate_kernel",
                               "kernel_ms": bwd_ms, "logical_gather_scatter_gbs": ach,
-                              "note": "the scatter is bound by memory-side float atomics (profiles/r0*_pmc_backward.txt); logical gather + "
+                              "hbm_bytes_per_sample_model": 1360,
+                              "hbm_model_gbs": VIEWS_PER_GPU * Me * S2 * 1360 / (bwd_ms * 1e-3) / 1e9,
+                              "note": "binned scatter: per sample the decoder-backward kernel writes a 256-byte feature-gradient row and three "
+                                      "32-byte records, the fill pass moves the records, and the accumulate pass (one wave owns an 8x8 texel "
+                                      "tile in LDS) reads each row three times: 1360 B/sample of HBM traffic by construction, which is what bounds "
+                                      "the accumulate pass (DESIGN.md 4.4; no counter file for this workload, so no frac).  logical gather + "
                                       "scatter bytes (9216 B/sample) / time is quoted for reference only (planes and gradients are cache resident)"})
 
     ffhq = args.workload == "ffhq"
