@@ -47,6 +47,32 @@ N_CU, N_SIMD = 256, 1024
 PMC_FILE = os.path.join(ROOT, "profiles", "r02_issue_floor.json")
 
 
+def backward_roofline(bwd_ms, samples, logical_gbs):
+    """Roofline block of the edit step.  The binned scatter moves 1360 B of HBM traffic per sample by construction
+    and its accumulate pass is HBM-bound; the committed counter file (tools/pmc.sh, PMC_KERNEL=bwd_accumulate) gives that kernel's
+    measured traffic and duration for the same 4-view launch."""
+    import json
+    import os
+    rec = None
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_backward_counters.json")
+    if os.path.exists(path):
+        rec = json.load(open(path))
+    ach = rec["hbm_bytes_per_launch"] / rec["avg_ns_profiled"] if rec else None            # GB/s
+    return {"bound": "hbm", "achieved": ach, "peak": 8000.0 if rec else None, "unit": "GB/s" if rec else None,
+            "frac": ach / 8000.0 if rec else None, "traffic": rec["hbm_bytes_per_launch"] if rec else None,
+            "kernel": "nfe::bwd_accumulate_kernel (of: render_kernel<EVAL>, bwd_ray_kernel, bwd_scatter_sorted_kernel<MFMA,BINNED>, "
+                      "bwd_bin_fill_kernel, bwd_accumulate_kernel)",
+            "kernel_ms": rec["avg_ns_profiled"] * 1e-6 if rec else None, "backward_ms": bwd_ms,
+            "hbm_bytes_per_sample_model": 1360, "hbm_model_gbs": samples * 1360 / (bwd_ms * 1e-3) / 1e9,
+            "logical_gather_scatter_gbs": logical_gbs,
+            "note": "achieved / traffic / kernel_ms: accumulate pass of one 4-view launch from profiles/r02_backward_counters.json "
+                    "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE, rocprofv3 duration), not re-measured by this run; "
+                    "backward_ms is this run's HIP-event time of the whole backward.  Per sample the decoder-backward kernel writes a "
+                    "256-byte feature-gradient row and three 32-byte records, the fill pass moves the records, the accumulate pass (one "
+                    "wave owns an 8x8 texel tile in LDS) reads each row three times.  logical gather + scatter bytes (9216 B/sample) / "
+                    "time is quoted for reference only (planes and gradients are cache resident)"}
+
+
 def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD):
     """The ceilings that can bind render_kernel, each as (cycles this resource is busy per launch) / (kernel cycles), with the
     kernel cycles = the kernel time measured HERE x the effective shader clock of the profiled run (GRBM_GUI_ACTIVE / 8 XCDs /
@@ -262,18 +288,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     config={"workload": "SURVEY 8(f)4 backward pass: 4 views/GPU/step, 128^2 rays, 48 + 48 samples, norm/denorm plane sets with "
                                         "swapped statistics, random cotangents for rgb/seg/depth/wsum, gradients w.r.t. both plane sets",
                             "views_per_step": n_total, "forward_ms": fwd_ms, "backward_ms": bwd_ms, "parallelism": f"views-dp{world}"},
-                    roofline={"bound": "hbm", "achieved": None, "peak": None, "unit": None, "frac": None,
-                              "traffic": None,
-                              "kernel": "nfe::render_kernel<EVAL> + bwd_ray_kernel + bwd_scatter_sorted_kernel<MFMA,BINNED> + bwd_bin_fill_kernel + "
-                                        "bwd_accumulate_kernel",
-                              "kernel_ms": bwd_ms, "logical_gather_scatter_gbs": ach,
-                              "hbm_bytes_per_sample_model": 1360,
-                              "hbm_model_gbs": VIEWS_PER_GPU * Me * S2 * 1360 / (bwd_ms * 1e-3) / 1e9,
-                              "note": "binned scatter: per sample the decoder-backward kernel writes a 256-byte feature-gradient row and three "
-                                      "32-byte records, the fill pass moves the records, and the accumulate pass (one wave owns an 8x8 texel "
-                                      "tile in LDS) reads each row three times: 1360 B/sample of HBM traffic by construction, which is what bounds "
-                                      "the accumulate pass (DESIGN.md 4.4; no counter file for this workload, so no frac).  logical gather + "
-                                      "scatter bytes (9216 B/sample) / time is quoted for reference only (planes and gradients are cache resident)"})
+                    roofline=backward_roofline(bwd_ms, VIEWS_PER_GPU * Me * S2, ach))
 
     ffhq = args.workload == "ffhq"
     conv_math = "bf16x3" if ffhq else "bf16"
