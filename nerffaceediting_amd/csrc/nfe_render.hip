@@ -1091,13 +1091,14 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int D = P.D, Di = P.Di;
-    int P2 = 64;                                         // fine depths are sorted on a power-of-two array padded with +inf
-    while (P2 < Di) P2 <<= 1;
-    const int stride = 3 * D + P2;                       // per-wave LDS floats
+    const int DiP = (Di + 2) & ~1;                       // key pairs are read two at a time; at least one +inf key pads the list
+    int stride = ((3 * D + 3) & ~3) + 2 * DiP + Di;      // per-wave LDS floats (same formula at the launch)
+    stride = (stride + 3) & ~3;                          // keep every wave's block 16-byte aligned
     float* tc = lds + wave * stride;                     // [D] coarse depths
     float* wq = tc + D;                                  // [D] weights, then smoothed weights
     float* cdf = wq + D;                                 // [D] cdf knots (D-2 used)
-    float* tf = cdf + D;                                 // [Di] fine depths
+    uint2* keys = reinterpret_cast<uint2*>(tc + ((3 * D + 3) & ~3));     // [DiP] (draw index, order-preserving depth bits), 16-byte aligned
+    float* tf = reinterpret_cast<float*>(keys + DiP);    // [Di] fine depths, ascending
     const int B = D - 3;                                 // number of pdf bins (weights[:,1:-1])
 
     for (long long ray = (long long)blockIdx.x * 4 + wave; ray < P.n_rays_total; ray += (long long)gridDim.x * 4) {
@@ -1158,28 +1159,45 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
             float den = ca - cb;
             if (den < 1e-5f) den = 1.0f;
             const float t = bb + (u - cb) / den * (ba - bb);
-            tf[e] = t;
+            keys[e] = make_uint2((unsigned)e, f2ord(t));
             if (P.tap_fine) P.tap_fine[ray * Di + e] = t;
         }
+        for (int e = Di + lane; e < DiP; e += 64) keys[e] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
         __threadfence_block();
         // merge (unify_samples, renderer.py:288-300: only the sorted depths leave this kernel, so ties need no order).
-        // 1. bitonic sort of the fine depths in LDS (padded to a power of two with +inf),
-        // 2. rank of each fine depth = its sorted index + #coarse <= it (binary search: coarse depths are ascending),
-        //    rank of each coarse depth = its index + #fine < it.
-        for (int i = Di + lane; i < P2; i += 64) tf[i] = INFINITY;
-        __threadfence_block();
-        for (int k = 2; k <= P2; k <<= 1)
-            for (int jj = k >> 1; jj > 0; jj >>= 1) {
-                for (int i = lane; i < P2; i += 64) {
-                    const int partner = i ^ jj;
-                    if (partner > i) {
-                        const float a = tf[i], c = tf[partner];
-                        const bool up = (i & k) == 0;
-                        if ((a > c) == up) { tf[i] = c; tf[partner] = a; }
-                    }
-                }
-                __threadfence_block();
+        // 1. rank of each fine depth among the fine depths by counting: the number of (depth, draw index) keys below its own - every
+        //    lane walks the whole key list (two keys per LDS read, broadcast) with one 64-bit compare and one add-with-carry per key;
+        //    no sorting network, no intermediate barriers.  The ranked depths go to tf[], which is therefore ascending.
+        // 2. position of each fine depth = its rank + #coarse <= it (binary search: coarse depths are ascending),
+        //    position of each coarse depth = its index + #fine < it (binary search in tf[]).
+        {
+            unsigned long long mine[NFE_MAX_SAMPLES / 64];
+            unsigned rank[NFE_MAX_SAMPLES / 64];
+#pragma unroll
+            for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+                const int e = c * 64 + lane;
+                const uint2 k = keys[min(e, DiP - 1)];
+                mine[c] = (unsigned long long)k.y << 32 | k.x;
+                rank[c] = 0;
             }
+            const uint4* kp = reinterpret_cast<const uint4*>(keys);
+            for (int j = 0; j < DiP / 2; ++j) {
+                const uint4 q = kp[j];
+                const unsigned long long k0 = (unsigned long long)q.y << 32 | q.x, k1 = (unsigned long long)q.w << 32 | q.z;
+#pragma unroll
+                for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+                    if (c * 64 >= Di) break;
+                    rank[c] += (k0 < mine[c]) ? 1u : 0u;
+                    rank[c] += (k1 < mine[c]) ? 1u : 0u;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+                const int e = c * 64 + lane;
+                if (e < Di) tf[rank[c]] = ord2f((unsigned)(mine[c] >> 32));
+            }
+        }
+        __threadfence_block();
         float* out = P.t_all + ray * (D + Di);
         for (int e = lane; e < Di; e += 64) {            // fine: #coarse <= v (upper bound)
             const float v = tf[e];
@@ -1536,9 +1554,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         ImportanceK I{};
         I.t_coarse = t_c; I.w_coarse = w_c; I.u_fine = a->u_fine; I.seed = a->seed; I.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device); I.n_rays_total = (long long)nr;
         I.D = D; I.Di = Di; I.t_all = t_all; I.src_all = src_all; I.tap_fine = a->tap_depths_fine;
-        int p2 = 64;
-        while (p2 < Di) p2 <<= 1;
-        const int lds_bytes = 4 * (3 * D + p2) * 4;
+        const int lds_bytes = 4 * ((((3 * D + 3) & ~3) + 2 * ((Di + 2) & ~1) + Di + 3) & ~3) * 4;      // four waves, importance_kernel's layout
         long long blocks = ((long long)nr + 3) / 4;
         if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
         hipLaunchKernelGGL(importance_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, st, I);
