@@ -1,5 +1,5 @@
 """Compare the scatter forms of nfe_render_backward on one editing-size case: each form runs in a child interpreter (the switch is
-read once per process), gradients are compared texel by texel.    python tools/cmp_bwd_forms.py [repeats]"""
+read once per process), gradients are compared texel by texel.    python tools/cmp_bwd_forms.py [repeats [N R D Di H]]"""
 import os
 import subprocess
 import sys
@@ -11,7 +11,7 @@ CHILD = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, %r)
 from nerffaceediting_amd import ops
-N, R, D, Di, H = 2, 128, 48, 48, 256
+N, R, D, Di, H = [int(v) for v in sys.argv[3:8]]
 dev = torch.device("cuda:0")
 g = torch.Generator(device="cpu").manual_seed(3)
 pn = torch.randn(N, 3, H, H, 32, generator=g).to(dev)
@@ -39,8 +39,9 @@ for rep in range(int(sys.argv[2])):
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+    shape = sys.argv[2:7] if len(sys.argv) >= 7 else ["2", "128", "48", "48", "256"]        # N R D Di H
     for form, env in (("sorted", {"NFE_BWD_SCATTER": "sorted"}), ("binned", {})):
-        subprocess.run([sys.executable, "-c", CHILD, "/tmp/cmp_" + form, str(reps)], env=dict(os.environ, **env), check=True)
+        subprocess.run([sys.executable, "-c", CHILD, "/tmp/cmp_" + form, str(reps)] + shape, env=dict(os.environ, **env), check=True)
     for which in "ga":
         ref = np.load(f"/tmp/cmp_sorted_{which}0.npy").astype(np.float64)
         scale = np.abs(ref).max()
