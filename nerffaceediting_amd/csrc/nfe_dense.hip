@@ -444,6 +444,9 @@ __global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict_
 }
 
 __device__ uint4 nfe_zero16[4];                                  // source of the zero padding for LDS-DMA
+#ifndef C3_FRAG_PIPE
+#define C3_FRAG_PIPE 1                                           // A/B switch of the fragment-read pipeline in conv3_kernel
+#endif
 #ifdef C3_PROFILE      // diagnostic build only (tools/c3_profile.py): shader cycles summed over all waves of all conv3 launches
 __device__ unsigned long long c3_prof[4];                        // {load phase, compute phase, epilogue, waves}
 #define C3_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -617,6 +620,61 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
         const unsigned char* ldsB = base + A_CHUNKS * 1024;
+#if C3_FRAG_PIPE
+        // Fragment reads run ONE (tap, N-block) step ahead of the MFMAs that use them (register double buffer, order pinned by
+        // sched_barrier): the compiler's own schedule issues a read one or two MFMAs before its use, which leaves the matrix pipe
+        // idle for most of the LDS latency some thirty times per K-group while this wave is the only one computing on its SIMD.
+        auto load_a = [&](int t, Frag8 (&ah_)[MBW], Frag8 (&al_)[MBW]) {
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) {
+                ah_[m].q = ldsA[((m * 9 + t) * PARTS + 0) * 64];
+                if (TERMS == 3) al_[m].q = ldsA[((m * 9 + t) * PARTS + 1) * 64];
+            }
+        };
+        auto load_b = [&](int t, int nb, Frag8& bh_, Frag8& bl_) {
+            const int kh = t / 3, kw = t % 3;
+            const int dy = UP2 ? 1 - (kh >> 1) : kh, dx = UP2 ? 1 - (kw >> 1) : kw;
+            bh_.q = *reinterpret_cast<const uint4*>(ldsB + brd[nb + dy][dx]);
+            if (TERMS == 3) bl_.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brd[nb + dy][dx]);
+        };
+        Frag8 ah[2][MBW], al[2][MBW], bh[2], bl[2];
+        load_a(0, ah[0], al[0]);
+        load_b(0, 0, bh[0], bl[0]);
+#pragma unroll
+        for (int s_ = 0; s_ < 9 * NBW; ++s_) {
+            const int t = s_ / NBW, nb = s_ % NBW, kh = t / 3, kw = t % 3;
+            const int a = UP2 ? (kh & 1) * 2 + (kw & 1) : 0;
+            if (s_ + 1 < 9 * NBW) {
+                const int t1 = (s_ + 1) / NBW, nb1 = (s_ + 1) % NBW;
+                load_b(t1, nb1, bh[(s_ + 1) & 1], bl[(s_ + 1) & 1]);
+                if (nb1 == 0) load_a(t1, ah[t1 & 1], al[t1 & 1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) {
+                acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
+                if (TERMS == 3) {
+                    acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, bl[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
+                    acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
+                }
+            }
+            if (UP2 && nb == NBW - 1 && kw == 2 && edge_tile && wave == 0) {   // wave-uniform
+                Frag8 eh, el;
+                const int dy = 1 - (kh >> 1);
+                eh.q = *reinterpret_cast<const uint4*>(ldsB + brde[dy]);
+                if (TERMS == 3) el.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brde[dy]);
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) {
+                    acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, eh.v, acce[kh & 1][m], 0, 0, 0);
+                    if (TERMS == 3) {
+                        acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, el.v, acce[kh & 1][m], 0, 0, 0);
+                        acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1][m].v, eh.v, acce[kh & 1][m], 0, 0, 0);
+                    }
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#else
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int kh = t / 3, kw = t % 3;
@@ -657,6 +715,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                 }
             }
         }
+#endif
         stage = stage + 1 == STAGES ? 0 : stage + 1;
 #ifdef C3_PROFILE
         { C3_STAMP(ts2); prof_load += ts1 - ts0; prof_comp += ts2 - ts1; }
