@@ -130,6 +130,9 @@ typedef struct nfe_conv_args {
 } nfe_conv_args;
 /* 1 if a NFE_CONV_3X3 call of these sizes evaluates rgb_* in its epilogue (LDS-DMA path, no split-K, rgb_channels <= 4) */
 int nfe_conv_fuses_rgb(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels);
+/* 1 if a NFE_CONV_3X3 call of these sizes writes next_split from its own epilogue (LDS-DMA path, no split-K): `out` may then be
+ * NULL when nobody else reads the fp32 activation.  Otherwise next_split is made by one more pass over `out`. */
+int nfe_conv_splits_in_epilogue(int mode, int n, int h, int w, int cin, int cout);
 int nfe_modulated_conv(const nfe_conv_args* args, nfe_stream_t stream);
 /* floats of a bf16 hi(+lo) activation image [n,h,w,c] (hi only for NFE_CONV_BF16) */
 uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c);

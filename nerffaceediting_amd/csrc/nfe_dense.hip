@@ -462,7 +462,8 @@ struct Conv3K {
     const float* rgb_w; const float* rgb_s; float* rgb_partial; int rgb_c;     // fused ToRGB (plain 3x3, no split-K): see rgb_combine_kernel
     int ksplit;         // > 1: blockIdx.z = n * ksplit + ks; this workgroup sums K-groups [ks*G/ksplit, (ks+1)*G/ksplit) and writes
     float* partial;     //      raw partial sums [ksplit][N,H,W,Cout] that splitk_reduce_kernel adds in slice order (+ epilogue)
-};
+    const float* next_styles; uint2* split_hi; uint2* split_lo;     // plain 3x3, no split-K: the consuming layer's modulated bf16 image
+};                                                                  // (what modsplit_kernel would make of `out`), written by the epilogue
 
 __host__ __device__ constexpr bool c3_xcd_order(int terms) { return terms == 3; }
 
@@ -796,6 +797,11 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         // every such load sits behind the previous store (the pointers may alias), which made the epilogue a chain of ~32 exposed
         // L2 round trips per wave, 20-30 % of the wave's life (tools/c3_profile.py).
         float nzv[NBW], rgb[NBW][4];
+        float4 ns[MBW];                                 // consuming layer's styles of the 4 channels this lane stores (lane & 7)
+#pragma unroll
+        for (int m = 0; m < MBW; ++m)
+            ns[m] = P.split_hi ? *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 32 * (mb0 + m) + 4 * (lane & 7))
+                               : make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             const int y = min(ty0 + NBW * wave + nb, P.H - 1), x = min(tx0 + j, P.W - 1);
@@ -826,7 +832,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                     v.y = epilogue_act(acc[0][m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
                     v.z = epilogue_act(acc[0][m][nb][4 * qq + 2] * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
                     v.w = epilogue_act(acc[0][m][nb][4 * qq + 3] * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-                    if (P.out) *reinterpret_cast<float4*>(stile + j * ST_STRIDE + 8 * qq + 4 * h) = v;
+                    if (P.out || P.split_hi) *reinterpret_cast<float4*>(stile + j * ST_STRIDE + 8 * qq + 4 * h) = v;
                     if (fuse_rgb) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
@@ -836,13 +842,22 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                             }
                     }
                 }
-                if (P.out) {            // same-wave LDS operations execute in order: no barrier between the writes above and these reads
-                    float* orow = P.out + (((long long)n * P.H + y) * P.W + tx0) * P.Cout + 32 * (mb0 + m);
+                if (P.out || P.split_hi) {      // same-wave LDS operations execute in order: no barrier between the writes above and these reads
+                    const long long o_row = (((long long)n * P.H + y) * P.W + tx0) * P.Cout + 32 * (mb0 + m);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int p = 8 * it + (lane >> 3), c = lane & 7;
                         const float4 v = *reinterpret_cast<const float4*>(stile + p * ST_STRIDE + 4 * c);
-                        if (tx0 + p < P.W) *reinterpret_cast<float4*>(orow + (long long)p * P.Cout + 4 * c) = v;
+                        if (tx0 + p < P.W) {
+                            const long long oi = o_row + (long long)p * P.Cout + 4 * c;
+                            if (P.out) *reinterpret_cast<float4*>(P.out + oi) = v;
+                            if (P.split_hi) {           // 8 pixels x 64 contiguous bytes per store instruction (per part)
+                                unsigned h0, l0, h1, l1;
+                                if (TERMS == 3) { split2<3>(v.x * ns[m].x, v.y * ns[m].y, h0, l0); split2<3>(v.z * ns[m].z, v.w * ns[m].w, h1, l1); P.split_lo[oi >> 2] = make_uint2(l0, l1); }
+                                else { split2<1>(v.x * ns[m].x, v.y * ns[m].y, h0, l0); split2<1>(v.z * ns[m].z, v.w * ns[m].w, h1, l1); }
+                                P.split_hi[oi >> 2] = make_uint2(h0, h1);
+                            }
+                        }
                     }
                 }
             }
@@ -1345,6 +1360,10 @@ static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout) {
     return ks > 1 ? ks : 0;
 }
 
+extern "C" int nfe_conv_splits_in_epilogue(int mode, int n, int h, int w, int cin, int cout) {
+    return mode == NFE_CONV_3X3 && conv3_eligible(mode, h, w, cin, cout) && cout % 4 == 0 && !conv3_ksplit(mode, n, h, w, cin, cout) ? 1 : 0;
+}
+
 extern "C" int nfe_conv_fuses_rgb(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels) {
     (void)math;
     if (mode != NFE_CONV_3X3 || rgb_channels < 1 || rgb_channels > 4 || cout > 256 || C3_BIG) return 0;
@@ -1437,7 +1456,9 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
                     "nfe_modulated_conv: this layer cannot evaluate ToRGB in its epilogue (ask nfe_conv_fuses_rgb first)");
         NFE_REQUIRE(!a->rgb_skip || (a->h % 2 == 0 && a->w % 2 == 0), "nfe_modulated_conv: rgb_skip needs even sizes");
     }
-    NFE_REQUIRE(a->mode == NFE_CONV_3X3_UP2 || a->out || fuse_rgb, "nfe_modulated_conv: `out` may only be NULL on up-sampling layers with next_split or with a fused ToRGB");
+    const bool split_only = a->next_split && fast && nfe_conv_splits_in_epilogue(a->mode, a->n, a->h, a->w, a->cin, a->cout);   // the epilogue writes the consumer's image itself
+    NFE_REQUIRE(a->mode == NFE_CONV_3X3_UP2 || a->out || fuse_rgb || split_only,
+                "nfe_modulated_conv: `out` may only be NULL on up-sampling layers with next_split, with a fused ToRGB, or where nfe_conv_splits_in_epilogue()");
     if (fast) {
         // fast path: modulate + split once, then the LDS-DMA implicit GEMM
         const bool up2 = a->mode == NFE_CONV_3X3_UP2;
@@ -1462,6 +1483,11 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         if (c3ks) {
             K.ksplit = c3ks;
             K.partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);       // behind the (possibly unused) split-image area
+        }
+        const bool split_in_epilogue = a->next_split && !up2 && !c3ks && a->cout % 4 == 0;   // else: split_tail() re-reads `out`
+        if (split_in_epilogue) {
+            K.next_styles = a->next_styles; K.split_hi = reinterpret_cast<uint2*>(a->next_split);
+            K.split_lo = a->math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a->next_split) + out_elems) : nullptr;
         }
         auto reduce_up = [&]() {                    // slices of the transposed-conv result -> a->scratch, in order, before the FIR
             if (!(c3ks && up2)) return;
@@ -1506,7 +1532,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             hipLaunchKernelGGL(rgb_combine_kernel, dim3(grid1d((long long)a->n * a->h * a->w, 256, 1 << 14)), dim3(256), 0, st, K.rgb_partial,
                                a->cout / 64, a->n, a->h, a->w, a->rgb_channels, a->rgb_bias, a->rgb_clamp, a->rgb_skip, a->rgb_out);
         NFE_CHECK_LAUNCH("conv3 kernels");
-        return split_tail();
+        return split_in_epilogue ? NFE_OK : split_tail();
     }
     const int up = a->mode == NFE_CONV_3X3_UP2;
     const int gh = a->h + up, gw = a->w + up;

@@ -191,13 +191,21 @@ def fuses_rgb(mode, math, n, h, w, cin, cout, rgb_channels):
     return bool(_lib.load().nfe_conv_fuses_rgb(int(mode), MATH[math], n, h, w, cin, cout, rgb_channels))
 
 
+def splits_in_epilogue(mode, n, h, w, cin, cout):
+    """True if a plain 3x3 layer of these sizes writes the consuming layer's SplitImage from its own epilogue
+    (nfe_conv_splits_in_epilogue): the fp32 output may then be skipped (want_out=False) when nobody else reads it."""
+    if not FAST_PATH:
+        return False
+    return bool(_lib.load().nfe_conv_splits_in_epilogue(int(mode), n, h, w, cin, cout))
+
+
 def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, noise_strength=0.0, lrelu=True,
                    act_gain=1.0, clamp=None, skip=None, out_planes=False, math=None, next_styles=None, want_out=True, rgb=None):
     """nfe_modulated_conv.  x [N,H,W,Cin] NHWC (or a SplitImage of the modulated input) -> [N,Ho,Wo,Cout]
     (or [N,3,Ho,Wo,32] if out_planes).  With next_styles [N,Cout] also returns the SplitImage for the consuming
-    3x3 layer: (out, split); out is None if want_out is False (up-sampling layers only).
+    3x3 layer: (out, split); out is None if want_out is False (up-sampling layers, and plain ones where splits_in_epilogue()).
     rgb = (weight [C,Cout], styles [N,Cout], bias [C], skip [N,H/2,W/2,C] or None, clamp): the block's ToRGB evaluated in
-    this layer's epilogue (only where fuses_rgb() is true) -> returns (out or None, rgb_image [N,H,W,C])."""
+    this layer's epilogue (only where fuses_rgb() is true) -> returns (out or None, rgb_image [N,H,W,C]) (+ split with next_styles)."""
     lib = _lib.load()
     a = _lib.ConvArgs()
     a.struct_size = ctypes.sizeof(_lib.ConvArgs)
@@ -259,7 +267,7 @@ def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, 
     keep += [dcoef, noise, bias, skip, scratch, next_styles, split]
     _call(dev, lambda: lib.nfe_modulated_conv(ctypes.byref(a), _stream()), "nfe_modulated_conv")
     if rgb is not None:
-        return out, rgb_out
+        return (out, rgb_out) if next_styles is None else (out, rgb_out, split)
     return out if next_styles is None else (out, split)
 
 

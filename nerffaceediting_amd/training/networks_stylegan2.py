@@ -10,6 +10,8 @@ Differences from the reference that do not change results:
 Inference only (no autograd through the HIP ops).
 """
 import numpy as np
+import os
+
 import torch
 
 from .. import _lib, dense_ops
@@ -234,12 +236,26 @@ class SynthesisBlock(torch.nn.Module):
             return None
         return (self.torgb.weight.detach(), st[-1], self.torgb.bias.detach(), img, self.torgb.conv_clamp)
 
-    def forward_nhwc(self, x, img, ws, noise_mode="random", out_planes=False, conv_math=None, pre=None, want_x=True, **_ignored):
+    def chains_to(self, nxt, n, conv_math):
+        """True if this block's conv1 can hand `nxt`'s conv0 its modulated bf16 input directly (conv1's epilogue writes it, the
+        up-sampling conv0 takes it): no modulate-and-split pass over the fp32 activation between the blocks."""
+        r = self.resolution
+        if os.environ.get("NFE_NO_BLOCK_CHAIN"):          # A/B switch
+            return False
+        return (self.in_channels != 0 and hasattr(nxt, "conv0") and nxt.conv0.in_channels == self.conv1.out_channels
+                and dense_ops.splits_in_epilogue(_lib.NFE_CONV_3X3, n, r, r, self.conv1.in_channels, self.conv1.out_channels)
+                and dense_ops.can_chain(_lib.NFE_CONV_3X3_UP2, conv_math, n, r, r, nxt.conv0.in_channels, nxt.conv0.out_channels))
+
+    def forward_nhwc(self, x, img, ws, noise_mode="random", out_planes=False, conv_math=None, pre=None, want_x=True, next_styles=None,
+                     **_ignored):
         """pre: (styles, dcoefs) of this block's layers when the caller batched them for the whole network.  want_x=False
-        (last block of a network): the activation itself is not returned, and not written where ToRGB runs fused."""
+        (last block of a network): the activation itself is not returned, and not written where ToRGB runs fused.
+        x may be the SplitImage the previous block made for conv0.  next_styles (only where chains_to(next block)): the styles of
+        the next block's conv0; the block then returns that layer's SplitImage in place of x."""
         assert ws.shape[1:] == (self.num_conv + self.num_torgb, self.w_dim), f"wrong ws shape {list(ws.shape)}"   # :419
         ws = ws.to(torch.float32)
         st, dc = pre if pre is not None else batch_styles(block_layers(self), ws, range(ws.shape[1]))
+        xs_next = None
         if self.in_channels == 0:
             const = getattr(self, "_const_nhwc", None)
             if const is None or self._const_key != (self.const.data_ptr(), self.const._version):
@@ -250,20 +266,26 @@ class SynthesisBlock(torch.nn.Module):
             x = self.conv1.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0])
         else:
             N, r, c1 = ws.shape[0], self.resolution, self.conv1.in_channels
+            kw1 = dict(noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1])
             if dense_ops.can_chain(_lib.NFE_CONV_3X3, conv_math, N, r, r, c1, self.conv1.out_channels) and c1 % 4 == 0:
                 # conv0's FIR epilogue writes conv1's modulated bf16 input directly: no fp32 round trip between them
                 _, xs = self.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0],
                                                 next_styles=st[1], want_out=False)
                 fused = self._fused_rgb(ws.shape, img, st, out_planes, conv_math)
                 if fused is not None:           # conv1 + ToRGB + skip in one pass over the activation
-                    return self.conv1.forward_nhwc(xs, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1],
-                                                   rgb=fused, want_out=want_x)
-                x = self.conv1.forward_nhwc(xs, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1])
+                    if next_styles is not None:     # ... and the next block's input image: the fp32 activation is never written
+                        _, img, xs_next = self.conv1.forward_nhwc(xs, None, rgb=fused, want_out=False, next_styles=next_styles, **kw1)
+                        return xs_next, img
+                    return self.conv1.forward_nhwc(xs, None, rgb=fused, want_out=want_x, **kw1)
+                x = xs
             else:
                 x = self.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0])
-                x = self.conv1.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1])
+            if next_styles is not None:
+                x, xs_next = self.conv1.forward_nhwc(x, None, next_styles=next_styles, **kw1)
+            else:
+                x = self.conv1.forward_nhwc(x, None, **kw1)
         img = self.torgb.forward_nhwc(x, None, skip=img, out_planes=out_planes, conv_math=conv_math, styles=st[-1])   # upsample2d(img) + y
-        return x, img
+        return (x if xs_next is None else xs_next), img
 
     def forward(self, x, img, ws, force_fp32=False, fused_modconv=None, update_emas=False, **layer_kwargs):
         x = None if x is None else dense_ops.nchw_to_nhwc(x.to(torch.float32))
@@ -309,12 +331,14 @@ class SynthesisNetwork(torch.nn.Module):
         st, dc = batch_styles(layers, ws, cols)
         x = img = None
         w_idx = k = 0
-        for res, block in zip(self.block_resolutions, blocks):
+        for i, (res, block) in enumerate(zip(self.block_resolutions, blocks)):
             n = block.num_conv + block.num_torgb
             cur = ws.narrow(1, w_idx, n)
             w_idx += block.num_conv
+            chain = i + 1 < len(blocks) and block.chains_to(blocks[i + 1], ws.shape[0], self.conv_math)
             x, img = block.forward_nhwc(x, img, cur, out_planes=out_planes and res == self.img_resolution,
-                                        conv_math=self.conv_math, pre=(st[k:k + n], dc[k:k + n]), **block_kwargs)
+                                        conv_math=self.conv_math, pre=(st[k:k + n], dc[k:k + n]),
+                                        next_styles=st[k + n] if chain else None, **block_kwargs)
             k += n
         return img
 

@@ -64,7 +64,9 @@ class _TwoBlockSR(torch.nn.Module):
             rgb = dense_ops.resize_bilinear(rgb, r, r, self.sr_antialias)
         ws = ws.to(torch.float32)
         st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2])   # all six in one launch
-        x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]))
+        chain = hasattr(self.block0, "chains_to") and self.block0.chains_to(self.block1, ws.shape[0], self.conv_math)
+        x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]),
+                                          next_styles=st[3] if chain else None)
         x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[3:], dc[3:]), want_x=False)
         return rgb
 
@@ -148,7 +150,9 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
             rgb = dense_ops.resize_bilinear(rgb, r, r, self.sr_antialias)
         ws = ws.to(torch.float32)
         st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2])   # all six in one launch
-        x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]))
+        chain = hasattr(self.block0, "chains_to") and self.block0.chains_to(self.block1, ws.shape[0], self.conv_math)
+        x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]),
+                                          next_styles=st[3] if chain else None)
         x, rgb = self.block1.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[3:], dc[3:]), want_x=False)
         return rgb
 
