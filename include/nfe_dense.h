@@ -110,10 +110,12 @@ typedef struct nfe_conv_args {
                                      layer additionally keeps a bf16 hi (+lo) image of the modulated input there and
                                      runs the LDS-DMA fast path; less (or NULL in mode 0) = generic path */
     uint64_t scratch_floats;      /* capacity of `scratch` in floats */
-    /* Layer chaining without an fp32 round trip (conv0 -> conv1 of a SynthesisBlock): */
+    /* Layer chaining without an fp32 round trip (conv0 -> conv1 of a SynthesisBlock, conv1 -> conv0 of the next block): */
     const float* next_styles;     /* [N,Cout] styles of the 3x3 layer that consumes this output, or NULL */
-    float* next_split;            /* out: bf16 hi(+lo) image of out * next_styles, nfe_conv_split_floats() floats; with it
-                                     `out` may be NULL (the fp32 output is then not written) */
+    float* next_split;            /* out: bf16 hi(+lo) image of out * next_styles, nfe_conv_split_floats() floats.  Mode 1 writes
+                                     it from the FIR epilogue, mode 0 from the conv epilogue where nfe_conv_splits_in_epilogue()
+                                     says so (elsewhere by one more pass over `out`); in those two cases `out` may be NULL (the
+                                     fp32 output is then not written) */
     const float* x_split;         /* in: such an image of this layer's modulated input (written by the producer with this
                                      layer's styles); `x` may then be NULL.  Needs the fast path (scratch as above). */
     /* Fused ToRGB: the image path of SynthesisBlock.forward (networks_stylegan2.py:450-457: y = torgb(x, w); img =
