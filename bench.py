@@ -371,7 +371,7 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
 
     def one_pass():
         gat = sharding.ChunkedFrameGather(V, chunk, (G.img_resolution, G.img_resolution, 3), torch.uint8, dev)
-        ring = apps.StreamRing(dev, getattr(args, "streams", 2))       # chunks alternate between two HIP streams
+        ring = apps.StreamRing(dev, getattr(args, "streams", 3))       # chunks rotate over the HIP streams
         for k in range(gat.rounds()):
             sl = gat.local_slice(k)
             gat.submit(k, ring.take(*ring.run(lambda: chunk_frames(*sl))))
@@ -408,7 +408,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["render", "full", "ffhq", "orbit", "twopass", "editstep"], default="render")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the full-synthesis workloads alternate their batches on")
+    ap.add_argument("--streams", type=int, default=3, help="HIP streams the full-synthesis workloads alternate their batches on")
     ap.add_argument("--orbit-frames", type=int, default=512, help="frames of the strong-scaling orbit job (BASELINE config 4)")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the config-4 orbit job reported beside the default line")
     args = ap.parse_args()

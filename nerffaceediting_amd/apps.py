@@ -84,7 +84,7 @@ class StreamRing:
     run(fn) executes fn() on the next stream of the ring and returns (result, event); the consumer stream calls
     take(result, event) before touching the result (stream-ordered wait, no host sync)."""
 
-    def __init__(self, device, n_streams=2):
+    def __init__(self, device, n_streams=3):
         self.main = torch.cuda.current_stream(device)
         self.streams = [torch.cuda.Stream(device) for _ in range(n_streams)] if n_streams > 1 else []
         for s in self.streams:
@@ -116,7 +116,7 @@ class StreamRing:
 
 
 @torch.no_grad()
-def render_views(G, ws, c, batch=4, gather=True, uint8=False, image_mode="image", overlap=True, streams=2, **synthesis_kwargs):
+def render_views(G, ws, c, batch=4, gather=True, uint8=False, image_mode="image", overlap=True, streams=3, **synthesis_kwargs):
     """Render V independent (ws[v], c[v]) pairs -> frames in view order on every rank: fp32 [V,3,H,W], or with
     uint8=True the gen_samples.py:177 conversion [V,H,W,3] (4x fewer bytes on the wire).
 
