@@ -49,7 +49,7 @@ struct BwdK {
     float* rec_sig; float* rec_a; float* rec_T;      // [N*M*S] each: (sigma, a, T) then (dL/dsigma, omega, -)
     const uint4* bfrag;                // split-bf16 MFMA fragments of the decoder and its transposes (bwd_frag_kernel), or null
     // binned scatter (one chunk of views x 64-ray tiles): feature gradients, bin records and their sorted list
-    float* df; uint2* rec_key; float4* rec_w; uint2* binrank; unsigned* counts; unsigned* offsets; uint2* list_key; float4* list_w;
+    float* df; uint2* rec_key; float4* rec_w; uint2* binrank; unsigned* counts; unsigned* offsets; unsigned* perm;
     int n0, t0, t_count, bins_x, bins_y;      // chunk origin (view, ray tile), ray tiles per view in the chunk, plane tiles
 };
 
@@ -273,24 +273,37 @@ __device__ __forceinline__ void segment(float s0, float s1, float t0, float t1, 
     dalpha_dsmid = dlt * e * (x > 20.0f ? 1.0f : sigmoid_t(x));
 }
 
+constexpr int RAY_CH = 16;     // samples per batch of bwd_ray_kernel: their loads are issued together, one memory round trip per batch
+
 __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
     const long long ray = (long long)blockIdx.x * 256 + threadIdx.x;
     if (ray >= (long long)P.N * P.M) return;
     const int S = P.S;
-    const float* t = P.depths + ray * S;
-    float* sig = P.rec_sig + ray * S; float* av = P.rec_a + ray * S; float* Tv = P.rec_T + ray * S;
-    // forward: transmittance of every segment, sum of weights, weighted depth
+    const float* __restrict__ t = P.depths + ray * S;
+    float* sig = P.rec_sig + ray * S; float* av = P.rec_a + ray * S; float* __restrict__ Tv = P.rec_T + ray * S;
+    // forward: transmittance of every segment, sum of weights, weighted depth.  A lane walks its own ray (stride S between lanes),
+    // so every load is its own cache line: the loop is batched by hand - a store per step kept the compiler from hoisting the next
+    // step's loads, and the kernel spent one memory latency per sample.
     float T = 1.0f, wtot = 0.0f, dnum = 0.0f;
     float s0 = sig[0], t0 = t[0];
-    for (int j = 0; j + 1 < S; ++j) {
-        const float s1 = sig[j + 1], t1 = t[j + 1];
-        float alpha, dummy;
-        segment(s0, s1, t0, t1, alpha, dummy);
-        Tv[j] = T;
-        const float w = alpha * T;
-        wtot += w; dnum = fmaf(w, (t0 + t1) * 0.5f, dnum);
-        T *= (1.0f - alpha + 1e-10f);                               // :85
-        s0 = s1; t0 = t1;
+    for (int j0 = 0; j0 + 1 < S; j0 += RAY_CH) {
+        float sc[RAY_CH], tc[RAY_CH], To[RAY_CH];
+#pragma unroll
+        for (int u = 0; u < RAY_CH; ++u) { const int i = min(j0 + 1 + u, S - 1); sc[u] = sig[i]; tc[u] = t[i]; }
+#pragma unroll
+        for (int u = 0; u < RAY_CH; ++u) {
+            To[u] = T;
+            if (j0 + 1 + u < S) {
+                float alpha, dummy;
+                segment(s0, sc[u], t0, tc[u], alpha, dummy);
+                const float w = alpha * T;
+                wtot += w; dnum = fmaf(w, (t0 + tc[u]) * 0.5f, dnum);
+                T *= (1.0f - alpha + 1e-10f);                       // :85
+                s0 = sc[u]; t0 = tc[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RAY_CH; ++u) if (j0 + 1 + u < S) Tv[j0 + u] = To[u];
     }
     const float d0 = dnum / wtot;
     const bool ok = wtot != 0.0f && isfinite(d0);                   // nan_to_num + clamp (:93-94) pass nothing otherwise
@@ -302,22 +315,32 @@ __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
         for (int c = 0; c < 32; ++c) s += cot_rgb(P, n, m, c);
         gconst -= s;
     }
-    // reverse: R_j = sum_{k>j} g_k alpha_k prod_{j<m<k} (1 - alpha_m + 1e-10)
+    // reverse: R_j = sum_{k>j} g_k alpha_k prod_{j<m<k} (1 - alpha_m + 1e-10).  Batches again: the loads of samples jh-7 .. jh first,
+    // then the recurrence, then the stores (to samples jh-6 .. jh+1: never a sample a later batch still has to read)
     float R = 0.0f;
     float s1 = sig[S - 1], a1 = av[S - 1], t1 = t[S - 1];
     float gs_hi = 0.0f, om_hi = 0.0f;          // contributions of segment j to sample j+1
-    for (int j = S - 2; j >= 0; --j) {
-        const float s0r = sig[j], a0 = av[j], t0r = t[j];
-        float alpha, dads;
-        segment(s0r, s1, t0r, t1, alpha, dads);
-        const float Tj = Tv[j];
-        const float gw = 0.5f * (a0 + a1) + gconst + (ok ? gd * ((t0r + t1) * 0.5f - d0) : 0.0f);
-        const float galpha = Tj * (gw - R);
-        R = fmaf(gw, alpha, (1.0f - alpha + 1e-10f) * R);
-        const float gs = 0.5f * galpha * dads, om = 0.5f * alpha * Tj;
-        sig[j + 1] = gs + gs_hi; av[j + 1] = om + om_hi;            // sample j+1 is complete: segments j and j+1 seen
-        gs_hi = gs; om_hi = om;
-        s1 = s0r; a1 = a0; t1 = t0r;
+    for (int jh = S - 2; jh >= 0; jh -= RAY_CH) {
+        float sc[RAY_CH], ac[RAY_CH], tc[RAY_CH], Tc[RAY_CH], gso[RAY_CH], omo[RAY_CH];
+#pragma unroll
+        for (int u = 0; u < RAY_CH; ++u) { const int i = max(jh - u, 0); sc[u] = sig[i]; ac[u] = av[i]; tc[u] = t[i]; Tc[u] = Tv[i]; }
+#pragma unroll
+        for (int u = 0; u < RAY_CH; ++u) {
+            gso[u] = 0.0f; omo[u] = 0.0f;
+            if (jh - u >= 0) {
+                float alpha, dads;
+                segment(sc[u], s1, tc[u], t1, alpha, dads);
+                const float gw = 0.5f * (ac[u] + a1) + gconst + (ok ? gd * ((tc[u] + t1) * 0.5f - d0) : 0.0f);
+                const float galpha = Tc[u] * (gw - R);
+                R = fmaf(gw, alpha, (1.0f - alpha + 1e-10f) * R);
+                const float gs = 0.5f * galpha * dads, om = 0.5f * alpha * Tc[u];
+                gso[u] = gs + gs_hi; omo[u] = om + om_hi;           // sample j+1 is complete: segments j and j+1 seen
+                gs_hi = gs; om_hi = om;
+                s1 = sc[u]; a1 = ac[u]; t1 = tc[u];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < RAY_CH; ++u) if (jh - u >= 0) { sig[jh - u + 1] = gso[u]; av[jh - u + 1] = omo[u]; }
     }
     sig[0] = gs_hi; av[0] = om_hi;
 }
@@ -948,7 +971,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 //                                            record (sample, four tile-local texels, 4 weights), its bin and its rank in the bin
 //                                            (one returning atomic per distinct bin of a wave)
 //   bwd_bin_scan_kernel                      exclusive scan of the bin counts
-//   bwd_bin_fill_kernel                      records to their sorted position
+//   bwd_bin_fill_kernel                      sorted list of record indices (offset of the bin + rank)
 //   bwd_accumulate_kernel                    one wave per (bin, segment): 64 records at a time (one per lane), then per record
 //                                            one 256-byte row load (lane = channel of both sets, 16 in flight) and 4 LDS updates
 // Work is cut into chunks (whole views, or ray tiles of one view) so that df stays within BWD_CHUNK_SAMPLES * 256 B.
@@ -976,9 +999,7 @@ __global__ __launch_bounds__(256) void bwd_bin_fill_kernel(BwdK P, unsigned long
     if (i >= slots) return;
     const uint2 br = P.binrank[i];
     if (br.x == KEY_INVALID) return;
-    const unsigned pos = P.offsets[br.x] + br.y;
-    P.list_key[pos] = P.rec_key[i];
-    P.list_w[pos] = P.rec_w[i];
+    P.perm[P.offsets[br.x] + br.y] = (unsigned)i;      // the records stay where they were written; only this index list is sorted
 }
 
 __global__ __launch_bounds__(64) void bwd_accumulate_kernel(BwdK P) {
@@ -999,8 +1020,9 @@ __global__ __launch_bounds__(64) void bwd_accumulate_kernel(BwdK P) {
     // load, lane = channel.  Two-deep pipeline: the next 64 records and the next 16 rows are in flight while 16 rows are added.
     auto load_keys = [&](unsigned r0, uint2& key, float4& wq) {
         const bool in = r0 + (unsigned)lane < last;
-        key = P.list_key[in ? r0 + (unsigned)lane : last - 1];
-        wq = P.list_w[in ? r0 + (unsigned)lane : last - 1];
+        const unsigned slot = P.perm[in ? r0 + (unsigned)lane : last - 1];
+        key = P.rec_key[slot];
+        wq = P.rec_w[slot];
         if (!in) wq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     };
     uint2 key; float4 wq;
@@ -1086,9 +1108,10 @@ static uint64_t chunk_slots(int n_views, int n_rays, int n_samples) {
     const uint64_t views = cap / per_view < (uint64_t)n_views ? cap / per_view : (uint64_t)n_views;
     return views * per_view;
 }
-// df rows + (key, weights) records and their sorted copy + (bin, rank) + counts and offsets
+// df rows + (key, weights) records + (bin, rank) + sorted record indices + counts and offsets
 static uint64_t binned_bytes(uint64_t slots) {
-    return align256(slots * 256) + 2 * (align256(slots * 3 * 8) + align256(slots * 3 * 16)) + align256(slots * 3 * 8) + 2 * align256(BWD_MAX_BINS * 4);
+    return align256(slots * 256) + align256(slots * 3 * 8) + align256(slots * 3 * 16) + align256(slots * 3 * 8) + align256(slots * 3 * 4) +
+           2 * align256(BWD_MAX_BINS * 4);
 }
 
 }  // namespace nfe
@@ -1197,10 +1220,9 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     char* bw = (char*)frags + align256(BWD_FRAG_BYTES);
     P.df = (float*)bw; bw += align256(slots_max * 256);
     P.rec_key = (uint2*)bw; bw += align256(slots_max * 3 * 8);
-    P.list_key = (uint2*)bw; bw += align256(slots_max * 3 * 8);
     P.rec_w = (float4*)bw; bw += align256(slots_max * 3 * 16);
-    P.list_w = (float4*)bw; bw += align256(slots_max * 3 * 16);
     P.binrank = (uint2*)bw; bw += align256(slots_max * 3 * 8);
+    P.perm = (unsigned*)bw; bw += align256(slots_max * 3 * 4);
     P.counts = (unsigned*)bw; bw += align256(BWD_MAX_BINS * 4);
     P.offsets = (unsigned*)bw;
     const uint64_t per_tile = 64ull * (uint64_t)a->n_samples, view_slots = (uint64_t)ray_tiles * per_tile;

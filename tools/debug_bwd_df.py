@@ -33,7 +33,7 @@ ns = N * M * S
 a256 = lambda x: (x + 255) & ~255
 off = 32768 + 3 * a256(ns * 4) + a256((4 * 2048 + 64 + 64 + 32 + 32 + 8192) * 4) + a256(52 * 64 * 16)
 slots = ns                      # one chunk (R*R is a multiple of 64)
-sizes = [("df", slots * 256), ("rec_key", slots * 24), ("list_key", slots * 24), ("rec_w", slots * 48), ("list_w", slots * 48), ("binrank", slots * 24)]
+sizes = [("df", slots * 256), ("rec_key", slots * 24), ("rec_w", slots * 48), ("binrank", slots * 24)]        # workspace order of nfe_render_backward
 snaps = []
 for rep in range(4):
     gg, ga = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, cam2world=c2w, intrinsics=K, resolution=R)
