@@ -48,7 +48,7 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r02_issue_floor.json")
 
 
 def backward_roofline(bwd_ms, samples, logical_gbs):
-    """Roofline block of the edit step.  The binned scatter moves 1360 B of HBM traffic per sample by construction
+    """Roofline block of the edit step.  The binned scatter moves 1240 B of HBM traffic per sample by construction
     and its accumulate pass is HBM-bound; the committed counter file (tools/pmc.sh, PMC_KERNEL=bwd_accumulate) gives that kernel's
     measured traffic and duration for the same 4-view launch."""
     import json
@@ -63,13 +63,13 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
             "kernel": "nfe::bwd_accumulate_kernel (of: render_kernel<EVAL>, bwd_ray_kernel, bwd_scatter_sorted_kernel<MFMA,BINNED>, "
                       "bwd_bin_fill_kernel, bwd_accumulate_kernel)",
             "kernel_ms": rec["avg_ns_profiled"] * 1e-6 if rec else None, "backward_ms": bwd_ms,
-            "hbm_bytes_per_sample_model": 1360, "hbm_model_gbs": samples * 1360 / (bwd_ms * 1e-3) / 1e9,
+            "hbm_bytes_per_sample_model": 1240, "hbm_model_gbs": samples * 1240 / (bwd_ms * 1e-3) / 1e9,
             "logical_gather_scatter_gbs": logical_gbs,
             "note": "achieved / traffic / kernel_ms: accumulate pass of one 4-view launch from profiles/r02_backward_counters.json "
                     "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE, rocprofv3 duration), not re-measured by this run; "
                     "backward_ms is this run's HIP-event time of the whole backward.  Per sample the decoder-backward kernel writes a "
-                    "256-byte feature-gradient row and three 32-byte records, the fill pass moves the records, the accumulate pass (one "
-                    "wave owns an 8x8 texel tile in LDS) reads each row three times.  logical gather + scatter bytes (9216 B/sample) / "
+                    "256-byte feature-gradient row and three 32-byte records, the fill pass sorts a 4-byte index per record, the accumulate "
+                    "pass (one wave owns an 8x8 texel tile in LDS) reads index, record and row once per plane.  logical gather + scatter bytes (9216 B/sample) / "
                     "time is quoted for reference only (planes and gradients are cache resident)"}
 
 
