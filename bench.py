@@ -313,9 +313,16 @@ def extra_workload(args, torch, dist, dev, rank, world):
             ev[i] = e
             return out
         dt = timed_steps(args, torch, dist, world, step, n_streams=args.streams)
+        # stage times: three more steps on ONE stream, outside the timed region (steps of the timed region overlap on the
+        # stream ring, which stretches every stage by the other streams' work)
+        torch.cuda.synchronize()
+        solo = [args.warmup + args.steps + i for i in range(3)]
+        for i in solo:
+            step(i)
+        torch.cuda.synchronize()
         G.stage_events = None
-        timed = [ev[args.warmup + i] for i in range(args.steps)]
-        avg = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in timed) / args.steps
+        timed = [ev[i] for i in solo]
+        avg = lambda a, b: sum(e[a].elapsed_time(e[b]) for e in timed) / len(timed)
         syn_ms = avg(0, 3)
         stage = {"backbone": avg(0, 1), "stats_render": avg(1, 2), "sr": avg(2, 3)}
         dense_ms = stage["backbone"] + stage["sr"]
@@ -331,12 +338,13 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     dtype="bf16x3" if ffhq else "bf16",
                     config={"workload": what,
                             "views_per_step": n_total, "synthesis_ms": syn_ms, "stage_ms": stage, "streams": args.streams,
-                            "stage_ms_note": "HIP-event times on the step's own stream; with streams > 1 consecutive steps overlap, so the "
-                                             "stages of one step are stretched by the other stream's work (use --streams 1 for stage times)",
+                            "stage_ms_note": "HIP-event times of three extra steps issued on one stream after the timed region (inside it "
+                                             "consecutive steps overlap on the stream ring); synthesis_ms is their sum",
                             "parallelism": f"views-dp{world}"},
                     roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv3_kernel<*> + upfir/torgb (backbone + SR stages)",
-                              "kernel_ms": dense_ms, "note": "289.1 GFLOP per view (SURVEY 8d) / time of the backbone + SR stages"})
+                              "kernel_ms": dense_ms, "note": "289.1 GFLOP per view (SURVEY 8d) / single-stream time of the backbone + SR stages (stage_ms); "
+                                                             "split-bf16 issues 3 MFMAs per product, so the matrix pipe does 3x these flops in that mode"})
 
     out = orbit_job(args, torch, dist, dev, rank, world, frames=args.orbit_frames, G=G, steps=args.steps, warmup=args.warmup)
     return dict(base, metric="512^2 views/s, 512-frame orbit (gen_videos camera path)", value=out["views_per_s"], unit="views/s",
