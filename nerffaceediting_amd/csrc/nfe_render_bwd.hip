@@ -877,13 +877,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         return;
     }
     const int plane_elems = P.H * P.W * 32;
+    const float livef = live ? 1.0f : 0.0f;
     unsigned key[3][4];                                 // element e = lane * 4 + r of each plane's list
 #pragma unroll
     for (int q = 0; q < 12; ++q) {
         const int p = q >> 2;
         wtab[lane * 12 + q] = geo.w[q];
         const unsigned texel = (unsigned)(geo.off[q] - p * plane_elems) >> 5;
-        key[p][q & 3] = (live ? geo.w[q] : 0.0f) != 0.0f ? (texel << 8 | (unsigned)lane << 2 | (unsigned)(q & 3)) : KEY_INVALID;
+        key[p][q & 3] = geo.w[q] * livef != 0.0f ? (texel << 8 | (unsigned)lane << 2 | (unsigned)(q & 3)) : KEY_INVALID;   // (a product: the compiler turns `(live ? w : 0) != 0` back into two compares and an s_and_b64)
     }
     __threadfence_block();
     // bitonic sort of the three 256-key lists in registers (ascending; invalid keys end up last): partners at distance
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int j = k >> 1; j > 0; j >>= 1) {
             if (j >= 4) {
                 const int lj = j >> 2;
-                const bool keep_min = ((lane & lj) == 0) == ((lane & (k >> 2)) == 0);
+                const bool keep_min = ((((unsigned)lane / (unsigned)lj) ^ ((unsigned)lane / (unsigned)(k >> 2))) & 1u) == 0u;   // one compare, no mask logic on the scalar unit (r02_lane_mask.md)
 #pragma unroll
                 for (int p = 0; p < 3; ++p)
 #pragma unroll
