@@ -102,6 +102,43 @@ def test_backward_sweep(seed, dev):
             assert float(np.abs(un(got) - want).max()) <= 1e-3 * float(np.abs(want).max()) + 1e-7, seed
 
 
+@pytest.mark.parametrize("D,Di", [(256, 0), (256, 256), (4, 256), (255, 1), (2, 0)])
+def test_sample_count_limits(D, Di, dev):
+    """The ends of the sample-count ranges the ABI accepts (depth_resolution 2..NFE_MAX_SAMPLES, importance 0..NFE_MAX_SAMPLES:
+    the merged march then has up to 512 samples, importance_kernel's key list and LDS layout are at their largest) against the C
+    oracle, forward; and the backward of the largest case against the analytic backward oracle."""
+    from nerffaceediting_amd import ops
+    rng = np.random.RandomState(4242 + D + 7 * Di)
+    N, M, H, W = 2, 40, 16, 24
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.2, ray_end=3.3, box_warp=1.0, white_back=False,
+                disparity_space_sampling=False, clamp_mode="softplus")
+    pn = rng.randn(N, 3, 32, H, W).astype(np.float32)
+    pd = (rng.randn(N, 3, 32, H, W) * 0.8 + 0.1).astype(np.float32)
+    dec = orc.random_decoder(D + Di, bias_scale=0.2)
+    o = np.tile(np.array([0.0, 0.0, 2.7], np.float32), (N, M, 1)) + rng.randn(N, M, 3).astype(np.float32) * 0.03
+    d = rng.uniform(-0.5, 0.5, (N, M, 3)).astype(np.float32) - o
+    d = (d / np.linalg.norm(d, axis=-1, keepdims=True)).astype(np.float32)
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, Di).astype(np.float32) if Di else None
+    want = c_oracle.render(pn, pd, dec, o, d, opts, u_c, u_f)
+    heads = [t(dec[k], dev) for k in NAMES]
+    pg, pa = ops.plane_pack(t(pn, dev)), ops.plane_pack(t(pd, dev))
+    kw = dict(origins=t(o, dev), dirs=t(d, dev))
+    got = ops.render(pg, pa, ops.decoder_pack(*heads), opts, u_coarse=t(u_c, dev), u_fine=None if u_f is None else t(u_f, dev), taps=True, **kw)
+    for k, g, w in zip(("rgb", "seg", "depth", "wsum"), got[:4], want):
+        assert max_abs(g.cpu().numpy(), w) <= 1e-3, (D, Di, k)
+    depths = got[4]["depths_all"]
+    assert depths.shape[-1] == D + Di and bool((depths[..., 1:] >= depths[..., :-1]).all())
+    if (D, Di) != (256, 256):
+        return
+    cot = [rng.randn(N, M, c).astype(np.float32) for c in (32, 15, 1, 1)]
+    gn, gd = bwd.render_backward(pn, pd, dec, o, d, depths.cpu().numpy().reshape(N, M, D + Di), opts, *cot)
+    gg, ga = ops.render_backward(pg, pa, heads, 1.0, opts, depths, tuple(t(x, dev) for x in cot), **kw)
+    un = lambda g: g.permute(0, 1, 4, 2, 3).contiguous().cpu().numpy()
+    for got_g, want_g in ((gg, gn), (ga, gd)):
+        assert float(np.abs(un(got_g) - want_g).max()) <= 1e-3 * float(np.abs(want_g).max()) + 1e-7
+
+
 @pytest.mark.parametrize("two_pass", [False, True])
 def test_pose_sweep_image_rays(two_pass, dev):
     """Image rays generated in-kernel from 12 cameras (frontal to grazing yaw / pitch, near and far radii, narrow and wide
