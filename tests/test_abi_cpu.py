@@ -121,3 +121,18 @@ def test_ops_refuse_cpu_tensors():
         ops.plane_pack(torch.zeros(1, 96, 4, 4))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.ray_sampler(torch.eye(4)[None], torch.eye(3)[None], 8)
+
+
+def test_backward_workspace_is_bounded():
+    """nfe_render_backward_workspace_bytes: three floats per sample for the march records, plus the binned scatter's chunk buffers,
+    which stop growing once a chunk holds 2^23 sample slots (256-byte feature-gradient row + 68 bytes of records per slot)."""
+    from nerffaceediting_amd import _lib
+    lib = _lib.load()
+    fixed = lambda n, m, s: lib.nfe_render_backward_workspace_bytes(n, m, s) - 3 * 4 * n * m * s
+    per_slot = 256 + 3 * (8 + 16 + 8 + 4)
+    small = fixed(3, 70, 12)                       # three views x two 64-ray tiles x 12 samples = 4608 slots
+    assert 4608 * per_slot <= small <= 4608 * per_slot + (6 << 20)
+    cap = fixed(1, 512 * 512, 192)
+    assert cap == fixed(8, 512 * 512, 192)         # more views, same chunk
+    assert (1 << 23) * per_slot * 0.99 <= cap <= (1 << 23) * per_slot + (8 << 20)
+    assert lib.nfe_render_backward_workspace_bytes(0, 64, 4) < (1 << 23)
