@@ -50,8 +50,8 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r02_issue_floor.json")
 def backward_roofline(bwd_ms, samples, logical_gbs):
     """Roofline block of the edit step.  The binned scatter moves 1240 B of HBM traffic per sample by construction (DESIGN.md 4.4);
     its accumulate pass runs at about half the HBM peak but is bound by its per-record instruction chain (halving the rows did not
-    shorten it), the decoder-backward and evaluation passes by the texture path; the committed counter file (tools/pmc.sh, PMC_KERNEL=bwd_accumulate) gives that kernel's
-    measured traffic and duration for the same 4-view launch."""
+    shorten it), the decoder-backward and evaluation passes by the texture path; the committed counter file (tools/pmc.sh,
+    PMC_KERNEL=bwd_accumulate) gives that kernel's measured traffic and duration for the same 4-view launch."""
     import json
     import os
     rec = None
@@ -59,15 +59,15 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
     if os.path.exists(path):
         rec = json.load(open(path))
     ach = rec["hbm_bytes_per_launch"] / rec["avg_ns_profiled"] if rec else None            # GB/s
-    return {"bound": "wave_issue", "achieved": ach, "peak": 8000.0 if rec else None, "unit": "GB/s" if rec else None,
-            "frac": ach / 8000.0 if rec else None, "traffic": rec["hbm_bytes_per_launch"] if rec else None,
+    return {"bound": "wave_issue", "achieved": None, "peak": None, "unit": None, "frac": None,
+            "traffic": rec["hbm_bytes_per_launch"] if rec else None, "hbm_gbs": ach, "hbm_frac": ach / 8000.0 if rec else None,
             "kernel": "nfe::bwd_accumulate_kernel (of: render_kernel<EVAL>, bwd_ray_kernel, bwd_scatter_sorted_kernel<MFMA,BINNED>, "
                       "bwd_bin_fill_kernel, bwd_accumulate_kernel)",
             "kernel_ms": rec["avg_ns_profiled"] * 1e-6 if rec else None, "backward_ms": bwd_ms,
             "hbm_bytes_per_sample_model": 1240, "hbm_model_gbs": samples * 1240 / (bwd_ms * 1e-3) / 1e9,
             "logical_gather_scatter_gbs": logical_gbs,
             "note": "bound: no unit saturated (accumulate pass: per-record readlane / scalar / LDS chain; decoder-backward and evaluation passes: TA 0.6-0.8). "
-                    "achieved / peak / frac are the accumulate pass's HBM rate for reference: achieved / traffic / kernel_ms of one 4-view launch from profiles/r02_backward_counters.json "
+                    "hbm_gbs / hbm_frac / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r02_backward_counters.json "
                     "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE, rocprofv3 duration), not re-measured by this run; "
                     "backward_ms is this run's HIP-event time of the whole backward.  Per sample the decoder-backward kernel writes a "
                     "256-byte feature-gradient row and three 32-byte records, the fill pass sorts a 4-byte index per record, the accumulate "
