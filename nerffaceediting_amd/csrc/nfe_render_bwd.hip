@@ -841,10 +841,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const bool any = (live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
             const unsigned bin = any ? ((unsigned)blockIdx.z * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
                                      : KEY_INVALID;
-            // rank inside the bin: one returning atomic per distinct bin of the wave.  The loop condition is made with scalar
-            // compares on purpose: the lane-mask form (v_cmp -> vcc, s_cbranch_vccz) of a uniform branch is not reliable in a
-            // 256-register kernel at two waves per SIMD (profiles/experiments/r02_square_branch.md; it went the wrong way here too)
-            unsigned rank = 0;
+            // rank inside the bin.  Pass 1 (registers only): for every distinct bin of the wave its first lane, the lanes' position
+            // among the wave's records of that bin and their number.  Pass 2: ONE returning atomic instruction, executed by the first
+            // lanes of all bins together - the bins' round trips to memory overlap instead of following each other.  The loop
+            // condition is made with scalar compares on purpose: the lane-mask form (v_cmp -> vcc, s_cbranch_vccz) of a uniform branch
+            // is not reliable in a 256-register kernel at two waves per SIMD (profiles/experiments/r02_square_branch.md).
+            unsigned rank = 0, group = 0;
+            int first_lane = -1;                      // stays -1 on lanes without a record
             const unsigned long long have = __ballot(any);
             unsigned todo_lo = (unsigned)have, todo_hi = (unsigned)(have >> 32);
             for (;;) {
@@ -854,12 +857,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const int leader = todo_lo ? __builtin_ctz(todo_lo) : 32 + __builtin_ctz(todo_hi);
                 const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
                 const unsigned long long same = __ballot(bin == b);          // b is a live record's bin, dead lanes hold KEY_INVALID
-                unsigned base = 0;
-                if (lane == leader) base = atomicAdd(P.counts + b, (unsigned)__popcll(same));
-                base = (unsigned)__builtin_amdgcn_readlane((int)base, leader);
-                if (bin == b) rank = base + (unsigned)__popcll(same & ((1ull << lane) - 1ull));
+                if (bin == b) { rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull)); group = (unsigned)__popcll(same); first_lane = leader; }
                 todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
             }
+            unsigned base = 0;
+            if (first_lane == lane) base = __hip_atomic_fetch_add(P.counts + bin, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            rank += (unsigned)__shfl((int)base, first_lane & 63);
             const size_t slot = (size_t)p * ((size_t)gridDim.z * P.t_count * P.S * 64) + idx;
             P.binrank[slot] = make_uint2(bin, rank);
             if (any) {
