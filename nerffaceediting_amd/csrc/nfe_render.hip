@@ -1078,6 +1078,13 @@ struct ImportanceK {
     float* tap_fine;         // optional [NR, Di] in draw order
 };
 
+// Orders this wave's LDS accesses for the compiler (other lanes of the wave read what a lane wrote).  The hardware executes a
+// wave's LDS operations in order; a workgroup-scope fence would also drain the outstanding global stores of the previous ray.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -1104,7 +1111,7 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
     for (long long ray = (long long)blockIdx.x * 4 + wave; ray < P.n_rays_total; ray += (long long)gridDim.x * 4) {
         for (int i = lane; i < D; i += 64) tc[i] = P.t_coarse[ray * D + i];
         for (int i = lane; i < D - 1; i += 64) wq[i] = P.w_coarse[ray * (D - 1) + i];
-        __threadfence_block();
+        wave_lds_fence();
         // smoothed weights a_i, i=0..D-2 (max_pool1d(k2,s1,p1) then avg_pool1d(k2,s1), +0.01): :205-207
         // only a[1..D-3] are used; q_i = a_{i+1} + 1e-5, i = 0..B-1 (:210, :228)
         float qv[NFE_MAX_SAMPLES / 64];
@@ -1136,7 +1143,7 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
             carry = __shfl(sc, 63);
         }
         if (lane == 0) cdf[0] = 0.0f;
-        __threadfence_block();
+        wave_lds_fence();
         // inverse-CDF sampling (:236-252)
         for (int e = lane; e < Di; e += 64) {
             float u;
@@ -1163,7 +1170,7 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
             if (P.tap_fine) P.tap_fine[ray * Di + e] = t;
         }
         for (int e = Di + lane; e < DiP; e += 64) keys[e] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        __threadfence_block();
+        wave_lds_fence();
         // merge (unify_samples, renderer.py:288-300: only the sorted depths leave this kernel, so ties need no order).
         // 1. rank of each fine depth among the fine depths by counting: the number of (depth, draw index) keys below its own - every
         //    lane walks the whole key list (two keys per LDS read, broadcast) with one 64-bit compare and one add-with-carry per key;
@@ -1197,7 +1204,7 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
                 if (e < Di) tf[rank[c]] = ord2f((unsigned)(mine[c] >> 32));
             }
         }
-        __threadfence_block();
+        wave_lds_fence();
         float* out = P.t_all + ray * (D + Di);
         for (int e = lane; e < Di; e += 64) {            // fine: #coarse <= v (upper bound)
             const float v = tf[e];
@@ -1213,7 +1220,7 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
             out[e + lo] = v;
             if (P.src_all) P.src_all[ray * (D + Di) + e + lo] = e;
         }
-        __threadfence_block();
+        wave_lds_fence();
     }
 }
 
