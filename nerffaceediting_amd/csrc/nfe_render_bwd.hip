@@ -695,7 +695,11 @@ __device__ __forceinline__ void gather_pair_coop(const BwdK& P, int n, const Sam
             float wsum = 0.0f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 5      // timing experiment: every tap reads texel row 0 (no gather traffic)
+                const int off = __shfl(geo.off[4 * p + k], src) & 0;
+#else
                 const int off = __shfl(geo.off[4 * p + k], src);
+#endif
                 const float w = __shfl(geo.w[4 * p + k], src);
                 wsum += w;
                 if (DO_G) sg = fma4(w, *reinterpret_cast<const float4*>(pg + off), sg);
