@@ -10,6 +10,8 @@ batch-of-views path does.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N ...            # no launcher: starts its own N ranks (children, before any GPU call), like
+                                            # the reference's train.py:98-103 spawn; rank 0's line is forwarded
 Prints ONE JSON line on rank 0.
 
 The default line also carries `strong_scaling`: the 512-frame orbit job of BASELINE config 4 (full synthesis, frames sharded
@@ -191,6 +193,11 @@ def timed_steps(args, torch, dist, world, step, n_streams=1):
                 return inner(i)
     for i in range(args.warmup):
         step(i)
+    t_pre = time.perf_counter()                # untimed clock-settling pre-roll (see main())
+    while args.warmup > 0 and time.perf_counter() - t_pre < getattr(args, "preroll_s", 0.0):
+        for i in range(4):
+            step(i % args.warmup)
+        torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -358,7 +365,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
                           "kernel": "whole step (dense flops of this rank / wall time)", "kernel_ms": None})
 
 
-def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, warmup=0, chunk=8):
+def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, warmup=0, chunk=8, return_frames=False):
     """BASELINE config 4, the strong-scaling job: `frames` (per-frame ws, camera) pairs on the gen_videos.py:128-133 camera
     path, full synthesis at 512^2 x 64 with bf16 convs, frames cut into contiguous blocks per rank and rendered `chunk` at a
     time; the uint8 frames ([chunk,512,512,3], what the video writer consumes, gen_videos.py:147-151) of chunk k are
@@ -386,7 +393,9 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
             sl = gat.local_slice(k)
             gat.submit(k, ring.take(*ring.run(lambda: chunk_frames(*sl))))
         return gat.finish()
-    G.synthesis(ws_local[:chunk].contiguous(), c_all[a:a + min(chunk, b - a)].contiguous(), noise_mode="const")     # weight packing, allocator
+    if b > a:                                 # weight packing, allocator (an empty shard - more ranks than frames - renders nothing)
+        nw = min(chunk, b - a)
+        G.synthesis(ws_local[:nw].contiguous(), c_all[a:a + nw].contiguous(), noise_mode="const")
     for _ in range(warmup):
         one_pass()
     if world > 1:
@@ -396,19 +405,76 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
     for _ in range(max(steps, 1)):
         out = one_pass()
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0         # this rank's own block + its share of the exchanges, before waiting for the others
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
+    blocks = [{"rank": rank, "frames": [a, b], "seconds_per_pass_before_barrier": dt_local / max(steps, 1)}]
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        gathered = [None] * world
+        dist.all_gather_object(gathered, blocks[0])
+        blocks = gathered
     assert out.shape == (V, G.img_resolution, G.img_resolution, 3)
     per_pass = dt / max(steps, 1)
-    return {"workload": f"BASELINE config 4: {V} (per-frame ws, camera) pairs, gen_videos.py:128-133 path, full synthesis 512^2 x 64 + SR, bf16 "
+    if return_frames:
+        return out
+    return {"rank_blocks": blocks, "workload": f"BASELINE config 4: {V} (per-frame ws, camera) pairs, gen_videos.py:128-133 path, full synthesis 512^2 x 64 + SR, bf16 "
                         f"convs, contiguous blocks per rank, uint8 frames all-gathered per {chunk}-frame chunk under the next chunk's render",
             "frames": V, "frames_per_rank": b - a, "chunk": chunk, "n_gpus": world, "seconds_per_pass": per_pass, "views_per_s": V / per_pass,
             "scaling": "strong", "dense_tflops": GFLOP_DENSE_PER_VIEW * (b - a) * 1e9 / per_pass / 1e12}
+
+
+def distributed_info(dist, world):
+    """What the process group itself reports (not what the command line asked for)."""
+    if world > 1:
+        assert dist.is_initialized() and dist.get_world_size() == world, (dist.get_world_size(), world)
+        return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
+                "launcher": os.environ.get("NFE_LAUNCHER", "torch.distributed.run")}
+    return {"backend": None, "world_size": 1, "launcher": None}
+
+
+def exchange_check(args, torch, dist, rank, world):
+    """--workload exchange: the launch + frame-exchange plumbing of the config-4 job WITHOUT rendering — every rank fills its
+    block of a synthetic frame list (frame f = all bytes f % 251) and the blocks travel through sharding.ChunkedFrameGather
+    exactly as orbit_job's frames do.  Runs on the gloo backend on CPU tensors (tests/test_sharding_cpu.py starts it through the
+    self-launch path) or on RCCL with device tensors.  Not a benchmark: it times nothing that BASELINE.json names."""
+    from nerffaceediting_amd import sharding
+    if args.backend == "nccl":
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+    else:
+        dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+    info = distributed_info(dist, world)
+    V, chunk, shape = int(args.orbit_frames), 3, (8, 8, 3)
+    t0 = time.perf_counter()
+    for _ in range(max(args.steps, 1)):
+        gat = sharding.ChunkedFrameGather(V, chunk, shape, torch.uint8, dev)
+        for k in range(gat.rounds()):
+            s_, e_ = gat.local_slice(k)
+            fr = torch.stack([torch.full(shape, f % 251, dtype=torch.uint8, device=dev) for f in range(s_, e_)]) if e_ > s_ \
+                else torch.zeros((0,) + shape, dtype=torch.uint8, device=dev)
+            gat.submit(k, fr)
+        out = gat.finish()
+    dt = time.perf_counter() - t0
+    want = (torch.arange(V) % 251).to(torch.uint8).to(dev).view(V, 1, 1, 1).expand(V, *shape)
+    ok = bool(torch.equal(out, want))
+    if world > 1:
+        flag = torch.tensor([int(ok)], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = bool(flag.item())
+        dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(f"rank {rank}: gathered frames differ from the expected frame list")
+    return {"metric": "frame-exchange plumbing check (no rendering)", "value": V * max(args.steps, 1) / dt, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": {"workload": f"exchange check: {V} 8x8x3 uint8 frames, "
+            f"chunk {chunk}, ChunkedFrameGather over {info['backend']}", "frames": V}, "distributed": info, "frames_ok": ok}
 
 
 def main():
@@ -417,30 +483,55 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["render", "full", "ffhq", "orbit", "twopass", "editstep"], default="render")
+    ap.add_argument("--workload", choices=["render", "full", "ffhq", "orbit", "twopass", "editstep", "exchange"], default="render")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend; 'nccl' is RCCL over xGMI.  'gloo' exists for --workload exchange, the CPU check of "
+                         "the launch + frame-exchange plumbing (it renders nothing and is not a benchmark)")
+    ap.add_argument("--preroll-s", type=float, default=1.0,
+                    help="untimed clock-settling pre-roll: the step is repeated for at least this long right before the timed region")
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the full-synthesis workloads alternate their batches on")
     ap.add_argument("--orbit-frames", type=int, default=512, help="frames of the strong-scaling orbit job (BASELINE config 4)")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the config-4 orbit job reported beside the default line")
     args = ap.parse_args()
 
+    from nerffaceediting_amd import launch
+    if args.gpus > 1 and not launch.launched_by_a_launcher():
+        # No launcher around us: start one fresh process per GPU (train.py:98-103 does the same with mp.spawn).  Nothing in
+        # this process has touched the GPU (torch is not even imported yet) and it never replaces itself: the ranks are
+        # children, their exit codes decide ours.
+        rc, _ = launch.spawn_ranks(__file__, sys.argv[1:], args.gpus)
+        sys.exit(rc)
+
     import torch
     import torch.distributed as dist
-    from nerffaceediting_amd import ops, sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: pass --gpus equal to the number of ranks the launcher started")
+    if args.workload == "exchange":
+        out = exchange_check(args, torch, dist, rank, world)
+        if rank == 0:
+            print(json.dumps(out))
+        return
+    if args.backend != "nccl":
+        raise SystemExit("only --workload exchange runs on the gloo backend; every rendering workload needs a GPU and RCCL")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback path exists)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
+    from nerffaceediting_amd import ops, sharding
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
+    dist_info = distributed_info(dist, world)
 
     if args.workload != "render":
         out = extra_workload(args, torch, dist, dev, rank, world)
+        out["distributed"] = dist_info
         if rank == 0:
             print(json.dumps(out))
         if world > 1:
@@ -483,6 +574,14 @@ def main():
 
     for i in range(args.warmup):
         step(i, False)
+    # clock-settling pre-roll (untimed): the same step back to back for >= preroll_s, so the timed region starts at the
+    # clock the chip holds under this load, not at the idle boost clock
+    t_pre, n_pre = time.perf_counter(), 0
+    while time.perf_counter() - t_pre < args.preroll_s:
+        for i in range(8):
+            step(i, False)
+        torch.cuda.synchronize()
+        n_pre += 8
     drain()
 
     def barrier():
@@ -534,7 +633,9 @@ def main():
                                    "(fp32 operands split into bf16 hi+lo, 3 bf16 MFMAs per product, fp32 accumulate: 2-6e-6 "
                                    "max-abs vs the reference; the exact-fp32 MFMA mode is timed beside it)",
                        "decoder_math": "bf16x3", "views_per_step": n_total, "views_per_s": n_total * args.steps / dt,
-                       "rays_per_view": M, "depth_samples": D, "parallelism": f"views-dp{world}"},
+                       "rays_per_view": M, "depth_samples": D, "parallelism": f"views-dp{world}",
+                       "preroll_steps": n_pre, "preroll_s": args.preroll_s},
+            "distributed": dist_info,
             "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                          "frac": frac.get(bound) if bound else None, "traffic": detail.get("hbm_bytes"),
                          "kernel": "nfe::render_kernel<DUAL=0,SIGMA_ONLY=0,BF16X3,...,SQUARE=1>", "kernel_ms": kern_ms,

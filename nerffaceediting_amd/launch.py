@@ -1,0 +1,80 @@
+"""Self-launch of a one-process-per-GPU job, the counterpart of the reference's own multi-process entry
+(`train.py:98-103`: `torch.multiprocessing.spawn(fn=subprocess_fn, nprocs=c.num_gpus)`; rendezvous `train.py:37-43`).
+
+`spawn_ranks(script, argv, nprocs)` starts `nprocs` FRESH interpreter processes of `script`, one per rank, with
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment (what `torch.distributed.run` would set),
+so the same script works under either launcher.  The parent never touches the GPU and never replaces itself: the ranks
+are children, the parent waits for them, forwards rank 0's standard output and returns non-zero if any rank failed
+(the remaining ranks are then terminated by PID — a rank that died before a collective would otherwise leave the others
+waiting in it).  No torch import here: this must stay safe to call before anything initialises HIP.
+"""
+import os
+import socket
+import subprocess
+import sys
+import threading
+import time
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launched_by_a_launcher(env=None):
+    """True inside a rank process (torch.distributed.run or spawn_ranks has set WORLD_SIZE)."""
+    env = os.environ if env is None else env
+    return "WORLD_SIZE" in env and "RANK" in env
+
+
+def spawn_ranks(script, argv, nprocs, env=None, timeout=None, stdout=None):
+    """Run `python script *argv` as `nprocs` ranks on this node.  Returns (exit_code, rank0_stdout_text).
+    Rank 0's stdout is captured (and echoed to `stdout`, default sys.stdout, line by line); the other ranks' stdout goes to
+    this process's stderr so that the caller still sees exactly one result line on stdout."""
+    stdout = sys.stdout if stdout is None else stdout
+    base = dict(os.environ if env is None else env)
+    base.update(WORLD_SIZE=str(nprocs), LOCAL_WORLD_SIZE=str(nprocs), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()),
+                NFE_LAUNCHER="self")
+    base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
+    procs = []
+    for r in range(nprocs):
+        e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=e,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0) or None))
+    captured = []
+
+    def pump():
+        for line in procs[0].stdout:
+            captured.append(line)
+            stdout.write(line)
+            stdout.flush()
+    t = threading.Thread(target=pump, daemon=True)
+    t.start()
+    deadline = None if timeout is None else time.time() + timeout
+    rc = 0
+    live = set(range(nprocs))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is not None:
+                live.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"[launch] rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+        if rc != 0 or (deadline is not None and time.time() > deadline):
+            if rc == 0:
+                rc = 124
+                print(f"[launch] timeout after {timeout} s; stopping all ranks", file=sys.stderr)
+            for r in live:
+                procs[r].terminate()                               # exact PIDs we started, never a pattern
+            for r in live:
+                try:
+                    procs[r].wait(10)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            live.clear()
+        else:
+            time.sleep(0.05)
+    t.join(5)
+    return rc, "".join(captured)

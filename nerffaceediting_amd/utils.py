@@ -1,6 +1,7 @@
 """demo.ipynb helpers with the reference's names (utils.py:32-88,146-199): encode / decode tri-planes,
 normalise / denormalise them (appearance transfer = swapping mean/std between identities), and the orbit of
-`render_video`.  File writing (imageio) is out of scope: `render_video_frames` returns the uint8 frames."""
+`render_video`.  mp4 encoding is out of scope: `render_video_frames` returns the uint8 frames and `render_video` (the reference's
+signature) hands them to imageio when it is installed, or to a caller-supplied writer."""
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -131,6 +132,51 @@ def render_video_frames(G, ws, norm_planes, denorm_planes, frames=150, a_degree=
         out.append(img.permute(0, 2, 3, 1))
     local = torch.cat(out, 0) if out else torch.zeros(0, G.img_resolution, G.img_resolution, 3, dtype=torch.uint8, device=dev)
     return sharding.all_gather_frames(local, V) if world > 1 else local
+
+
+@torch.no_grad()
+def render_video(G, fn, ws, norm_planes, denorm_planes, frames=150, fps=30, a_degree=15.0, b_degree=12.0,
+                 init_pitch=5 * np.pi / 12, init_yaw=np.pi / 2, writer=None, batch=4):
+    """utils.render_video (utils.py:32-88), same positional signature.  The frames come from `render_video_frames` (cameras
+    batched and sharded); rank 0 hands them, one HxWx3 uint8 array at a time, to `writer` — an object with
+    `append_data(frame)` / `close()` like imageio's, or a callable `writer(frame)`.  With writer=None the reference's own
+    `imageio.get_writer(fn, fps=fps, quality=8)` is used when imageio is importable; a `.npy` file name is written with numpy;
+    anything else raises (mp4 encoding itself is not part of this package).  Returns the uint8 frames [F,H,W,3]."""
+    import os
+    out = render_video_frames(G, ws, norm_planes, denorm_planes, frames=frames, a_degree=a_degree, b_degree=b_degree,
+                              init_pitch=init_pitch, init_yaw=init_yaw, batch=batch)
+    if dist.is_available() and dist.is_initialized() and dist.get_rank() != 0:
+        return out
+    if fn and os.path.dirname(fn):
+        os.makedirs(os.path.dirname(fn), exist_ok=True)                # utils.py:75
+    host = out.cpu().numpy()
+    if writer is None and fn is not None and str(fn).endswith(".npy"):
+        np.save(fn, host)
+        return out
+    own = writer is None
+    if own:
+        try:
+            import imageio
+        except ImportError as e:
+            raise RuntimeError("render_video(): imageio is not installed; pass writer=<object with append_data/close, or a "
+                               "callable taking one HxWx3 uint8 frame>, or a '.npy' file name") from e
+        writer = imageio.get_writer(fn, fps=fps, quality=8)           # utils.py:76
+    put = writer.append_data if hasattr(writer, "append_data") else writer
+    for frame in host:
+        put(frame)
+    if own:
+        writer.close()
+    return out
+
+
+def get_camera_samples(G, device):
+    """utils.py:130-144: the 3 x 3 grid of (pitch, yaw) in {5,6,7}*pi/12 demo.ipynb renders -> list of nine c [1,25]."""
+    intrinsics = FOV_to_intrinsics(18.837, device=device)
+    cam_pivot = torch.tensor(G.rendering_kwargs.get("avg_camera_pivot", [0, 0, 0]), device=device)
+    cam_radius = G.rendering_kwargs.get("avg_camera_radius", 2.7)
+    angles = [5 * np.pi / 12, 6 * np.pi / 12, 7 * np.pi / 12]
+    return [torch.cat([LookAtPoseSampler.sample(pitch, yaw, cam_pivot, radius=cam_radius, device=device).reshape(-1, 16),
+                       intrinsics.reshape(-1, 9)], 1) for pitch in angles for yaw in angles]
 
 
 PART_COLORS = [[0, 0, 0], [127, 212, 255], [255, 212, 255], [255, 255, 170], [255, 255, 130], [76, 153, 0], [0, 255, 170],

@@ -374,6 +374,45 @@ def gen_ray_sampler():
     print("  wrote ray_sampler.npz")
 
 
+def gen_camera_samples():
+    """utils.get_camera_samples (utils.py:130-144) and the camera schedule of utils.render_video (:45-73), by importing the
+    reference's utils.py itself.  It imports imageio and torchvision (absent here, used only by the mp4 writer / make_grid):
+    empty placeholder modules let the import proceed; render_video is run with a recording stand-in for the writer and for
+    decode(), so the (pitch, yaw) list it visits is captured from the reference's own loop."""
+    import types
+    io = types.ModuleType("imageio")
+    tv, tvu = types.ModuleType("torchvision"), types.ModuleType("torchvision.utils")
+    tvu.make_grid = None
+    tv.utils = tvu
+    for name, mod in (("imageio", io), ("torchvision", tv), ("torchvision.utils", tvu)):
+        sys.modules.setdefault(name, mod)
+    import utils as ref_utils
+    G = types.SimpleNamespace(rendering_kwargs={"avg_camera_pivot": [0, 0, 0.2], "avg_camera_radius": 2.7})
+    cams_ref = torch.cat(ref_utils.get_camera_samples(G, torch.device("cpu")), 0).numpy()
+    G0 = types.SimpleNamespace(rendering_kwargs={})
+    cams_default = torch.cat(ref_utils.get_camera_samples(G0, torch.device("cpu")), 0).numpy()
+    seen = []
+
+    class Writer:
+        def append_data(self, img): pass
+        def close(self): pass
+    io.get_writer = lambda fn, **k: Writer()
+    real_decode = ref_utils.decode
+    ref_utils.decode = lambda G_, ws, cam, n, d, **k: (seen.append(cam.numpy().copy()), {"image": torch.zeros(1, 3, 2, 2)})[1]
+    try:
+        ref_utils.render_video(G, "/tmp/_nfe_golden/x.mp4", torch.zeros(1, 14, 512), None, None, frames=12, a_degree=15.0, b_degree=12.0)
+        video = np.concatenate(seen, 0)
+        del seen[:]
+        ref_utils.render_video(G0, "/tmp/_nfe_golden/x.mp4", torch.zeros(1, 14, 512), None, None, frames=9, a_degree=10.0, b_degree=20.0,
+                               init_pitch=1.2, init_yaw=1.7)
+        video2 = np.concatenate(seen, 0)
+    finally:
+        ref_utils.decode = real_decode
+    np.savez_compressed(os.path.join(OUT, "camera_samples.npz"), cams_pivot02=cams_ref, cams_default=cams_default,
+                        video_cams_12=video, video_cams_9_interp=video2)
+    print(f"  wrote camera_samples.npz ({cams_ref.shape}, video {video.shape})")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     front3 = [(0.4, -0.2), (0.0, -0.2), (-0.4, -0.2)]
@@ -402,6 +441,7 @@ def main():
     gen_plane_stats()
     print("ray sampler:")
     gen_ray_sampler()
+    gen_camera_samples()
     sz = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print(f"total fixture size {sz/1e6:.2f} MB")
 
@@ -416,6 +456,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "segmentation_decoder":
         os.makedirs(OUT, exist_ok=True)
         gen_segmentation_decoder()
+    elif len(sys.argv) > 1 and sys.argv[1] == "camera_samples":
+        os.makedirs(OUT, exist_ok=True)
+        gen_camera_samples()
     elif len(sys.argv) > 1 and sys.argv[1] == "decoder_forward":
         os.makedirs(OUT, exist_ok=True)
         gen_decoder_forward()

@@ -44,3 +44,30 @@ def test_create_samples_and_volume_match_reference():
     assert abs(float(pts[0, 1, 2] - pts[0, 0, 2]) - voxel) < 1e-6 and 0 < float(pts[0, 1, 1] - pts[0, 0, 1]) < voxel
     vol = apps.density_to_volume(torch.from_numpy(z["sigma_grid"]))
     assert np.array_equal(vol.numpy(), z["sigma_volume"])
+
+
+def test_camera_samples_and_video_schedule_match_reference():
+    """utils.get_camera_samples (utils.py:130-144) and the cameras utils.render_video visits (:45-80), against captures of the
+    reference's own functions (oracle/gen_golden.py:gen_camera_samples)."""
+    import types
+    from tests._golden import load
+    from nerffaceediting_amd import utils
+    from nerffaceediting_amd.camera_utils import FOV_to_intrinsics, LookAtPoseSampler
+    z = load("camera_samples")
+    G = types.SimpleNamespace(rendering_kwargs={"avg_camera_pivot": [0, 0, 0.2], "avg_camera_radius": 2.7})
+    cams = utils.get_camera_samples(G, torch.device("cpu"))
+    assert len(cams) == 9 and all(c.shape == (1, 25) for c in cams)
+    assert np.allclose(torch.cat(cams, 0).numpy(), z["cams_pivot02"], atol=1e-6)
+    G0 = types.SimpleNamespace(rendering_kwargs={})
+    assert np.allclose(torch.cat(utils.get_camera_samples(G0, torch.device("cpu")), 0).numpy(), z["cams_default"], atol=1e-6)
+
+    def cams_of(G_, sched):
+        intr = FOV_to_intrinsics(18.837)
+        pivot = torch.tensor(G_.rendering_kwargs.get("avg_camera_pivot", [0, 0, 0]), dtype=torch.float32)
+        radius = G_.rendering_kwargs.get("avg_camera_radius", 2.7)
+        return torch.cat([torch.cat([LookAtPoseSampler.sample(p, y, pivot, radius=radius).reshape(-1, 16), intr.reshape(-1, 9)], 1)
+                          for p, y in sched], 0).numpy()
+    s12 = utils.video_camera_schedule(12, 15.0, 12.0)
+    assert len(s12) == 12 and np.allclose(cams_of(G, s12), z["video_cams_12"], atol=1e-6)      # default start: no interpolation leg
+    s9 = utils.video_camera_schedule(9, 10.0, 20.0, init_pitch=1.2, init_yaw=1.7)
+    assert len(s9) == 9 + 9 // 4 and np.allclose(cams_of(G0, s9), z["video_cams_9_interp"], atol=1e-6)

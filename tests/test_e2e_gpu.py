@@ -209,6 +209,41 @@ def test_demo_helpers_encode_decode(setup):
     assert len(U.video_camera_schedule(8, init_pitch=1.0)) == 10
 
 
+def test_render_video_reference_signature(setup, tmp_path):
+    """utils.render_video(G, fn, ws, norm_planes, denorm_planes, frames, fps, ...) (utils.py:32-88): positional signature of the
+    reference; frames go to a caller-supplied writer (imageio's protocol or a callable) or a .npy file."""
+    from nerffaceediting_amd import utils as U
+    G, z, dev = setup
+    ws = t(z["ws"], dev)[:1]
+    G.neural_rendering_resolution = int(z["R"])
+    planes = U.encode(G, ws, noise_mode="const")
+    norm, _, _ = U.normalize_plane(planes)
+
+    class Writer:
+        def __init__(self): self.frames, self.closed = [], False
+        def append_data(self, f): self.frames.append(f)
+        def close(self): self.closed = True
+    torch.manual_seed(5)
+    want = U.render_video_frames(G, ws, norm, planes, frames=5, a_degree=10.0, b_degree=8.0, batch=2)
+    w = Writer()
+    torch.manual_seed(5)
+    got = U.render_video(G, str(tmp_path / "sub" / "v.mp4"), ws, norm, planes, 5, 30, 10.0, 8.0, writer=w, batch=2)
+    assert len(w.frames) == 5 and not w.closed and w.frames[0].shape == (512, 512, 3) and w.frames[0].dtype == np.uint8
+    assert torch.equal(got, want) and np.array_equal(np.stack(w.frames), want.cpu().numpy())
+    seen = []
+    torch.manual_seed(5)
+    U.render_video(G, None, ws, norm, planes, frames=5, a_degree=10.0, b_degree=8.0, writer=seen.append, batch=2)
+    assert np.array_equal(np.stack(seen), want.cpu().numpy())
+    fn = str(tmp_path / "v.npy")
+    torch.manual_seed(5)
+    U.render_video(G, fn, ws, norm, planes, frames=5, a_degree=10.0, b_degree=8.0, batch=2)
+    assert np.array_equal(np.load(fn), want.cpu().numpy())
+    cams = U.get_camera_samples(G, dev)
+    assert len(cams) == 9 and cams[0].shape == (1, 25) and cams[0].device.type == "cuda"
+    out = U.decode(G, ws, torch.cat(cams[:2], 0), norm, planes, noise_mode="const")
+    assert out["image"].shape == (2, 3, 512, 512)
+
+
 def test_disable_disentangle_ablation(setup):
     """disable_disentangle=True (triplane.py:93,104-107,119): both heads read the raw planes; equals the renderer called
     with norm_planes = denorm_planes = raw planes, and returns no plane statistics."""

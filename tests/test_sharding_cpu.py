@@ -99,3 +99,76 @@ def test_all_gather_single_process_is_identity():
     assert sharding.all_gather_frames(x, 2) is x
     w, y = sharding.all_gather_frames_async(x, 2)
     assert w is None and y is x
+
+
+# ---- bench.py's own launch path: `python bench.py --gpus N` with no launcher around it ----
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _last_json(text):
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, text
+    return json.loads(lines[0])
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    return env
+
+
+def test_bench_self_launches_its_ranks_on_gloo():
+    """`python bench.py --gpus 2` starts two ranks itself (children, before anything touches a GPU), the ranks form a process
+    group, the chunked frame exchange of the config-4 job runs (ragged blocks: 7 frames, chunk 3) and exactly one JSON line
+    comes back, stating what the process group reported."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "exchange", "--backend", "gloo",
+                        "--orbit-frames", "7", "--steps", "2"], capture_output=True, text=True, timeout=120, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 2 and line["frames_ok"] is True
+    assert line["distributed"] == {"backend": "gloo", "world_size": 2, "launcher": "self"}
+
+
+def test_bench_under_torch_distributed_run_on_gloo():
+    """The driver's multi-GPU form keeps working: torch.distributed.run sets the rank environment, bench.py must not re-launch."""
+    from nerffaceediting_amd.launch import free_port
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "exchange",
+                        "--backend", "gloo", "--orbit-frames", "5", "--steps", "1"], capture_output=True, text=True, timeout=180, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["distributed"]["world_size"] == 2 and line["distributed"]["launcher"] == "torch.distributed.run"
+
+
+def test_bench_gpus_mismatch_is_refused():
+    env = dict(_clean_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "exchange", "--backend", "gloo"],
+                       capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_spawn_ranks_reports_a_failed_rank(tmp_path):
+    """A rank that dies makes the launch fail (non-zero) and the surviving ranks are stopped instead of waiting forever."""
+    from nerffaceediting_amd import launch
+    script = tmp_path / "ranks.py"
+    script.write_text("import os, sys, time\n"
+                      "r = int(os.environ['RANK'])\n"
+                      "assert os.environ['WORLD_SIZE'] == '3' and os.environ['MASTER_ADDR'] == '127.0.0.1'\n"
+                      "if r == 1:\n    sys.exit(3)\n"
+                      "if r == 0:\n    print('hello from rank 0', flush=True)\n"
+                      "time.sleep(60)\n")
+    import io
+    import time as _t
+    buf = io.StringIO()
+    t0 = _t.time()
+    rc, text = launch.spawn_ranks(str(script), [], 3, stdout=buf)
+    assert rc == 3 and _t.time() - t0 < 30
+    assert "hello from rank 0" in text and text == buf.getvalue()
+    ok = tmp_path / "ok.py"
+    ok.write_text("import os\nprint('rank', os.environ['RANK'], flush=True)\n")
+    rc, text = launch.spawn_ranks(str(ok), [], 2, stdout=io.StringIO())
+    assert rc == 0 and text == "rank 0\n"
