@@ -135,6 +135,10 @@ int nfe_conv_fuses_rgb(int mode, int math, int n, int h, int w, int cin, int cou
 /* 1 if a NFE_CONV_3X3 call of these sizes writes next_split from its own epilogue (LDS-DMA path, no split-K): `out` may then be
  * NULL when nobody else reads the fp32 activation.  Otherwise next_split is made by one more pass over `out`. */
 int nfe_conv_splits_in_epilogue(int mode, int n, int h, int w, int cin, int cout);
+/* ABI v10.  Human-readable description of the kernels nfe_modulated_conv() launches for a layer of these sizes ("conv3[32x16/8w]
+ * bf16 ksplit=0 fuse_rgb=1 ..."): which tile shape, split-K factor and fused epilogues the batch size n selects.  Diagnostic only
+ * (tests log it per layer); rgb_channels = 0 when no ToRGB fusion is requested.  Writes a NUL-terminated string into buf. */
+int nfe_conv_describe(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels, char* buf, int buf_len);
 int nfe_modulated_conv(const nfe_conv_args* args, nfe_stream_t stream);
 /* floats of a bf16 hi(+lo) activation image [n,h,w,c] (hi only for NFE_CONV_BF16) */
 uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c);

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 9
+NFE_ABI_VERSION = 10
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_DECODER_CROSS_FLOATS = 2048
@@ -129,6 +129,7 @@ _SIGNATURES = {
     "nfe_conv_accepts_split": (c_int, [c_int] * 5),
     "nfe_conv_fuses_rgb": (c_int, [c_int] * 8),
     "nfe_conv_splits_in_epilogue": (c_int, [c_int] * 6),
+    "nfe_conv_describe": (c_int, [c_int] * 8 + [c_char_p, c_int]),
     "nfe_resize_bilinear": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
                                 FP, FP, FP, c_float, c_uint64, FP, c_void_p]),

@@ -131,17 +131,19 @@ def render_views(G, ws, c, batch=4, gather=True, uint8=False, image_mode="image"
     dev = c.device
     rank, world = (dist.get_rank(), dist.get_world_size()) if (dist.is_available() and dist.is_initialized()) else (0, 1)
 
+    # frame geometry per output key (triplane.py:131-138): `image` is the SR output, the others are neural-render sized
+    channels = {"image": 3, "image_raw": 3, "image_seg": 15, "image_depth": 1}[image_mode]
+    res = G.img_resolution if image_mode == "image" else (synthesis_kwargs.get("neural_rendering_resolution") or G.neural_rendering_resolution)
+    frame_shape = (res, res, channels) if uint8 else (channels, res, res)
+
     def frames_of(i, j):
         if j <= i:
-            shape = (0, G.img_resolution, G.img_resolution, 3) if uint8 else (0, 3, G.img_resolution, G.img_resolution)
-            return torch.zeros(shape, dtype=torch.uint8 if uint8 else torch.float32, device=dev)
+            return torch.zeros((0,) + frame_shape, dtype=torch.uint8 if uint8 else torch.float32, device=dev)
         img = G.synthesis(ws[i:j].contiguous(), c[i:j].contiguous(), **synthesis_kwargs)[image_mode]
         return to_uint8(img) if uint8 else img
     ring = StreamRing(dev, streams)
     if gather and world > 1 and overlap:
-        res = G.img_resolution if image_mode == "image" else G.neural_rendering_resolution
-        shape = (res, res, 3) if uint8 else (3, res, res)
-        gat = sharding.ChunkedFrameGather(V, batch, shape, torch.uint8 if uint8 else torch.float32, dev)
+        gat = sharding.ChunkedFrameGather(V, batch, frame_shape, torch.uint8 if uint8 else torch.float32, dev)
         for k in range(gat.rounds()):
             sl = gat.local_slice(k)
             gat.submit(k, ring.take(*ring.run(lambda: frames_of(*sl))))

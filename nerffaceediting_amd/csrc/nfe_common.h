@@ -83,6 +83,9 @@ struct Taps { int xc0, xc1, yc0, yc1; float w[4]; float wdef; };   // wdef = (su
 // combined form `(vx && vy) ? w : 0` compiles to v_cmp -> SGPR pair, s_and_b64 vcc, v_cndmask, and that SALU step has returned
 // a stale mask for lanes 48-63 in a 256-register kernel at two waves per SIMD (profiles/experiments/r02_lane_mask.md).
 struct Axis { int c0, c1; float a0, a1; float in; };
+// Hide a value from the optimiser (no instruction): used where it would otherwise re-combine two per-lane conditions into one
+// scalar-unit mask operation (see above).
+__device__ __forceinline__ float opaque_f(float v) { asm volatile("" : "+v"(v)); return v; }
 __device__ __forceinline__ Axis axis_geometry(int size, float g) {
     Axis a;
     const float i = (g + 1.0f) * (0.5f * (float)size) - 0.5f;
@@ -93,14 +96,17 @@ __device__ __forceinline__ Axis axis_geometry(int size, float g) {
     a.a0 = (unsigned)x0 < (unsigned)size ? e : 0.0f;
     a.a1 = (unsigned)x1 < (unsigned)size ? d : 0.0f;
     a.c0 = min(max(x0, 0), size - 1); a.c1 = min(max(x1, 0), size - 1);
-    a.in = (unsigned)x0 < (unsigned)(size - 1) ? 1.0f : 0.0f;           // 0 <= x0 and x0 + 1 < size
+    a.in = opaque_f((unsigned)x0 < (unsigned)(size - 1) ? 1.0f : 0.0f);   // 0 <= x0 and x0 + 1 < size; opaque: see taps_from_axes
     return a;
 }
 __device__ __forceinline__ Taps taps_from_axes(const Axis& u, const Axis& v) {      // u indexes W, v indexes H
     Taps t;
     t.xc0 = u.c0; t.xc1 = u.c1; t.yc0 = v.c0; t.yc1 = v.c1;
     t.w[0] = u.a0 * v.a0; t.w[1] = u.a1 * v.a0; t.w[2] = u.a0 * v.a1; t.w[3] = u.a1 * v.a1;
-    t.wdef = u.in * v.in != 0.0f ? 0.0f : ((t.w[0] + t.w[1]) + (t.w[2] + t.w[3])) - 1.0f;
+    // (sum - 1) when a tap is outside, exactly 0 when all four are inside - as arithmetic on the two 1.0 / 0.0 flags.  The select
+    // form `u.in * v.in != 0 ? 0 : sum - 1` was folded back by the compiler into v_cmp, v_cmp, s_and_b64, v_cndmask: the shape the
+    // comment above keeps out of these kernels (tools/lint_lane_masks.py, S1).
+    t.wdef = (1.0f - u.in * v.in) * (((t.w[0] + t.w[1]) + (t.w[2] + t.w[3])) - 1.0f);
     return t;
 }
 // Bilinear tap geometry of one sample on one plane: F.grid_sample(bilinear, zeros, align_corners=False), renderer.py:64,

@@ -1360,6 +1360,20 @@ static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout) {
     return ks > 1 ? ks : 0;
 }
 
+// Which conv3_kernel instantiation a fast-path layer runs (one place: the launcher and nfe_conv_describe both ask here).
+enum { C3V_UP = 0, C3V_BIG, C3V_MID, C3V_X3_TALL4, C3V_TALL8, C3V_BASE };
+static int conv3_variant(int mode, int math, int n, int h, int w, int cout) {
+    const bool bf16 = math == NFE_CONV_BF16;
+    if (mode == NFE_CONV_3X3_UP2) return C3V_UP;
+    const bool tall = h >= 16 * C3_TALL_MIN_TILES;
+    const bool fills = (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense();
+    if (C3_BIG && cout % 128 == 0 && h >= 16 && (long long)((h + 15) / 16) * ((w + 31) / 32) * (cout / 128) * n >= 2LL * num_cus_dense()) return C3V_BIG;
+    if (C3_MID && tall && bf16) return C3V_MID;
+    if (!bf16 && tall && fills) return C3V_X3_TALL4;
+    if (tall && fills) return C3V_TALL8;
+    return C3V_BASE;
+}
+
 extern "C" int nfe_conv_splits_in_epilogue(int mode, int n, int h, int w, int cin, int cout) {
     return mode == NFE_CONV_3X3 && conv3_eligible(mode, h, w, cin, cout) && cout % 4 == 0 && !conv3_ksplit(mode, n, h, w, cin, cout) ? 1 : 0;
 }
@@ -1409,6 +1423,28 @@ extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, in
         fl += (uint64_t)ks * n * (mode == NFE_CONV_3X3_UP2 ? (uint64_t)(2 * h + 1) * (2 * w + 1) : (uint64_t)h * w) * cout;   // partial sums
     }
     return fl;
+}
+
+// Text description of the kernels nfe_modulated_conv would launch for a layer of these sizes (tests log it so that a parity
+// failure names the variant; batch-dependent: split-K, fused ToRGB, epilogue split and the tile shape all depend on n).
+extern "C" int nfe_conv_describe(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels, char* buf, int buf_len) {
+    NFE_REQUIRE(buf && buf_len > 0, "nfe_conv_describe: no buffer");
+    const char* m = math == NFE_CONV_BF16 ? "bf16" : "bf16x3";
+    if (mode != NFE_CONV_1X1 && conv3_eligible(mode, h, w, cin, cout)) {
+        static const char* names[] = {"up2 1x(32x8)/4w", "big 128ch 32x16/4w", "mid 32x16/4w", "x3 32x16/4w (2x4 blocks)", "32x16/8w", "32x8/4w"};
+        const int ks = conv3_ksplit(mode, n, h, w, cin, cout);
+        snprintf(buf, (size_t)buf_len, "conv3[%s] %s ksplit=%d fuse_rgb=%d split_in_epilogue=%d%s", names[conv3_variant(mode, math, n, h, w, cout)], m, ks,
+                 rgb_channels > 0 ? nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, rgb_channels) : 0,
+                 nfe_conv_splits_in_epilogue(mode, n, h, w, cin, cout), mode == NFE_CONV_3X3_UP2 ? " +upfir" : "");
+        return NFE_OK;
+    }
+    const int ks = splitk_slices(mode, math, n, h, w, cin, cout);
+    const int mb1 = (cout + 31) / 32, parts1 = math == NFE_CONV_BF16 ? 1 : 2;
+    const bool torgb_fast = mode == NFE_CONV_1X1 && !ks && cin % 16 == 0 && (mb1 == 1 || mb1 == 3) &&
+                            (long long)mb1 * (cin / 16) * parts1 * 1024 <= 64 * 1024 && (long long)h * w >= 1024;
+    snprintf(buf, (size_t)buf_len, "%s %s splitk=%d%s", torgb_fast ? "torgb[lds-resident]" : (mode == NFE_CONV_1X1 ? "generic1x1" : "generic3x3"), m, ks,
+             mode == NFE_CONV_3X3_UP2 ? " +upfir" : "");
+    return NFE_OK;
 }
 
 extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
@@ -1495,7 +1531,8 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             P.ksplit = c3ks; P.partial = K.partial;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, 1);
         };
-        if (up2) {
+        switch (conv3_variant(a->mode, a->math, a->n, a->h, a->w, a->cout)) {
+        case C3V_UP: {
             // (round 2 measured, without gain: a double-buffered stage (C3_STAGES_X3_UP = 2) and the 32 x 16 tile on 8 waves: DESIGN.md 5)
             const int ext_w = (a->w % C3_TW) == 0 ? 0 : ext;       // EDGE mode: the extra column rides on the right-most tiles
             if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext_w, st);
@@ -1503,23 +1540,25 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             reduce_up();
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
             hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
-        } else if (C3_BIG && a->cout % 128 == 0 && a->h >= 16 &&
-                   (long long)((a->h + 15) / 16) * ((a->w + 31) / 32) * (a->cout / 128) * a->n >= 2LL * num_cus_dense()) {
-            // big tile, one wave per SIMD: 128 channels x 32x16 pixels on 4 waves, as long as the grid still fills the chip twice
+            break;
+        }
+        case C3V_BIG:       // big tile, one wave per SIMD: 128 channels x 32x16 pixels on 4 waves, as long as the grid still fills the chip twice
             if (bf16) launch_conv3<1, 4, false, 2, 4, 4>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, 2, 4, 4>(K, a->h, a->w, st);
-        } else if (C3_MID && a->h >= 16 * C3_TALL_MIN_TILES && bf16) {   // 32 x 16 tiles on 4 waves (2 x 4 blocks per wave)
+            break;
+        case C3V_MID:       // 32 x 16 tiles on 4 waves (2 x 4 blocks per wave)
             launch_conv3<1, 2, false, 2, 4, 4>(K, a->h, a->w, st);
-        } else if (!bf16 && a->h >= 16 * C3_TALL_MIN_TILES &&
-                   (long long)((a->h + 15) / 16) * ((a->w + 31) / 32) * ((a->cout + 63) / 64) * a->n >= num_cus_dense()) {
+            break;
+        case C3V_X3_TALL4:
             // split-bf16: the 32 x 16 tile on FOUR waves (2 x 4 blocks per wave): the kernel is co-limited by LDS fragment reads,
             // and a wave that owns four rows re-uses each weight fragment four times (0.5 instead of 0.67 reads per MFMA): +1.5 %
             launch_conv3<3, 2, false, C3_STAGES_X3, 4, 4>(K, a->h, a->w, st);
-        } else if (a->h >= 16 * C3_TALL_MIN_TILES &&           // 32 x 16 tiles (8 waves): half the weight bytes per MFMA - as long as
-                   (long long)((a->h + 15) / 16) * ((a->w + 31) / 32) * ((a->cout + 63) / 64) * a->n >= num_cus_dense()) {   // they still fill the chip
+            break;
+        case C3V_TALL8:     // 32 x 16 tiles (8 waves): half the weight bytes per MFMA - as long as they still fill the chip
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, C3_STAGES_X3, 8>(K, a->h, a->w, st);
-        } else {
+            break;
+        default:
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 4>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, C3_STAGES_X3, 4>(K, a->h, a->w, st);
         }

@@ -104,12 +104,14 @@ __device__ __forceinline__ float relu_bits(float y) { return __int_as_float(max(
 // v_max before the v_min)
 __device__ __forceinline__ float min126_bits(float y) { return __int_as_float(min(__float_as_int(y), 0x42fc0000)); }
 
-// softplus_log2 over a whole accumulator as log2(1 + 2^min(y, 126)): 3.5 instructions per value (v_min, v_exp, half a
-// v_pk_add, v_log) against 4 for the max(y,0) + log2(1 + 2^-|y|) form.  min(y, 126) keeps 2^y finite (torch's threshold select
-// y > 20 -> y is reproduced by the arithmetic itself: log2(1 + 2^y) == y to fp32 rounding from y = 25 up); for y << 0 the sum
-// 1 + 2^y rounds exactly as 1 + 2^-|y| did in the old form, so the two agree to an ulp everywhere.
+// softplus_log2 over a whole accumulator.  Default: max(y,0) + log2(1 + 2^-|y|) - 4 instructions per value (v_exp with a free
+// -|y| source modifier, half a v_pk_add, v_log, v_max_i32, half a v_pk_add), no overflow, no threshold select, and exact for
+// every y: torch's Softplus returns x itself above its threshold and so does this form (the log term is 0 there).
+// NFE_SOFTPLUS_MINFORM=1 is the 3.5-instruction form log2(1 + 2^min(y, 126)) tried in round 2: it measured the same kernel
+// time (6.77 vs 6.79 ms) but saturates at y = 126, i.e. returns 87.3 for a hidden pre-activation x > 87.3 where the reference
+// returns x (edited / optimised planes can reach that), so it is not the default.
 #ifndef NFE_SOFTPLUS_MINFORM
-#define NFE_SOFTPLUS_MINFORM 1
+#define NFE_SOFTPLUS_MINFORM 0
 #endif
 __device__ __forceinline__ void softplus_log2_x16(f32x16& a) {
 #pragma unroll
@@ -920,7 +922,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
                 const bool first = k == kfirst;
                 const float dlt = t - (first ? t : prev_t);
                 const float dens = softplus_f((prev_sig + og[0]) * 0.5f - 1.0f);
-                const float alpha = 1.0f - exp2_fast(-(dens * dlt) * LOG2E);
+                // `first` forces alpha = 0 by a select on the (scalar) condition: with dlt = 0 a non-finite density (sigma = +inf,
+                // or a huge value + density_noise) would give 0 * inf = NaN and poison T and every accumulator of the ray; the
+                // reference's first interval starts at the NEXT sample, where inf gives alpha = 1 (ray_marcher.py:79-83).
+                const float alpha = first ? 0.0f : 1.0f - exp2_fast(-(dens * dlt) * LOG2E);
                 const float w = alpha * T;
                 T = T * (1.0f - alpha + 1e-10f);
                 if (P.out_weights && valid && h == 0 && !first) P.out_weights[ray * (S - 1) + (k - 1)] = w;

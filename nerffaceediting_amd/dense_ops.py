@@ -199,6 +199,13 @@ def splits_in_epilogue(mode, n, h, w, cin, cout):
     return bool(_lib.load().nfe_conv_splits_in_epilogue(int(mode), n, h, w, cin, cout))
 
 
+def describe(mode, math, n, h, w, cin, cout, rgb_channels=0):
+    """nfe_conv_describe: which kernels a layer of these sizes runs at batch n (diagnostic text)."""
+    buf = ctypes.create_string_buffer(256)
+    _lib.check(_lib.load().nfe_conv_describe(int(mode), MATH[math], n, h, w, cin, cout, int(rgb_channels), buf, 256), "nfe_conv_describe")
+    return buf.value.decode()
+
+
 def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, noise_strength=0.0, lrelu=True,
                    act_gain=1.0, clamp=None, skip=None, out_planes=False, math=None, next_styles=None, want_out=True, rgb=None):
     """nfe_modulated_conv.  x [N,H,W,Cin] NHWC (or a SplitImage of the modulated input) -> [N,Ho,Wo,Cout]

@@ -282,6 +282,13 @@ class TriPlaneGenerator(torch.nn.Module):
         self._last_planes = nchw
         self._last_packed = ((nchw.data_ptr(), nchw._version, tuple(nchw.shape)), packed, mean, var)
 
+    def invalidate_cached_planes(self):
+        """Drop the gather-layout copy of `_last_planes` (and the renderer's pack cache).  The copies are keyed on (storage
+        pointer, autograd version counter, shape); an in-place write that bypasses the counter (`.data`, a raw-pointer kernel)
+        needs this call before the next use_cached_backbone=True / renderer call — the reference re-reads the tensor each time."""
+        self._last_packed = None
+        self.renderer.invalidate_plane_cache()
+
     def _cached_planes(self):
         p = self._last_planes
         key = (p.data_ptr(), p._version, tuple(p.shape))

@@ -69,6 +69,7 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         self.last_taps = None
         self.decoder_math = None          # None -> split-bf16 MFMA; 'fp32' -> exact fp32 MFMA
         self.seed_tensor = None
+        self.cache_planes = True          # False: re-pack the NCHW plane arguments on every call (see _packed)
         self._pack_cache = []
 
     # -- parity hook ---------------------------------------------------------------------------------
@@ -93,16 +94,37 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         """Gather-layout copy of an NCHW plane tensor, cached on the tensor's identity (storage pointer, in-place version
         counter, shape): an orbit over fixed planes (utils.py:78-80 calls the renderer once per frame with the same two
         tensors) re-packs nothing; an optimiser step bumps `_version` and invalidates the entry.  Two entries: norm + denorm.
-        Each entry keeps its source tensor alive, so the allocator cannot hand the same address to different data."""
+        Each entry keeps its source tensor alive, so the allocator cannot hand the same address to different data.
+
+        The copy is published to other HIP streams by an event, not by a host sync: the entry remembers the stream that
+        packed it and an event recorded behind the pack kernel; a hit on another stream (apps.StreamRing) waits for that event
+        on the device.  So a plane-editing loop (one new version per optimiser step) never blocks the host here.
+
+        Caveat (the reference re-reads the tensor on every call): writes that do not bump the version counter —
+        `planes.data.add_(...)`, a view made from `.data`, a raw-pointer kernel writing in place — are invisible to the key.
+        After such a write call `invalidate_plane_cache()`, or set `cache_planes = False` to pack on every call."""
+        stream = torch.cuda.current_stream(planes.device)
+        if not self.cache_planes:
+            return ops.plane_pack(planes)
         key = (planes.data_ptr(), planes._version, tuple(planes.shape), tuple(planes.stride()), planes.device)
-        for k, _, v in self._pack_cache:
+        for k, _, v, ev, src in self._pack_cache:
             if k == key:
+                if src != stream and ev is not None:
+                    stream.wait_event(ev)
+                    v.record_stream(stream)       # allocated on `src`: keep the allocator from recycling it under this stream
                 return v
         v = ops.plane_pack(planes)
+        ev = None
         if not torch.cuda.is_current_stream_capturing():
-            torch.cuda.current_stream().synchronize()         # cached for later calls, possibly on another stream (apps.StreamRing)
-        self._pack_cache = [(key, planes, v)] + self._pack_cache[:1]
+            ev = torch.cuda.Event()
+            ev.record(stream)
+        self._pack_cache = [(key, planes, v, ev, stream)] + self._pack_cache[:1]
         return v
+
+    def invalidate_plane_cache(self):
+        """Forget the cached gather-layout copies (see `_packed`: needed after an in-place write that bypasses autograd's
+        version counter)."""
+        self._pack_cache = []
 
     def _pack_pair(self, norm_planes, denorm_planes):
         pg = self._packed(norm_planes)

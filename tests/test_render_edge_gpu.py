@@ -169,3 +169,56 @@ def test_point_query_density_noise_matches_oracle(dev):
     assert torch.equal(a, b) and not torch.equal(a, c)
     with pytest.raises(RuntimeError, match="density_noise"):
         ops.point_query(packed, packed, decp, t(coords, dev), 1.0, density_noise=-0.5)
+
+
+@pytest.mark.parametrize("math", ["bf16x3", "fp32"])
+def test_large_preactivations_are_not_clamped(math, dev):
+    """Hidden pre-activations far above torch's Softplus threshold (x > 20 -> x; edited / optimised planes can drive them there):
+    softplus must return x itself, for any x - an earlier log2(1 + 2^min(y,126)) form saturated at x = 87.3.  seg is
+    a linear read-out of the hidden layer, so a clamp shows up there at full size; bar relative to the magnitude."""
+    from nerffaceediting_amd import ops
+    rng = np.random.RandomState(77)
+    N, M, H, D = 1, 64, 16, 8
+    pn = (rng.randn(N, 3, 32, H, H) * 400.0).astype(np.float32)         # pre-activations of a few hundred (rms ~ 230)
+    dec = orc.random_decoder(9, bias_scale=0.2)
+    o, d = rays(rng, N, M)
+    coords = (rng.rand(N, 500, 3).astype(np.float32) - 0.5) * 0.9
+    want = orc.run_model(pn, pn, dec, coords, dict(box_warp=1))
+    hid = np.abs(want[2]).max()
+    assert hid > 300.0, hid                                             # seg magnitudes only reachable with hidden units >> 87.3
+    decp = ops.decoder_pack(*[t(dec[k], dev) for k in NAMES])
+    p = ops.plane_pack(t(pn, dev))
+    got = ops.point_query(p, p, decp, t(coords, dev), 1.0, decoder_math=math)
+    for k, i in (("rgb", 0), ("sigma", 1), ("seg", 2)):
+        w = want[i]
+        e = float(np.abs(got[k].cpu().numpy() - w).max())
+        assert e <= 1e-3 + 2e-5 * float(np.abs(w).max()), (k, e)
+    opts = dict(depth_resolution=D, depth_resolution_importance=0, ray_start=2.25, ray_end=3.3, box_warp=1)
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    wr = c_oracle.render(pn, pn, dec, o, d, opts, u_c, None)
+    gr = ops.render(p, p, decp, opts, origins=t(o, dev), dirs=t(d, dev), u_coarse=t(u_c, dev), decoder_math=math)
+    for k, g, w in zip(("rgb", "seg", "depth", "wsum"), gr, wr):
+        e = max_abs(g.cpu().numpy(), w)
+        assert e <= 1e-3 + 2e-5 * float(np.abs(w).max()), (k, e)
+
+
+@pytest.mark.parametrize("Di", [0, 6])
+def test_infinite_density_does_not_poison_the_ray(Di, dev):
+    """sigma = +inf at every sample (geometry output bias +inf): the reference's first interval gets alpha = 1 and takes all the
+    weight (ray_marcher.py:76-88).  The kernel composites the first sample of a march / depth segment with a zero-length
+    interval: that must be alpha = 0 by construction, not 1 - exp(-(inf * 0)) = NaN."""
+    rng = np.random.RandomState(31)
+    N, M, H, D = 1, 40, 8, 9
+    pn = rng.randn(N, 3, 32, H, H).astype(np.float32)
+    dec = orc.random_decoder(4, bias_scale=0.1)
+    dec["geo_net.2.bias"][0] = np.inf
+    o, d = rays(rng, N, M)
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1)
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, Di).astype(np.float32) if Di else None
+    want = orc.render(pn, pn, dec, o, d, opts, u_c, u_f)
+    assert all(np.isfinite(w).all() for w in want) and np.allclose(want[3], 1.0, atol=1e-6)
+    got, _ = run_both(dev, pn, pn, dec, o, d, opts, u_c, u_f)
+    for k, g, w in zip(("rgb", "seg", "depth", "wsum"), got, want):
+        assert np.isfinite(g).all(), k
+        assert max_abs(g, w) <= TOL, k
