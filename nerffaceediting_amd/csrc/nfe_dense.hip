@@ -447,6 +447,12 @@ __device__ uint4 nfe_zero16[4];                                  // source of th
 #ifndef C3_FRAG_PIPE
 #define C3_FRAG_PIPE 1                                           // A/B switch of the fragment-read pipeline in conv3_kernel
 #endif
+#ifndef C3_DMA_INTERLEAVE
+#define C3_DMA_INTERLEAVE 0                                      // round 3 A/B: issue the next K-group's LDS-DMA between the MFMA steps
+#endif
+#ifndef C3_DMA_SPREAD_PCT
+#define C3_DMA_SPREAD_PCT 67                                     // ... over this share of the steps (the tail leaves them time to land)
+#endif
 #ifdef C3_PROFILE      // diagnostic build only (tools/c3_profile.py): shader cycles summed over all waves of all conv3 launches
 __device__ unsigned long long c3_prof[4];                        // {load phase, compute phase, epilogue, waves}
 #define C3_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
@@ -593,6 +599,32 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         }
     };
 
+    // The same loads one LDS-DMA instruction at a time (C3_DMA_INTERLEAVE): instruction idx of this wave's share of K-group g.
+    // idx < NA: weight chunk wave + WV * idx; then the patch chunks, part-major inside a chunk.
+    constexpr int NA = (A_CHUNKS + WV - 1) / WV;
+    constexpr int NI = NA + B_PER_WAVE * PARTS;
+    auto issue_one = [&](int g, int stage, int idx) {
+        unsigned char* base = lds + stage * STAGE_BYTES;
+        if (idx < NA) {
+            const int c = wave + WV * idx;
+            if (c < A_CHUNKS) {
+                const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
+                const uint4* src = P.packed + (((long long)(mb0 + m) * G_all + g_base + g) * 18 + t * 2 + part) * 64 + lane;
+                lds_dma16(src, base + c * 1024);
+            }
+        } else {
+            const int k = (idx - NA) / PARTS, part = (idx - NA) % PARTS;
+            const int c = wave + WV * k;
+            if (c < C3_B_CHUNKS) {
+                const unsigned short* xs = part ? P.xl : P.xh;
+                const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + 16 * (g_base + g)) : (const void*)nfe_zero16;
+                lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
+            }
+        }
+    };
+    constexpr bool DMA_INTERLEAVE = C3_DMA_INTERLEAVE && STAGES == 2 && C3_FRAG_PIPE;
+    constexpr int DMA_STEPS = (9 * NBW * C3_DMA_SPREAD_PCT) / 100;      // the loads are spread over the first DMA_STEPS MFMA steps
+
     f32x16 acc[NACC][MBW][NBW];
 #pragma unroll
     for (int a = 0; a < NACC; ++a)
@@ -616,7 +648,9 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
         __syncthreads();
-        if (STAGES >= 2 && g + STAGES - 1 < G) issue(g + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);
+        const bool more = g + STAGES - 1 < G;
+        const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
+        if (STAGES >= 2 && more && !DMA_INTERLEAVE) issue(g + STAGES - 1, nstage);
         C3_STAMP(ts1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
@@ -649,6 +683,11 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                 const int t1 = (s_ + 1) / NBW, nb1 = (s_ + 1) % NBW;
                 load_b(t1, nb1, bh[(s_ + 1) & 1], bl[(s_ + 1) & 1]);
                 if (nb1 == 0) load_a(t1, ah[t1 & 1], al[t1 & 1]);
+            }
+            if (DMA_INTERLEAVE && more) {        // next K-group's loads, a few per MFMA step instead of a burst after the barrier
+#pragma unroll
+                for (int idx = 0; idx < NI; ++idx)
+                    if (idx * DMA_STEPS / NI == s_) issue_one(g + 1, nstage, idx);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

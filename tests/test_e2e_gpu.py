@@ -224,19 +224,20 @@ def test_render_video_reference_signature(setup, tmp_path):
         def append_data(self, f): self.frames.append(f)
         def close(self): self.closed = True
     torch.manual_seed(5)
-    want = U.render_video_frames(G, ws, norm, planes, frames=5, a_degree=10.0, b_degree=8.0, batch=2)
+    want = U.render_video_frames(G, ws, norm, planes, frames=8, a_degree=10.0, b_degree=8.0, batch=2)
     w = Writer()
     torch.manual_seed(5)
-    got = U.render_video(G, str(tmp_path / "sub" / "v.mp4"), ws, norm, planes, 5, 30, 10.0, 8.0, writer=w, batch=2)
-    assert len(w.frames) == 5 and not w.closed and w.frames[0].shape == (512, 512, 3) and w.frames[0].dtype == np.uint8
+    got = U.render_video(G, str(tmp_path / "sub" / "v.mp4"), ws, norm, planes, 8, 30, 10.0, 8.0, writer=w, batch=2)
+    assert len(w.frames) == 10 and not w.closed      # 8 orbit frames + 8 // 4 lead-in frames (utils.py:45-66)
+    assert True and w.frames[0].shape == (512, 512, 3) and w.frames[0].dtype == np.uint8
     assert torch.equal(got, want) and np.array_equal(np.stack(w.frames), want.cpu().numpy())
     seen = []
     torch.manual_seed(5)
-    U.render_video(G, None, ws, norm, planes, frames=5, a_degree=10.0, b_degree=8.0, writer=seen.append, batch=2)
+    U.render_video(G, None, ws, norm, planes, frames=8, a_degree=10.0, b_degree=8.0, writer=seen.append, batch=2)
     assert np.array_equal(np.stack(seen), want.cpu().numpy())
     fn = str(tmp_path / "v.npy")
     torch.manual_seed(5)
-    U.render_video(G, fn, ws, norm, planes, frames=5, a_degree=10.0, b_degree=8.0, batch=2)
+    U.render_video(G, fn, ws, norm, planes, frames=8, a_degree=10.0, b_degree=8.0, batch=2)
     assert np.array_equal(np.load(fn), want.cpu().numpy())
     cams = U.get_camera_samples(G, dev)
     assert len(cams) == 9 and cams[0].shape == (1, 25) and cams[0].device.type == "cuda"
@@ -368,11 +369,12 @@ def test_full_size_synthesis_cfg3(conv_math):
         for k, e in means.items():
             assert e <= 1e-4, (k, e)
         assert err(out["plane_mean"], z["plane_mean"]) <= TOL and err(out["plane_var"], z["plane_var"]) <= TOL
-    else:
+    else:       # 2 x the errors measured on MI355X (profiles/r03_bf16_error.md): max-abs, then per-channel means
+        bound = {"image": (0.025, 0.006), "image_raw": (0.0025, 0.0006), "image_seg": (0.0035, 0.0004), "image_depth": (0.0015, 0.0001)}
         for k, e in errs.items():
-            assert e <= 0.05 * max(float(z[k + "_absmax"]), 1.0), (k, e)
+            assert e <= bound[k][0], (k, e)
         for k, e in means.items():
-            assert e <= 0.01 * max(float(z[k + "_absmax"]), 1.0), (k, e)
+            assert e <= bound[k][1], (k, e)
 
 
 def test_converted_checkpoint_renders_reference_outputs(tmp_path):

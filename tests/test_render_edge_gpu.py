@@ -175,7 +175,8 @@ def test_point_query_density_noise_matches_oracle(dev):
 def test_large_preactivations_are_not_clamped(math, dev):
     """Hidden pre-activations far above torch's Softplus threshold (x > 20 -> x; edited / optimised planes can drive them there):
     softplus must return x itself, for any x - an earlier log2(1 + 2^min(y,126)) form saturated at x = 87.3.  seg is
-    a linear read-out of the hidden layer, so a clamp shows up there at full size; bar relative to the magnitude."""
+    a linear read-out of the hidden layer, so a clamp shows up there at full size (hundreds); bar relative to the magnitude:
+    split-bf16 drops the lo x lo term of every product (2^-16 relative), the exact-fp32 mode is held to fp32 rounding."""
     from nerffaceediting_amd import ops
     rng = np.random.RandomState(77)
     N, M, H, D = 1, 64, 16, 8
@@ -184,6 +185,7 @@ def test_large_preactivations_are_not_clamped(math, dev):
     o, d = rays(rng, N, M)
     coords = (rng.rand(N, 500, 3).astype(np.float32) - 0.5) * 0.9
     want = orc.run_model(pn, pn, dec, coords, dict(box_warp=1))
+    rel = 5e-5 if math == "bf16x3" else 1e-5
     hid = np.abs(want[2]).max()
     assert hid > 300.0, hid                                             # seg magnitudes only reachable with hidden units >> 87.3
     decp = ops.decoder_pack(*[t(dec[k], dev) for k in NAMES])
@@ -192,14 +194,14 @@ def test_large_preactivations_are_not_clamped(math, dev):
     for k, i in (("rgb", 0), ("sigma", 1), ("seg", 2)):
         w = want[i]
         e = float(np.abs(got[k].cpu().numpy() - w).max())
-        assert e <= 1e-3 + 2e-5 * float(np.abs(w).max()), (k, e)
+        assert e <= 1e-3 + rel * float(np.abs(w).max()), (k, e)
     opts = dict(depth_resolution=D, depth_resolution_importance=0, ray_start=2.25, ray_end=3.3, box_warp=1)
     u_c = rng.rand(N, M, D).astype(np.float32)
     wr = c_oracle.render(pn, pn, dec, o, d, opts, u_c, None)
     gr = ops.render(p, p, decp, opts, origins=t(o, dev), dirs=t(d, dev), u_coarse=t(u_c, dev), decoder_math=math)
     for k, g, w in zip(("rgb", "seg", "depth", "wsum"), gr, wr):
         e = max_abs(g.cpu().numpy(), w)
-        assert e <= 1e-3 + 2e-5 * float(np.abs(w).max()), (k, e)
+        assert e <= 1e-3 + rel * float(np.abs(w).max()), (k, e)
 
 
 @pytest.mark.parametrize("Di", [0, 6])
