@@ -112,7 +112,9 @@ typedef struct nfe_conv_args {
     uint64_t scratch_floats;      /* capacity of `scratch` in floats */
     /* Layer chaining without an fp32 round trip (conv0 -> conv1 of a SynthesisBlock, conv1 -> conv0 of the next block): */
     const float* next_styles;     /* [N,Cout] styles of the 3x3 layer that consumes this output, or NULL */
-    float* next_split;            /* out: bf16 hi(+lo) image of out * next_styles, nfe_conv_split_floats() floats.  Mode 1 writes
+    float* next_split;            /* out: bf16 hi(+lo) image of out * next_styles, nfe_conv_split_floats() floats, opaque to the
+                                     caller (ABI v10: stored as cout/16 planes of [H][W][16 channels] per sample, so that a
+                                     16-channel K-group of the consuming GEMM reads contiguous patch rows; cout % 16 == 0).  Mode 1 writes
                                      it from the FIR epilogue, mode 0 from the conv epilogue where nfe_conv_splits_in_epilogue()
                                      says so (elsewhere by one more pass over `out`); in those two cases `out` may be NULL (the
                                      fp32 output is then not written) */

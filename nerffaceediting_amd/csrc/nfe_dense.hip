@@ -428,6 +428,17 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
 // a wave owns two image rows of 32 pixels (two N-blocks) x two M-blocks.  A 32-pixel row read is conflict-free
 // under the b128 lane groups with a compact patch layout.
 // ------------------------------------------------------------------------------------------------
+// Split-image layout ("group-major", round 3): the bf16 image a 3x3 layer consumes is stored as Cin/16 planes of
+// [H][W][16 channels] per sample - element (n, y, x, c) at (((n * G + c/16) * H + y) * W + x) * 16 + c%16, G = Cin/16, hi plane set
+// first, lo plane set (split-bf16) behind it.  A K-group of the implicit GEMM is 16 input channels, so a patch row of a K-group
+// (34 pixels x 32 bytes) is one contiguous run and a 1-KiB LDS-DMA instruction is ~17 L1 requests.  With the NHWC order of
+// round 2 every pixel's 32 bytes sat 2*Cin bytes apart: ~42 requests per instruction (TCP_TOTAL_CACHE_ACCESSES / SQ_INSTS_VMEM_RD),
+// the texture addresser 51 % busy and the waves stuck ~900 cycles in every LDS-DMA issue behind it (tools/c3_profile.py).
+// uint2 index (4 channels) of channel-quad c4 of pixel (n, y, x):
+__device__ __forceinline__ long long split_index(int n, int G, int H, int W, int y, int x, int c4) {
+    return ((((long long)n * G + (c4 >> 2)) * H + y) * W + x) * 4 + (c4 & 3);
+}
+
 __global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict__ x, const float* __restrict__ styles, long long n_vec,
                                                        long long hw_vec, int c4, uint2* __restrict__ hi, uint2* __restrict__ lo) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
@@ -437,24 +448,26 @@ __global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict_
         float4 v = x[i];
         v.x *= s.x; v.y *= s.y; v.z *= s.z; v.w *= s.w;
         unsigned h0, l0, h1, l1;
-        if (lo) { split2<3>(v.x, v.y, h0, l0); split2<3>(v.z, v.w, h1, l1); lo[i] = make_uint2(l0, l1); }
+        const long long pix = i / c4;                                  // (n, y, x) flattened; hw_vec / c4 pixels per sample
+        const long long o = ((n * (c4 >> 2) + (q >> 2)) * (hw_vec / c4) + (pix - n * (hw_vec / c4))) * 4 + (q & 3);
+        if (lo) { split2<3>(v.x, v.y, h0, l0); split2<3>(v.z, v.w, h1, l1); lo[o] = make_uint2(l0, l1); }
         else { split2<1>(v.x, v.y, h0, l0); split2<1>(v.z, v.w, h1, l1); }
-        hi[i] = make_uint2(h0, h1);
+        hi[o] = make_uint2(h0, h1);
     }
 }
 
 __device__ uint4 nfe_zero16[4];                                  // source of the zero padding for LDS-DMA
+#ifndef C3_ABLATE
+#define C3_ABLATE 0       // timing experiments only (wrong results): 1 no LDS-DMA, 2 no MFMA, 3 no barriers in the K loop, 4 no fragment reads
+#endif
+#ifndef C3_DMA_BUILTIN
+#define C3_DMA_BUILTIN 0                                         // 1: the round-2 form (compiler-tracked LDS-DMA), kept for A/B
+#endif
 #ifndef C3_FRAG_PIPE
 #define C3_FRAG_PIPE 1                                           // A/B switch of the fragment-read pipeline in conv3_kernel
 #endif
-#ifndef C3_DMA_INTERLEAVE
-#define C3_DMA_INTERLEAVE 0                                      // round 3 A/B: issue the next K-group's LDS-DMA between the MFMA steps
-#endif
-#ifndef C3_DMA_SPREAD_PCT
-#define C3_DMA_SPREAD_PCT 67                                     // ... over this share of the steps (the tail leaves them time to land)
-#endif
 #ifdef C3_PROFILE      // diagnostic build only (tools/c3_profile.py): shader cycles summed over all waves of all conv3 launches
-__device__ unsigned long long c3_prof[4];                        // {load phase, compute phase, epilogue, waves}
+__device__ unsigned long long c3_prof[8];                        // {load phase, compute phase, epilogue, waves, vmcnt wait, barrier wait, prologue, -}
 #define C3_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
 #else
 #define C3_STAMP(var)
@@ -482,9 +495,24 @@ template <int ROWS> struct C3Tile {
     static constexpr int B_BYTES = B_CHUNKS * 1024;
 };
 
+// One LDS-DMA instruction: 64 lanes x 16 bytes, per-lane global address -> 1 KiB of LDS at lds_dst (wave-uniform).
+// Issued as inline asm on purpose.  Through __builtin_amdgcn_global_load_lds the compiler knows that an asynchronous write to
+// LDS is in flight and, unable to prove that the fragment reads of the CURRENT stage do not alias the stage being filled (same
+// extern __shared__ array), it puts `s_waitcnt vmcnt(0)` in front of the first ds_read of every MFMA phase - i.e. every K-group
+// waited for the NEXT K-group's loads to land before computing, and the two-stage ring overlapped nothing (tools/c3_profile.py
+// showed it as ~4 300 cycles of "issue" per K-group; round 3).  The waits this kernel needs are its own explicit
+// `s_waitcnt vmcnt(N)` + s_barrier at the top of each K-group.
 __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
+#if C3_ABLATE == 1
+    return;
+#endif
+#if C3_DMA_BUILTIN
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
+#else
+    const unsigned l = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds_dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory", "m0");
+#endif
 }
 
 // UP2: the stride-2 transposed convolution of the up-sampling layers as four output phases over the (H+1)x(W+1)
@@ -539,6 +567,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
     const int G = min(G_all, g_base + g_per) - g_base;        // K-groups of this workgroup: g_base + [0, G)
 
     // this wave's share of the patch chunks: chunk c = wave + WV k; per-lane element offset of the pixel (or -1 = padding)
+    const long long plane16 = (long long)P.H * P.W * 16;      // elements of one 16-channel plane of the group-major split image
     long long boff[B_PER_WAVE];
 #pragma unroll
     for (int k = 0; k < B_PER_WAVE; ++k) {
@@ -549,7 +578,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         const int pp = item >> 1, hh = (item & 1) ^ ((pp >> 3) & 1), py = pp / C3_PW, px = pp % C3_PW;
         const int y = ty0 - 1 + py, x = tx0 - 1 + px;
         const bool ok = pp < C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
-        boff[k] = ok ? (((long long)n * P.H + y) * P.W + x) * P.Cin + 8 * hh : -1;
+        boff[k] = ok ? (((long long)n * G_all * P.H + y) * P.W + x) * 16 + 8 * hh : -1;     // group-major image: + g * H*W*16 per K-group
     }
 
     // byte offsets of this lane's B fragments inside the patch: rows NBW*wave + (0..NBW+1), columns j + (0..2)
@@ -592,38 +621,12 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
 #pragma unroll
                 for (int part = 0; part < PARTS; ++part) {
                     const unsigned short* xs = part ? P.xl : P.xh;
-                    const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + 16 * (g_base + g)) : (const void*)nfe_zero16;
+                    const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + (long long)(g_base + g) * plane16) : (const void*)nfe_zero16;
                     lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
                 }
             }
         }
     };
-
-    // The same loads one LDS-DMA instruction at a time (C3_DMA_INTERLEAVE): instruction idx of this wave's share of K-group g.
-    // idx < NA: weight chunk wave + WV * idx; then the patch chunks, part-major inside a chunk.
-    constexpr int NA = (A_CHUNKS + WV - 1) / WV;
-    constexpr int NI = NA + B_PER_WAVE * PARTS;
-    auto issue_one = [&](int g, int stage, int idx) {
-        unsigned char* base = lds + stage * STAGE_BYTES;
-        if (idx < NA) {
-            const int c = wave + WV * idx;
-            if (c < A_CHUNKS) {
-                const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
-                const uint4* src = P.packed + (((long long)(mb0 + m) * G_all + g_base + g) * 18 + t * 2 + part) * 64 + lane;
-                lds_dma16(src, base + c * 1024);
-            }
-        } else {
-            const int k = (idx - NA) / PARTS, part = (idx - NA) % PARTS;
-            const int c = wave + WV * k;
-            if (c < C3_B_CHUNKS) {
-                const unsigned short* xs = part ? P.xl : P.xh;
-                const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + 16 * (g_base + g)) : (const void*)nfe_zero16;
-                lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
-            }
-        }
-    };
-    constexpr bool DMA_INTERLEAVE = C3_DMA_INTERLEAVE && STAGES == 2 && C3_FRAG_PIPE;
-    constexpr int DMA_STEPS = (9 * NBW * C3_DMA_SPREAD_PCT) / 100;      // the loads are spread over the first DMA_STEPS MFMA steps
 
     f32x16 acc[NACC][MBW][NBW];
 #pragma unroll
@@ -636,7 +639,8 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                 for (int r = 0; r < 16; ++r) acc[a][m][nb][r] = 0.0f;
 
 #ifdef C3_PROFILE
-    unsigned long long prof_load = 0, prof_comp = 0;
+    unsigned long long prof_load = 0, prof_comp = 0, prof_vm = 0, prof_bar = 0;
+    const unsigned long long ts_start = __builtin_amdgcn_s_memtime();
 #endif
     for (int pre = 0; pre < STAGES - 1; ++pre)
         if (pre < G) issue(pre, pre);
@@ -647,10 +651,12 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
         if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
-        __syncthreads();
+        C3_STAMP(ts0a);
+        if (C3_ABLATE != 3) __syncthreads();
+        C3_STAMP(ts0b);
         const bool more = g + STAGES - 1 < G;
         const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
-        if (STAGES >= 2 && more && !DMA_INTERLEAVE) issue(g + STAGES - 1, nstage);
+        if (STAGES >= 2 && more) issue(g + STAGES - 1, nstage);
         C3_STAMP(ts1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
@@ -660,6 +666,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         // sched_barrier): the compiler's own schedule issues a read one or two MFMAs before its use, which leaves the matrix pipe
         // idle for most of the LDS latency some thirty times per K-group while this wave is the only one computing on its SIMD.
         auto load_a = [&](int t, Frag8 (&ah_)[MBW], Frag8 (&al_)[MBW]) {
+            if (C3_ABLATE == 4 && (g > 0 || t > 0)) return;
 #pragma unroll
             for (int m = 0; m < MBW; ++m) {
                 ah_[m].q = ldsA[((m * 9 + t) * PARTS + 0) * 64];
@@ -667,6 +674,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
             }
         };
         auto load_b = [&](int t, int nb, Frag8& bh_, Frag8& bl_) {
+            if (C3_ABLATE == 4 && (g > 0 || t > 0)) return;
             const int kh = t / 3, kw = t % 3;
             const int dy = UP2 ? 1 - (kh >> 1) : kh, dx = UP2 ? 1 - (kw >> 1) : kw;
             bh_.q = *reinterpret_cast<const uint4*>(ldsB + brd[nb + dy][dx]);
@@ -684,19 +692,19 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                 load_b(t1, nb1, bh[(s_ + 1) & 1], bl[(s_ + 1) & 1]);
                 if (nb1 == 0) load_a(t1, ah[t1 & 1], al[t1 & 1]);
             }
-            if (DMA_INTERLEAVE && more) {        // next K-group's loads, a few per MFMA step instead of a burst after the barrier
-#pragma unroll
-                for (int idx = 0; idx < NI; ++idx)
-                    if (idx * DMA_STEPS / NI == s_) issue_one(g + 1, nstage, idx);
-            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MBW; ++m) {
+#if C3_ABLATE == 2
+                acc[a][m][nb][0] += __builtin_bit_cast(float, ah[t & 1][m].u[0] ^ bh[s_ & 1].u[0]);
+                if (TERMS == 3) acc[a][m][nb][1] += __builtin_bit_cast(float, al[t & 1][m].u[0] ^ bl[s_ & 1].u[0]);
+#else
                 acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
                 if (TERMS == 3) {
                     acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, bl[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
                     acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
                 }
+#endif
             }
             if (UP2 && nb == NBW - 1 && kw == 2 && edge_tile && wave == 0) {   // wave-uniform
                 Frag8 eh, el;
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
 #endif
         stage = stage + 1 == STAGES ? 0 : stage + 1;
 #ifdef C3_PROFILE
-        { C3_STAMP(ts2); prof_load += ts1 - ts0; prof_comp += ts2 - ts1; }
+        { C3_STAMP(ts2); prof_load += ts1 - ts0; prof_comp += ts2 - ts1; prof_vm += ts0a - ts0; prof_bar += ts0b - ts0a; }
 #endif
     }
 #ifdef C3_PROFILE
@@ -836,10 +844,11 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
         // every such load sits behind the previous store (the pointers may alias), which made the epilogue a chain of ~32 exposed
         // L2 round trips per wave, 20-30 % of the wave's life (tools/c3_profile.py).
         float nzv[NBW], rgb[NBW][4];
-        float4 ns[MBW];                                 // consuming layer's styles of the 4 channels this lane stores (lane & 7)
+        const int cq_s = 4 * (lane >> 5) + (lane & 3);  // channel quad (of the M-block's 8) this lane writes to the consumer's image
+        float4 ns[MBW];                                 // consuming layer's styles of those 4 channels
 #pragma unroll
         for (int m = 0; m < MBW; ++m)
-            ns[m] = P.split_hi ? *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 32 * (mb0 + m) + 4 * (lane & 7))
+            ns[m] = P.split_hi ? *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 32 * (mb0 + m) + 4 * cq_s)
                                : make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
@@ -881,21 +890,26 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
                             }
                     }
                 }
-                if (P.out || P.split_hi) {      // same-wave LDS operations execute in order: no barrier between the writes above and these reads
+                if (P.out) {                    // same-wave LDS operations execute in order: no barrier between the writes above and these reads
                     const long long o_row = (((long long)n * P.H + y) * P.W + tx0) * P.Cout + 32 * (mb0 + m);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int p = 8 * it + (lane >> 3), c = lane & 7;
                         const float4 v = *reinterpret_cast<const float4*>(stile + p * ST_STRIDE + 4 * c);
+                        if (tx0 + p < P.W) *reinterpret_cast<float4*>(P.out + o_row + (long long)p * P.Cout + 4 * c) = v;
+                    }
+                }
+                if (P.split_hi) {               // group-major image of the consumer: lane = (16-channel group of the M-block, pixel of 8,
+#pragma unroll                                  // channel quad): 8 pixels x 32 contiguous bytes per half wave and store instruction
+                    for (int it = 0; it < 4; ++it) {
+                        const int p = 8 * it + ((lane & 31) >> 2);
+                        const float4 v = *reinterpret_cast<const float4*>(stile + p * ST_STRIDE + 4 * cq_s);
                         if (tx0 + p < P.W) {
-                            const long long oi = o_row + (long long)p * P.Cout + 4 * c;
-                            if (P.out) *reinterpret_cast<float4*>(P.out + oi) = v;
-                            if (P.split_hi) {           // 8 pixels x 64 contiguous bytes per store instruction (per part)
-                                unsigned h0, l0, h1, l1;
-                                if (TERMS == 3) { split2<3>(v.x * ns[m].x, v.y * ns[m].y, h0, l0); split2<3>(v.z * ns[m].z, v.w * ns[m].w, h1, l1); P.split_lo[oi >> 2] = make_uint2(l0, l1); }
-                                else { split2<1>(v.x * ns[m].x, v.y * ns[m].y, h0, l0); split2<1>(v.z * ns[m].z, v.w * ns[m].w, h1, l1); }
-                                P.split_hi[oi >> 2] = make_uint2(h0, h1);
-                            }
+                            const long long si = split_index(n, P.Cout >> 4, P.H, P.W, y, tx0 + p, 8 * (mb0 + m) + cq_s);
+                            unsigned h0, l0, h1, l1;
+                            if (TERMS == 3) { split2<3>(v.x * ns[m].x, v.y * ns[m].y, h0, l0); split2<3>(v.z * ns[m].z, v.w * ns[m].w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
+                            else { split2<1>(v.x * ns[m].x, v.y * ns[m].y, h0, l0); split2<1>(v.z * ns[m].z, v.w * ns[m].w, h1, l1); }
+                            P.split_hi[si] = make_uint2(h0, h1);
                         }
                     }
                 }
@@ -917,6 +931,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
     if (lane == 0) {
         C3_STAMP(ts_ep1);
         atomicAdd(&c3_prof[0], prof_load); atomicAdd(&c3_prof[1], prof_comp); atomicAdd(&c3_prof[2], ts_ep1 - ts_ep0); atomicAdd(&c3_prof[3], 1ull);
+        atomicAdd(&c3_prof[4], prof_vm); atomicAdd(&c3_prof[5], prof_bar); atomicAdd(&c3_prof[6], ts_ep1 - ts_start);
     }
 #endif
 }
@@ -1143,11 +1158,12 @@ __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
                     o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
                     const long long oi = (((long long)n * OH + Y) * OW + X) * C4 + c4;
                     if (P.out) reinterpret_cast<float4*>(P.out)[oi] = o;
-                    if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer
+                    if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer (group-major)
                         unsigned h0, l0, h1, l1;
-                        if (P.split_lo) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[oi] = make_uint2(l0, l1); }
+                        const long long si = split_index(n, C4 >> 2, OH, OW, Y, X, c4);
+                        if (P.split_lo) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
                         else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
-                        P.split_hi[oi] = make_uint2(h0, h1);
+                        P.split_hi[si] = make_uint2(h0, h1);
                     }
                 }
 #pragma unroll
@@ -1358,6 +1374,9 @@ static int num_cus_dense() {
 #ifndef C3_TALL_MIN_TILES
 #define C3_TALL_MIN_TILES 4          // use the 8-wave 32x16 tile from 64 rows up
 #endif
+#ifndef C3_WIDE8_DEFAULT
+#define C3_WIDE8_DEFAULT 0
+#endif
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st) {
     constexpr int ROWS = NBW * WV;
@@ -1400,7 +1419,7 @@ static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout) {
 }
 
 // Which conv3_kernel instantiation a fast-path layer runs (one place: the launcher and nfe_conv_describe both ask here).
-enum { C3V_UP = 0, C3V_BIG, C3V_MID, C3V_X3_TALL4, C3V_TALL8, C3V_BASE };
+enum { C3V_UP = 0, C3V_BIG, C3V_MID, C3V_X3_TALL4, C3V_TALL8, C3V_BASE, C3V_WIDE8 };
 static int conv3_variant(int mode, int math, int n, int h, int w, int cout) {
     const bool bf16 = math == NFE_CONV_BF16;
     if (mode == NFE_CONV_3X3_UP2) return C3V_UP;
@@ -1408,6 +1427,10 @@ static int conv3_variant(int mode, int math, int n, int h, int w, int cout) {
     const bool fills = (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense();
     if (C3_BIG && cout % 128 == 0 && h >= 16 && (long long)((h + 15) / 16) * ((w + 31) / 32) * (cout / 128) * n >= 2LL * num_cus_dense()) return C3V_BIG;
     if (C3_MID && tall && bf16) return C3V_MID;
+    // round 3: 128 channels x 32x16 pixels on EIGHT waves (4 M-blocks x 2 rows per wave, 128 accumulator registers, one workgroup per
+    // CU): 1.37x fewer staged bytes per MFMA than the 64-channel tile and 72 MFMAs per wave between barriers instead of 36
+    static const int wide8 = [] { const char* e = getenv("NFE_C3_WIDE8"); return e ? atoi(e) : C3_WIDE8_DEFAULT; }();
+    if (wide8 && bf16 && tall && cout % 128 == 0 && (long long)((h + 15) / 16) * ((w + 31) / 32) * (cout / 128) * n >= num_cus_dense()) return C3V_WIDE8;
     if (!bf16 && tall && fills) return C3V_X3_TALL4;
     if (tall && fills) return C3V_TALL8;
     return C3V_BASE;
@@ -1470,7 +1493,7 @@ extern "C" int nfe_conv_describe(int mode, int math, int n, int h, int w, int ci
     NFE_REQUIRE(buf && buf_len > 0, "nfe_conv_describe: no buffer");
     const char* m = math == NFE_CONV_BF16 ? "bf16" : "bf16x3";
     if (mode != NFE_CONV_1X1 && conv3_eligible(mode, h, w, cin, cout)) {
-        static const char* names[] = {"up2 1x(32x8)/4w", "big 128ch 32x16/4w", "mid 32x16/4w", "x3 32x16/4w (2x4 blocks)", "32x16/8w", "32x8/4w"};
+        static const char* names[] = {"up2 1x(32x8)/4w", "big 128ch 32x16/4w", "mid 32x16/4w", "x3 32x16/4w (2x4 blocks)", "32x16/8w", "32x8/4w", "128ch 32x16/8w"};
         const int ks = conv3_ksplit(mode, n, h, w, cin, cout);
         snprintf(buf, (size_t)buf_len, "conv3[%s] %s ksplit=%d fuse_rgb=%d split_in_epilogue=%d%s", names[conv3_variant(mode, math, n, h, w, cout)], m, ks,
                  rgb_channels > 0 ? nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, rgb_channels) : 0,
@@ -1512,7 +1535,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     // plain 3x3 with a consumer image: one extra elementwise pass over the fp32 output
     auto split_tail = [&]() -> int {
         if (!(a->next_split && a->mode == NFE_CONV_3X3)) return NFE_OK;
-        NFE_REQUIRE(a->out && a->cout % 4 == 0, "nfe_modulated_conv: next_split on a 3x3 layer needs `out` and cout %% 4 == 0");
+        NFE_REQUIRE(a->out && a->cout % 16 == 0, "nfe_modulated_conv: next_split on a 3x3 layer needs `out` and cout %% 16 == 0");
         unsigned short* sh = reinterpret_cast<unsigned short*>(a->next_split);
         hipLaunchKernelGGL(modsplit_kernel, dim3(grid1d(out_elems / 4, 256, 1 << 15)), dim3(256), 0, st, reinterpret_cast<const float4*>(a->out), a->next_styles,
                            out_elems / 4, (long long)a->h * a->w * (a->cout / 4), a->cout / 4, reinterpret_cast<uint2*>(sh),
@@ -1570,6 +1593,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             P.ksplit = c3ks; P.partial = K.partial;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, 1);
         };
+        int rgb_groups = a->cout / 64;               // M-block groups (workgroups along Cout) that leave a fused-ToRGB partial sum
         switch (conv3_variant(a->mode, a->math, a->n, a->h, a->w, a->cout)) {
         case C3V_UP: {
             // (round 2 measured, without gain: a double-buffered stage (C3_STAGES_X3_UP = 2) and the 32 x 16 tile on 8 waves: DESIGN.md 5)
@@ -1593,6 +1617,10 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             // and a wave that owns four rows re-uses each weight fragment four times (0.5 instead of 0.67 reads per MFMA): +1.5 %
             launch_conv3<3, 2, false, C3_STAGES_X3, 4, 4>(K, a->h, a->w, st);
             break;
+        case C3V_WIDE8:
+            launch_conv3<1, 4, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);
+            rgb_groups = a->cout / 128;
+            break;
         case C3V_TALL8:     // 32 x 16 tiles (8 waves): half the weight bytes per MFMA - as long as they still fill the chip
             if (bf16) launch_conv3<1, 2, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);
             else launch_conv3<3, 2, false, C3_STAGES_X3, 8>(K, a->h, a->w, st);
@@ -1608,7 +1636,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         }
         if (fuse_rgb)
             hipLaunchKernelGGL(rgb_combine_kernel, dim3(grid1d((long long)a->n * a->h * a->w, 256, 1 << 14)), dim3(256), 0, st, K.rgb_partial,
-                               a->cout / 64, a->n, a->h, a->w, a->rgb_channels, a->rgb_bias, a->rgb_clamp, a->rgb_skip, a->rgb_out);
+                               rgb_groups, a->n, a->h, a->w, a->rgb_channels, a->rgb_bias, a->rgb_clamp, a->rgb_skip, a->rgb_out);
         NFE_CHECK_LAUNCH("conv3 kernels");
         return split_in_epilogue ? NFE_OK : split_tail();
     }
@@ -1658,9 +1686,9 @@ extern "C" int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, 
 }
 
 #ifdef C3_PROFILE
-extern "C" int nfe_debug_c3_profile(unsigned long long* out4, int reset) {
-    if (hipMemcpyFromSymbol(out4, HIP_SYMBOL(nfe::c3_prof), 32) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(nfe::c3_prof), z, 32) != hipSuccess) return -1; }
+extern "C" int nfe_debug_c3_profile(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(nfe::c3_prof), 64) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(nfe::c3_prof), z, 64) != hipSuccess) return -1; }
     return 0;
 }
 #endif

@@ -229,7 +229,7 @@ def test_render_video_reference_signature(setup, tmp_path):
     torch.manual_seed(5)
     got = U.render_video(G, str(tmp_path / "sub" / "v.mp4"), ws, norm, planes, 8, 30, 10.0, 8.0, writer=w, batch=2)
     assert len(w.frames) == 10 and not w.closed      # 8 orbit frames + 8 // 4 lead-in frames (utils.py:45-66)
-    assert True and w.frames[0].shape == (512, 512, 3) and w.frames[0].dtype == np.uint8
+    assert w.frames[0].shape == (512, 512, 3) and w.frames[0].dtype == np.uint8
     assert torch.equal(got, want) and np.array_equal(np.stack(w.frames), want.cpu().numpy())
     seen = []
     torch.manual_seed(5)
