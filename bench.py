@@ -77,7 +77,7 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
                     "time is quoted for reference only (planes and gradients are cache resident)"}
 
 
-def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD):
+def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD, clock_ghz=None):
     """The ceilings that can bind render_kernel, each as (cycles this resource is busy per launch) / (kernel cycles), with the
     kernel cycles = the kernel time measured HERE x the effective shader clock of the profiled run (GRBM_GUI_ACTIVE / 8 XCDs /
     profiled kernel time; SQ_* counters are quad-cycles, MI355X_MICROARCH.md):
@@ -99,7 +99,10 @@ def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD):
     except (OSError, ValueError):
         return None, {}, {"note": f"{os.path.relpath(PMC_FILE, ROOT)} missing: run tools/r02_profile.sh"}
     t = kern_ms * 1e-3
-    clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["avg_ns_profiled"] * 1e-9)          # effective shader clock of the profiled launches, Hz
+    clk_prof = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["avg_ns_profiled"] * 1e-9)     # effective shader clock of the profiled launches, Hz
+    # kernel cycles of THIS run: its own in-kernel clock (s_memtime against the 100 MHz s_memrealtime, stamped at both ends of every
+    # timed launch: nfe_render_args.clock_probe) when available, else the profiled run's clock
+    clk = clock_ghz * 1e9 if clock_ghz else clk_prof
     cycles = t * clk
     hbm_bytes = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0
     frac = {"wave_issue": c["SQ_ACTIVE_INST_ANY"] * 4.0 / resident_waves / cycles,
@@ -110,7 +113,8 @@ def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD):
     physical = {k: v for k, v in frac.items() if k != "logical_gather"}
     bound = max(physical, key=physical.get)
     detail = {"counters_file": os.path.relpath(PMC_FILE, ROOT), "kernel_profiled": c.get("kernel"), "kernel_ms_profiled": c["avg_ns_profiled"] / 1e6,
-              "effective_clock_ghz": clk / 1e9, "valu_instructions": c["SQ_INSTS_VALU"], "mfma_instructions": c["SQ_INSTS_MFMA"],
+              "effective_clock_ghz": clk / 1e9, "effective_clock_source": "in-run s_memtime / s_memrealtime" if clock_ghz else "profiled run",
+              "profiled_clock_ghz": clk_prof / 1e9, "valu_instructions": c["SQ_INSTS_VALU"], "mfma_instructions": c["SQ_INSTS_MFMA"],
               "l1_requests": c["TCP_TOTAL_CACHE_ACCESSES"], "hbm_bytes": hbm_bytes,
               "wave_life_split": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                                   "waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
@@ -548,6 +552,7 @@ def main():
     M = R * R
     n_total = world * VIEWS_PER_GPU
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    probes = torch.zeros(max(args.steps, 1), 4, dtype=torch.int64, device=dev)      # in-run shader clock of every timed launch
 
     pending = []                                                # outstanding frame exchanges (work, gathered frames)
 
@@ -562,7 +567,8 @@ def main():
         if timed:
             ev[i][0].record()
         rgb, seg, depth, wsum = ops.render(packed, packed, dec_packed, opts, cam2world=c2w_t, intrinsics=K_t,
-                                           resolution=R, affines=aff, seed=seed + i, channels_first=True)
+                                           resolution=R, affines=aff, seed=seed + i, channels_first=True,
+                                           clock_probe=probes[i] if timed else None)
         if timed:
             ev[i][1].record()
         if world > 1:                                           # frames of every rank, in view order; the exchange of step i
@@ -617,7 +623,10 @@ def main():
         rays_per_step = n_total * M
         value = rays_per_step * args.steps / dt
         launch_bytes = VIEWS_PER_GPU * M * BYTES_PER_RAY_S1
-        bound, frac, detail = issue_model(kern_ms, launch_bytes)
+        pr = probes.cpu().numpy().astype(np.float64)
+        ok = (pr[:, 3] > pr[:, 1]) & (pr[:, 2] > pr[:, 0])
+        clock_ghz = float(np.median((pr[ok, 2] - pr[ok, 0]) / (pr[ok, 3] - pr[ok, 1]) * 0.1)) if ok.any() else None   # 100 MHz reference
+        bound, frac, detail = issue_model(kern_ms, launch_bytes, clock_ghz=clock_ghz)
         if bound == "hbm":              # achieved / peak in the binding resource's own unit
             ach, peak, unit = frac[bound] * HBM_PEAK_GBS, HBM_PEAK_GBS, "GB/s"
         elif bound is not None:         # busy cycles per second of the binding unit (wave issue port, matrix pipe, L1, TA)

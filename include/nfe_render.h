@@ -157,6 +157,9 @@ typedef struct nfe_render_args {
                                           draws keyed by (seed, ray, draw index), 0 = off.  With importance sampling the
                                           workspace must hold N*M*(D+Di)*4 more bytes (rounded up to 256). */
     const float* decoder_cross;        /* optional, from nfe_decoder_pack_cross (SegmentationOSGDecoder); NULL = none */
+    uint64_t* clock_probe;             /* ABI v10, optional, device [4]: the final render launch stamps {shader-cycle counter,
+                                          100 MHz reference counter} at its start and its end (workgroup 0): effective shader clock
+                                          of that launch = (p[2]-p[0]) / (p[3]-p[1]) x 100 MHz.  Measurement only; NULL = off */
 } nfe_render_args;
 
 /* bytes of workspace nfe_render needs for these sizes: the depth min/max words, 13.6 MB for the segment composites of

@@ -457,6 +457,9 @@ __global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict_
 }
 
 __device__ uint4 nfe_zero16[4];                                  // source of the zero padding for LDS-DMA
+#ifndef C3_LC_GENERIC_LOOP
+#define C3_LC_GENERIC_LOOP 0     // 1: the compute waves of the loader / compute split run the generic fragment pipeline (A/B)
+#endif
 #ifndef C3_ABLATE
 #define C3_ABLATE 0       // timing experiments only (wrong results): 1 no LDS-DMA, 2 no MFMA, 3 no barriers in the K loop, 4 no fragment reads
 #endif
@@ -484,7 +487,10 @@ struct Conv3K {
     const float* next_styles; uint2* split_hi; uint2* split_lo;     // plain 3x3, no split-K: the consuming layer's modulated bf16 image
 };                                                                  // (what modsplit_kernel would make of `out`), written by the epilogue
 
-__host__ __device__ constexpr bool c3_xcd_order(int terms) { return terms == 3; }
+#ifndef C3_XCD_ALL
+#define C3_XCD_ALL 0
+#endif
+__host__ __device__ constexpr bool c3_xcd_order(int terms) { return terms == 3 || C3_XCD_ALL; }
 
 // WV waves per workgroup, each owning NBW image rows of 32 pixels: tile = 32 x (NBW * WV) pixels (ROWS rows).
 constexpr int C3_TW = 32, C3_PW = C3_TW + 2;
@@ -526,20 +532,28 @@ constexpr int conv3_stage_bytes() { return (MBW * 9 + C3Tile<ROWS>::B_CHUNKS) * 
 // NBW = 2: up to four waves per SIMD (two workgroups per CU).  NBW = 4 with MBW = 4 is the big tile: 128 channels x
 // 32 x 16 pixels on four waves, ONE wave per SIMD with 256 accumulator registers - half the LDS reads and half the
 // L1->LDS bytes per MFMA of the small tiles.
-template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
-__global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && WV == 8)) ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
+// LW > 0 (round 3): LW extra LOADER waves per workgroup.  Waves 0..WV-1 only compute (fragment reads + MFMA + epilogue), waves
+// WV..WV+LW-1 only stage operands: they keep STAGES-1 K-groups of LDS-DMA in flight, wait for the oldest one and meet the compute
+// waves at the one barrier per K-group.  The load stream no longer stops while a wave is in its MFMA phase (and vice versa): in
+// the symmetric form the two halves of the work overlapped by a quarter only (profiles/experiments/r03_conv3_negative.md).
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
+__global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 8 || (UP2 && TERMS == 3 && WV == 8)) ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
     constexpr int NACC = UP2 ? 4 : 1;
     constexpr int A_CHUNKS = MBW * 9 * PARTS;
     constexpr int ROWS = NBW * WV;
     constexpr int STAGE_BYTES = conv3_stage_bytes<TERMS, MBW, ROWS>();
     constexpr int C3_TH = C3Tile<ROWS>::TH, C3_HALF_ITEMS = C3Tile<ROWS>::HALF_ITEMS, C3_B_CHUNKS = C3Tile<ROWS>::B_CHUNKS, C3_B_BYTES = C3Tile<ROWS>::B_BYTES;
-    constexpr int B_PER_WAVE = (C3_B_CHUNKS + WV - 1) / WV;
-    constexpr int MIN_LOADS = A_CHUNKS / WV + (C3_B_CHUNKS / WV) * PARTS;    // fewest LDS-DMA instructions any wave issues per stage
+    constexpr int IW = LW ? LW : WV;                                          // waves that issue the LDS-DMA of a stage
+    constexpr int B_PER_WAVE = (C3_B_CHUNKS + IW - 1) / IW;
+    constexpr int MIN_LOADS = A_CHUNKS / IW + (C3_B_CHUNKS / IW) * PARTS;    // fewest LDS-DMA instructions any issuing wave issues per stage
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool loader = LW > 0 && wave >= WV;              // wave-uniform role
+    const bool issues = LW == 0 || loader;
+    const int iw = LW ? wave - WV : wave;                  // index among the issuing waves
     // Tile grid: output pixels, or the (H+1) x (W+1) extended input grid of the transposed conv.  EDGE mode (W a multiple of
     // the tile width): the extra column x = W is not tiled (a 32-wide tile for one column); the right-most tile of every tile
     // row computes it as ONE extra N-block on wave 0 (lane = tile row): that column only sees input column W-1 through the
@@ -571,7 +585,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
     long long boff[B_PER_WAVE];
 #pragma unroll
     for (int k = 0; k < B_PER_WAVE; ++k) {
-        const int item = (wave + WV * k) * 64 + lane;
+        const int item = ((issues ? iw : 0) + IW * k) * 64 + lane;
         // LDS item 2p + (hh ^ bit3(p)) holds channel half hh of patch pixel p: the two halves of a pixel (32 contiguous
         // bytes in NHWC) are fetched by adjacent lanes = one L1 request, and the XOR keeps the 32-byte-stride fragment
         // reads conflict-free (pixels p and p+8 share a bank pair, their halves are swapped).
@@ -609,14 +623,14 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
     auto issue = [&](int g, int stage) {
         unsigned char* base = lds + stage * STAGE_BYTES;
         // weights: chunk (m, t, part) <- packed[((mb0+m)*G + g)*18 + t*2 + part]
-        for (int c = wave; c < A_CHUNKS; c += WV) {
+        for (int c = iw; c < A_CHUNKS; c += IW) {
             const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
             const uint4* src = P.packed + (((long long)(mb0 + m) * G_all + g_base + g) * 18 + t * 2 + part) * 64 + lane;
             lds_dma16(src, base + c * 1024);
         }
 #pragma unroll
         for (int k = 0; k < B_PER_WAVE; ++k) {
-            const int c = wave + WV * k;
+            const int c = iw + IW * k;
             if (c < C3_B_CHUNKS) {
 #pragma unroll
                 for (int part = 0; part < PARTS; ++part) {
@@ -642,25 +656,69 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
     unsigned long long prof_load = 0, prof_comp = 0, prof_vm = 0, prof_bar = 0;
     const unsigned long long ts_start = __builtin_amdgcn_s_memtime();
 #endif
-    for (int pre = 0; pre < STAGES - 1; ++pre)
-        if (pre < G) issue(pre, pre);
+    static_assert(LW == 0 || (STAGES >= 2 && !UP2), "loader waves need a ring of at least two stages; plain 3x3 only");
+    if (issues)
+        for (int pre = 0; pre < STAGES - 1; ++pre)
+            if (pre < G) issue(pre, pre);
     int stage = 0;
+    if (loader) {                       // ---- loader waves: the whole K loop, then done (no epilogue, no further barriers) ----
+        for (int g = 0; g < G; ++g) {
+            // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
+            if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
+            __syncthreads();            // stage g is complete for everybody; the compute waves are done with stage g-1
+            if (g + STAGES - 1 < G) issue(g + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);
+            stage = stage + 1 == STAGES ? 0 : stage + 1;
+        }
+        return;
+    }
     for (int g = 0; g < G; ++g) {
         C3_STAMP(ts0);
         if (STAGES == 1) { __syncthreads(); issue(g, 0); }
         // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
-        if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (LW > 0) {}                  // compute waves issue no loads: the loader waves wait for them
+        else if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
         C3_STAMP(ts0a);
         if (C3_ABLATE != 3) __syncthreads();
         C3_STAMP(ts0b);
         const bool more = g + STAGES - 1 < G;
         const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
-        if (STAGES >= 2 && more) issue(g + STAGES - 1, nstage);
+        if (LW == 0 && STAGES >= 2 && more) issue(g + STAGES - 1, nstage);
         C3_STAMP(ts1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
         const unsigned char* ldsB = base + A_CHUNKS * 1024;
+        if constexpr (LW > 0 && TERMS == 1 && !UP2 && NBW == 4 && !C3_LC_GENERIC_LOOP) {
+            // Compute wave of the loader / compute split, plain bf16: this wave is alone on its SIMD's matrix pipe, so the LDS latency
+            // of a fragment read must be covered by its own MFMAs.  All 18 weight fragments of the K-group stay in registers (72
+            // VGPRs; each is used by 4 rows), the 18 patch fragments (6 patch rows x 3 columns) stream through a ring of four,
+            // read three fragments (>= 6 MFMAs = 192 cycles) ahead; a patch fragment (rr, dx) feeds every row nb with a tap
+            // kh = rr - nb in 0..2: 36 reads per 72 MFMAs.
+            Frag8 A[MBW][9], Bq[4];
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int m = 0; m < MBW; ++m) A[m][t].q = ldsA[(m * 9 + t) * 64];
+            auto load_bf = [&](int f) { Bq[f & 3].q = *reinterpret_cast<const uint4*>(ldsB + brd[f / 3][f % 3]); };
+            load_bf(0); load_bf(1); load_bf(2);
+#pragma unroll
+            for (int f = 0; f < 18; ++f) {
+                if (f + 3 < 18) load_bf(f + 3);
+                __builtin_amdgcn_sched_barrier(0);
+                const int rr = f / 3, dx = f % 3;
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    const int kh = rr - nb;
+                    if (kh >= 0 && kh <= 2) {
+#pragma unroll
+                        for (int m = 0; m < MBW; ++m)
+                            acc[0][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][kh * 3 + dx].v, Bq[f & 3].v, acc[0][m][nb], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #if C3_FRAG_PIPE
         // Fragment reads run ONE (tap, N-block) step ahead of the MFMAs that use them (register double buffer, order pinned by
         // sched_barrier): the compiler's own schedule issues a read one or two MFMAs before its use, which leaves the matrix pipe
@@ -764,6 +822,7 @@ __global__ __launch_bounds__(64 * WV, ((NBW * MBW > 8 || (UP2 && TERMS == 3 && W
             }
         }
 #endif
+        }
         stage = stage + 1 == STAGES ? 0 : stage + 1;
 #ifdef C3_PROFILE
         { C3_STAMP(ts2); prof_load += ts1 - ts0; prof_comp += ts2 - ts1; prof_vm += ts0a - ts0; prof_bar += ts0b - ts0a; }
@@ -1377,18 +1436,22 @@ static int num_cus_dense() {
 #ifndef C3_WIDE8_DEFAULT
 #define C3_WIDE8_DEFAULT 0
 #endif
-template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2>
+#ifndef C3_LC_DEFAULT
+#define C3_LC_DEFAULT 0
+#endif
+
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st) {
     constexpr int ROWS = NBW * WV;
     constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>();
     static bool once = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     (void)once;
     const unsigned tiles = ((mode_h + ROWS - 1) / ROWS) * ((mode_w + C3_TW - 1) / C3_TW);
     Conv3K K2 = K; K2.c3_tiles = (int)tiles;
     dim3 grid(c3_xcd_order(TERMS) ? (tiles + 7) / 8 * 8 : tiles, K.Cout / (32 * MBW), K.N * (K.ksplit > 1 ? K.ksplit : 1));
-    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW>), grid, dim3(64 * WV), bytes, st, K2);
+    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), grid, dim3(64 * (WV + LW)), bytes, st, K2);
 }
 
 static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
@@ -1419,13 +1482,17 @@ static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout) {
 }
 
 // Which conv3_kernel instantiation a fast-path layer runs (one place: the launcher and nfe_conv_describe both ask here).
-enum { C3V_UP = 0, C3V_BIG, C3V_MID, C3V_X3_TALL4, C3V_TALL8, C3V_BASE, C3V_WIDE8 };
+enum { C3V_UP = 0, C3V_BIG, C3V_MID, C3V_X3_TALL4, C3V_TALL8, C3V_BASE, C3V_WIDE8, C3V_LC };
 static int conv3_variant(int mode, int math, int n, int h, int w, int cout) {
     const bool bf16 = math == NFE_CONV_BF16;
     if (mode == NFE_CONV_3X3_UP2) return C3V_UP;
     const bool tall = h >= 16 * C3_TALL_MIN_TILES;
     const bool fills = (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense();
     if (C3_BIG && cout % 128 == 0 && h >= 16 && (long long)((h + 15) / 16) * ((w + 31) / 32) * (cout / 128) * n >= 2LL * num_cus_dense()) return C3V_BIG;
+    // round 3: 32x16 tile, four compute waves (4 rows x 2 M-blocks each) + four loader waves, one workgroup per CU, ring of 4 (bf16)
+    // or 2 (split-bf16) stages
+    static const int lc = [] { const char* e = getenv("NFE_C3_LC"); return e ? atoi(e) : C3_LC_DEFAULT; }();
+    if (lc && tall && (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense()) return C3V_LC;
     if (C3_MID && tall && bf16) return C3V_MID;
     // round 3: 128 channels x 32x16 pixels on EIGHT waves (4 M-blocks x 2 rows per wave, 128 accumulator registers, one workgroup per
     // CU): 1.37x fewer staged bytes per MFMA than the 64-channel tile and 72 MFMAs per wave between barriers instead of 36
@@ -1493,7 +1560,7 @@ extern "C" int nfe_conv_describe(int mode, int math, int n, int h, int w, int ci
     NFE_REQUIRE(buf && buf_len > 0, "nfe_conv_describe: no buffer");
     const char* m = math == NFE_CONV_BF16 ? "bf16" : "bf16x3";
     if (mode != NFE_CONV_1X1 && conv3_eligible(mode, h, w, cin, cout)) {
-        static const char* names[] = {"up2 1x(32x8)/4w", "big 128ch 32x16/4w", "mid 32x16/4w", "x3 32x16/4w (2x4 blocks)", "32x16/8w", "32x8/4w", "128ch 32x16/8w"};
+        static const char* names[] = {"up2 1x(32x8)/4w", "big 128ch 32x16/4w", "mid 32x16/4w", "x3 32x16/4w (2x4 blocks)", "32x16/8w", "32x8/4w", "128ch 32x16/8w", "32x16/4w compute + 4w loaders"};
         const int ks = conv3_ksplit(mode, n, h, w, cin, cout);
         snprintf(buf, (size_t)buf_len, "conv3[%s] %s ksplit=%d fuse_rgb=%d split_in_epilogue=%d%s", names[conv3_variant(mode, math, n, h, w, cout)], m, ks,
                  rgb_channels > 0 ? nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, rgb_channels) : 0,
@@ -1616,6 +1683,10 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             // split-bf16: the 32 x 16 tile on FOUR waves (2 x 4 blocks per wave): the kernel is co-limited by LDS fragment reads,
             // and a wave that owns four rows re-uses each weight fragment four times (0.5 instead of 0.67 reads per MFMA): +1.5 %
             launch_conv3<3, 2, false, C3_STAGES_X3, 4, 4>(K, a->h, a->w, st);
+            break;
+        case C3V_LC:
+            if (bf16) launch_conv3<1, 2, false, 4, 4, 4, 4>(K, a->h, a->w, st);
+            else launch_conv3<3, 2, false, 2, 4, 4, 4>(K, a->h, a->w, st);
             break;
         case C3V_WIDE8:
             launch_conv3<1, 4, false, C3_STAGES_BF16, 8>(K, a->h, a->w, st);

@@ -48,6 +48,7 @@ struct RenderK {
     const float* ev_g_rgb; const float* ev_g_seg; int ev_channels_first; float* ev_sig; float* ev_a;
     int seg_count;                 // SPLIT variants: depth segments per ray block (each marched by its own wave)
     float* partials;               // SPLIT variants: [N*M, seg_count, PARTIAL_FLOATS] segment composites, see render_combine_kernel
+    unsigned long long* clock_probe;   // optional [4]: {s_memtime, s_memrealtime} of workgroup 0 / wave 0 at kernel start and end
 };
 
 // LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then per wave AFF_FLOATS of
@@ -780,6 +781,10 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     float* aff = lds + LDS_AFF + wave * WAVE_LDS_FLOATS;
     float* xp = aff + AFF_FLOATS;
     __syncthreads();
+    // In-run shader clock (bench.py): shader-cycle counter against the 100 MHz reference counter, stamped by one lane at the two
+    // ends of the launch (the grid is persistent: workgroup 0 lives as long as the kernel).  Nothing is stamped inside the loop.
+    const bool probe = P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0;
+    if (probe && lane == 0) { P.clock_probe[0] = __builtin_amdgcn_s_memtime(); P.clock_probe[1] = __builtin_amdgcn_s_memrealtime(); }
 
     const int S = P.S;
     const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
@@ -1014,6 +1019,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             atomicMax(P.depth_minmax + 1, f2ord(tmax));
         }
     }
+    if (probe && lane == 0) { P.clock_probe[2] = __builtin_amdgcn_s_memtime(); P.clock_probe[3] = __builtin_amdgcn_s_memrealtime(); }
 }
 
 
@@ -1531,6 +1537,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.seed = a->seed; P.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device);
     P.density_noise = a->density_noise;
     P.dec_cross = a->decoder_cross;
+    P.clock_probe = reinterpret_cast<unsigned long long*>(a->clock_probe);
     P.partials = a->decoder_cross ? nullptr : partials;
     if (a->decoder_cross)
         NFE_REQUIRE(a->planes_geo == a->planes_app && a->decoder_math == NFE_MATH_BF16X3 && a->density_noise == 0.0f,

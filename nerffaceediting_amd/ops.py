@@ -186,8 +186,9 @@ def decoder_forward(features_geo, features_app, decoder_packed, decoder_math=Non
 
 def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dirs=None, cam2world=None,
            intrinsics=None, resolution=0, affines=None, u_coarse=None, u_fine=None, seed=0,
-           channels_first=False, taps=False, ray_limits=None, decoder_math=None, decoder_cross=None):
+           channels_first=False, taps=False, ray_limits=None, decoder_math=None, decoder_cross=None, clock_probe=None):
     """nfe_render.  planes_* are packed [Np,3,H,W,32] (Np == N or 1); affines = 4x [N,96] or None.
+    clock_probe: optional int64 device tensor [4] the final render launch stamps (nfe_render_args.clock_probe).
 
     Returns (rgb, seg, depth, wsum[, taps]) with rgb [N,M,32] (or [N,32,M] if channels_first),
     seg [N,M,15], depth [N,M,1], wsum [N,M,1] — the tuple DisentangledImportanceRenderer.forward
@@ -229,6 +230,10 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
         decoder_cross = _dev(decoder_cross, "decoder_cross", (_lib.NFE_DECODER_CROSS_FLOATS,))
         a.decoder_cross = decoder_cross.data_ptr()
         keep.append(decoder_cross)
+    if clock_probe is not None:
+        assert clock_probe.is_cuda and clock_probe.dtype == torch.int64 and clock_probe.numel() >= 4
+        a.clock_probe = clock_probe.data_ptr()
+        keep.append(clock_probe)
     a.n_views, a.n_rays = N, M
     if origins is not None:
         a.origins, a.dirs = origins.data_ptr(), dirs.data_ptr()
