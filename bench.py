@@ -267,8 +267,8 @@ def extra_workload(args, torch, dist, dev, rank, world):
         planes, dec_t, _, c2w_t, K_t, _, _, _ = synth_inputs(torch, dev, seed)
         mean, std = ops.plane_stats(planes)
         gs, gb, as_, ab = ops.make_affine(mean, std, mean.roll(1, 0).contiguous(), std.roll(1, 0).contiguous())
-        norm = ops.plane_pack(ops.plane_affine(planes, gs, gb))
-        denorm = ops.plane_pack(ops.plane_affine(planes, as_, ab))
+        norm_nchw = ops.plane_affine(planes, gs, gb)       # what the optimiser holds: NCHW planes, a new version every step
+        denorm_nchw = ops.plane_affine(planes, as_, ab)
         names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
                  "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
         heads = [dec_t[k] for k in names]
@@ -283,6 +283,9 @@ def extra_workload(args, torch, dist, dev, rank, world):
         def step(i):
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             e[0].record()
+            # an optimiser step changed the planes: the gather-layout copies are re-made inside the step, as
+            # DisentangledImportanceRenderer._packed does on a new tensor version (2 x 25 MB x views, no host sync)
+            norm, denorm = ops.plane_pack(norm_nchw), ops.plane_pack(denorm_nchw)
             out = ops.render(norm, denorm, dec_packed, opts, cam2world=c2w_t, intrinsics=K_t, resolution=Re, seed=seed + i, taps=True)
             e[1].record()
             ops.render_backward(norm, denorm, heads, 1.0, opts, out[4]["depths_all"], cots, cam2world=c2w_t, intrinsics=K_t, resolution=Re)
@@ -299,7 +302,8 @@ def extra_workload(args, torch, dist, dev, rank, world):
         return dict(base, metric="rays/s, plane-editing step: 128^2 x (48+48) dual-plane render forward + backward w.r.t. both plane sets",
                     value=n_total * Me * args.steps / dt, unit="rays/s", ms_per_step=dt / args.steps * 1e3, scaling="weak", dtype="f32",
                     config={"workload": "SURVEY 8(f)4 backward pass: 4 views/GPU/step, 128^2 rays, 48 + 48 samples, norm/denorm plane sets with "
-                                        "swapped statistics, random cotangents for rgb/seg/depth/wsum, gradients w.r.t. both plane sets",
+                                        "swapped statistics, random cotangents for rgb/seg/depth/wsum, gradients w.r.t. both plane sets; forward_ms "
+                                        "includes the per-step NCHW -> gather-layout re-pack of both plane sets",
                             "views_per_step": n_total, "forward_ms": fwd_ms, "backward_ms": bwd_ms, "parallelism": f"views-dp{world}"},
                     roofline=backward_roofline(bwd_ms, VIEWS_PER_GPU * Me * S2, ach))
 

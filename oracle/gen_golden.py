@@ -155,6 +155,11 @@ def gen_render_case(tag, seed, N, R, H, D, Ni, angles, white_back=False, swap=Fa
     print(f"  wrote render_{tag}.npz")
 
 
+CHUNK_NOTE = ("reference run in ray chunks: ray_marcher.py:94 clamps depth to the [min, max] of the depths tensor of EACH CALL, i.e. per chunk here "
+              "(not per whole view); a weighted mean of sampled depths lies inside any chunk's range, so the clamp can bind only on rays whose "
+              "weights sum to 0 (depth NaN -> inf -> clamp); min(wsum) over the stored rays is recorded as wsum_min")
+
+
 def gen_render_full_size(name="fullsize_render", seed=401, N=1, R=512, H=256, D=64, Ni=0, swap=False, stride=61, chunk=32768,
                          angles=((0.3, -0.2),)):
     """Real-size render cases through the reference renderer, in ray chunks (the only cross-ray term, the depth clamp to
@@ -194,7 +199,7 @@ def gen_render_full_size(name="fullsize_render", seed=401, N=1, R=512, H=256, D=
                         cam2world=c2w.numpy(), intrinsics=K.numpy(), options=np.array(repr(opts_s)),
                         rgb=rgb[:, idx], seg=seg[:, idx], depth=depth[:, idx], wsum=wsum[:, idx],
                         rgb_mean=rgb.astype(np.float64).mean(axis=(0, 1)), wsum_mean=float(wsum.astype(np.float64).mean()),
-                        torch_version=np.array(torch.__version__))
+                        wsum_min=float(wsum[:, idx].min()), note=np.array(CHUNK_NOTE), torch_version=np.array(torch.__version__))
     print(f"  wrote {name}.npz")
 
 

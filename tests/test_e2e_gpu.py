@@ -479,7 +479,7 @@ def test_interpolation_video_frames(setup):
     old = G.neural_rendering_resolution
     G.neural_rendering_resolution = 32
     try:
-        torch.manual_seed(3)
+        G.renderer.seed_tensor = torch.tensor([4242], dtype=torch.int64, device=dev)      # one Philox key for every call below
         frames = apps.interpolation_video_frames(G, [0, 1], w_frames=2, batch=3)
         assert frames.shape == (4, 512, 512, 3) and frames.dtype == torch.uint8
         c = apps.orbit_cameras(4, dev)
@@ -487,12 +487,18 @@ def test_interpolation_video_frames(setup):
         c2w = apps.camera_utils.LookAtPoseSampler.sample(3.14 / 2, 3.14 / 2, torch.tensor([0, 0, 0.2], device=dev), radius=2.7, device=dev)
         c_front = torch.cat([c2w.reshape(-1, 16), torch.tensor(apps.FFHQ_INTRINSICS, device=dev).reshape(-1, 9)], 1).repeat(2, 1)
         ws_key = G.mapping(zs, c_front, truncation_psi=1.0, truncation_cutoff=14)       # gen_videos.py:95-98
-        torch.manual_seed(3)
         want = apps.to_uint8(G.synthesis(ws_key[:1], c[:1], noise_mode="const")["image"])
-        # frame 0 is keyframe 0 under orbit camera 0 (jitter differs per call: compare loosely, it is a 32^2 render)
-        assert float((frames[0].float() - want[0].float()).abs().mean()) < 6.0
+        # frame 0 is keyframe 0 under orbit camera 0.  Same Philox key and view index 0 in both calls -> same jitter; the only
+        # difference left is the dense kernels' batch-dependent variants (3 views vs 1): at most one uint8 level on a few values
+        d = (frames[0].int() - want[0].int()).abs()
+        assert int(d.max()) <= 1 and float(d.float().mean()) < 0.01, (int(d.max()), float(d.float().mean()))
+        # ... and the interpolated latents are gen_videos.py's: frame 1 = cubic interpolation at t = 1/2 between the keyframes
+        ws_all = apps.interpolate_ws(ws_key, w_frames=2)
+        want1 = apps.to_uint8(G.synthesis(ws_all[:3].contiguous(), c[:3].contiguous(), noise_mode="const")["image"])
+        assert torch.equal(frames[:3], want1)
     finally:
         G.neural_rendering_resolution = old
+        G.renderer.seed_tensor = None
 
 
 def test_decode_is_differentiable_wrt_planes(setup):
