@@ -53,6 +53,9 @@ def test_layout_roundtrip_and_stats(dev):
     m0, s0 = ops.plane_stats(x)
     m1, s1 = dense_ops.plane_stats_nhwc(y)
     assert maxerr(m1, m0.cpu()) <= 1e-6 and maxerr(s1, s0.cpu()) <= 1e-6
+    for C in (1, 3, 4, 15, 33):               # 1: copy, 3 / 15: the per-pixel kernel of the image / segmentation outputs, others: LDS tiles
+        xs = t(rng.randn(2, C, 37, 19), dev)
+        assert torch.equal(dense_ops.nhwc_to_nchw(xs.permute(0, 2, 3, 1).contiguous()), xs), C
 
 
 def test_mapping_network(dev):
@@ -121,6 +124,13 @@ def test_resize_bilinear(dev):
             y = dense_ops.resize_bilinear(x, oh, ow, aa)
             ref = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(oh, ow), mode="bilinear", align_corners=False, antialias=aa)
             assert float((y - ref.permute(0, 2, 3, 1)).abs().max()) <= 1e-5, (aa, oh, ow)
+    # the SR head's own case (superresolution.py:283-286): 32- and 3-channel images, 4x antialiased down-scale (9 taps per axis: the
+    # 4-channel fast kernel and the scalar one), and a 6x down-scale whose 13 taps exceed the fast kernel's table
+    for C, (H, oh) in ((32, (64, 16)), (3, (64, 16)), (8, (96, 16))):
+        x = torch.randn(2, H, H, C, generator=g).to(dev)
+        y = dense_ops.resize_bilinear(x, oh, oh, True)
+        ref = torch.nn.functional.interpolate(x.permute(0, 3, 1, 2), size=(oh, oh), mode="bilinear", align_corners=False, antialias=True)
+        assert float((y - ref.permute(0, 2, 3, 1)).abs().max()) <= 1e-5, (C, H, oh)
 
 
 def test_reduced_synthesis_network(dev):
