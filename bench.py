@@ -44,9 +44,9 @@ HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
 PEAK_CLOCK_GHZ = 2.4                         # MI355X shader clock (hipDeviceProp clockRate); the chip holds 1.9-2.2 GHz under this load
 N_CU, N_SIMD = 256, 1024
 # Per-launch hardware counters of the dominant kernel, from rocprofv3 --pmc passes of THIS command on the shipped build
-# (tools/r02_profile.sh: tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed).  PMC cannot be collected
+# (tools/r03_profile.sh: tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed).  PMC cannot be collected
 # inside the timed process.
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_issue_floor.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_issue_floor.json")
 
 
 def backward_roofline(bwd_ms, samples, logical_gbs):
@@ -97,7 +97,7 @@ def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD, clock_ghz=Non
         with open(PMC_FILE) as f:
             c = json.load(f)
     except (OSError, ValueError):
-        return None, {}, {"note": f"{os.path.relpath(PMC_FILE, ROOT)} missing: run tools/r02_profile.sh"}
+        return None, {}, {"note": f"{os.path.relpath(PMC_FILE, ROOT)} missing: run tools/r03_profile.sh"}
     t = kern_ms * 1e-3
     clk_prof = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["avg_ns_profiled"] * 1e-9)     # effective shader clock of the profiled launches, Hz
     # kernel cycles of THIS run: its own in-kernel clock (s_memtime against the 100 MHz s_memrealtime, stamped at both ends of every

@@ -149,6 +149,14 @@ int nfe_conv_accepts_split(int mode, int h, int w, int cin, int cout);
 /* floats of scratch a call with these sizes can use (0 = none) */
 uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout);
 
+/* ABI v10.  upfirdn2d (torch_utils/ops/upfirdn2d.py:120-205) with the path's filter setup_filter([1,3,3,1]) (separable, symmetric,
+ * normalised), NHWC fp32: zero-insert by `up` (1 or 2), pad pad0 / pad1 on both axes, 4x4 FIR, keep every `down`-th (1 or 2) sample,
+ * multiply by gain.  out is [n, oh, ow, c] with oh = (h*up + pad0 + pad1 - 4) / down + 1.  upsample2d(x) (upfirdn2d.py:315-350) is
+ * up=2, pad=(2,1), gain=4.  The forward path fuses its FIRs into conv / ToRGB epilogues; this entry serves the transposed
+ * filters of the SR-head input gradient and callers that want the reference's op by itself. */
+int nfe_upfirdn2d(const float* in, int n, int h, int w, int c, int up, int down, int pad0, int pad1, float gain, float* out,
+                  nfe_stream_t stream);
+
 /* ---- F.interpolate(mode='bilinear', align_corners=False, antialias=...) (superresolution.py:283-286)
  * NHWC [N,H,W,C] -> [N,OH,OW,C] */
 int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int ow, int antialias, float* out,

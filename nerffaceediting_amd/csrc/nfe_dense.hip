@@ -1334,6 +1334,39 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_small_kernel(const float* __
     }
 }
 
+// upfirdn2d with the path's one filter ([1,3,3,1] x [1,3,3,1] / 64, symmetric: flip_filter is moot), NHWC, C % 4 == 0 or any C:
+// zero-insert by `up`, pad (pad0 before, pad1 after, both axes), 4 x 4 FIR, keep every `down`-th sample, times gain
+// (torch_utils/ops/upfirdn2d.py:169-205 _upfirdn2d_ref).  The forward path never calls it (its FIRs are fused into the conv and
+// ToRGB epilogues); it exists for the transposes the SR-head input gradient needs (sr_grad.py) and as the reference's op itself:
+//   upsample2d(x)            = upfirdn2d(x, up=2, pad=(2,1), gain=4)         upfirdn2d.py:341-350
+//   its transpose            = upfirdn2d(g, down=2, pad=(1,2), gain=4)
+//   up-conv FIR (pad 1,1)^T  = upfirdn2d(g, pad=(2,2), gain=4)                conv2d_resample.py:114-128
+__global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ in, int N, int H, int W, int C, int up, int down, int pad0,
+                                                      float gain, int OH, int OW, float* __restrict__ out) {
+    const float F[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    const long long total = (long long)N * OH * OW * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); long long r = i / C;
+        const int X = (int)(r % OW); r /= OW;
+        const int Y = (int)(r % OH); const int n = (int)(r / OH);
+        float acc = 0.0f;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int u = Y * down + a - pad0;                 // row of the zero-inserted image
+            if (u < 0 || u % up != 0 || u / up >= H) continue;
+            float rowv = 0.0f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int v = X * down + b - pad0;
+                if (v < 0 || v % up != 0 || v / up >= W) continue;
+                rowv = fmaf(F[b], in[(((long long)n * H + u / up) * W + v / up) * C + c], rowv);
+            }
+            acc = fmaf(F[a], rowv, acc);
+        }
+        out[i] = acc * gain;
+    }
+}
+
 static unsigned grid1d(long long total, int per_block, long long cap = 1 << 16) {
     long long b = (total + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -1803,6 +1836,18 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     }
     NFE_CHECK_LAUNCH("conv kernels");
     return split_tail();
+}
+
+extern "C" int nfe_upfirdn2d(const float* in, int n, int h, int w, int c, int up, int down, int pad0, int pad1, float gain, float* out,
+                             nfe_stream_t stream) {
+    NFE_REQUIRE(in && out && n > 0 && h > 0 && w > 0 && c > 0, "nfe_upfirdn2d: bad arguments");
+    NFE_REQUIRE((up == 1 || up == 2) && (down == 1 || down == 2) && pad0 >= 0 && pad1 >= 0, "nfe_upfirdn2d: up / down must be 1 or 2, pads >= 0");
+    const int oh = (h * up + pad0 + pad1 - 4) / down + 1, ow = (w * up + pad0 + pad1 - 4) / down + 1;
+    NFE_REQUIRE(oh > 0 && ow > 0, "nfe_upfirdn2d: empty output");
+    hipLaunchKernelGGL(upfirdn_kernel, dim3(grid1d((long long)n * oh * ow * c, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream,
+                       in, n, h, w, c, up, down, pad0, gain, oh, ow, out);
+    NFE_CHECK_LAUNCH("upfirdn_kernel");
+    return NFE_OK;
 }
 
 extern "C" int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int ow, int antialias, float* out, nfe_stream_t stream) {

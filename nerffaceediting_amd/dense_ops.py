@@ -278,6 +278,23 @@ def modulated_conv(x, styles, packed, cout, mode, bias, dcoef=None, noise=None, 
     return out if next_styles is None else (out, split)
 
 
+def upfirdn2d(x, up=1, down=1, padding=(0, 0), gain=1.0):
+    """upfirdn2d (torch_utils/ops/upfirdn2d.py:120) with the path's [1,3,3,1] filter on NHWC: x [N,H,W,C] -> [N,OH,OW,C]."""
+    lib = _lib.load()
+    x = _dev(x, "x", (None, None, None, None))
+    N, H, W, C = x.shape
+    p0, p1 = int(padding[0]), int(padding[1])
+    oh, ow = (H * up + p0 + p1 - 4) // down + 1, (W * up + p0 + p1 - 4) // down + 1
+    out = torch.empty(N, oh, ow, C, device=x.device)
+    _call(x.device, lambda: lib.nfe_upfirdn2d(_ptr(x), N, H, W, C, int(up), int(down), p0, p1, float(gain), _ptr(out), _stream()), "nfe_upfirdn2d")
+    return out
+
+
+def upsample2d(x):
+    """upfirdn2d.upsample2d(x, f, up=2) (upfirdn2d.py:315-350): the skip path of SynthesisBlock (networks_stylegan2.py:453)."""
+    return upfirdn2d(x, up=2, padding=(2, 1), gain=4.0)
+
+
 def resize_bilinear(x, oh, ow, antialias=True):
     """F.interpolate(mode='bilinear', align_corners=False, antialias=...) on NHWC."""
     lib = _lib.load()

@@ -1,0 +1,159 @@
+"""Input gradient of the super-resolution head: d image / d (neural-rendered feature image), weights and ws constant.
+
+The reference's `utils.decode` is differentiable end to end, the super-resolved `image` included (utils.py:165-199,
+training/superresolution.py:279-290): an editing loss may mix a segmentation term with an image term.  Round 2 tied `image` to
+a node that raised in backward.  Here the gradient is computed by the SAME hand-written MFMA kernels as the forward, called
+through `nfe_modulated_conv` with re-packed weights:
+
+  plain 3x3 layer  y = act((W * (s x)) d + noise + b):   dL/dx = s . [ W^T_flipped * (d . g_pre) ]            -> one NFE_CONV_3X3 call,
+                                                         styles := d, dcoef := s, bias 0, no activation
+  up-sampling layer (transposed conv stride 2, then the 4x4 FIR with pad (1,1), conv2d_resample.py:114-128):
+                   g_T = FIR^T (d . g_pre)  = nfe_upfirdn2d(pad=(2,2), gain=4)            [2H+1]^2
+                   dL/dx[y,x] = s . sum_{kh,kw} W[:, :, kh, kw]^T g_T[2y+kh, 2x+kw]  = a 2x2-tap convolution over the four
+                   polyphase images of g_T stacked along the channels, embedded in one NFE_CONV_3X3 call (taps (1+dy, 1+dx))
+  ToRGB 1x1        dL/dx = s . (g_y W)        (K = 3: a [N,H,W,3] x [3,C] product, torch glue)
+  skip path        img = upsample2d(img_prev) + y:   dL/dimg_prev = nfe_upfirdn2d(g, down=2, pad=(1,2), gain=4)
+  activation       g_pre = g_out * gain * (0.2 if out < 0 else 1) * (|out| < clamp), from the saved layer outputs
+
+Elementwise masks, the polyphase re-arrangement and the K = 3 product are torch tensor expressions (glue); every convolution
+and FIR runs in libnfe_render.so.  The forward of this path evaluates the head layer by layer and keeps the six activations
+(~0.4 GB per view at 512^2): it is the editing path (a few views), not the throughput path, which is unchanged.
+"""
+import numpy as np
+import torch
+
+from . import _lib, dense_ops
+from .training.networks_stylegan2 import _publish, batch_styles, block_layers
+
+GRAD_MATH = "bf16x3"      # fp32-grade split-bf16 MFMA for every backward convolution
+
+
+def supported(sr, resolution):
+    """True where SRImage can run: the 512^2 head of the FFHQ configuration fed at its own input resolution."""
+    return type(sr).__name__ == "SuperresolutionHybrid8XDC" and int(resolution) == sr.input_resolution
+
+
+def _act_grad(out, g, gain, clamp):
+    """d bias_act('lrelu', gain, clamp) / d pre-activation, applied to the incoming gradient (bias_act.py:93-125)."""
+    g = g * torch.where(out < 0, 0.2 * gain, gain)
+    if clamp is not None:
+        g = g * (out.abs() < clamp)
+    return g
+
+
+def _bwd_plain(layer):
+    """Packed fragments of the backward-data kernel of a plain 3x3 layer: Wb[ci][co][kh][kw] = W[co][ci][2-kh][2-kw]."""
+    key = (layer.weight.data_ptr(), layer.weight._version)
+    if getattr(layer, "_bwd_key", None) != key:
+        layer._bwd_packed = dense_ops.conv_pack(layer.weight.detach().flip(2, 3).transpose(0, 1).contiguous())[0]
+        _publish()
+        layer._bwd_key = key
+    return layer._bwd_packed
+
+
+def _bwd_up(layer):
+    """Backward-data kernel of an up-sampling layer over the polyphase stack: input channel (a, b, co) = g_T[2y+a, 2x+b, co],
+    tap (1+dy, 1+dx) carries W[co][ci][2dy+a][2dx+b] where that index exists (kh, kw <= 2)."""
+    key = (layer.weight.data_ptr(), layer.weight._version)
+    if getattr(layer, "_bwd_key", None) != key:
+        W = layer.weight.detach()
+        Co, Ci = W.shape[:2]
+        wb = W.new_zeros(Ci, 2, 2, Co, 3, 3)
+        for a in range(2):
+            for b in range(2):
+                for dy in range(2):
+                    for dx in range(2):
+                        kh, kw = 2 * dy + a, 2 * dx + b
+                        if kh <= 2 and kw <= 2:
+                            wb[:, a, b, :, 1 + dy, 1 + dx] = W[:, :, kh, kw].t()
+        layer._bwd_packed = dense_ops.conv_pack(wb.reshape(Ci, 4 * Co, 3, 3).contiguous())[0]
+        _publish()
+        layer._bwd_key = key
+    return layer._bwd_packed
+
+
+def _conv_bwd_plain(layer, g_pre, s, d):
+    zeros = torch.zeros(layer.in_channels, device=g_pre.device)
+    return dense_ops.modulated_conv(g_pre.contiguous(), d, _bwd_plain(layer), layer.in_channels, _lib.NFE_CONV_3X3, zeros, dcoef=s,
+                                    lrelu=False, act_gain=1.0, clamp=None, math=GRAD_MATH)
+
+
+def _conv_bwd_up(layer, g_pre, s, d):
+    N, H2, _, Co = g_pre.shape
+    H = H2 // 2
+    gT = dense_ops.upfirdn2d((g_pre * d[:, None, None, :]).contiguous(), padding=(2, 2), gain=4.0)          # [N,2H+1,2H+1,Co]
+    pad = torch.zeros(N, 2 * H + 2, 2 * H + 2, Co, device=g_pre.device)
+    pad[:, :2 * H + 1, :2 * H + 1] = gT
+    stack = pad.view(N, H + 1, 2, H + 1, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(N, H + 1, H + 1, 4 * Co).contiguous()
+    ones = torch.ones(N, 4 * Co, device=g_pre.device)
+    zeros = torch.zeros(layer.in_channels, device=g_pre.device)
+    gx = dense_ops.modulated_conv(stack, ones, _bwd_up(layer), layer.in_channels, _lib.NFE_CONV_3X3, zeros, dcoef=s, lrelu=False,
+                                  act_gain=1.0, clamp=None, math=GRAD_MATH)
+    return gx[:, :H, :H].contiguous()
+
+
+def block_forward_saving(blk, x, img, styles, dcoefs, noise_mode, conv_math):
+    """One SynthesisBlock (networks_stylegan2.py:417-461, skip architecture) layer by layer -> (x_out, img_out, saved).
+    styles = (conv0, conv1, torgb), dcoefs = (conv0, conv1)."""
+    s0, s1, st_rgb = styles
+    d0, d1 = dcoefs
+    o0 = blk.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=s0, dcoef=d0)
+    o1 = blk.conv1.forward_nhwc(o0, None, noise_mode=noise_mode, conv_math=conv_math, styles=s1, dcoef=d1)
+    y = blk.torgb.forward_nhwc(o1, None, skip=None, conv_math=conv_math, styles=st_rgb)              # clamped ToRGB output
+    img = dense_ops.upsample2d(img) + y                                                       # :453-457
+    return o1, img, (o0, o1, y, s0, s1, st_rgb, d0, d1)
+
+
+def block_backward(blk, saved, g_img, g_x):
+    """Transpose of block_forward_saving: g_img = dL/d img_out [N,r,r,3], g_x = dL/d x_out or None -> (dL/d x_in, dL/d img_in)."""
+    o0, o1, y, s0, s1, st_rgb, d0, d1 = saved
+    g_img = g_img.contiguous()
+    clamp = blk.torgb.conv_clamp
+    g_y = g_img * (y.abs() < clamp) if clamp is not None else g_img
+    Wt = blk.torgb.weight.detach().reshape(blk.torgb.out_channels, blk.torgb.in_channels)
+    g_o1 = torch.matmul(g_y, Wt) * st_rgb[:, None, None, :]                                       # ToRGB: K = 3
+    if g_x is not None:
+        g_o1 = g_o1 + g_x
+    c1, c0 = blk.conv1, blk.conv0
+    g_o0 = _conv_bwd_plain(c1, _act_grad(o1, g_o1, c1.act_gain, c1.conv_clamp), s1, d1)
+    g_in = _conv_bwd_up(c0, _act_grad(o0, g_o0, c0.act_gain, c0.conv_clamp), s0, d0)
+    return g_in, dense_ops.upfirdn2d(g_img, down=2, padding=(1, 2), gain=4.0)                     # transpose of upsample2d
+
+
+def sr_forward_saving(sr, feat, ws, noise_mode):
+    """SuperresolutionHybrid8XDC.forward_nhwc layer by layer, keeping what the backward needs.  feat [N,R,R,32] NHWC, R = 128."""
+    assert type(sr).__name__ == "SuperresolutionHybrid8XDC", "the SR-head gradient is built for SuperresolutionHybrid8XDC"
+    if feat.shape[1] != sr.input_resolution:
+        raise NotImplementedError(f"SR-head gradient: neural_rendering_resolution must equal the head's input resolution "
+                                  f"{sr.input_resolution} (the antialiased pre-resize has no backward here); got {feat.shape[1]}")
+    ws3 = ws[:, -1:, :].repeat(1, 3, 1).to(torch.float32)                                   # superresolution.py:280
+    st, dc = batch_styles(block_layers(sr.block0) + block_layers(sr.block1), ws3, [0, 1, 2, 0, 1, 2])
+    x, img = feat, feat[..., :3].contiguous()
+    saved = []
+    for b, blk in enumerate((sr.block0, sr.block1)):
+        x, img, sv = block_forward_saving(blk, x, img, st[3 * b:3 * b + 3], (dc[3 * b], dc[3 * b + 1]), noise_mode, sr.conv_math)
+        saved.append(sv)
+    return img, saved
+
+
+def sr_backward(sr, saved, g_img):
+    """g_img [N,512,512,3] NHWC -> gradient w.r.t. the feature image [N,128,128,32] (its first 3 channels also feed the skip path)."""
+    g_x = None                                      # gradient w.r.t. the current block's activation from the block after it
+    for blk, sv in zip((sr.block1, sr.block0), reversed(saved)):
+        g_x, g_img = block_backward(blk, sv, g_img, g_x)
+    g_x[..., :3] += g_img                                                                         # rgb = feat[..., :3]
+    return g_x
+
+
+class SRImage(torch.autograd.Function):
+    """image = SR(feature image); backward = sr_backward.  ws, weights and noise are constants of this function."""
+
+    @staticmethod
+    def forward(ctx, feat, sr, ws, noise_mode):
+        img, saved = sr_forward_saving(sr, feat.detach(), ws.detach(), noise_mode)
+        ctx.sr, ctx.saved = sr, saved
+        return img
+
+    @staticmethod
+    def backward(ctx, g_img):
+        return sr_backward(ctx.sr, ctx.saved, g_img), None, None, None      # saved stays: backward may run again (retain_graph)

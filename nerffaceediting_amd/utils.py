@@ -6,7 +6,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import dense_ops, ops, sharding
+from . import dense_ops, ops, sharding, sr_grad
 from .camera_utils import FOV_to_intrinsics, LookAtPoseSampler
 
 
@@ -49,9 +49,9 @@ def denormalize_plane(planes, mean, var):
 
 
 class _NotDifferentiableImage(torch.autograd.Function):
-    """The super-resolution head runs on raw-pointer HIP ops, outside autograd.  When the planes are being optimised, `image`
-    is tied to the graph through this node so that a loss term on it fails loudly in backward() instead of silently
-    contributing a zero plane gradient (the reference's utils.decode back-propagates through the SR head)."""
+    """Fallback for the SR configurations sr_grad.py does not cover (heads other than SuperresolutionHybrid8XDC, or a neural
+    rendering resolution that needs the antialiased pre-resize): `image` is tied to the graph through this node so that a loss
+    term on it fails loudly in backward() instead of silently contributing a zero plane gradient."""
 
     @staticmethod
     def forward(ctx, image, anchor):
@@ -59,9 +59,9 @@ class _NotDifferentiableImage(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        raise RuntimeError("decode(): out['image'] is not differentiable with respect to the planes in this package (the SR head "
-                           "runs outside autograd): build the editing loss on image_raw / image_seg / image_depth, or detach "
-                           "out['image'] explicitly")
+        raise RuntimeError("decode(): out['image'] is differentiable with respect to the planes only for SuperresolutionHybrid8XDC at "
+                           "neural_rendering_resolution == 128 (sr_grad.py); for this configuration build the editing loss on "
+                           "image_raw / image_seg / image_depth, or detach out['image'] explicitly")
 
 
 def encode(G, ws, **synthesis_kwargs):
@@ -84,11 +84,18 @@ def decode(G, ws, cam, norm_planes, denorm_planes, **synthesis_kwargs):
     rgb = feat[..., :3].contiguous()
     if ws.shape[0] == 1 and N > 1:
         ws = ws.expand(N, -1, -1).contiguous()
-    sr = G.superresolution.forward_nhwc(rgb, feat, ws, noise_mode=G.rendering_kwargs["superresolution_noise_mode"],
-                                        **{k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"})
-    image = dense_ops.nhwc_to_nchw(sr)
-    if torch.is_grad_enabled() and feature_samples.requires_grad:
-        image = _NotDifferentiableImage.apply(image, feature_samples)
+    sr_noise = G.rendering_kwargs["superresolution_noise_mode"]
+    in_graph = torch.is_grad_enabled() and feature_samples.requires_grad
+    if in_graph and sr_grad.supported(G.superresolution, R):
+        # planes are being optimised: the head runs layer by layer and keeps its activations, `image` carries the gradient
+        # back to the feature image through the same MFMA kernels (sr_grad.py), as the reference's decode() does by autograd
+        image = sr_grad.SRImage.apply(feat, G.superresolution, ws, sr_noise).permute(0, 3, 1, 2)
+    else:
+        sr = G.superresolution.forward_nhwc(rgb, feat, ws, noise_mode=sr_noise,
+                                            **{k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"})
+        image = dense_ops.nhwc_to_nchw(sr)
+        if in_graph:                             # other SR heads / a pre-resize in front of the head: no backward built
+            image = _NotDifferentiableImage.apply(image, feature_samples)
     return {"image_raw": dense_ops.nhwc_to_nchw(rgb), "image": image,
             "image_depth": depth_samples.permute(0, 2, 1).reshape(N, 1, R, R),
             "image_seg": dense_ops.nhwc_to_nchw(seg_samples.view(N, R, R, 15))}

@@ -167,6 +167,67 @@ def gen_sr():
     print("  wrote dense_sr.npz")
 
 
+def gen_sr_backward():
+    """Input gradient of the SR head by the reference's own autograd (what utils.decode's differentiable `image` gives,
+    utils.py:165-199): SuperresolutionHybrid8XDC at full width, one 128^2 x 32 feature image (rgb = its first 3 channels), a
+    seeded cotangent on the 512^2 image -> d<cot, image>/d feature image.  A second case pushes activations into the +-256
+    clamp (scaled input) so the clamp masks are exercised.  Stored: the gradient at every second pixel + fp64 channel sums."""
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=4, sr_antialias=True,
+                                   channel_base=32768, channel_max=512, fused_modconv_default="inference_only")
+    load(sr, sr_params(41))
+    rng = np.random.RandomState(77)
+    data = {}
+    with torch.enable_grad():
+        for tag, scale in dict(plain=0.5, clamped=40.0).items():
+            x = t(rng.randn(1, 32, 128, 128) * scale).requires_grad_(True)
+            ws = t(rng.randn(1, 14, 512))
+            cot = t(rng.randn(1, 3, 512, 512))
+            img = sr(x[:, :3], x, ws, noise_mode="none")
+            (g,) = torch.autograd.grad((img * cot).sum(), x)
+            frac = float((img.detach().abs() >= 255.999).float().mean())
+            print(f"    sr_backward.{tag}: |image| max {float(img.abs().max()):.3g}, clamped share of the image {frac:.4f}, |grad| max {float(g.abs().max()):.3g}")
+            # inputs are regenerated by the test from the same RandomState(77) sequence (x, ws, cot per case, in this order)
+            data.update({f"{tag}.scale": scale, f"{tag}.grad_s2": g[:, :, ::2, ::2].numpy(),
+                         f"{tag}.grad_sum": g.double().sum(dim=(0, 2, 3)).numpy(), f"{tag}.grad_absmax": float(g.abs().max()),
+                         f"{tag}.image_s8": img.detach()[:, :, ::8, ::8].numpy(), f"{tag}.clamped_share": frac})
+    np.savez_compressed(os.path.join(OUT, "sr_backward.npz"), seed=41, **data)
+    print("  wrote sr_backward.npz")
+
+
+def gen_block_backward():
+    """One reference SynthesisBlock (skip architecture, up-sampling conv0 + conv1 + ToRGB + upsample2d skip; conv_clamp 256 as the
+    SR head's) under autograd: d<cot_x, x_out> + <cot_img, img_out> / d (x_in, img_in).  Small enough (32 -> 64 channels, 32^2 ->
+    64^2) to keep, besides the gradients, the SIGN of every leaky-ReLU unit and the clamp masks of the forward: a unit whose
+    pre-activation sits within fp32 rounding of zero may land on the other slope in another implementation of the same forward,
+    and the test pins the slopes to the reference's so that every gradient entry can be held to the bar."""
+    from training.networks_stylegan2 import SynthesisBlock
+    from oracle.dense_params import block_params
+    blk = SynthesisBlock(32, 64, w_dim=512, resolution=64, img_channels=3, is_last=False, architecture="skip", conv_clamp=256,
+                         use_fp16=False, fused_modconv_default="inference_only").eval().requires_grad_(False)
+    load(blk, block_params(91, 32, 64, 512, 64, 3))
+    rng = np.random.RandomState(92)
+    N = 2
+    x = t(rng.randn(N, 32, 32, 32) * 150.0).requires_grad_(True)         # large enough to push some units into the +-256 clamp
+    img = t(rng.randn(N, 3, 32, 32)).requires_grad_(True)
+    ws = t(rng.randn(N, 3, 512))
+    cot_x, cot_img = t(rng.randn(N, 64, 64, 64)), t(rng.randn(N, 3, 64, 64))
+    acts = {}
+    hooks = [getattr(blk, n).register_forward_hook(lambda m, i, o, n=n: acts.__setitem__(n, o.detach())) for n in ("conv0", "conv1", "torgb")]
+    with torch.enable_grad():
+        xo, io = blk(x, img, ws, noise_mode="const")
+        gx, gi = torch.autograd.grad((xo * cot_x).sum() + (io * cot_img).sum(), (x, img))
+    for h in hooks:
+        h.remove()
+    neg0, neg1 = (acts["conv0"] < 0).numpy(), (acts["conv1"] < 0).numpy()
+    cl0, cl1, cly = (acts["conv0"].abs() >= 256).numpy(), (acts["conv1"].abs() >= 256).numpy(), (acts["torgb"].abs() >= 256).numpy()
+    print(f"    block_backward: clamped units conv0 {cl0.mean():.4f} conv1 {cl1.mean():.4f} torgb {cly.mean():.4f}; |gx| max {float(gx.abs().max()):.3g}")
+    # inputs and cotangents are regenerated by the test from RandomState(92) in this order: x (x 150), img, ws, cot_x, cot_img
+    np.savez_compressed(os.path.join(OUT, "block_backward.npz"), seed=91, x_out=xo.detach().numpy()[:, :, ::8, ::8], img_out=io.detach().numpy()[:, :, ::4, ::4],
+                        grad_x=gx.numpy(), grad_img=gi.numpy(), neg0=np.packbits(neg0), neg1=np.packbits(neg1), clamp0=np.packbits(cl0),
+                        clamp1=np.packbits(cl1), clampy=np.packbits(cly), torch_version=np.array(torch.__version__))
+    print("  wrote block_backward.npz")
+
+
 E2E_KW = dict(
     rendering_kwargs=dict(superresolution_module="training.superresolution.SuperresolutionHybrid8XDC", sr_antialias=True,
                           c_gen_conditioning_zero=False, c_scale=1, superresolution_noise_mode="none", depth_resolution=12,
@@ -400,6 +461,8 @@ if __name__ == "__main__":
     gen_synthesis()
     gen_synthesis_full()
     gen_sr()
+    gen_sr_backward()
+    gen_block_backward()
     gen_e2e()
     gen_e2e_full()
     gen_e2e_cfg1()

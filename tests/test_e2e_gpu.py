@@ -527,8 +527,8 @@ def test_decode_is_differentiable_wrt_planes(setup):
         n1, d1 = norm.clone().requires_grad_(True), denorm.clone().requires_grad_(True)
         loss, out = loss_of(n1, d1)
         assert out["image"].shape == (1, 3, 512, 512)
-        with pytest.raises(RuntimeError, match="not differentiable"):       # the SR image is outside the graph, and says so
-            out["image"].sum().backward(retain_graph=True)
+        with pytest.raises(RuntimeError, match="differentiable with respect to the planes only for"):   # R = 32: the antialiased
+            out["image"].sum().backward(retain_graph=True)                      # pre-resize has no backward; it says so
         n1.grad = d1.grad = None
         loss.backward()
         assert n1.grad is not None and d1.grad is not None and torch.isfinite(n1.grad).all() and float(n1.grad.abs().max()) > 0
@@ -548,6 +548,49 @@ def test_decode_is_differentiable_wrt_planes(setup):
                 fd = float(a - b) / (2 * eps)
                 an = float((leaf.grad.double() * V.double()).sum())
                 assert abs(fd - an) <= 3e-2 * max(abs(an), 1.0), (which, fd, an)
+    finally:
+        G.neural_rendering_resolution, G.rendering_kwargs, G.renderer.decoder_math = old_res, old_kw, old_math
+
+
+def test_decode_image_is_differentiable_at_the_head_resolution(setup):
+    """utils.decode at neural_rendering_resolution 128 (the FFHQ configuration): out['image'] carries plane gradients through
+    the SR head (sr_grad.py) as the reference's decode does by autograd (utils.py:165-199), so an editing loss may mix an image
+    term with a segmentation term.  Directional finite difference of decode() itself (fixed jitter, fp32 decoder)."""
+    from nerffaceediting_amd import utils as U
+    G, z, dev = setup
+    ws, c = t(z["ws"], dev)[:1], t(z["c"], dev)[:1]
+    R, D = 128, 12
+    old_res, old_kw, old_math = G.neural_rendering_resolution, G.rendering_kwargs, G.renderer.decoder_math
+    G.neural_rendering_resolution = R
+    G.rendering_kwargs = dict(old_kw, depth_resolution=D, depth_resolution_importance=0)
+    G.renderer.decoder_math = "fp32"
+    try:
+        planes = U.encode(G, ws, noise_mode="const")
+        norm, mean, var = U.normalize_plane(planes)
+        u = torch.rand(1, R * R, D, device=dev)
+        gt = torch.Generator(device="cpu").manual_seed(2)
+        t_img, t_seg = torch.randn(1, 3, 512, 512, generator=gt).to(dev), torch.randn(1, 15, R, R, generator=gt).to(dev)
+
+        def loss_of(n_):
+            G.renderer.inject_jitter(u)
+            out = U.decode(G, ws, c, n_, U.denormalize_plane(n_, mean, var), noise_mode="const")
+            return (out["image"] * t_img).sum() + (out["image_seg"] * t_seg).sum(), (out["image"] * t_img).sum()
+        n1 = norm.clone().requires_grad_(True)
+        loss, img_term = loss_of(n1)
+        g_img, = torch.autograd.grad(img_term, n1, retain_graph=True)          # the image term alone reaches the planes
+        assert torch.isfinite(g_img).all() and float(g_img.abs().max()) > 0
+        loss.backward()
+        with torch.no_grad():
+            V = torch.randn_like(norm)
+            eps = 1e-2
+            fd_img = float(loss_of(norm + eps * V)[1] - loss_of(norm - eps * V)[1]) / (2 * eps)
+            an_img = float((g_img.double() * V.double()).sum())
+            # a central difference across ~1e8 leaky-ReLU kinks and the +-256 clamps of the head: agreement to a few per cent is
+            # what the step allows; the entry-by-entry check against the reference's autograd is tests/test_sr_grad_gpu.py
+            assert abs(fd_img - an_img) <= 8e-2 * max(abs(an_img), 1.0), (fd_img, an_img)
+            fd = float(loss_of(norm + eps * V)[0] - loss_of(norm - eps * V)[0]) / (2 * eps)
+            an = float((n1.grad.double() * V.double()).sum())
+            assert abs(fd - an) <= 8e-2 * max(abs(an), 1.0), (fd, an)
     finally:
         G.neural_rendering_resolution, G.rendering_kwargs, G.renderer.decoder_math = old_res, old_kw, old_math
 
