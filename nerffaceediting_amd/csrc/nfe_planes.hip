@@ -34,15 +34,16 @@ __global__ void ray_limits_kernel(const float* __restrict__ origins, const float
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
         const float ox = origins[i * 3], oy = origins[i * 3 + 1], oz = origins[i * 3 + 2];
         const float ix = 1.0f / dirs[i * 3], iy = 1.0f / dirs[i * 3 + 1], iz = 1.0f / dirs[i * 3 + 2];
-        bool valid = true;
+        // validity as a chain of selects, each fed by its own compare (no lane masks combined on the scalar unit: lint shape S1)
         float tmin = ((ix < 0 ? half : -half) - ox) * ix, tmax = ((ix < 0 ? -half : half) - ox) * ix;
         const float tymin = ((iy < 0 ? half : -half) - oy) * iy, tymax = ((iy < 0 ? -half : half) - oy) * iy;
-        if (tmin > tymax || tymin > tmax) valid = false;
+        auto flag = [](bool c) { int v = c ? 1 : 0; asm volatile("" : "+v"(v)); return v; };     // opaque: stays a per-lane integer
+        int invalid = flag(tmin > tymax) | flag(tymin > tmax);
         tmin = fmaxf(tmin, tymin); tmax = fminf(tmax, tymax);          // torch.max/min propagate like fmax here
         const float tzmin = ((iz < 0 ? half : -half) - oz) * iz, tzmax = ((iz < 0 ? -half : half) - oz) * iz;
-        if (tmin > tzmax || tzmin > tmax) valid = false;
+        invalid |= flag(tmin > tzmax) | flag(tzmin > tmax);
         tmin = fmaxf(tmin, tzmin); tmax = fminf(tmax, tzmax);
-        if (!valid) { tmin = -1.0f; tmax = -2.0f; }
+        tmin = invalid != 0 ? -1.0f : tmin; tmax = invalid != 0 ? -2.0f : tmax;
         rs[i] = tmin; re[i] = tmax;
         if (tmax > tmin) { lo = fminf(lo, tmin); hi = fmaxf(hi, tmin); }  // is_ray_valid = ray_end > ray_start
     }
@@ -153,12 +154,13 @@ __device__ __forceinline__ int hidden_unit(int mb, int r, int h) { return 32 * m
 
 // MFMA output row i of the geometry head -> geo_net.2 output index (0 = sigma, 1..15 = seg), -1 = unused.
 // Row i is register ri of lane half hi; sigma is duplicated into both halves.
+// (as a table: the compound range tests it stands for would be combined on the scalar unit into one lane mask feeding a select -
+// shape S1 of tools/lint_lane_masks.py, kept out of every kernel of this library)
+__device__ const signed char GEO_ROW_TO_OUT[32] = {0, -1, 1, 2, 0, -1, 9, 10, 3, 4, 5, 6, 11, 12, 13, 14, 7, 8, -1, -1, 15, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1, -1};
 __device__ __forceinline__ int geo_row_to_out(int i) {
-    const int ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1;
-    if (ri == 0) return 0;                          // sigma in register 0 of both halves
-    if (hi == 0 && ri >= 2 && ri <= 9) return ri - 1;       // seg 0..7 in registers 2..9 (even start: packed pairs)
-    if (hi == 1 && ri >= 2 && ri <= 8) return ri + 7;       // seg 8..14 in registers 2..8
-    return -1;
+    // ri = (i & 3) + 4 * (i >> 3), hi = (i >> 2) & 1:  ri == 0 -> 0 (sigma, register 0 of both halves);
+    // hi == 0, ri in 2..9 -> ri - 1 (seg 0..7, even start: packed pairs);  hi == 1, ri in 2..8 -> ri + 7 (seg 8..14);  else -1
+    return GEO_ROW_TO_OUT[i & 31];
 }
 __device__ __forceinline__ int app_row_to_out(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 

@@ -13,8 +13,8 @@ def segmentation_loss(image_seg, target_labels):
 
 
 def optimize_planes(G, ws, cam, norm_planes, mean, var, loss_fn, steps=100, lr=0.05, optimize="norm", callback=None, **synthesis_kwargs):
-    """Optimise tri-planes against `loss_fn(out)` where `out` is `utils.decode`'s dict (image_raw, image_seg, image_depth; the
-    super-resolved `image` is outside the graph).
+    """Optimise tri-planes against `loss_fn(out)` where `out` is `utils.decode`'s dict (image_raw, image_seg, image_depth, and the
+    super-resolved `image`, which carries plane gradients for SuperresolutionHybrid8XDC at neural_rendering_resolution 128).
 
     norm_planes [N,3,32,H,W] (from utils.normalize_plane), mean / var its statistics.  optimize='norm': the normalised planes
     are the leaf and the appearance planes are re-derived from them every step (geometry editing, appearance kept);

@@ -17,8 +17,8 @@ where the scalar consumer can be close enough in time to matter.  S2far is the s
 in the kernel's text (linear scan, the pair not overwritten by a scalar instruction since): masks of loop-invariant conditions.
 
     python tools/lint_lane_masks.py [--report FILE] [--enforce-s1 name.hip ...] [files...]
-Exit code 1 when a file named by --enforce-s1 has S1 > 0 (default: the render, backward and dense files; nfe_planes.hip holds
-one-off set-up kernels of < 64 registers and is reported only).  tests/test_lint_cpu.py runs it (compile-only, no GPU).
+Exit code 1 when a file named by --enforce-s1 has S1 > 0 (default: all four .hip files).  tests/test_lint_cpu.py runs it
+(compile-only, no GPU).
 """
 import argparse
 import collections
@@ -138,7 +138,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("files", nargs="*")
     ap.add_argument("--report")
-    ap.add_argument("--enforce-s1", nargs="*", default=["nfe_render.hip", "nfe_render_bwd.hip", "nfe_dense.hip"])
+    ap.add_argument("--enforce-s1", nargs="*", default=list(ALL))
     ap.add_argument("--asm-dir", default=os.path.join(CSRC, "build", "lint"))
     ap.add_argument("--flag", action="append", default=[], help="extra hipcc flag (e.g. -DNFE_BWD_FIX=0)")
     args = ap.parse_args()
