@@ -637,7 +637,10 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 constexpr int SORT_TILE_STRIDE = 68;      // floats per sample row: rows stay 16-byte aligned (the gather exchange uses ds_*_b128)
 constexpr unsigned KEY_INVALID = 0xFFFFFFFFu;
 constexpr int BIN_SHIFT = 3, BIN_MASK = 7, BIN_TEXELS = 9;       // plane tiles of the binned form: 8 x 8 texels + the far taps' row/column
-constexpr int BIN_SEGMENT = 1024;                                // records per workgroup before a bin is split (at most BIN_SPLIT ways)
+#ifndef NFE_BIN_SEGMENT
+#define NFE_BIN_SEGMENT 4096
+#endif
+constexpr int BIN_SEGMENT = NFE_BIN_SEGMENT;                                // records per workgroup before a bin is split (at most BIN_SPLIT ways)
 constexpr int BIN_SPLIT = 4;
 constexpr int BIN_BATCH = 16;                                    // records (256-byte row loads) a wave keeps in flight
 constexpr uint64_t BWD_CHUNK_SAMPLES = 1ull << 23;               // 2 GiB of feature gradients per chunk
@@ -1101,6 +1104,165 @@ __global__ __launch_bounds__(64) void bwd_accumulate_kernel(BwdK P) {
     }
 }
 
+// The same pass with the tile in REGISTERS (default).  The LDS form above spends ~330 cycles per record on a dependent chain
+// (LDS read latency -> fma -> write, per record, seven waves per CU).  With lane = channel the 9 x 9 tile is 81 values per lane:
+// it lives in v[ACC_TB .. ACC_TB+80], a register range the compiler cannot allocate (amdgpu_num_vgpr caps its own use below
+// ACC_TB), and a record's four taps are four v_fma_f32 whose destination / addend registers are indexed by the wave-uniform
+// texel through the VGPR index mode (s_set_gpr_idx_on: M0 = tile-local texel, applied to vdst and src2 only): the taps sit at
+// fixed offsets 0, 1, 9, 10 from the first, so one index serves all four.  No LDS, no memory latency in the chain: six
+// instructions per record after the five v_readlane that fetch its key and weights.
+#define ACC_TB 80                      // first tile register
+#define ACC_TOP "v160"                 // ACC_TB + 80: named once as a clobber so that the kernel's register count covers the tile
+#define ACC_STR2(x) #x
+#define ACC_STR(x) ACC_STR2(x)
+#define ACC_V(k) "v[" ACC_STR(ACC_TB) "+" k "]"
+static_assert(BIN_TEXELS == 9, "tap offsets 0, 1, 9, 10 below");
+
+__device__ __forceinline__ void acc_tile_zero() {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"      // "clobber list contains reserved registers": reserving them is the point
+    asm volatile(".set nfe_i, 0\n.rept 81\nv_mov_b32 v[" ACC_STR(ACC_TB) "+nfe_i], 0\n.set nfe_i, nfe_i+1\n.endr" ::: ACC_TOP);
+#pragma clang diagnostic pop
+}
+__device__ __forceinline__ void acc_tile_add(unsigned texel, float w0, float w1, float w2, float w3, float row) {
+    asm volatile("s_set_gpr_idx_on %0, 0xc\n"                                 // 0xc: index vdst and src2
+                 "v_fma_f32 " ACC_V("0") ", %1, %5, " ACC_V("0") "\n"
+                 "v_fma_f32 " ACC_V("1") ", %2, %5, " ACC_V("1") "\n"
+                 "v_fma_f32 " ACC_V("9") ", %3, %5, " ACC_V("9") "\n"
+                 "v_fma_f32 " ACC_V("10") ", %4, %5, " ACC_V("10") "\n"
+                 "s_set_gpr_idx_off" :: "s"(texel), "s"(w0), "s"(w1), "s"(w2), "s"(w3), "v"(row));
+}
+// four records under one index-mode window (s_set_gpr_idx_idx moves the index; the mode switch is paid once per four)
+__device__ __forceinline__ void acc_tile_add4(const unsigned (&t)[4], const float (&w)[4][4], const float (&r)[4]) {
+#define ACC_FMA4(T, A, B, C, D, R) \
+                 "v_fma_f32 " ACC_V("0") ", " A ", " R ", " ACC_V("0") "\n" \
+                 "v_fma_f32 " ACC_V("1") ", " B ", " R ", " ACC_V("1") "\n" \
+                 "v_fma_f32 " ACC_V("9") ", " C ", " R ", " ACC_V("9") "\n" \
+                 "v_fma_f32 " ACC_V("10") ", " D ", " R ", " ACC_V("10") "\n"
+    asm volatile("s_set_gpr_idx_on %0, 0xc\n"
+                 ACC_FMA4("%0", "%4", "%5", "%6", "%7", "%20")
+                 "s_set_gpr_idx_idx %1\n"
+                 ACC_FMA4("%1", "%8", "%9", "%10", "%11", "%21")
+                 "s_set_gpr_idx_idx %2\n"
+                 ACC_FMA4("%2", "%12", "%13", "%14", "%15", "%22")
+                 "s_set_gpr_idx_idx %3\n"
+                 ACC_FMA4("%3", "%16", "%17", "%18", "%19", "%23")
+                 "s_set_gpr_idx_off"
+                 :: "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]),
+                    "s"(w[0][0]), "s"(w[0][1]), "s"(w[0][2]), "s"(w[0][3]), "s"(w[1][0]), "s"(w[1][1]), "s"(w[1][2]), "s"(w[1][3]),
+                    "s"(w[2][0]), "s"(w[2][1]), "s"(w[2][2]), "s"(w[2][3]), "s"(w[3][0]), "s"(w[3][1]), "s"(w[3][2]), "s"(w[3][3]),
+                    "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+#undef ACC_FMA4
+}
+#ifndef ACC_GROUP
+#define ACC_GROUP 4
+#endif
+template <int K> __device__ __forceinline__ float acc_tile_get() {
+    float v;
+    asm volatile("v_mov_b32 %0, v[" ACC_STR(ACC_TB) "+%1]" : "=v"(v) : "n"(K));
+    return v;
+}
+template <int K> __device__ __forceinline__ void acc_tile_flush(float* g, float sc, int y0, int x0, int H, int W) {
+    constexpr int ly = K / BIN_TEXELS, lx = K % BIN_TEXELS;
+    const float v = acc_tile_get<K>();
+    if (y0 + ly < H && x0 + lx < W && v != 0.0f) unsafeAtomicAdd(g + ((long long)(y0 + ly) * W + (x0 + lx)) * 32, v * sc);
+    if constexpr (K + 1 < BIN_TEXELS * BIN_TEXELS) acc_tile_flush<K + 1>(g, sc, y0, x0, H, W);
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(ACC_TB))) void bwd_accumulate_reg_kernel(BwdK P) {
+    const unsigned bin = blockIdx.x;
+    const unsigned count = P.counts[bin];
+    const unsigned seg_len = max((unsigned)BIN_SEGMENT, (count + gridDim.y - 1) / gridDim.y);
+    const unsigned seg0 = blockIdx.y * seg_len;
+    if (seg0 >= count) return;
+    const unsigned seg1 = min(seg0 + seg_len, count);
+    const int lane = threadIdx.x;
+    acc_tile_zero();
+    const unsigned first = P.offsets[bin] + seg0, last = P.offsets[bin] + seg1;
+    const float* __restrict__ df = P.df + lane;
+    auto load_keys = [&](unsigned r0, uint2& key, float4& wq) {
+        const bool in = r0 + (unsigned)lane < last;
+        const unsigned slot = P.perm[in ? r0 + (unsigned)lane : last - 1];
+        key = P.rec_key[slot];
+        wq = P.rec_w[slot];
+        if (!in) wq = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    };
+    uint2 key; float4 wq;
+    load_keys(first, key, wq);
+    for (unsigned r0 = first; r0 < last; r0 += 64) {
+        uint2 nkey; float4 nwq;
+        load_keys(min(r0 + 64, last - 1), nkey, nwq);
+        float va[BIN_BATCH], vb[BIN_BATCH];
+        auto fetch = [&](float (&v)[BIN_BATCH], int i0) {
+#pragma unroll
+            for (int u = 0; u < BIN_BATCH; ++u) {
+#if defined(ACC_ABLATE) && ACC_ABLATE == 1      // timing experiment: no row loads
+                v[u] = __int_as_float(__builtin_amdgcn_readlane((int)key.x, i0 + u) + lane);
+#else
+                v[u] = df[(size_t)(unsigned)__builtin_amdgcn_readlane((int)key.x, i0 + u) * 64];
+#endif
+            }
+        };
+        auto rl = [&](float x, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i)); };
+        auto add = [&](const float (&v)[BIN_BATCH], int i0) {
+#if defined(ACC_ABLATE) && ACC_ABLATE == 2          // timing experiment: rows loaded, nothing added
+#pragma unroll
+            for (int u = 0; u < BIN_BATCH; ++u) asm volatile("" :: "v"(v[u]));
+#elif ACC_GROUP == 4
+#pragma unroll
+            for (int u = 0; u < BIN_BATCH; u += 4) {
+                unsigned t[4]; float w[4][4], r[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int i = i0 + u + k;
+                    t[k] = (unsigned)__builtin_amdgcn_readlane((int)key.y, i);
+                    w[k][0] = rl(wq.x, i); w[k][1] = rl(wq.y, i); w[k][2] = rl(wq.z, i); w[k][3] = rl(wq.w, i);
+                    r[k] = v[u + k];
+                }
+                acc_tile_add4(t, w, r);
+            }
+#else
+#pragma unroll
+            for (int u = 0; u < BIN_BATCH; ++u) {
+                const int i = i0 + u;
+                acc_tile_add((unsigned)__builtin_amdgcn_readlane((int)key.y, i), rl(wq.x, i), rl(wq.y, i), rl(wq.z, i), rl(wq.w, i), v[u]);
+            }
+#endif
+        };
+        const int cnt = (int)min(64u, last - r0);
+        fetch(va, 0);
+        if (cnt > 16) fetch(vb, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        add(va, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 32) fetch(va, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 16) add(vb, 16);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 48) fetch(vb, 48);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 32) add(va, 32);
+        __builtin_amdgcn_sched_barrier(0);
+        if (cnt > 48) add(vb, 48);
+        key = nkey; wq = nwq;
+    }
+    const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
+    const unsigned vp = bin / bins_per_plane, tb = bin - vp * bins_per_plane;
+    const int n = P.n0 + (int)(vp / 3), p = (int)(vp % 3);
+    const int ty = (int)(tb / P.bins_x), tx = (int)(tb - ty * P.bins_x);
+    const int ch = lane & 31, set = lane >> 5;
+    float* g = set ? ((P.grad_a && P.g_rgb) ? P.grad_a : nullptr) : P.grad_g;
+    const float* scale = P.aff[2 * set] ? P.aff[2 * set] + n * 96 : nullptr;
+    const float sc = scale ? scale[p * 32 + ch] : 1.0f;
+    if (!g) return;
+    g += (long long)n * P.grad_view_stride + (long long)p * P.H * P.W * 32 + ch;
+#if defined(ACC_ABLATE) && ACC_ABLATE == 3          // timing experiment: the tile is not added to the planes
+    asm volatile("" :: "v"(acc_tile_get<0>()), "v"(acc_tile_get<80>()));
+    return;
+#endif
+    acc_tile_flush<0>(g, sc, ty << BIN_SHIFT, tx << BIN_SHIFT, P.H, P.W);
+}
+
 static uint64_t align256(uint64_t x) { return (x + 255) & ~uint64_t(255); }
 
 // Chunking of the binned scatter: sample slots (64 per wave, whole 64-ray tiles x all depths) of the largest chunk
@@ -1203,6 +1365,7 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     NFE_CHECK_LAUNCH("bwd_ray_kernel");
     static const char scatter_mode = [] { const char* e = getenv("NFE_BWD_SCATTER"); return e ? e[0] : 'b'; }();     // A/B knob: "direct", "sorted", default binned
     static const bool valu_dec = [] { const char* e = getenv("NFE_BWD_DECODER"); return e && e[0] == 'v'; }();      // A/B knob: "valu"
+    static const bool acc_lds = [] { const char* e = getenv("NFE_BWD_ACC"); return e && e[0] == 'l'; }();            // A/B knob: "lds" = tile in LDS
     unsigned* frags = (unsigned*)((char*)P.rec_T + align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4));
     if (scatter_mode == 'd' || (long long)a->plane_h * a->plane_w > (1ll << 24)) {      // sort keys carry a 24-bit texel index
         hipLaunchKernelGGL(bwd_scatter_kernel, sgrid, dim3(256), 0, st, P);
@@ -1252,7 +1415,8 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
             NFE_CHECK_LAUNCH("bwd_scatter_sorted_kernel<binned>");
             hipLaunchKernelGGL(bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, P.counts, P.offsets, (int)nbins);
             hipLaunchKernelGGL(bwd_bin_fill_kernel, dim3((unsigned)((slots * 3 + 255) / 256)), dim3(256), 0, st, P, slots * 3);
-            hipLaunchKernelGGL(bwd_accumulate_kernel, dim3(nbins, BIN_SPLIT), dim3(64), 0, st, P);
+            if (acc_lds) hipLaunchKernelGGL(bwd_accumulate_kernel, dim3(nbins, BIN_SPLIT), dim3(64), 0, st, P);
+            else hipLaunchKernelGGL(bwd_accumulate_reg_kernel, dim3(nbins, BIN_SPLIT), dim3(64), 0, st, P);
             NFE_CHECK_LAUNCH("bwd_accumulate_kernel");
         }
     }
