@@ -462,8 +462,11 @@ __device__ uint4 nfe_zero16[4];                                  // source of th
 #define C3_LC_GENERIC_LOOP 0     // 1: the compute waves of the loader / compute split run the generic fragment pipeline (A/B)
 #endif
 #ifndef C3_ABLATE
-#define C3_ABLATE 0       // timing experiments only (wrong results): 1 no LDS-DMA, 2 no MFMA, 3 no barriers in the K loop, 4 no fragment reads
+#define C3_ABLATE 0       // timing experiments only (wrong results): 1 no LDS-DMA, 2 no MFMA, 3 no barriers in the K loop, 4 no fragment reads, 5 all workgroups stage the same tile, 6 = 5 + 2
 #endif
+#ifndef C3_ABM            // the same as a bit mask, so that experiments combine: 1 no LDS-DMA, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 same tile,
+#define C3_ABM (C3_ABLATE == 1 ? 1 : C3_ABLATE == 2 ? 2 : C3_ABLATE == 3 ? 4 : C3_ABLATE == 4 ? 8 : C3_ABLATE == 5 ? 16 : C3_ABLATE == 6 ? 18 : 0)
+#endif                    // 32 every patch lane reads its aligned slot of one contiguous KiB, 64 no vmcnt wait
 #ifndef C3_DMA_BUILTIN
 #define C3_DMA_BUILTIN 0                                         // 1: the round-2 form (compiler-tracked LDS-DMA), kept for A/B
 #endif
@@ -510,7 +513,7 @@ template <int ROWS> struct C3Tile {
 // showed it as ~4 300 cycles of "issue" per K-group; round 3).  The waits this kernel needs are its own explicit
 // `s_waitcnt vmcnt(N)` + s_barrier at the top of each K-group.
 __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
-#if C3_ABLATE == 1
+#if (C3_ABM) & 1
     return;
 #endif
 #if C3_DMA_BUILTIN
@@ -591,9 +594,15 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         // bytes in NHWC) are fetched by adjacent lanes = one L1 request, and the XOR keeps the 32-byte-stride fragment
         // reads conflict-free (pixels p and p+8 share a bank pair, their halves are swapped).
         const int pp = item >> 1, hh = (item & 1) ^ ((pp >> 3) & 1), py = pp / C3_PW, px = pp % C3_PW;
+#if (C3_ABM) & 16      // timing experiment: every workgroup stages tile 0 of view 0 (operands L2-resident); 6: and no MFMA
+        const int y = 7 + py, x = 7 + px;
+        const bool ok = pp < C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
+        boff[k] = ok ? (((long long)0 * G_all * P.H + y) * P.W + x) * 16 + 8 * hh : -1;
+#else
         const int y = ty0 - 1 + py, x = tx0 - 1 + px;
         const bool ok = pp < C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
         boff[k] = ok ? (((long long)n * G_all * P.H + y) * P.W + x) * 16 + 8 * hh : -1;     // group-major image: + g * H*W*16 per K-group
+#endif
     }
 
     // byte offsets of this lane's B fragments inside the patch: rows NBW*wave + (0..NBW+1), columns j + (0..2)
@@ -636,7 +645,11 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
 #pragma unroll
                 for (int part = 0; part < PARTS; ++part) {
                     const unsigned short* xs = part ? P.xl : P.xh;
+#if (C3_ABM) & 32
+                    const void* src = (const void*)(xs + (long long)(g_base + g) * plane16 + (c * 64 + lane) * 8);
+#else
                     const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + (long long)(g_base + g) * plane16) : (const void*)nfe_zero16;
+#endif
                     lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
                 }
             }
@@ -678,10 +691,11 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         if (STAGES == 1) { __syncthreads(); issue(g, 0); }
         // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
         if (LW > 0) {}                  // compute waves issue no loads: the loader waves wait for them
+        else if ((C3_ABM) & 64) {}
         else if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
         C3_STAMP(ts0a);
-        if (C3_ABLATE != 3) __syncthreads();
+        if (!((C3_ABM) & 4)) __syncthreads();
         C3_STAMP(ts0b);
         const bool more = g + STAGES - 1 < G;
         const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
@@ -725,7 +739,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         // sched_barrier): the compiler's own schedule issues a read one or two MFMAs before its use, which leaves the matrix pipe
         // idle for most of the LDS latency some thirty times per K-group while this wave is the only one computing on its SIMD.
         auto load_a = [&](int t, Frag8 (&ah_)[MBW], Frag8 (&al_)[MBW]) {
-            if (C3_ABLATE == 4 && (g > 0 || t > 0)) return;
+            if (((C3_ABM) & 8) && (g > 0 || t > 0)) return;
 #pragma unroll
             for (int m = 0; m < MBW; ++m) {
                 ah_[m].q = ldsA[((m * 9 + t) * PARTS + 0) * 64];
@@ -733,7 +747,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
             }
         };
         auto load_b = [&](int t, int nb, Frag8& bh_, Frag8& bl_) {
-            if (C3_ABLATE == 4 && (g > 0 || t > 0)) return;
+            if (((C3_ABM) & 8) && (g > 0 || t > 0)) return;
             const int kh = t / 3, kw = t % 3;
             const int dy = UP2 ? 1 - (kh >> 1) : kh, dx = UP2 ? 1 - (kw >> 1) : kw;
             bh_.q = *reinterpret_cast<const uint4*>(ldsB + brd[nb + dy][dx]);
@@ -754,7 +768,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MBW; ++m) {
-#if C3_ABLATE == 2
+#if (C3_ABM) & 2
                 acc[a][m][nb][0] += __builtin_bit_cast(float, ah[t & 1][m].u[0] ^ bh[s_ & 1].u[0]);
                 if (TERMS == 3) acc[a][m][nb][1] += __builtin_bit_cast(float, al[t & 1][m].u[0] ^ bl[s_ & 1].u[0]);
 #else
@@ -1149,9 +1163,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK P, long long n
 
 // FIR + epilogue of the up-conv: out[Y][X] = act(dcoef * sum_ab F[a]F[b] T[Y+a-1][X+b-1] + noise + bias),
 // F = [1,3,3,1]/4 per axis (setup_filter/64 * gain 4; conv2d_resample.py:127, upfirdn2d.py:169-207)
-constexpr int UPFIR_ROWS = 4;     // 2-row output blocks per thread: consecutive blocks share 3 of their 5 filtered rows
+#ifndef NFE_UPFIR_ROWS
+#define NFE_UPFIR_ROWS 4
+#endif
+constexpr int UPFIR_ROWS = NFE_UPFIR_ROWS;     // 2-row output blocks per thread: consecutive blocks share 3 of their 5 filtered rows
 
-__global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
+#ifndef UPFIR_WAVES
+#define UPFIR_WAVES 1
+#endif
+__global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
     // One thread = 4 channels x 2 output columns x 2*UPFIR_ROWS output rows, walking down the image with a sliding
     // window of row-filtered values: 10 loads of T per 4 outputs (separable 4-tap filter per axis) instead of 64,
     // and each T row is fetched by one workgroup instead of by the two that own the rows above and below it.
@@ -1169,16 +1189,32 @@ __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
         const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
         float4 s2 = make_float4(0, 0, 0, 0);
         if (P.split_hi) s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
-        // row-filtered T row ty: rf[dx] = sum_b F[b] T[ty][X0+dx+b-1]
+        // row-filtered T row ty: rf[dx] = sum_b F[b] T[ty][X0+dx+b-1].  The five loads are unconditional (clamped address, value
+        // zeroed by a select afterwards): with the bounds tests as branches every load sat in its own exec-masked block behind an
+        // `s_waitcnt vmcnt(0)` and a thread had one load in flight at a time (round 3: 126 -> see DESIGN 5).
+        const float* __restrict__ tbase = P.scratch + (long long)n * TH * TW * P.Cout + 4 * c4;
+        int toff[5]; bool tok[5];
+#pragma unroll
+        for (int jj = 0; jj < 5; ++jj) {
+            const int tx = X0 - 1 + jj;
+            tok[jj] = tx >= 0 && tx < TW;
+            toff[jj] = min(max(tx, 0), TW - 1) * P.Cout;
+        }
         auto filter_row = [&](int ty, float4 (&rf)[2]) {
             float4 t[5];
+            const bool rok = ty >= 0 && ty < TH;
+            const float* __restrict__ trow = tbase + (long long)min(max(ty, 0), TH - 1) * TW * P.Cout;
 #pragma unroll
             for (int jj = 0; jj < 5; ++jj) {
-                const int tx = X0 - 1 + jj;
-                t[jj] = (ty >= 0 && ty < TH && tx >= 0 && tx < TW)
-                            ? *reinterpret_cast<const float4*>(P.scratch + (((long long)n * TH + ty) * TW + tx) * P.Cout + 4 * c4)
-                            : make_float4(0, 0, 0, 0);
+#if defined(UPFIR_ABLATE) && UPFIR_ABLATE == 1      // timing experiment: no scratch reads
+                t[jj] = make_float4((float)ty, (float)jj, (float)c4, 1.0f);
+#else
+                t[jj] = *reinterpret_cast<const float4*>(trow + toff[jj]);
+#endif
             }
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj)
+                if (!(rok && tok[jj])) t[jj] = make_float4(0, 0, 0, 0);
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 float4 a = make_float4(0, 0, 0, 0);
@@ -1193,7 +1229,11 @@ __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
         const int by0 = bg * UPFIR_ROWS;
         float4 win[5][2];                                  // filtered rows 2by-1 .. 2by+3
         filter_row(2 * by0 - 1, win[0]); filter_row(2 * by0, win[1]); filter_row(2 * by0 + 1, win[2]);
+#if defined(UPFIR_ROLLED)
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
         for (int rr = 0; rr < UPFIR_ROWS; ++rr) {
             const int by = by0 + rr;
             if (by >= P.H) break;
@@ -1217,6 +1257,10 @@ __global__ __launch_bounds__(256) void upfir_kernel(ConvK P) {
                     o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
                     o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
                     const long long oi = (((long long)n * OH + Y) * OW + X) * C4 + c4;
+#if defined(UPFIR_ABLATE) && UPFIR_ABLATE == 2      // timing experiment: no stores
+                    asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(s2.x));
+                    continue;
+#endif
                     if (P.out) reinterpret_cast<float4*>(P.out)[oi] = o;
                     if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer (group-major)
                         unsigned h0, l0, h1, l1;
