@@ -466,7 +466,7 @@ __device__ uint4 nfe_zero16[4];                                  // source of th
 #endif
 #ifndef C3_ABM            // the same as a bit mask, so that experiments combine: 1 no LDS-DMA, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 same tile,
 #define C3_ABM (C3_ABLATE == 1 ? 1 : C3_ABLATE == 2 ? 2 : C3_ABLATE == 3 ? 4 : C3_ABLATE == 4 ? 8 : C3_ABLATE == 5 ? 16 : C3_ABLATE == 6 ? 18 : 0)
-#endif                    // 32 every patch lane reads its aligned slot of one contiguous KiB, 64 no vmcnt wait
+#endif                    // 32 every patch lane reads its aligned slot of one contiguous KiB, 64 no vmcnt wait, 128 no epilogue
 #ifndef C3_DMA_BUILTIN
 #define C3_DMA_BUILTIN 0                                         // 1: the round-2 form (compiler-tracked LDS-DMA), kept for A/B
 #endif
@@ -474,10 +474,20 @@ __device__ uint4 nfe_zero16[4];                                  // source of th
 #define C3_FRAG_PIPE 1                                           // A/B switch of the fragment-read pipeline in conv3_kernel
 #endif
 #ifdef C3_PROFILE      // diagnostic build only (tools/c3_profile.py): shader cycles summed over all waves of all conv3 launches
-__device__ unsigned long long c3_prof[8];                        // {load phase, compute phase, epilogue, waves, vmcnt wait, barrier wait, prologue, -}
+__device__ unsigned long long c3_prof[8];
+#if C3_PROFILE + 0 == 2
+constexpr unsigned C3_PROF_SLOTS = 1u << 19;                     // light form: one record per wave, no atomics (they serialise the waves' ends)
+__device__ unsigned long long c3_prof_w[C3_PROF_SLOTS][2];       // {K loop incl. prologue, epilogue} cycles; slot = wave index mod table size
+#endif                        // {load phase, compute phase, epilogue, waves, vmcnt wait, barrier wait, prologue, -}
 #define C3_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#if C3_PROFILE + 0 == 2   // light form: only wave start, epilogue start and end are stamped (the K loop runs undisturbed)
+#define C3_STAMPK(var) const unsigned long long var = 0
+#else
+#define C3_STAMPK(var) C3_STAMP(var)
+#endif
 #else
 #define C3_STAMP(var)
+#define C3_STAMPK(var)
 #endif
 
 struct Conv3K {
@@ -666,6 +676,25 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][m][nb][r] = 0.0f;
 
+    // Per-channel epilogue constants of this workgroup's 32 * MBW channels go to LDS now (1 KiB behind the ring): loaded in the
+    // epilogue they were a dependent global round trip with nothing to hide it (8 % of the kernel, tools/r03_abm_stats.sh).
+    // [0] demodulation coefficients, [1] bias, [2] the consuming layer's styles.  Visible after the first barrier of the K loop.
+    float* ec = reinterpret_cast<float*>(lds + STAGES * STAGE_BYTES);
+    constexpr int EC = 32 * MBW;
+    const bool own_epilogue = !UP2 && KS == 1;
+    if (own_epilogue && tid < EC && !((C3_ABM) & 256)) {
+        const int ch = 32 * mb0 + tid;
+        ec[tid] = P.dcoef ? P.dcoef[(long long)n * P.Cout + ch] : 1.0f;
+        ec[EC + tid] = P.bias[ch];
+        ec[2 * EC + tid] = P.split_hi ? P.next_styles[(long long)n * P.Cout + ch] : 0.0f;
+    }
+    float nzv[NBW];                                            // noise of this lane's pixels: in flight during the K loop
+#pragma unroll
+    for (int nb = 0; nb < NBW; ++nb) {
+        const int y = min(ty0 + NBW * min(wave, WV - 1) + nb, P.H - 1), x = min(tx0 + j, P.W - 1);
+        nzv[nb] = (own_epilogue && P.noise && !((C3_ABM) & 256)) ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
+    }
+
 #ifdef C3_PROFILE
     unsigned long long prof_load = 0, prof_comp = 0, prof_vm = 0, prof_bar = 0;
     const unsigned long long ts_start = __builtin_amdgcn_s_memtime();
@@ -687,20 +716,20 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         return;
     }
     for (int g = 0; g < G; ++g) {
-        C3_STAMP(ts0);
+        C3_STAMPK(ts0);
         if (STAGES == 1) { __syncthreads(); issue(g, 0); }
         // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
         if (LW > 0) {}                  // compute waves issue no loads: the loader waves wait for them
         else if ((C3_ABM) & 64) {}
         else if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
-        C3_STAMP(ts0a);
+        C3_STAMPK(ts0a);
         if (!((C3_ABM) & 4)) __syncthreads();
-        C3_STAMP(ts0b);
+        C3_STAMPK(ts0b);
         const bool more = g + STAGES - 1 < G;
         const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
         if (LW == 0 && STAGES >= 2 && more) issue(g + STAGES - 1, nstage);
-        C3_STAMP(ts1);
+        C3_STAMPK(ts1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
         const unsigned char* ldsB = base + A_CHUNKS * 1024;
@@ -840,13 +869,24 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         }
         stage = stage + 1 == STAGES ? 0 : stage + 1;
 #ifdef C3_PROFILE
-        { C3_STAMP(ts2); prof_load += ts1 - ts0; prof_comp += ts2 - ts1; prof_vm += ts0a - ts0; prof_bar += ts0b - ts0a; }
+        { C3_STAMPK(ts2); prof_load += ts1 - ts0; prof_comp += ts2 - ts1; prof_vm += ts0a - ts0; prof_bar += ts0b - ts0a; }
 #endif
     }
 #ifdef C3_PROFILE
     C3_STAMP(ts_ep0);
 #endif
 
+#if (C3_ABM) & 128      // timing experiment: no epilogue (the accumulators are only kept alive)
+    {
+#pragma unroll
+        for (int a = 0; a < NACC; ++a)
+#pragma unroll
+            for (int m = 0; m < MBW; ++m)
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) asm volatile("" :: "v"(acc[a][m][nb][0]), "v"(acc[a][m][nb][15]));
+        return;
+    }
+#endif
     // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of pixel (row, j) ----
     if (UP2 && edge_tile && wave == 0 && j < C3_TH && ty0 + j <= P.H) {           // edge column: T[2y + a][2W], a = 0, 1
         const int TH2 = 2 * P.H + 1, TW2 = 2 * P.W + 1, y = ty0 + j;
@@ -868,10 +908,11 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
     const bool fuse_rgb = !UP2 && P.rgb_w != nullptr;
     float* wmod = reinterpret_cast<float*>(lds);       // [rgb_c][32 * MBW]: ToRGB weight x style of this workgroup's channels
     // per-wave 32 px x 32 channel tile (row stride 36 floats) behind wmod: the activation goes through it so that every store
-    // instruction writes 8 pixels x 128 contiguous bytes (full lines) instead of 64 separate 16-byte pieces
+    // instruction writes full lines (8 pixels x 128 contiguous bytes of fp32, or 32 pixels x 32 bytes = 1 KiB of one 16-channel
+    // plane of the consumer's bf16 image) instead of 64 separate 16-byte pieces
     constexpr int ST_STRIDE = 36;
     float* stile = reinterpret_cast<float*>(lds) + 4 * 32 * MBW + wave * (32 * ST_STRIDE);
-    if (!UP2 && KS == 1) __syncthreads();              // every wave is done with the last K-group's fragments: LDS is free
+    if (KS == 1 || UP2) __syncthreads();               // every wave is done with the last K-group's fragments: LDS is free
     if (fuse_rgb) {
         for (int i = tid; i < P.rgb_c * 32 * MBW; i += 64 * WV) {
             const int c = i / (32 * MBW), ch = 32 * mb0 + i % (32 * MBW);
@@ -880,23 +921,32 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         __syncthreads();
     }
     if (UP2) {
+        // T[2y + ay][2x + bx][channels]: the 32 channels of an M-block are one 128-byte line of a scratch pixel; through the
+        // wave's LDS tile a store instruction writes 8 such lines instead of 16 bytes of 64 (round 3: the scattered form cost
+        // 64 address cycles per instruction, 46 % of the up-sampling kernel's time)
+        const int TH2 = 2 * P.H + 1, TW2 = 2 * P.W + 1;
+        float* tdst = (KS > 1 ? P.partial + (long long)ks * P.N * TH2 * TW2 * P.Cout : P.scratch) + (long long)n * TH2 * TW2 * P.Cout;
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
-            const int y = ty0 + NBW * wave + nb, x = tx0 + j;
-            if (y > P.H || x > P.W) continue;
-            const int TH2 = 2 * P.H + 1, TW2 = 2 * P.W + 1;
+            const int y = ty0 + NBW * wave + nb;
+            if (y > P.H) continue;                     // wave-uniform
 #pragma unroll
             for (int a = 0; a < NACC; ++a) {
-                const int Y = 2 * y + (a >> 1), X = 2 * x + (a & 1);
-                if (Y >= TH2 || X >= TW2) continue;
+                const int Y = 2 * y + (a >> 1);
+                if (Y >= TH2) continue;                // wave-uniform
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) {
-                    float* dst = (KS > 1 ? P.partial + (long long)ks * P.N * TH2 * TW2 * P.Cout : P.scratch) +
-                                 (((long long)n * TH2 + Y) * TW2 + X) * P.Cout + 32 * (mb0 + m) + 4 * h;
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq)
-                        *reinterpret_cast<float4*>(dst + 8 * qq) = make_float4(acc[a][m][nb][4 * qq], acc[a][m][nb][4 * qq + 1],
-                                                                                acc[a][m][nb][4 * qq + 2], acc[a][m][nb][4 * qq + 3]);
+                        *reinterpret_cast<float4*>(stile + j * ST_STRIDE + 8 * qq + 4 * h) =
+                            make_float4(acc[a][m][nb][4 * qq], acc[a][m][nb][4 * qq + 1], acc[a][m][nb][4 * qq + 2], acc[a][m][nb][4 * qq + 3]);
+                    float* row = tdst + ((long long)Y * TW2 + (a & 1)) * P.Cout + 32 * (mb0 + m);
+#pragma unroll
+                    for (int it = 0; it < 4; ++it) {   // same-wave LDS operations execute in order: no barrier needed
+                        const int p = 8 * it + (lane >> 3), c = lane & 7, x = tx0 + p;
+                        const float4 v = *reinterpret_cast<const float4*>(stile + p * ST_STRIDE + 4 * c);
+                        if (x <= P.W && 2 * x + (a & 1) < TW2) *reinterpret_cast<float4*>(row + (long long)(2 * x) * P.Cout + 4 * c) = v;
+                    }
                 }
             }
         }
@@ -914,32 +964,14 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                                                                                       acc[0][m][nb][4 * qq + 2], acc[0][m][nb][4 * qq + 3]);
         }
     } else {
-        // Per-channel epilogue constants and the noise values are loaded up front, one M-block at a time: inside the store loop
-        // every such load sits behind the previous store (the pointers may alias), which made the epilogue a chain of ~32 exposed
-        // L2 round trips per wave, 20-30 % of the wave's life (tools/c3_profile.py).
-        float nzv[NBW], rgb[NBW][4];
-        const int cq_s = 4 * (lane >> 5) + (lane & 3);  // channel quad (of the M-block's 8) this lane writes to the consumer's image
-        float4 ns[MBW];                                 // consuming layer's styles of those 4 channels
+        float rgb[NBW][4];
 #pragma unroll
-        for (int m = 0; m < MBW; ++m)
-            ns[m] = P.split_hi ? *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 32 * (mb0 + m) + 4 * cq_s)
-                               : make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int nb = 0; nb < NBW; ++nb) {
-            const int y = min(ty0 + NBW * wave + nb, P.H - 1), x = min(tx0 + j, P.W - 1);
-            nzv[nb] = P.noise ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
+        for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
             for (int c = 0; c < 4; ++c) rgb[nb][c] = 0.0f;
-        }
+        const int sp = lane >> 1, sh = lane & 1;        // consumer's image: lane = (pixel of 32, 8-channel half of a 16-channel plane)
 #pragma unroll
         for (int m = 0; m < MBW; ++m) {
-            float4 dq[4], bq[4];
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) {
-                const int o0 = 32 * (mb0 + m) + 8 * qq + 4 * h;
-                dq[qq] = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + o0) : make_float4(1, 1, 1, 1);
-                bq[qq] = *reinterpret_cast<const float4*>(P.bias + o0);
-            }
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb) {
                 const int y = ty0 + NBW * wave + nb;
@@ -947,8 +979,13 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                 const float nz = nzv[nb];
 #pragma unroll
                 for (int qq = 0; qq < 4; ++qq) {
-                    const int o0 = 32 * (mb0 + m) + 8 * qq + 4 * h;
-                    const float4 d = dq[qq], b = bq[qq];
+                    // constants from LDS where they are used: held in registers across the (m, nb) blocks they made the 128-register
+                    // variants spill 40 registers into scratch inside the epilogue (32 k cycles per wave, tools/c3_profile.py light form)
+                    float4 d = make_float4(1, 1, 1, 1), b = make_float4(0.1f, 0.2f, 0.3f, 0.4f);
+                    if (!((C3_ABM) & 256)) {
+                        d = *reinterpret_cast<const float4*>(ec + 32 * m + 8 * qq + 4 * h);
+                        b = *reinterpret_cast<const float4*>(ec + EC + 32 * m + 8 * qq + 4 * h);
+                    }
                     float4 v;
                     v.x = epilogue_act(acc[0][m][nb][4 * qq + 0] * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
                     v.y = epilogue_act(acc[0][m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
@@ -970,20 +1007,27 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                     for (int it = 0; it < 4; ++it) {
                         const int p = 8 * it + (lane >> 3), c = lane & 7;
                         const float4 v = *reinterpret_cast<const float4*>(stile + p * ST_STRIDE + 4 * c);
-                        if (tx0 + p < P.W) *reinterpret_cast<float4*>(P.out + o_row + (long long)p * P.Cout + 4 * c) = v;
+                        if ((C3_ABM) & 512) asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                        else if (tx0 + p < P.W) *reinterpret_cast<float4*>(P.out + o_row + (long long)p * P.Cout + 4 * c) = v;
                     }
                 }
-                if (P.split_hi) {               // group-major image of the consumer: lane = (16-channel group of the M-block, pixel of 8,
-#pragma unroll                                  // channel quad): 8 pixels x 32 contiguous bytes per half wave and store instruction
-                    for (int it = 0; it < 4; ++it) {
-                        const int p = 8 * it + ((lane & 31) >> 2);
-                        const float4 v = *reinterpret_cast<const float4*>(stile + p * ST_STRIDE + 4 * cq_s);
-                        if (tx0 + p < P.W) {
-                            const long long si = split_index(n, P.Cout >> 4, P.H, P.W, y, tx0 + p, 8 * (mb0 + m) + cq_s);
-                            unsigned h0, l0, h1, l1;
-                            if (TERMS == 3) { split2<3>(v.x * ns[m].x, v.y * ns[m].y, h0, l0); split2<3>(v.z * ns[m].z, v.w * ns[m].w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
-                            else { split2<1>(v.x * ns[m].x, v.y * ns[m].y, h0, l0); split2<1>(v.z * ns[m].z, v.w * ns[m].w, h1, l1); }
-                            P.split_hi[si] = make_uint2(h0, h1);
+                if (P.split_hi) {               // one store instruction = the 32 pixels x 16 channels of one plane of the group-major image:
+#pragma unroll                                  // 1 KiB contiguous (round 3; was 16 pieces of 32 bytes per instruction)
+                    for (int gI = 0; gI < 2; ++gI) {
+                        const float* tp = stile + sp * ST_STRIDE + 16 * gI + 8 * sh;
+                        const float* np_ = ec + 2 * EC + 32 * m + 16 * gI + 8 * sh;
+                        const float4 v0 = *reinterpret_cast<const float4*>(tp), v1 = *reinterpret_cast<const float4*>(tp + 4);
+                        float4 s0 = make_float4(1, 1, 1, 1), s1 = s0;
+                        if (!((C3_ABM) & 256)) { s0 = *reinterpret_cast<const float4*>(np_); s1 = *reinterpret_cast<const float4*>(np_ + 4); }
+                        uint4 hi4, lo4;
+                        split2<TERMS>(v0.x * s0.x, v0.y * s0.y, hi4.x, lo4.x); split2<TERMS>(v0.z * s0.z, v0.w * s0.w, hi4.y, lo4.y);
+                        split2<TERMS>(v1.x * s1.x, v1.y * s1.y, hi4.z, lo4.z); split2<TERMS>(v1.z * s1.z, v1.w * s1.w, hi4.w, lo4.w);
+                        // uint2 units of split_index: 4 per (pixel, plane); this lane's 8 channels are units 2 sh, 2 sh + 1
+                        const long long si = split_index(n, P.Cout >> 4, P.H, P.W, y, tx0 + sp, 4 * (2 * (mb0 + m) + gI) + 2 * sh);
+                        if ((C3_ABM) & 512) asm volatile("" :: "v"(hi4.x), "v"(hi4.y), "v"(hi4.z), "v"(hi4.w), "v"(lo4.x), "v"(lo4.w));
+                        else if (tx0 + sp < P.W) {
+                            *reinterpret_cast<uint4*>(P.split_hi + si) = hi4;
+                            if (TERMS == 3) *reinterpret_cast<uint4*>(P.split_lo + si) = lo4;
                         }
                     }
                 }
@@ -1001,7 +1045,13 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
             }
         }
     }
-#ifdef C3_PROFILE
+#if C3_PROFILE + 0 == 2
+    if (lane == 0) {
+        C3_STAMP(ts_ep1);
+        const unsigned slot = ((((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WV + wave) & (C3_PROF_SLOTS - 1);
+        c3_prof_w[slot][0] = ts_ep0 - ts_start; c3_prof_w[slot][1] = ts_ep1 - ts_ep0;
+    }
+#elif defined(C3_PROFILE)
     if (lane == 0) {
         C3_STAMP(ts_ep1);
         atomicAdd(&c3_prof[0], prof_load); atomicAdd(&c3_prof[1], prof_comp); atomicAdd(&c3_prof[2], ts_ep1 - ts_ep0); atomicAdd(&c3_prof[3], 1ull);
@@ -1169,7 +1219,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK P, long long n
 constexpr int UPFIR_ROWS = NFE_UPFIR_ROWS;     // 2-row output blocks per thread: consecutive blocks share 3 of their 5 filtered rows
 
 #ifndef UPFIR_WAVES
-#define UPFIR_WAVES 1
+#define UPFIR_WAVES 3
 #endif
 __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
     // One thread = 4 channels x 2 output columns x 2*UPFIR_ROWS output rows, walking down the image with a sliding
@@ -1200,9 +1250,7 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
             tok[jj] = tx >= 0 && tx < TW;
             toff[jj] = min(max(tx, 0), TW - 1) * P.Cout;
         }
-        auto filter_row = [&](int ty, float4 (&rf)[2]) {
-            float4 t[5];
-            const bool rok = ty >= 0 && ty < TH;
+        auto load_row = [&](int ty, float4 (&t)[5]) {
             const float* __restrict__ trow = tbase + (long long)min(max(ty, 0), TH - 1) * TW * P.Cout;
 #pragma unroll
             for (int jj = 0; jj < 5; ++jj) {
@@ -1212,6 +1260,9 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
                 t[jj] = *reinterpret_cast<const float4*>(trow + toff[jj]);
 #endif
             }
+        };
+        auto reduce_row = [&](int ty, float4 (&t)[5], float4 (&rf)[2]) {
+            const bool rok = ty >= 0 && ty < TH;
 #pragma unroll
             for (int jj = 0; jj < 5; ++jj)
                 if (!(rok && tok[jj])) t[jj] = make_float4(0, 0, 0, 0);
@@ -1228,17 +1279,20 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
         };
         const int by0 = bg * UPFIR_ROWS;
         float4 win[5][2];                                  // filtered rows 2by-1 .. 2by+3
-        filter_row(2 * by0 - 1, win[0]); filter_row(2 * by0, win[1]); filter_row(2 * by0 + 1, win[2]);
-#if defined(UPFIR_ROLLED)
+        float4 ta[5], tb[5];                               // raw rows in flight: the NEXT block's two rows are requested before this
+        {                                                  // block's outputs are computed and stored (round 3: the loads used to start
+            float4 tc[5];                                  // only after the previous block's stores, half of the time nothing was in flight)
+            load_row(2 * by0 - 1, ta); load_row(2 * by0, tb); load_row(2 * by0 + 1, tc);
+            reduce_row(2 * by0 - 1, ta, win[0]); reduce_row(2 * by0, tb, win[1]); reduce_row(2 * by0 + 1, tc, win[2]);
+        }
+        load_row(2 * by0 + 2, ta); load_row(2 * by0 + 3, tb);
 #pragma unroll 1
-#else
-#pragma unroll
-#endif
         for (int rr = 0; rr < UPFIR_ROWS; ++rr) {
             const int by = by0 + rr;
             if (by >= P.H) break;
             const int Y0 = 2 * by;
-            filter_row(Y0 + 2, win[3]); filter_row(Y0 + 3, win[4]);
+            reduce_row(Y0 + 2, ta, win[3]); reduce_row(Y0 + 3, tb, win[4]);
+            if (rr + 1 < UPFIR_ROWS && by + 1 < P.H) { load_row(Y0 + 4, ta); load_row(Y0 + 5, tb); }
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -1577,7 +1631,7 @@ static int num_cus_dense() {
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st) {
     constexpr int ROWS = NBW * WV;
-    constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>();
+    constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>() + 1024;      // ring + the epilogue constants
     static bool once = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
@@ -1910,6 +1964,19 @@ extern "C" int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, 
 
 #ifdef C3_PROFILE
 extern "C" int nfe_debug_c3_profile(unsigned long long* out8, int reset) {
+#if C3_PROFILE + 0 == 2
+    {   // light form: average the per-wave records written since the last reset: out8 = {0, K loop sum, epilogue sum, waves, 0, 0, life sum, 0}
+        static std::vector<unsigned long long> host(2ull * nfe::C3_PROF_SLOTS);
+        if (hipDeviceSynchronize() != hipSuccess) return -1;
+        if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(nfe::c3_prof_w), host.size() * 8) != hipSuccess) return -1;
+        unsigned long long k = 0, e = 0, nw = 0;
+        for (unsigned i = 0; i < nfe::C3_PROF_SLOTS; ++i)
+            if (host[2 * i] | host[2 * i + 1]) { k += host[2 * i]; e += host[2 * i + 1]; ++nw; }
+        out8[0] = 0; out8[1] = k; out8[2] = e; out8[3] = nw ? nw : 1; out8[4] = 0; out8[5] = 0; out8[6] = k + e; out8[7] = 0;
+        if (reset) { std::fill(host.begin(), host.end(), 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(nfe::c3_prof_w), host.data(), host.size() * 8) != hipSuccess) return -1; }
+        return 0;
+    }
+#endif
     if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(nfe::c3_prof), 64) != hipSuccess) return -1;
     if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(nfe::c3_prof), z, 64) != hipSuccess) return -1; }
     return 0;

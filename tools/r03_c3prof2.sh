@@ -1,8 +1,5 @@
 #!/bin/bash
-# conv3_kernel phase profile (cycles per wave) of the shipped loop and of its timing-only ablations: which part makes the LDS-DMA slow?
+# conv3_kernel: share of a wave's life spent in the epilogue (light profile build: three s_memtime stamps per wave)
 mkdir -p gpurun_out/r03_c3prof
 V=nerffaceediting_amd/csrc/build/variants
-for v in c3prof c3prof_m2 c3prof_m8 c3prof_m10; do
-  echo "== $v (C3_ABM: 2 no MFMA, 8 no fragment reads)"
-  NFE_RENDER_LIB=$V/$v.so python3 tools/c3_profile.py bf16 8 2>&1 | grep -v "^/opt" | head -2 | cut -c1-420
-done | tee gpurun_out/r03_c3prof/profile_abm.txt
+for m in bf16 bf16x3; do NFE_RENDER_LIB=$V/c3prof2.so python3 tools/c3_profile.py $m 8 2>&1 | grep -v "^/opt" | cut -c1-30,60-75,95-330; done | tee gpurun_out/r03_c3prof/profile_light.txt
