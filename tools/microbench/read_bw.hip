@@ -51,6 +51,53 @@ __global__ __launch_bounds__(256) void reader(const uint4* __restrict__ buf, uns
     if (acc == 123.456f) sink[0] = acc;
 }
 
+// upfir_kernel's read pattern on its own: a (2H+1) x (2W+1) x C fp32 scratch, H = W = 256, C = 128 (row pitch 262 656 B).  A
+// workgroup of 4 waves owns 8 input columns (19 scratch columns of 512 B) and 8 output rows (11 scratch rows); per scratch row
+// every wave issues 5 loads of 16 B per lane, lanes 0-31 at column X0 - 1 + jj, lanes 32-63 two columns (1 KiB) further.
+// PAIR = false: the same bytes, but every instruction reads 1 KiB contiguous (both half waves side by side).
+template <bool PAIR>
+__global__ __launch_bounds__(256) void upfir_pattern(const uint4* __restrict__ buf, int views, float* sink) {
+    const int TH = 513, TW = 513, C16 = 32;                       // 16-byte items per scratch pixel
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int groups = 256 / 4, cblocks = 256 / 8;                // 4 two-row blocks per workgroup pass, 8 input columns per workgroup
+    float acc = 0.0f;
+    for (int wg = blockIdx.x; wg < views * groups * cblocks; wg += gridDim.x) {
+        const int cb = wg % cblocks, bg = (wg / cblocks) % groups, n = wg / (cblocks * groups);
+        const int X0 = 2 * (8 * cb + 2 * wave + (PAIR ? (lane >> 5) : 0));
+        const uint4* vb = buf + (unsigned long long)n * TH * TW * C16;
+        for (int r = 0; r < 11; ++r) {
+            const int ty = min(max(2 * 4 * bg - 1 + r, 0), TH - 1);
+            uint4 v[5];
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) {
+                const int tx = PAIR ? min(max(X0 - 1 + jj, 0), TW - 1) : min(max(X0 - 1 + 2 * jj + (lane >> 5), 0), TW - 1);
+                v[jj] = vb[((unsigned long long)ty * TW + tx) * C16 + (lane & 31)];
+            }
+#pragma unroll
+            for (int jj = 0; jj < 5; ++jj) acc += __uint_as_float(v[jj].x ^ v[jj].y ^ v[jj].z ^ v[jj].w);
+        }
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+template <bool PAIR>
+static void run_upfir(const uint4* buf, float* sink, int cus) {
+    const int views = 8;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; ++rep) {
+        CK(hipEventRecord(e0));
+        hipLaunchKernelGGL((upfir_pattern<PAIR>), dim3(cus * 8), dim3(256), 0, 0, buf, views, sink);
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+    }
+    float ms = 0;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    const double unique = 8.0 * 513 * 513 * 512;
+    printf("upfir read pattern (%s): %.1f us for %.2f GB of scratch = %.2f TB/s of unique bytes (loads issued: %.2fx)\n",
+           PAIR ? "half waves 1 KiB apart, as shipped" : "1 KiB contiguous per instruction", ms * 1e3, unique / 1e9, unique / (ms * 1e-3) / 1e12,
+           PAIR ? 11.0 / 8 * 5 / 2 : 11.0 / 8 * 5 / 2);
+}
+
 template <int MODE, int DEPTH>
 static void run(const char* what, const uint4* buf, unsigned long long set_bytes, unsigned long long window_bytes, int wgs_per_cu, int cus, float* sink,
                 double clock_ghz) {
@@ -92,6 +139,8 @@ int main() {
         {"HBM (4 GiB)", 4ull << 30, 256ull << 10},
         {"HBM (4 GiB), 4 MiB windows", 4ull << 30, 4ull << 20},
     };
+    run_upfir<true>(buf, sink, cus);
+    run_upfir<false>(buf, sink, cus);
     for (auto& c : cases) {
         char nm[96];
         snprintf(nm, sizeof nm, "load -> VGPR, %s", c.name);
