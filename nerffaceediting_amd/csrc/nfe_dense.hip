@@ -495,6 +495,8 @@ struct Conv3K {
     long long noise_n_stride; float noise_strength; const float* bias; int N, H, W, Cin, Cout; int lrelu; float act_gain, clamp;
     float* out; float* scratch;
     int c3_tiles;       // real tile count (grid.x is padded to a multiple of 8 for the XCD-aware order)
+    int up_fused;       // UP2: the 4 x 4 FIR, demodulation, noise, bias and activation run in this kernel's epilogue on overlapping tiles
+                        // (30 x (ROWS - 2) new extended-input pixels per 32 x ROWS tile); no (2H+1)^2 scratch, no upfir_kernel
     const float* rgb_w; const float* rgb_s; float* rgb_partial; int rgb_c;     // fused ToRGB (plain 3x3, no split-K): see rgb_combine_kernel
     int ksplit;         // > 1: blockIdx.z = n * ksplit + ks; this workgroup sums K-groups [ks*G/ksplit, (ks+1)*G/ksplit) and writes
     float* partial;     //      raw partial sums [ksplit][N,H,W,Cout] that splitk_reduce_kernel adds in slice order (+ epilogue)
@@ -572,9 +574,10 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
     // the tile width): the extra column x = W is not tiled (a 32-wide tile for one column); the right-most tile of every tile
     // row computes it as ONE extra N-block on wave 0 (lane = tile row): that column only sees input column W-1 through the
     // three kw = 2 taps, i.e. phases (a, b = 0), and its B fragments are column 32 of the patch the tile has staged anyway.
-    const bool edge_mode = UP2 && (P.W % C3_TW) == 0;
+    const bool fusedup = UP2 && P.up_fused;                // wave-uniform
+    const bool edge_mode = UP2 && !fusedup && (P.W % C3_TW) == 0;
     const int gw = UP2 ? (edge_mode ? P.W : P.W + 1) : P.W;
-    const int tiles_x = (gw + C3_TW - 1) / C3_TW;
+    const int tiles_x = fusedup ? (P.W + 29) / 30 : (gw + C3_TW - 1) / C3_TW;
     // XCD-aware order (split-bf16 variants): workgroups reach the 8 XCDs round-robin in dispatch order and every XCD has its own
     // L2.  XCD x takes the tiles = x (mod 8) and walks the M-block groups of a tile back to back, so the tile's input patch is
     // fetched into that L2 once instead of once per M-block group (the single-buffered split-bf16 stage cannot hide the longer
@@ -587,7 +590,10 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         tile_ = (k_ / MBG) * 8 + (L & 7); mbg_ = k_ % MBG;
         if (tile_ >= P.c3_tiles) return;              // grid.x is padded to a multiple of 8
     }
-    const int ty0 = (tile_ / tiles_x) * C3_TH, tx0 = (tile_ % tiles_x) * C3_TW;
+    // fused up-sampling tiles overlap by two extended-input pixels per axis and start at -1: tile (ky, kx) produces the output
+    // pixels [2 ky (ROWS-2), 2 (ky+1)(ROWS-2)) x [60 kx, 60 kx + 60), whose FIR needs the scratch pixels one before and two after
+    const int ty0 = fusedup ? (tile_ / tiles_x) * (C3_TH - 2) - 1 : (tile_ / tiles_x) * C3_TH;
+    const int tx0 = fusedup ? (tile_ % tiles_x) * 30 - 1 : (tile_ % tiles_x) * C3_TW;
     const int KS = P.ksplit > 1 ? P.ksplit : 1;
     const int mb0 = mbg_ * MBW, n = blockIdx.z / KS, ks = blockIdx.z % KS;
     const int G_all = P.Cin >> 4;
@@ -679,10 +685,12 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
     // Per-channel epilogue constants of this workgroup's 32 * MBW channels go to LDS now (1 KiB behind the ring): loaded in the
     // epilogue they were a dependent global round trip with nothing to hide it (8 % of the kernel, tools/r03_abm_stats.sh).
     // [0] demodulation coefficients, [1] bias, [2] the consuming layer's styles.  Visible after the first barrier of the K loop.
-    float* ec = reinterpret_cast<float*>(lds + STAGES * STAGE_BYTES);
+    constexpr int FUSED_T_BYTES = UP2 ? 2 * (2 * ROWS) * 64 * 16 : 0;          // the fused up-sampling epilogue's scratch slice (8 channels)
+    constexpr int EC_OFFSET = STAGES * STAGE_BYTES > FUSED_T_BYTES ? STAGES * STAGE_BYTES : FUSED_T_BYTES;
+    float* ec = reinterpret_cast<float*>(lds + EC_OFFSET);
     constexpr int EC = 32 * MBW;
     const bool own_epilogue = !UP2 && KS == 1;
-    if (own_epilogue && tid < EC && !((C3_ABM) & 256)) {
+    if ((own_epilogue || fusedup) && tid < EC && !((C3_ABM) & 256)) {
         const int ch = 32 * mb0 + tid;
         ec[tid] = P.dcoef ? P.dcoef[(long long)n * P.Cout + ch] : 1.0f;
         ec[EC + tid] = P.bias[ch];
@@ -920,7 +928,85 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         }
         __syncthreads();
     }
-    if (UP2) {
+    if constexpr (UP2) { if (fusedup) {
+        // Fused FIR (round 3).  Per slice of 8 channels (accumulator registers 4 qq .. 4 qq + 3 of both lane halves) the tile's
+        // transposed-conv result goes to LDS as Tl[h][2 ROWS][64] float4; thread = (row segment, lane half, output column) then
+        // walks down its segment with a sliding window of row-filtered values (4 LDS reads + 8 FMA x 4 channels per output):
+        // out[Y][X] = act(dcoef * sum_ab F[a] F[b] T[Y+a-1][X+b-1] + noise + bias), F = [1,3,3,1]/4 - upfir_kernel's arithmetic in
+        // its order.  The tile yields the output rows / columns 2 .. 2 ROWS - 3 / 2 .. 61 of its 2 ROWS x 64 scratch pixels.
+        static_assert(MBW == 1 && (WV == 4 || WV == 8), "fused up-sampling epilogue: one M-block, 4 or 8 waves");
+        constexpr int TYL = 2 * ROWS, XS = 64, NSEG = WV / 2, SEG_ROWS = (2 * ROWS - 4) / NSEG;
+        static_assert(SEG_ROWS * NSEG == 2 * ROWS - 4 && 120 * NSEG <= 64 * WV, "row segments");
+        float4* Tl = reinterpret_cast<float4*>(lds);
+        const int OH = 2 * P.H, OW = 2 * P.W;
+        const int seg = tid / 120, hs = (tid % 120) / 60, xs = tid % 60;
+        const bool active = seg < NSEG;
+        const int Xl = 2 + xs, y0 = 2 + seg * SEG_ROWS;
+        const int X = 2 * tx0 + Xl;
+        const bool xok = active && X >= 0 && X < OW;
+        const float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+        float nzs[SEG_ROWS];
+#pragma unroll
+        for (int r = 0; r < SEG_ROWS; ++r) {
+            const int Y = 2 * ty0 + y0 + r;
+            nzs[r] = (P.noise && xok && Y >= 0 && Y < OH) ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
+        }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                for (int a = 0; a < NACC; ++a)
+                    Tl[(h * TYL + 2 * (NBW * wave + nb) + (a >> 1)) * XS + 2 * j + (a & 1)] =
+                        make_float4(acc[a][0][nb][4 * qq], acc[a][0][nb][4 * qq + 1], acc[a][0][nb][4 * qq + 2], acc[a][0][nb][4 * qq + 3]);
+            __syncthreads();
+            if (active) {
+                const float4 d = *reinterpret_cast<const float4*>(ec + 8 * qq + 4 * hs);
+                const float4 b = *reinterpret_cast<const float4*>(ec + EC + 8 * qq + 4 * hs);
+                const float4 s2 = *reinterpret_cast<const float4*>(ec + 2 * EC + 8 * qq + 4 * hs);
+                const float4* col = Tl + (hs * TYL) * XS + Xl - 1;
+                auto hrow = [&](int yl) {
+                    const float4* rp = col + yl * XS;
+                    const float4 t0 = rp[0], t1 = rp[1], t2 = rp[2], t3 = rp[3];
+                    float4 a4 = make_float4(0, 0, 0, 0);
+                    a4.x = fmaf(F[0], t0.x, a4.x); a4.y = fmaf(F[0], t0.y, a4.y); a4.z = fmaf(F[0], t0.z, a4.z); a4.w = fmaf(F[0], t0.w, a4.w);
+                    a4.x = fmaf(F[1], t1.x, a4.x); a4.y = fmaf(F[1], t1.y, a4.y); a4.z = fmaf(F[1], t1.z, a4.z); a4.w = fmaf(F[1], t1.w, a4.w);
+                    a4.x = fmaf(F[2], t2.x, a4.x); a4.y = fmaf(F[2], t2.y, a4.y); a4.z = fmaf(F[2], t2.z, a4.z); a4.w = fmaf(F[2], t2.w, a4.w);
+                    a4.x = fmaf(F[3], t3.x, a4.x); a4.y = fmaf(F[3], t3.y, a4.y); a4.z = fmaf(F[3], t3.z, a4.z); a4.w = fmaf(F[3], t3.w, a4.w);
+                    return a4;
+                };
+                float4 w0 = hrow(y0 - 1), w1 = hrow(y0), w2 = hrow(y0 + 1);
+#pragma unroll
+                for (int r = 0; r < SEG_ROWS; ++r) {
+                    const float4 w3 = hrow(y0 + r + 2);
+                    float4 sm = make_float4(0, 0, 0, 0);
+                    sm.x = fmaf(F[0], w0.x, sm.x); sm.y = fmaf(F[0], w0.y, sm.y); sm.z = fmaf(F[0], w0.z, sm.z); sm.w = fmaf(F[0], w0.w, sm.w);
+                    sm.x = fmaf(F[1], w1.x, sm.x); sm.y = fmaf(F[1], w1.y, sm.y); sm.z = fmaf(F[1], w1.z, sm.z); sm.w = fmaf(F[1], w1.w, sm.w);
+                    sm.x = fmaf(F[2], w2.x, sm.x); sm.y = fmaf(F[2], w2.y, sm.y); sm.z = fmaf(F[2], w2.z, sm.z); sm.w = fmaf(F[2], w2.w, sm.w);
+                    sm.x = fmaf(F[3], w3.x, sm.x); sm.y = fmaf(F[3], w3.y, sm.y); sm.z = fmaf(F[3], w3.z, sm.z); sm.w = fmaf(F[3], w3.w, sm.w);
+                    w0 = w1; w1 = w2; w2 = w3;
+                    const int Y = 2 * ty0 + y0 + r;
+                    if (!(xok && Y >= 0 && Y < OH)) continue;
+                    const float nz = nzs[r];
+                    float4 o;
+                    o.x = epilogue_act(sm.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+                    o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+                    o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+                    o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+                    const int c4 = 8 * mb0 + 2 * qq + hs;          // channel / 4
+                    if (P.out) *reinterpret_cast<float4*>(P.out + (((long long)n * OH + Y) * OW + X) * P.Cout + 4 * c4) = o;
+                    if (P.split_hi) {
+                        unsigned h0, l0, h1, l1;
+                        const long long si = split_index(n, P.Cout >> 4, OH, OW, Y, X, c4);
+                        if (TERMS == 3) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
+                        else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
+                        P.split_hi[si] = make_uint2(h0, h1);
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    } else {
         // T[2y + ay][2x + bx][channels]: the 32 channels of an M-block are one 128-byte line of a scratch pixel; through the
         // wave's LDS tile a store instruction writes 8 such lines instead of 16 bytes of 64 (round 3: the scattered form cost
         // 64 address cycles per instruction, 46 % of the up-sampling kernel's time)
@@ -950,7 +1036,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                 }
             }
         }
-    } else if (KS > 1) {                                // raw partial sums of this K slice; the epilogue runs in splitk_reduce_kernel
+    } } else if (KS > 1) {                              // raw partial sums of this K slice; the epilogue runs in splitk_reduce_kernel
 #pragma unroll
         for (int nb = 0; nb < NBW; ++nb) {
             const int y = ty0 + NBW * wave + nb, x = tx0 + j;
@@ -1628,15 +1714,27 @@ static int num_cus_dense() {
 #define C3_LC_DEFAULT 0
 #endif
 
+// Up-sampling layers on the conv3 fast path: FIR + layer epilogue fused into the transposed conv (overlapping 32 x 8 tiles, 1.5x the
+// K-loop work, no fp32 scratch round trip) where that pays: measured per math mode and input width (tools/r03_upfused_ab.sh) -
+// plain bf16 up to 256 input channels; split-bf16, whose K loop is MFMA-bound, only the 32-channel layer at the head's entry.
+// NFE_UP_FUSED=0 switches it off, NFE_UP_FUSED_CIN_BF16 / NFE_UP_FUSED_CIN_X3 move the thresholds (A/B knobs).
+static bool up_fused(int math, int ksplit, int cin) {
+    static const bool on = [] { const char* e = getenv("NFE_UP_FUSED"); return !e || e[0] != '0'; }();
+    static const int max_x3 = [] { const char* e = getenv("NFE_UP_FUSED_CIN_X3"); return e ? atoi(e) : 32; }();
+    static const int max_bf16 = [] { const char* e = getenv("NFE_UP_FUSED_CIN_BF16"); return e ? atoi(e) : 256; }();
+    return on && !ksplit && cin <= (math == NFE_CONV_BF16 ? max_bf16 : max_x3);
+}
+
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
-static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st) {
+static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override = 0) {
     constexpr int ROWS = NBW * WV;
-    constexpr int bytes = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>() + 1024;      // ring + the epilogue constants
+    constexpr int ring = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>(), fused_t = UP2 ? 2 * (2 * ROWS) * 64 * 16 : 0;
+    constexpr int bytes = (ring > fused_t ? ring : fused_t) + 1024;                  // ring (or the fused FIR's tile) + the epilogue constants
     static bool once = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     (void)once;
-    const unsigned tiles = ((mode_h + ROWS - 1) / ROWS) * ((mode_w + C3_TW - 1) / C3_TW);
+    const unsigned tiles = tiles_override ? tiles_override : ((mode_h + ROWS - 1) / ROWS) * ((mode_w + C3_TW - 1) / C3_TW);
     Conv3K K2 = K; K2.c3_tiles = (int)tiles;
     dim3 grid(c3_xcd_order(TERMS) ? (tiles + 7) / 8 * 8 : tiles, K.Cout / (32 * MBW), K.N * (K.ksplit > 1 ? K.ksplit : 1));
     hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), grid, dim3(64 * (WV + LW)), bytes, st, K2);
@@ -1752,7 +1850,8 @@ extern "C" int nfe_conv_describe(int mode, int math, int n, int h, int w, int ci
         const int ks = conv3_ksplit(mode, n, h, w, cin, cout);
         snprintf(buf, (size_t)buf_len, "conv3[%s] %s ksplit=%d fuse_rgb=%d split_in_epilogue=%d%s", names[conv3_variant(mode, math, n, h, w, cout)], m, ks,
                  rgb_channels > 0 ? nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, rgb_channels) : 0,
-                 nfe_conv_splits_in_epilogue(mode, n, h, w, cin, cout), mode == NFE_CONV_3X3_UP2 ? " +upfir" : "");
+                 nfe_conv_splits_in_epilogue(mode, n, h, w, cin, cout),
+                 mode != NFE_CONV_3X3_UP2 ? "" : (up_fused(math, ks, cin) ? " fused FIR epilogue (overlapping tiles)" : " +upfir"));
         return NFE_OK;
     }
     const int ks = splitk_slices(mode, math, n, h, w, cin, cout);
@@ -1852,6 +1951,13 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         switch (conv3_variant(a->mode, a->math, a->n, a->h, a->w, a->cout)) {
         case C3V_UP: {
             // (round 2 measured, without gain: a double-buffered stage (C3_STAGES_X3_UP = 2) and the 32 x 16 tile on 8 waves: DESIGN.md 5)
+            if (up_fused(a->math, c3ks, a->cin)) {                 // FIR and layer epilogue inside the conv kernel, overlapping tiles
+                K.up_fused = 1; K.next_styles = P.next_styles; K.split_hi = P.split_hi; K.split_lo = P.split_lo;
+                const unsigned tiles = (unsigned)((a->h + 5) / 6) * (unsigned)((a->w + 29) / 30);      // ROWS = 8: 6 x 30 new extended-input pixels per tile
+                if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, 0, 0, st, tiles);
+                else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, 0, 0, st, tiles);
+                break;
+            }
             const int ext_w = (a->w % C3_TW) == 0 ? 0 : ext;       // EDGE mode: the extra column rides on the right-most tiles
             if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, a->h + ext, a->w + ext_w, st);
             else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext_w, st);
