@@ -106,7 +106,9 @@ typedef struct nfe_conv_args {
     int32_t out_planes;           /* mode 2 only: 1 = write [N,3,H,W,32] instead of [N,H,W,Cout] */
     float* out;
     float* scratch;               /* mode 1 (required): at least N*(2H+1)*(2W+1)*Cout floats, the transposed-conv
-                                     result before the FIR.  With nfe_conv_scratch_floats() floats (modes 0 and 1) the
+                                     result before the FIR (unused where the fast path runs the FIR in the conv kernel's own
+                                     epilogue on overlapping tiles: nfe_conv_describe() says which; results are the same bits
+                                     either way).  With nfe_conv_scratch_floats() floats (modes 0 and 1) the
                                      layer additionally keeps a bf16 hi (+lo) image of the modulated input there and
                                      runs the LDS-DMA fast path; less (or NULL in mode 0) = generic path */
     uint64_t scratch_floats;      /* capacity of `scratch` in floats */

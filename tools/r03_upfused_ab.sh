@@ -4,6 +4,5 @@ run() { echo "== $*"; env "$@" python3 tools/time_full.py 8 128 64 0 bf16 2>&1 |
 run NFE_UP_FUSED=0
 run NFE_UP_FUSED=1
 run NFE_UP_FUSED_TALL=1
-run NFE_UP_FUSED_CIN_X3=256 NFE_UP_FUSED_CIN_BF16=256
-run NFE_UP_FUSED_CIN_X3=32 NFE_UP_FUSED_CIN_BF16=32
 run NFE_UP_FUSED_TALL=1 NFE_UP_FUSED_CIN_X3=256
+run NFE_UP_FUSED_CIN_X3=256
