@@ -1125,7 +1125,7 @@ __device__ __forceinline__ void acc_tile_zero() {
 #pragma clang diagnostic pop
 }
 __device__ __forceinline__ void acc_tile_add(unsigned texel, float w0, float w1, float w2, float w3, float row) {
-    asm volatile("s_set_gpr_idx_on %0, 0xc\n"                                 // 0xc: index vdst and src2
+    asm volatile("s_set_gpr_idx_on %0, 0xc\n" "s_nop 3\n"                       // 0xc: index vdst and src2; wait states: see ACC_NOP_A
                  "v_fma_f32 " ACC_V("0") ", %1, %5, " ACC_V("0") "\n"
                  "v_fma_f32 " ACC_V("1") ", %2, %5, " ACC_V("1") "\n"
                  "v_fma_f32 " ACC_V("9") ", %3, %5, " ACC_V("9") "\n"
@@ -1139,18 +1139,33 @@ __device__ __forceinline__ void acc_tile_add4(const unsigned (&t)[4], const floa
                  "v_fma_f32 " ACC_V("1") ", " B ", " R ", " ACC_V("1") "\n" \
                  "v_fma_f32 " ACC_V("9") ", " C ", " R ", " ACC_V("9") "\n" \
                  "v_fma_f32 " ACC_V("10") ", " D ", " R ", " ACC_V("10") "\n"
-    asm volatile("s_set_gpr_idx_on %0, 0xc\n"
+#ifndef ACC_WC
+#define ACC_WC "s"                 // experiment: "v" keeps SGPR operands out of the index-mode VOP3
+#endif
+#ifndef ACC_NOP_A                // REQUIRED wait states between an index-mode change (s_set_gpr_idx_on / _idx: an SALU write of M0 and
+#define ACC_NOP_A "s_nop 3\n"    // MODE) and the first indexed VALU.  Without them that VALU occasionally ran with the stale index or
+#endif                           // mode: `bench.py --workload editstep` died with "Memory access fault" in 2 of 14 runs (a write through
+                                 // a stale M0 lands outside the wave's registers); 44 of 44 clean with them, 4 of 48 failing with the
+                                 // wait states placed before the change or after s_set_gpr_idx_off instead (tools/r03_edit_rep.sh).
+                                 // The compiler inserts such wait states around its own M0 users, not inside inline asm.
+#ifndef ACC_NOP_B
+#define ACC_NOP_B ""            // experiment: wait states between the last indexed VALU and the next index-mode change
+#endif
+#ifndef ACC_NOP_C
+#define ACC_NOP_C ""            // experiment: wait states after s_set_gpr_idx_off
+#endif
+    asm volatile("s_set_gpr_idx_on %0, 0xc\n" ACC_NOP_A
                  ACC_FMA4("%0", "%4", "%5", "%6", "%7", "%20")
-                 "s_set_gpr_idx_idx %1\n"
+                 ACC_NOP_B "s_set_gpr_idx_idx %1\n" ACC_NOP_A
                  ACC_FMA4("%1", "%8", "%9", "%10", "%11", "%21")
-                 "s_set_gpr_idx_idx %2\n"
+                 ACC_NOP_B "s_set_gpr_idx_idx %2\n" ACC_NOP_A
                  ACC_FMA4("%2", "%12", "%13", "%14", "%15", "%22")
-                 "s_set_gpr_idx_idx %3\n"
+                 ACC_NOP_B "s_set_gpr_idx_idx %3\n" ACC_NOP_A
                  ACC_FMA4("%3", "%16", "%17", "%18", "%19", "%23")
-                 "s_set_gpr_idx_off"
+                 ACC_NOP_B "s_set_gpr_idx_off\n" ACC_NOP_C
                  :: "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]),
-                    "s"(w[0][0]), "s"(w[0][1]), "s"(w[0][2]), "s"(w[0][3]), "s"(w[1][0]), "s"(w[1][1]), "s"(w[1][2]), "s"(w[1][3]),
-                    "s"(w[2][0]), "s"(w[2][1]), "s"(w[2][2]), "s"(w[2][3]), "s"(w[3][0]), "s"(w[3][1]), "s"(w[3][2]), "s"(w[3][3]),
+                    ACC_WC(w[0][0]), ACC_WC(w[0][1]), ACC_WC(w[0][2]), ACC_WC(w[0][3]), ACC_WC(w[1][0]), ACC_WC(w[1][1]), ACC_WC(w[1][2]), ACC_WC(w[1][3]),
+                    ACC_WC(w[2][0]), ACC_WC(w[2][1]), ACC_WC(w[2][2]), ACC_WC(w[2][3]), ACC_WC(w[3][0]), ACC_WC(w[3][1]), ACC_WC(w[3][2]), ACC_WC(w[3][3]),
                     "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
 #undef ACC_FMA4
 }

@@ -244,6 +244,39 @@ def test_backward_is_repeatable(dev):
             assert float((r[k] - runs[0][k]).abs().max()) <= 1e-6 * scale
 
 
+def test_backward_survives_many_launches(dev):
+    """200 launches of the editing-size backward (4 views, the `bench.py --workload editstep` shape) stay finite and agree with the
+    first to 1e-6 of the largest entry.  Round 3: the accumulate pass keeps its tile in registers addressed through the VGPR index
+    mode; without wait states between `s_set_gpr_idx_on / _idx` and the first indexed VALU, about one launch in a hundred wrote
+    through a stale index - outside the wave's registers - and the process died with "Memory access fault" (DESIGN.md 4.4).  A
+    recurrence shows up here as a dead process or as a gradient that differs from run to run."""
+    from nerffaceediting_amd import ops
+    N, R, D, Di, H = 4, 128, 48, 48, 256
+    g = torch.Generator(device="cpu").manual_seed(11)
+    pn = torch.randn(N, 3, H, H, 32, generator=g).to(dev)
+    pd = (torch.randn(N, 3, H, H, 32, generator=g) * 1.3 + 0.2).to(dev)
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+    heads = [torch.randn(*s, generator=g).to(dev) * (1.0 if len(s) == 2 else 0.2) for s in shapes]
+    heads[3][0] += 2.0
+    c2w = np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2, [0, 0, 0.2], 2.7).reshape(1, 4, 4) for y in (-0.4, -0.1, 0.1, 0.4)])
+    K = np.stack([orc.fov_to_intrinsics(18.837)] * N)
+    kw = dict(cam2world=t(c2w.astype(np.float32), dev), intrinsics=t(K.astype(np.float32), dev), resolution=R)
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    cots = tuple(torch.randn(N, R * R, c, generator=g).to(dev) for c in (32, 15, 1, 1))
+    out = ops.render(pn, pd, ops.decoder_pack(*heads), opts, seed=1, taps=True, **kw)
+    first, worst = None, 0.0
+    for i in range(200):
+        gg, ga = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, **kw)
+        if first is None:
+            first = (gg.clone(), ga.clone())
+            scale = (float(gg.abs().max()), float(ga.abs().max()))
+            assert scale[0] > 0 and scale[1] > 0 and torch.isfinite(gg).all() and torch.isfinite(ga).all()
+        elif i % 8 == 0 or i == 199:                  # compare a sample of the launches (the comparison costs as much as a launch)
+            worst = max(worst, float((gg - first[0]).abs().max()) / scale[0], float((ga - first[1]).abs().max()) / scale[1])
+    torch.cuda.synchronize()
+    assert worst <= 1e-6, worst
+
+
 def test_backward_finite_differences_larger_size(dev):
     """Size-independent property: <grad, V> equals the directional derivative of the forward kernel (single pass, fp32
     decoder, fixed jitter) for a random direction V — at 64^2 rays x 48 samples on 128^2 planes."""
