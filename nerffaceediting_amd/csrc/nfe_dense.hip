@@ -1329,13 +1329,16 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
         // zeroed by a select afterwards): with the bounds tests as branches every load sat in its own exec-masked block behind an
         // `s_waitcnt vmcnt(0)` and a thread had one load in flight at a time (round 3: 126 -> see DESIGN 5).
         const float* __restrict__ tbase = P.scratch + (long long)n * TH * TW * P.Cout + 4 * c4;
-        int toff[5]; bool tok[5];
+        int toff[5]; float Fm[2][4];                       // filter taps with the column bounds folded in (a tap outside the scratch = 0)
 #pragma unroll
-        for (int jj = 0; jj < 5; ++jj) {
-            const int tx = X0 - 1 + jj;
-            tok[jj] = tx >= 0 && tx < TW;
-            toff[jj] = min(max(tx, 0), TW - 1) * P.Cout;
-        }
+        for (int jj = 0; jj < 5; ++jj) toff[jj] = min(max(X0 - 1 + jj, 0), TW - 1) * P.Cout;
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx)
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                const int tx = X0 - 1 + dx + bb;
+                Fm[dx][bb] = (unsigned)tx < (unsigned)TW ? F[bb] : 0.0f;      // one compare: no lane masks to combine (tools/lint_lane_masks.py)
+            }
         auto load_row = [&](int ty, float4 (&t)[5]) {
             const float* __restrict__ trow = tbase + (long long)min(max(ty, 0), TH - 1) * TW * P.Cout;
 #pragma unroll
@@ -1348,19 +1351,16 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
             }
         };
         auto reduce_row = [&](int ty, float4 (&t)[5], float4 (&rf)[2]) {
-            const bool rok = ty >= 0 && ty < TH;
-#pragma unroll
-            for (int jj = 0; jj < 5; ++jj)
-                if (!(rok && tok[jj])) t[jj] = make_float4(0, 0, 0, 0);
+            const float rs = (unsigned)ty < (unsigned)TH ? 1.0f : 0.0f;      // the loads are clamped, so every t is a finite scratch value
 #pragma unroll
             for (int dx = 0; dx < 2; ++dx) {
                 float4 a = make_float4(0, 0, 0, 0);
 #pragma unroll
                 for (int bb = 0; bb < 4; ++bb) {
-                    a.x = fmaf(F[bb], t[dx + bb].x, a.x); a.y = fmaf(F[bb], t[dx + bb].y, a.y);
-                    a.z = fmaf(F[bb], t[dx + bb].z, a.z); a.w = fmaf(F[bb], t[dx + bb].w, a.w);
+                    a.x = fmaf(Fm[dx][bb], t[dx + bb].x, a.x); a.y = fmaf(Fm[dx][bb], t[dx + bb].y, a.y);
+                    a.z = fmaf(Fm[dx][bb], t[dx + bb].z, a.z); a.w = fmaf(Fm[dx][bb], t[dx + bb].w, a.w);
                 }
-                rf[dx] = a;
+                rf[dx] = make_float4(a.x * rs, a.y * rs, a.z * rs, a.w * rs);
             }
         };
         const int by0 = bg * UPFIR_ROWS;
