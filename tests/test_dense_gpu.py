@@ -240,6 +240,62 @@ def test_upconv_fast_path_matches_generic(shape, math, dev):
     assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
 
 
+_UP_FUSED_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nerffaceediting_amd import _lib, dense_ops as D
+dev = torch.device("cuda:0")
+out = {}
+for ci, (N, H, W, cin, cout) in enumerate([(2, 40, 72, 32, 64), (1, 64, 64, 32, 96), (2, 33, 63, 16, 32), (1, 128, 128, 32, 64)]):
+    for math in ("bf16x3", "bf16"):
+        g = torch.Generator(device="cpu").manual_seed(21 + ci)
+        x = torch.randn(N, H, W, cin, generator=g).to(dev)
+        styles = (torch.randn(N, cin, generator=g) * 0.5 + 1.0).to(dev)
+        nstyles = (torch.randn(N, cout, generator=g) * 0.5 + 1.0).to(dev)
+        weight = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+        bias = torch.randn(cout, generator=g).to(dev)
+        noise = torch.randn(2 * H, 2 * W, generator=g).to(dev)
+        packed, wsq = D.conv_pack(weight)
+        dcoef = D.conv_demod(styles, wsq)
+        kw = dict(bias=bias, dcoef=dcoef, noise=noise, noise_strength=0.3, lrelu=True, act_gain=2 ** 0.5, clamp=2.5, math=math)
+        o = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_3X3_UP2, **kw)
+        out[f"out_{ci}_{math}"] = o.cpu().numpy()
+        if cout % 16 == 0:
+            o2, sp = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_3X3_UP2, next_styles=nstyles, want_out=True, **kw)
+            nbytes = N * 2 * H * 2 * W * cout * 2 * (2 if math == "bf16x3" else 1)       # bf16 hi (+ lo) planes; the buffer may be padded
+            out[f"split_{ci}_{math}"] = sp.data.cpu().numpy().view(np.uint8).reshape(-1)[:nbytes]
+            out[f"out2_{ci}_{math}"] = o2.cpu().numpy()
+        out[f"how_{ci}_{math}"] = np.frombuffer(D.describe(_lib.NFE_CONV_3X3_UP2, math, N, H, W, cin, cout).encode(), dtype=np.uint8)
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_fused_up_layer_is_bit_identical_to_scratch_form(dev, tmp_path):
+    """the up-sampling layers whose 4x4 FIR runs inside the transposed-conv kernel (overlapping tiles) give the SAME
+    BITS as the (2H+1)^2 fp32 scratch + upfir_kernel form - fp32 output and the consumer's bf16 image, odd sizes, both math modes,
+    noise, bias, clamp.  The switch is read once per process, so each form runs in its own child process (NFE_UP_FUSED=0 / 1 with the
+    per-mode thresholds lifted)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "up_fused.py"
+    script.write_text(_UP_FUSED_SCRIPT)
+    res = {}
+    for tag, env in (("scratch", {"NFE_UP_FUSED": "0"}), ("fused", {"NFE_UP_FUSED": "1", "NFE_UP_FUSED_CIN_X3": "512", "NFE_UP_FUSED_CIN_BF16": "512"})):
+        f = tmp_path / f"{tag}.npz"
+        subprocess.run([sys.executable, str(script), root, str(f)], check=True, env=dict(os.environ, **env), timeout=600)
+        res[tag] = np.load(f)
+    keys = sorted(res["scratch"].files)
+    assert keys == sorted(res["fused"].files) and len(keys) >= 20
+    for k in keys:
+        a, b = res["scratch"][k], res["fused"][k]
+        if k.startswith("how_"):
+            assert b"upfir" in a.tobytes() and b"fused FIR" in b.tobytes(), (k, a.tobytes(), b.tobytes())
+        else:
+            assert a.shape == b.shape and np.array_equal(a, b), k
+
+
 @pytest.mark.parametrize("math", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("shape", [(2, 8, 8, 512, 96), (1, 32, 32, 256, 3), (3, 4, 4, 128, 96), (2, 64, 64, 128, 96), (1, 96, 40, 64, 3)])
 def test_torgb_fast_paths_match_generic(shape, math, dev):
