@@ -286,9 +286,12 @@ def extra_workload(args, torch, dist, dev, rank, world):
             # an optimiser step changed the planes: the gather-layout copies are re-made inside the step, as
             # DisentangledImportanceRenderer._packed does on a new tensor version (2 x 25 MB x views, no host sync)
             norm, denorm = ops.plane_pack(norm_nchw), ops.plane_pack(denorm_nchw)
-            out = ops.render(norm, denorm, dec_packed, opts, cam2world=c2w_t, intrinsics=K_t, resolution=Re, seed=seed + i, taps=True)
+            # as the renderer's autograd function calls it: the forward keeps the decoders' per-sample outputs for the backward
+            out = ops.render(norm, denorm, dec_packed, opts, cam2world=c2w_t, intrinsics=K_t, resolution=Re, seed=seed + i, taps=True,
+                             sample_colors=True)
             e[1].record()
-            ops.render_backward(norm, denorm, heads, 1.0, opts, out[4]["depths_all"], cots, cam2world=c2w_t, intrinsics=K_t, resolution=Re)
+            ops.render_backward(norm, denorm, heads, 1.0, opts, out[4]["depths_all"], cots, cam2world=c2w_t, intrinsics=K_t, resolution=Re,
+                                sample_colors=out[4]["sample_colors"])
             e[2].record()
             ev[i] = e
         dt = timed_steps(args, torch, dist, world, step)
@@ -297,7 +300,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
         bwd_ms = sum(e[1].elapsed_time(e[2]) for e in timed) / args.steps
         n_total = world * VIEWS_PER_GPU
         S2 = 2 * Dc
-        bytes_sample = 2 * 2 * 1536 + 2 * 1536              # two gather passes over two plane sets + one scatter into two sets
+        bytes_sample = 2 * 1536 + 192 + 2 * 1536            # one gather pass over two plane sets + the kept decoder outputs + one scatter into two sets
         ach = VIEWS_PER_GPU * Me * S2 * bytes_sample / (bwd_ms * 1e-3) / 1e9
         return dict(base, metric="rays/s, plane-editing step: 128^2 x (48+48) dual-plane render forward + backward w.r.t. both plane sets",
                     value=n_total * Me * args.steps / dt, unit="rays/s", ms_per_step=dt / args.steps * 1e3, scaling="weak", dtype="f32",

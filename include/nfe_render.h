@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NFE_ABI_VERSION 10
+#define NFE_ABI_VERSION 11
 
 #define NFE_OK 0
 #define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */
@@ -160,7 +160,15 @@ typedef struct nfe_render_args {
     uint64_t* clock_probe;             /* ABI v10, optional, device [4]: the final render launch stamps {shader-cycle counter,
                                           100 MHz reference counter} at its start and its end (workgroup 0): effective shader clock
                                           of that launch = (p[2]-p[0]) / (p[3]-p[1]) x 100 MHz.  Measurement only; NULL = off */
+    float* tap_sample_colors;          /* ABI v11, optional, nfe_render_sample_colors_floats() floats, opaque: what the decoders
+                                          returned for every sample of the final march (32 colour features, 15 segmentation
+                                          logits, sigma).  Handed to nfe_render_backward as `sample_colors` it replaces that call's
+                                          re-evaluation pass (gather + both decoder heads for every sample) by one pass over these
+                                          values.  Only with the split-bf16 decoder, no density_noise, no decoder_cross. */
 } nfe_render_args;
+
+/* floats of nfe_render_args.tap_sample_colors / nfe_render_backward_args.sample_colors for these sizes (S = D + Di) */
+uint64_t nfe_render_sample_colors_floats(int n_views, int n_rays, int n_samples);
 
 /* bytes of workspace nfe_render needs for these sizes: the depth min/max words, 13.6 MB for the segment composites of
  * depth-split launches (few rays: every ray block's march is cut into segments marched by different waves), and with
@@ -234,6 +242,8 @@ typedef struct nfe_render_backward_args {
     float* grad_planes_app;
     int64_t grad_view_stride;          /* floats between views of the gradient buffers (0: all views add into one set) */
     void* workspace; uint64_t workspace_bytes;
+    const float* sample_colors;        /* ABI v11, optional: tap_sample_colors of the forward call that produced `depths` (same rays,
+                                          planes and decoder); NULL = the samples are re-evaluated here */
 } nfe_render_backward_args;
 
 uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples);

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 10
+NFE_ABI_VERSION = 11
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_DECODER_CROSS_FLOATS = 2048
@@ -38,7 +38,7 @@ class RenderArgs(ctypes.Structure):
         ("channels_first", c_int32),
         ("tap_weights_coarse", FP), ("tap_depths_fine", FP), ("tap_depths_all", FP),
         ("workspace", FP), ("workspace_bytes", c_uint64), ("density_noise", c_float), ("decoder_cross", FP),
-        ("clock_probe", FP),
+        ("clock_probe", FP), ("tap_sample_colors", FP),
     ]
 
 
@@ -62,7 +62,7 @@ class RenderBackwardArgs(ctypes.Structure):
         ("channels_first", c_int32),
         ("grad_planes_geo", FP), ("grad_planes_app", FP),
         ("grad_view_stride", c_int64),
-        ("workspace", FP), ("workspace_bytes", c_uint64),
+        ("workspace", FP), ("workspace_bytes", c_uint64), ("sample_colors", FP),
     ]
 
 
@@ -108,6 +108,7 @@ _SIGNATURES = {
     "nfe_decoder_pack_cross": (c_int, [FP, c_float, FP, c_void_p]),
     "nfe_decoder_forward": (c_int, [FP, FP, c_int, c_int, c_int64, FP, c_int, FP, FP, FP, FP, c_void_p]),
     "nfe_render_workspace_bytes": (c_uint64, [c_int, c_int, c_int, c_int]),
+    "nfe_render_sample_colors_floats": (c_uint64, [c_int, c_int, c_int]),
     "nfe_render": (c_int, [POINTER(RenderArgs), c_void_p]),
     "nfe_render_backward_workspace_bytes": (c_uint64, [c_int, c_int, c_int]),
     "nfe_render_backward": (c_int, [POINTER(RenderBackwardArgs), c_void_p]),

@@ -12,6 +12,7 @@ namespace nfe {
 int fail(int code, const char* fmt, ...);   // records the thread-local message, returns code
 // nfe_render.hip: the evaluation pass of nfe_render_backward on the forward kernel (see there)
 int render_eval_pass(const nfe_render_backward_args* a, const float* decoder_packed, float* rec_sig, float* rec_a, hipStream_t st);
+int render_color_dot_pass(const nfe_render_backward_args* a, float* rec_sig, float* rec_a, hipStream_t st);
 const char* last_error();
 
 #define NFE_REQUIRE(cond, ...)                                   \

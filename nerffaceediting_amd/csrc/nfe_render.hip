@@ -46,6 +46,7 @@ struct RenderK {
     const float* dec_cross;        // CROSS variants: packed cross fragments (nfe_decoder_pack_cross)
     // EVAL variants (first pass of nfe_render_backward): per sample sigma and a = <2 g_rgb, rgb> + <g_seg, seg> instead of a march
     const float* ev_g_rgb; const float* ev_g_seg; int ev_channels_first; float* ev_sig; float* ev_a;
+    float* tap_colors;     // STORE variants: [N * blocks_per_view][S][48][32 lanes] decoder outputs of every sample (rgb 0..31, seg 32..46, sigma 47)
     int seg_count;                 // SPLIT variants: depth segments per ray block (each marched by its own wave)
     float* partials;               // SPLIT variants: [N*M, seg_count, PARTIAL_FLOATS] segment composites, see render_combine_kernel
     unsigned long long* clock_probe;   // optional [4]: {s_memtime, s_memrealtime} of workgroup 0 / wave 0 at kernel start and end
@@ -770,7 +771,7 @@ __device__ __forceinline__ float sample_gaussian(unsigned long long seed, unsign
     return sqrtf(-2.0f * LN2 * log2_fast(u1)) * __builtin_amdgcn_cosf(u2);       // v_cos_f32 takes revolutions
 }
 
-template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false, bool SPLIT = false, bool SQUARE = false, bool EVAL = false>
+template <bool DUAL, bool SIGMA_ONLY, int MATH, bool NOISE = false, bool CROSS = false, bool SPLIT = false, bool SQUARE = false, bool EVAL = false, bool STORE = false>
 __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     stage_decoder<MATH>(P.dec, lds);
@@ -910,6 +911,15 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             if (NOISE) {
                 const unsigned draw = (P.depth_mode == DEPTH_BUFFER && P.src_buf) ? (unsigned)P.src_buf[ray * S + k] : (unsigned)k;
                 og[0] = fmaf(P.density_noise, sample_gaussian(seed, (unsigned)ray, draw), og[0]);
+            }
+            if (STORE) {      // keep what the decoders returned (nfe_render_args.tap_sample_colors): lane = ray of the block, 128-byte rows
+                float* cb = P.tap_colors + (((long long)rb * S + k) * 48) * 32 + j;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cb[(16 * h + r) * 32] = oa[r];
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (8 * h + c < 15) cb[(32 + 8 * h + c) * 32] = og[2 + c];
+                if (h == 0) cb[47 * 32] = og[0];
             }
             if (EVAL) {
                 float a = 0.0f;
@@ -1372,6 +1382,8 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
     } else {
         if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+        else if (P.tap_colors && !SIGMA_ONLY)
+            hipLaunchKernelGGL((render_kernel<DUAL, false, NFE_MATH_BF16X3, false, false, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else if (P.H == P.W && !DUAL && !NFE_SQUARE_RT)      // shared axis geometry: measured faster with one plane set (-2.5 %), not with two (+0.8 %)
             hipLaunchKernelGGL((render_kernel<false, SIGMA_ONLY, NFE_MATH_BF16X3, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
@@ -1416,6 +1428,9 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
         else hipLaunchKernelGGL((render_kernel<DU, SG, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
         if (sigma_only) {
             if (dual) { NFE_LAUNCH_SPLIT(true, true) } else { NFE_LAUNCH_SPLIT(false, true) }
+        } else if (P.tap_colors) {
+            if (dual) hipLaunchKernelGGL((render_kernel<true, false, NFE_MATH_BF16X3, false, false, true, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
+            else hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, false, true, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
         } else {
             if (dual) { NFE_LAUNCH_SPLIT(true, false) } else { NFE_LAUNCH_SPLIT(false, false) }
         }
@@ -1469,9 +1484,73 @@ int render_eval_pass(const nfe_render_backward_args* a, const float* decoder_pac
     return NFE_OK;
 }
 
+// The same two quantities from the colours the forward kept (nfe_render_args.tap_sample_colors): one pass over 192 bytes per sample
+// instead of the gathers and both decoder heads.  Thread = (ray block, sample, lane of the block); the sums run in the evaluation
+// pass's order (16 colour features and 8 logits per channel half, halves added last).
+constexpr int DOT_K = 8;              // samples per thread: the ray's 47 cotangents are loaded once per DOT_K samples
+__global__ __launch_bounds__(256) void color_dot_kernel(RenderK P, const float* __restrict__ colors) {
+    const int S = P.S, blocks_per_view = (P.M + 31) >> 5, ksegs = (S + DOT_K - 1) / DOT_K;
+    const long long total = (long long)P.N * blocks_per_view * ksegs * 32;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int j = (int)(i & 31);
+        const long long rs = i >> 5;
+        const int ks = (int)(rs % ksegs);
+        const long long rb = rs / ksegs;
+        const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
+        int m;
+        if (P.tiled) { const int tiles_x = P.R >> 3; m = ((b / tiles_x) * 4 + (j >> 3)) * P.R + (b % tiles_x) * 8 + (j & 7); }
+        else m = b * 32 + j;
+        if (m >= P.M) continue;
+        const long long ray = (long long)n * P.M + m;
+        float gr[32], gs[16];
+#pragma unroll
+        for (int c = 0; c < 32; ++c)
+            gr[c] = P.ev_g_rgb ? 2.0f * (P.ev_channels_first ? P.ev_g_rgb[((long long)n * 32 + c) * P.M + m] : P.ev_g_rgb[ray * 32 + c]) : 0.0f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            gs[c] = (P.ev_g_seg && c < 15) ? (P.ev_channels_first ? P.ev_g_seg[((long long)n * 15 + c) * P.M + m] : P.ev_g_seg[ray * 15 + c]) : 0.0f;
+        const int k1 = min(S, (ks + 1) * DOT_K);
+#pragma unroll 2
+        for (int k = ks * DOT_K; k < k1; ++k) {
+            const float* cb = colors + ((rb * S + k) * 48) * 32 + j;
+            float a2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                float a = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) a = fmaf(gr[16 * h + r], cb[(16 * h + r) * 32], a);
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) a = fmaf(gs[8 * h + cc], (8 * h + cc < 15) ? cb[(32 + 8 * h + cc) * 32] : 0.0f, a);
+                a2[h] = a;
+            }
+            P.ev_sig[ray * S + k] = cb[47 * 32];
+            P.ev_a[ray * S + k] = a2[0] + a2[1];
+        }
+    }
+}
+
+int render_color_dot_pass(const nfe_render_backward_args* a, float* rec_sig, float* rec_a, hipStream_t st) {
+    RenderK P{};
+    P.N = a->n_views; P.M = a->n_rays; P.S = a->n_samples;
+    P.R = (a->resolution > 0 && (long long)a->resolution * a->resolution == a->n_rays) ? a->resolution : 0;
+    P.tiled = (P.R > 0 && (P.R % 8) == 0) ? 1 : 0;
+    P.ev_g_rgb = a->grad_rgb; P.ev_g_seg = a->grad_seg; P.ev_channels_first = a->channels_first; P.ev_sig = rec_sig; P.ev_a = rec_a;
+    const long long total = (long long)P.N * ((P.M + 31) >> 5) * ((P.S + DOT_K - 1) / DOT_K) * 32;
+    long long blocks = (total + 255) / 256;
+    if (blocks > (1 << 16)) blocks = 1 << 16;
+    hipLaunchKernelGGL(color_dot_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P, a->sample_colors);
+    NFE_CHECK_LAUNCH("color_dot_kernel");
+    return NFE_OK;
+}
+
 }  // namespace nfe
 
 using namespace nfe;
+
+extern "C" uint64_t nfe_render_sample_colors_floats(int n_views, int n_rays, int n_samples) {
+    if (n_views <= 0 || n_rays <= 0 || n_samples <= 0) return 0;
+    return (uint64_t)n_views * (uint64_t)((n_rays + 31) / 32) * (uint64_t)n_samples * 48ull * 32ull;
+}
 
 extern "C" uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int D, int Di) {
     uint64_t nr = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0);
@@ -1549,9 +1628,13 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     hipLaunchKernelGGL(minmax_init_kernel, dim3(1), dim3(1), 0, st, minmax);
     NFE_CHECK_LAUNCH("minmax_init_kernel");
 
+    if (a->tap_sample_colors)
+        NFE_REQUIRE(math == NFE_MATH_BF16X3 && a->density_noise == 0.0f && !a->decoder_cross,
+                    "nfe_render: tap_sample_colors needs NFE_MATH_BF16X3, density_noise == 0 and no decoder_cross");
     if (Di == 0) {
         P.S = D; P.depth_mode = mode; P.u = a->u_coarse; P.depth_minmax = minmax;
         P.out_depths = a->tap_depths_all;
+        P.tap_colors = a->tap_sample_colors;
         int rc = launch_render(P, dual, false, math, st);
         if (rc) return rc;
     } else {
@@ -1581,6 +1664,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         // pass 3: march the merged samples
         RenderK F = P;
         F.S = D + Di; F.depth_mode = DEPTH_BUFFER; F.depth_buf = t_all; F.src_buf = src_all; F.depth_minmax = minmax;
+        F.tap_colors = a->tap_sample_colors;
         rc = launch_render(F, dual, false, math, st);
         if (rc) return rc;
         if (a->tap_depths_all) {

@@ -1365,7 +1365,10 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     const dim3 sgrid((unsigned)((per_view + 255) / 256), (unsigned)a->n_views);
     // pass 1: on the forward kernel's machinery (quad gather + split-bf16 MFMA decoder, nfe_render.hip) unless NFE_BWD_EVAL=valu
     static const bool valu_eval = [] { const char* e = getenv("NFE_BWD_EVAL"); return e && e[0] == 'v'; }();
-    if (valu_eval || (long long)a->plane_h * a->plane_w > (1ll << 25)) {
+    if (a->sample_colors) {             // the forward kept the decoders' outputs: no gather, no decoder here (ABI v11)
+        int rc = render_color_dot_pass(a, P.rec_sig, P.rec_a, st);
+        if (rc) return rc;
+    } else if (valu_eval || (long long)a->plane_h * a->plane_w > (1ll << 25)) {
         hipLaunchKernelGGL(bwd_eval_kernel, sgrid, dim3(256), 0, st, P);
         NFE_CHECK_LAUNCH("bwd_eval_kernel");
     } else {

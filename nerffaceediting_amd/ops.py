@@ -186,7 +186,8 @@ def decoder_forward(features_geo, features_app, decoder_packed, decoder_math=Non
 
 def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dirs=None, cam2world=None,
            intrinsics=None, resolution=0, affines=None, u_coarse=None, u_fine=None, seed=0,
-           channels_first=False, taps=False, ray_limits=None, decoder_math=None, decoder_cross=None, clock_probe=None):
+           channels_first=False, taps=False, ray_limits=None, decoder_math=None, decoder_cross=None, clock_probe=None,
+           sample_colors=False):
     """nfe_render.  planes_* are packed [Np,3,H,W,32] (Np == N or 1); affines = 4x [N,96] or None.
     clock_probe: optional int64 device tensor [4] the final render launch stamps (nfe_render_args.clock_probe).
 
@@ -278,6 +279,13 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
             tap["weights_coarse"] = torch.empty(N, M, D - 1, device=dev)
             tap["depths_fine"] = torch.empty(N, M, Di, device=dev)
             a.tap_weights_coarse, a.tap_depths_fine = tap["weights_coarse"].data_ptr(), tap["depths_fine"].data_ptr()
+        if sample_colors:
+            # the decoders' outputs for every sample of the final march (192 bytes per sample, opaque): render_backward(...,
+            # sample_colors=) then skips its re-evaluation pass.  Split-bf16 decoder without density noise / cross decoder only.
+            assert a.decoder_math == _lib.NFE_MATH_BF16X3 and a.density_noise == 0 and decoder_cross is None, \
+                "sample_colors needs the split-bf16 decoder, no density_noise and no cross decoder"
+            tap["sample_colors"] = torch.empty(lib.nfe_render_sample_colors_floats(N, M, D + Di), device=dev)
+            a.tap_sample_colors = tap["sample_colors"].data_ptr()
     need = lib.nfe_render_workspace_bytes(N, M, D, Di)
     if Di > 0 and a.density_noise > 0:                      # draw index of every merged sample (include/nfe_render.h)
         need += (N * M * (D + Di) * 4 + 255) // 256 * 256
@@ -289,7 +297,8 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
 
 
 def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, depths_all, grads, *, origins=None, dirs=None,
-                    cam2world=None, intrinsics=None, resolution=0, affines=None, channels_first=False, need=(True, True)):
+                    cam2world=None, intrinsics=None, resolution=0, affines=None, channels_first=False, need=(True, True),
+                    sample_colors=None):
     """nfe_render_backward: the vector-Jacobian product of `render` w.r.t. the two plane sets (what autograd does for
     renderer.py:301-363 with the planes as leaves; depths are constants, renderer.py:198,211).
 
@@ -363,6 +372,10 @@ def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, dept
     a.grad_planes_geo = gg.data_ptr() if gg is not None else None
     a.grad_planes_app = ga.data_ptr() if ga is not None else None
     a.grad_view_stride = 0 if bcast else 3 * H * W * 32
+    if sample_colors is not None:           # the `sample_colors` tap of the forward call: no re-evaluation pass
+        sample_colors = _dev(sample_colors, "sample_colors", (lib.nfe_render_sample_colors_floats(N, M, S),))
+        a.sample_colors = sample_colors.data_ptr()
+        keep.append(sample_colors)
     ws = _workspace(dev, lib.nfe_render_backward_workspace_bytes(N, M, S))
     a.workspace, a.workspace_bytes = ws.data_ptr(), ws.numel()
     with torch.cuda.device(dev):

@@ -37,9 +37,13 @@ class _RenderWithPlaneGrad(torch.autograd.Function):
             raise RuntimeError("plane gradients are not built for SegmentationOSGDecoder (disable_alignment)")
         same = norm_planes is denorm_planes
         pg, pa = renderer._pack_pair(norm_planes.detach(), norm_planes.detach() if same else denorm_planes.detach())
+        # with the split-bf16 decoder and no density noise the forward keeps the decoders' per-sample outputs (192 B per sample) and
+        # the backward skips its re-evaluation pass (nfe_render_args.tap_sample_colors, ABI v11)
+        colors = renderer.decoder_math in (None, "bf16x3") and not float(options.get("density_noise", 0) or 0) and renderer.keep_sample_colors
         out = ops.render(pg, pa, decoder.packed(), options, origins=ray_origins, dirs=ray_directions, u_coarse=jitter[0],
-                         u_fine=jitter[1], seed=seed, ray_limits=limits, taps=True, decoder_math=renderer.decoder_math)
+                         u_fine=jitter[1], seed=seed, ray_limits=limits, taps=True, decoder_math=renderer.decoder_math, sample_colors=colors)
         ctx.save_for_backward(pg, pa, ray_origins, ray_directions, out[4]["depths_all"])
+        ctx.sample_colors = out[4].get("sample_colors")
         ctx.decoder, ctx.options, ctx.same = decoder, dict(options), same
         ctx.shape = tuple(norm_planes.shape)
         if renderer.keep_taps:
@@ -52,7 +56,7 @@ class _RenderWithPlaneGrad(torch.autograd.Function):
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         gg, ga = ops.render_backward(pg, pg if ctx.same else pa, ctx.decoder.heads(), ctx.decoder.lr_mul, ctx.options, depths_all,
                                      (g_rgb, g_seg, g_depth, g_wsum), origins=o, dirs=d,
-                                     need=(need[0] or (ctx.same and need[1]), need[1] and not ctx.same))
+                                     need=(need[0] or (ctx.same and need[1]), need[1] and not ctx.same), sample_colors=ctx.sample_colors)
         unpack = lambda g: None if g is None else g.permute(0, 1, 4, 2, 3).reshape(ctx.shape)   # gather layout -> [N,3,32,H,W]
         if ctx.same:        # one tensor fed both inputs: its whole gradient goes to whichever slot autograd asked for first
             g = unpack(gg)
@@ -68,6 +72,7 @@ class DisentangledImportanceRenderer(torch.nn.Module):
         self.keep_taps = False
         self.last_taps = None
         self.decoder_math = None          # None -> split-bf16 MFMA; 'fp32' -> exact fp32 MFMA
+        self.keep_sample_colors = True    # plane-gradient forward: keep the per-sample decoder outputs for the backward (1.2 GB per 4 x 128^2 x 96)
         self.seed_tensor = None
         self.cache_planes = True          # False: re-pack the NCHW plane arguments on every call (see _packed)
         self._pack_cache = []

@@ -244,6 +244,37 @@ def test_backward_is_repeatable(dev):
             assert float((r[k] - runs[0][k]).abs().max()) <= 1e-6 * scale
 
 
+@pytest.mark.parametrize("two_pass", [False, True])
+@pytest.mark.parametrize("N,R", [(1, 64), (2, 128), (3, 40)])
+def test_backward_from_kept_sample_colors(N, R, two_pass, dev):
+    """nfe_render_backward fed the decoders' per-sample outputs the forward kept (tap_sample_colors, ABI v11) instead of
+    re-evaluating every sample: same gradients as the re-evaluating form to 1e-6 of the largest entry - depth-split and plain
+    forward launches (1 x 64^2 and 2 x 128^2 rays), a ray count that is no multiple of 8 x 8 tiles (40^2), single- and two-pass
+    marches, channels-last cotangents."""
+    from nerffaceediting_amd import ops
+    D, Di, H = (24, 24, 128) if two_pass else (32, 0, 128)
+    g = torch.Generator(device="cpu").manual_seed(5 + N)
+    pn = torch.randn(N, 3, H, H, 32, generator=g).to(dev)
+    pd = (torch.randn(N, 3, H, H, 32, generator=g) * 1.3 + 0.2).to(dev)
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+    heads = [torch.randn(*s, generator=g).to(dev) * (1.0 if len(s) == 2 else 0.2) for s in shapes]
+    heads[3][0] += 2.0
+    c2w = np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2, [0, 0, 0.2], 2.7).reshape(1, 4, 4) for y in np.linspace(-0.4, 0.4, N)])
+    K = np.stack([orc.fov_to_intrinsics(18.837)] * N)
+    kw = dict(cam2world=t(c2w.astype(np.float32), dev), intrinsics=t(K.astype(np.float32), dev), resolution=R)
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    cots = tuple(torch.randn(N, R * R, c, generator=g).to(dev) for c in (32, 15, 1, 1))
+    out = ops.render(pn, pd, ops.decoder_pack(*heads), opts, seed=1, taps=True, sample_colors=True, **kw)
+    plain = ops.render(pn, pd, ops.decoder_pack(*heads), opts, seed=1, taps=True, **kw)
+    for a, b in zip(out[:4], plain[:4]):
+        assert torch.equal(a, b)                        # keeping the colours does not change the forward's outputs
+    ref = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, **kw)
+    got = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, sample_colors=out[4]["sample_colors"], **kw)
+    for r_, g_ in zip(ref, got):
+        scale = float(r_.abs().max())
+        assert scale > 0 and float((r_ - g_).abs().max()) <= 1e-6 * scale
+
+
 def test_backward_survives_many_launches(dev):
     """200 launches of the editing-size backward (4 views, the `bench.py --workload editstep` shape) stay finite and agree with the
     first to 1e-6 of the largest entry.  Round 3: the accumulate pass keeps its tile in registers addressed through the VGPR index

@@ -34,14 +34,18 @@ def main():
     if os.environ.get("NO_RGB_COT"):          # geometry-only loss (seg / depth): the appearance head drops out of every kernel
         cots = (None,) + cots[1:]
 
+    KEEP = not os.environ.get("NO_SAMPLE_COLORS")      # the forward keeps the decoders' per-sample outputs (ABI v11)
+
     def fwd():
-        return ops.render(planes_n, planes_d, dec, opts, cam2world=c2w, intrinsics=K, resolution=R, seed=1, taps=True)
+        return ops.render(planes_n, planes_d, dec, opts, cam2world=c2w, intrinsics=K, resolution=R, seed=1, taps=True, sample_colors=KEEP)
 
     out = fwd()
     depths = out[4]["depths_all"]
+    colors = out[4].get("sample_colors")
 
     def bwd(need=(True, True)):
-        return ops.render_backward(planes_n, planes_d, heads, 1.0, opts, depths, cots, cam2world=c2w, intrinsics=K, resolution=R, need=need)
+        return ops.render_backward(planes_n, planes_d, heads, 1.0, opts, depths, cots, cam2world=c2w, intrinsics=K, resolution=R, need=need,
+                                   sample_colors=colors)
 
     def timeit(fn, it=10):
         fn(); torch.cuda.synchronize()
