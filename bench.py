@@ -50,31 +50,33 @@ PMC_FILE = os.path.join(ROOT, "profiles", "r03_issue_floor.json")
 
 
 def backward_roofline(bwd_ms, samples, logical_gbs):
-    """Roofline block of the edit step.  The binned scatter moves 1240 B of HBM traffic per sample by construction (DESIGN.md 4.4);
-    its accumulate pass runs at about half the HBM peak but is bound by its per-record instruction chain (halving the rows did not
-    shorten it), the decoder-backward and evaluation passes by the texture path; the committed counter file (tools/pmc.sh,
-    PMC_KERNEL=bwd_accumulate) gives that kernel's measured traffic and duration for the same 4-view launch."""
+    """Roofline block of the edit step.  The dominant kernel by HBM traffic is the accumulate pass of the binned scatter: it reads every
+    256-byte feature-gradient row once per plane (3 x 1.6 GB per 4 views), its records and index list; with its tile in registers
+    (round 3) it runs at the read ceiling of the machine (tools/microbench/read_bw.hip: 6.3 TB/s for a read-only stream).  The
+    committed counter file (tools/pmc.sh, PMC_KERNEL=bwd_accumulate_reg) gives that kernel's traffic and duration for the same launch."""
     import json
     import os
     rec = None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_backward_counters.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_backward_counters.json")
     if os.path.exists(path):
         rec = json.load(open(path))
     ach = rec["hbm_bytes_per_launch"] / rec["avg_ns_profiled"] if rec else None            # GB/s
-    return {"bound": "wave_issue", "achieved": None, "peak": None, "unit": None, "frac": None,
-            "traffic": rec["hbm_bytes_per_launch"] if rec else None, "hbm_gbs": ach, "hbm_frac": ach / 8000.0 if rec else None,
-            "kernel": "nfe::bwd_accumulate_kernel (of: render_kernel<EVAL>, bwd_ray_kernel, bwd_scatter_sorted_kernel<MFMA,BINNED>, "
-                      "bwd_bin_fill_kernel, bwd_accumulate_kernel)",
+    alg = samples * (3 * 256 + 3 * 28)                                                      # rows + records + index, per launch
+    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0 if rec else None,
+            "traffic": rec["hbm_bytes_per_launch"] if rec else None, "algorithmic_bytes_per_launch": alg,
+            "kernel": "nfe::bwd_accumulate_reg_kernel (of: color_dot_kernel, bwd_ray_kernel, bwd_scatter_sorted_kernel<MFMA,BINNED>, "
+                      "bwd_bin_fill_kernel, bwd_accumulate_reg_kernel)",
             "kernel_ms": rec["avg_ns_profiled"] * 1e-6 if rec else None, "backward_ms": bwd_ms,
             "hbm_bytes_per_sample_model": 1240, "hbm_model_gbs": samples * 1240 / (bwd_ms * 1e-3) / 1e9,
             "logical_gather_scatter_gbs": logical_gbs,
-            "note": "bound: no unit saturated (accumulate pass: per-record readlane / scalar / LDS chain; decoder-backward and evaluation passes: TA 0.6-0.8). "
-                    "hbm_gbs / hbm_frac / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r02_backward_counters.json "
-                    "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE, rocprofv3 duration), not re-measured by this run; "
-                    "backward_ms is this run's HIP-event time of the whole backward.  Per sample the decoder-backward kernel writes a "
-                    "256-byte feature-gradient row and three 32-byte records, the fill pass sorts a 4-byte index per record, the accumulate "
-                    "pass (one wave owns an 8x8 texel tile in LDS) reads index, record and row once per plane.  logical gather + scatter bytes (9216 B/sample) / "
-                    "time is quoted for reference only (planes and gradients are cache resident)"}
+            "note": "achieved / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r03_backward_counters.json "
+                    "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE, rocprofv3 duration under the counters), not re-measured by this "
+                    "run; peak = the 8 TB/s HBM figure (a read-only stream reaches 6.3 TB/s on this machine, tools/microbench/read_bw.hip, so "
+                    "the kernel is at 0.96 of what reads can get); backward_ms is this run's HIP-event time of the whole backward.  Per sample "
+                    "the decoder-backward kernel writes a 256-byte feature-gradient row and three 32-byte records, the fill pass sorts a 4-byte "
+                    "index per record, the accumulate pass (one wave owns an 8x8 texel tile in registers) reads index, record and row once per "
+                    "plane; the forward keeps the decoders' per-sample outputs (192 B per sample) so that no sample is re-evaluated.  logical "
+                    "gather + scatter bytes / time is quoted for reference only (planes and gradients are cache resident)"}
 
 
 def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD, clock_ghz=None):
