@@ -56,6 +56,9 @@ def main():
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / it
 
+    if os.environ.get("BOTH_ONLY"):                    # per-kernel statistics of one mode (rocprofv3 averages over every launch)
+        print(f"N={N} R={R} D={D}+{Di} planes {H}^2: backward (both sets) {timeit(bwd, 20):.3f} ms   [{N * M * (D + Di) / 1e6:.2f} M samples]")
+        return
     print(f"N={N} R={R} D={D}+{Di} planes {H}^2: forward {timeit(fwd):.3f} ms, backward (both sets) {timeit(bwd):.3f} ms, "
           f"backward (geometry set only) {timeit(lambda: bwd((True, False))):.3f} ms   [{N * M * (D + Di) / 1e6:.2f} M samples]")
 
