@@ -163,6 +163,10 @@ int nfe_upfirdn2d(const float* in, int n, int h, int w, int c, int up, int down,
  * NHWC [N,H,W,C] -> [N,OH,OW,C] */
 int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int ow, int antialias, float* out,
                         nfe_stream_t stream);
+/* its adjoint (the input gradient autograd derives for that F.interpolate call): grad_out [N,OH,OW,C] -> grad_in [N,H,W,C],
+ * written (not accumulated).  Serves the SR-head input gradient when the feature image is not at the head's input resolution. */
+int nfe_resize_bilinear_backward(const float* grad_out, int n, int h, int w, int c, int oh, int ow, int antialias, float* grad_in,
+                                 nfe_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -2059,6 +2059,63 @@ extern "C" int nfe_upfirdn2d(const float* in, int n, int h, int w, int c, int up
     return NFE_OK;
 }
 
+namespace nfe {
+// Adjoint of resize_kernel (the input gradient of F.interpolate(bilinear, antialias=...)): g_in[y][x] = sum over the outputs whose
+// window contains (y, x) of wy(oy, y) wx(ox, x) g_out[oy][ox], with exactly the forward's normalised weights.  Gather form: one
+// thread per input element walks the few candidate outputs per axis (the window test is axis_setup's own lo / n), so no atomics
+// and a fixed summation order.  The SR-head gradient at neural_rendering_resolution != 128 (sr_grad.py) is its only caller.
+__device__ __forceinline__ int resize_bwd_candidates(int i, int in, int out, int aa, int& o0) {
+    const float scale = (float)in / (float)out;
+    const float sup = aa ? fmaxf(scale, 1.0f) : 1.0f;
+    const float lo = ((float)i + 0.5f - sup) / scale - 0.5f, hi = ((float)i + 0.5f + sup) / scale - 0.5f;
+    o0 = max((int)floorf(lo) - 1, 0);
+    const int o1 = min((int)ceilf(hi) + 1, out - 1);
+    return o1 - o0 + 1;
+}
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict__ gout, int N, int H, int W, int C, int OH, int OW, int aa,
+                                                          float* __restrict__ gin) {
+    const long long total = (long long)N * H * W * C;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C); long long r = i / C;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H); const int n = (int)(r / H);
+        int oy0, ox0;
+        const int ny = resize_bwd_candidates(y, H, OH, aa, oy0), nx = resize_bwd_candidates(x, W, OW, aa, ox0);
+        float acc = 0.0f;
+        for (int a = 0; a < ny; ++a) {
+            const int oy = oy0 + a;
+            const AxisW ay = axis_setup(oy, H, OH, aa);
+            const int ky = y - ay.lo;
+            if (ky < 0 || ky >= ay.n) continue;
+            float sy = 0.0f;
+            for (int k = 0; k < ay.n; ++k) sy += axis_weight(ay, k, oy, aa);
+            const float wy = axis_weight(ay, ky, oy, aa) / (aa ? sy : 1.0f);
+            float rowv = 0.0f;
+            for (int b = 0; b < nx; ++b) {
+                const int ox = ox0 + b;
+                const AxisW ax = axis_setup(ox, W, OW, aa);
+                const int kx = x - ax.lo;
+                if (kx < 0 || kx >= ax.n) continue;
+                float sx = 0.0f;
+                for (int k = 0; k < ax.n; ++k) sx += axis_weight(ax, k, ox, aa);
+                rowv = fmaf(axis_weight(ax, kx, ox, aa) / (aa ? sx : 1.0f), gout[(((long long)n * OH + oy) * OW + ox) * C + c], rowv);
+            }
+            acc = fmaf(wy, rowv, acc);
+        }
+        gin[i] = acc;
+    }
+}
+}  // namespace nfe
+
+extern "C" int nfe_resize_bilinear_backward(const float* grad_out, int n, int h, int w, int c, int oh, int ow, int antialias, float* grad_in,
+                                            nfe_stream_t stream) {
+    NFE_REQUIRE(grad_out && grad_in && n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0, "nfe_resize_bilinear_backward: bad arguments");
+    hipLaunchKernelGGL(nfe::resize_bwd_kernel, dim3(nfe::grid1d((long long)n * h * w * c, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream,
+                       grad_out, n, h, w, c, oh, ow, antialias, grad_in);
+    NFE_CHECK_LAUNCH("resize_bwd_kernel");
+    return NFE_OK;
+}
+
 extern "C" int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int ow, int antialias, float* out, nfe_stream_t stream) {
     NFE_REQUIRE(in && out && n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0, "nfe_resize_bilinear: bad arguments");
     // taps per axis: ceil(2 * support) + 1 with support = max(in / out, 1) when antialiasing, 2 otherwise

@@ -295,6 +295,17 @@ def upsample2d(x):
     return upfirdn2d(x, up=2, padding=(2, 1), gain=4.0)
 
 
+def resize_bilinear_backward(g, h, w, antialias=True):
+    """Adjoint of resize_bilinear: g [N,OH,OW,C] (gradient of the resized image) -> [N,h,w,C] (gradient of its input)."""
+    lib = _lib.load()
+    g = _dev(g, "g", (None, None, None, None))
+    N, OH, OW, C = g.shape
+    out = torch.empty(N, int(h), int(w), C, device=g.device)
+    _call(g.device, lambda: lib.nfe_resize_bilinear_backward(_ptr(g), N, int(h), int(w), C, OH, OW, int(bool(antialias)), _ptr(out), _stream()),
+          "nfe_resize_bilinear_backward")
+    return out
+
+
 def resize_bilinear(x, oh, ow, antialias=True):
     """F.interpolate(mode='bilinear', align_corners=False, antialias=...) on NHWC."""
     lib = _lib.load()

@@ -29,8 +29,9 @@ GRAD_MATH = "bf16x3"      # fp32-grade split-bf16 MFMA for every backward convol
 
 
 def supported(sr, resolution):
-    """True where SRImage can run: the 512^2 head of the FFHQ configuration fed at its own input resolution."""
-    return type(sr).__name__ == "SuperresolutionHybrid8XDC" and int(resolution) == sr.input_resolution
+    """True where SRImage can run: the 512^2 head of the FFHQ configuration (SuperresolutionHybrid8XDC), fed at any neural
+    rendering resolution (the bilinear / antialiased pre-resize to its 128^2 input has its adjoint in nfe_resize_bilinear_backward)."""
+    return type(sr).__name__ == "SuperresolutionHybrid8XDC" and int(resolution) > 0
 
 
 def _act_grad(out, g, gain, clamp):
@@ -121,15 +122,16 @@ def block_backward(blk, saved, g_img, g_x):
 
 
 def sr_forward_saving(sr, feat, ws, noise_mode):
-    """SuperresolutionHybrid8XDC.forward_nhwc layer by layer, keeping what the backward needs.  feat [N,R,R,32] NHWC, R = 128."""
+    """SuperresolutionHybrid8XDC.forward_nhwc layer by layer, keeping what the backward needs.  feat [N,R,R,32] NHWC."""
     assert type(sr).__name__ == "SuperresolutionHybrid8XDC", "the SR-head gradient is built for SuperresolutionHybrid8XDC"
-    if feat.shape[1] != sr.input_resolution:
-        raise NotImplementedError(f"SR-head gradient: neural_rendering_resolution must equal the head's input resolution "
-                                  f"{sr.input_resolution} (the antialiased pre-resize has no backward here); got {feat.shape[1]}")
     ws3 = ws[:, -1:, :].repeat(1, 3, 1).to(torch.float32)                                   # superresolution.py:280
     st, dc = batch_styles(block_layers(sr.block0) + block_layers(sr.block1), ws3, [0, 1, 2, 0, 1, 2])
     x, img = feat, feat[..., :3].contiguous()
-    saved = []
+    r = sr.input_resolution
+    if feat.shape[1] != r:                                                                    # superresolution.py:283-286
+        x = dense_ops.resize_bilinear(x, r, r, sr.sr_antialias)
+        img = dense_ops.resize_bilinear(img, r, r, sr.sr_antialias)
+    saved = [(feat.shape[1], feat.shape[2])]
     for b, blk in enumerate((sr.block0, sr.block1)):
         x, img, sv = block_forward_saving(blk, x, img, st[3 * b:3 * b + 3], (dc[3 * b], dc[3 * b + 1]), noise_mode, sr.conv_math)
         saved.append(sv)
@@ -137,10 +139,14 @@ def sr_forward_saving(sr, feat, ws, noise_mode):
 
 
 def sr_backward(sr, saved, g_img):
-    """g_img [N,512,512,3] NHWC -> gradient w.r.t. the feature image [N,128,128,32] (its first 3 channels also feed the skip path)."""
+    """g_img [N,512,512,3] NHWC -> gradient w.r.t. the feature image [N,R,R,32] (its first 3 channels also feed the skip path)."""
     g_x = None                                      # gradient w.r.t. the current block's activation from the block after it
-    for blk, sv in zip((sr.block1, sr.block0), reversed(saved)):
+    (h_in, w_in), blocks = saved[0], saved[1:]
+    for blk, sv in zip((sr.block1, sr.block0), reversed(blocks)):
         g_x, g_img = block_backward(blk, sv, g_img, g_x)
+    if h_in != sr.input_resolution:                 # transpose of the pre-resize of both inputs
+        g_x = dense_ops.resize_bilinear_backward(g_x, h_in, w_in, sr.sr_antialias)
+        g_img = dense_ops.resize_bilinear_backward(g_img.contiguous(), h_in, w_in, sr.sr_antialias)
     g_x[..., :3] += g_img                                                                         # rgb = feat[..., :3]
     return g_x
 

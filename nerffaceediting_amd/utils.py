@@ -59,9 +59,9 @@ class _NotDifferentiableImage(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        raise RuntimeError("decode(): out['image'] is differentiable with respect to the planes only for SuperresolutionHybrid8XDC at "
-                           "neural_rendering_resolution == 128 (sr_grad.py); for this configuration build the editing loss on "
-                           "image_raw / image_seg / image_depth, or detach out['image'] explicitly")
+        raise RuntimeError("decode(): out['image'] is differentiable with respect to the planes only for SuperresolutionHybrid8XDC "
+                           "(sr_grad.py); for this head build the editing loss on image_raw / image_seg / image_depth, or detach "
+                           "out['image'] explicitly")
 
 
 def encode(G, ws, **synthesis_kwargs):

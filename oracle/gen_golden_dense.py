@@ -194,6 +194,49 @@ def gen_sr_backward():
     print("  wrote sr_backward.npz")
 
 
+RESIZE_BWD_CASES = [(1, 3, 64, 64, 128, 128, True), (2, 4, 37, 41, 64, 24, True), (1, 8, 96, 96, 24, 24, True), (1, 3, 50, 50, 128, 128, False),
+                    (2, 5, 128, 96, 64, 40, False), (1, 2, 512, 512, 128, 128, True)]
+
+
+def gen_resize_backward():
+    """Input gradient of F.interpolate(mode='bilinear', align_corners=False, antialias=...) - the reference's pre-resize of the SR
+    head's inputs (superresolution.py:283-286) - by autograd: up- and down-scaling, odd sizes, both antialias settings.  The test
+    regenerates x and the cotangent from RandomState(300 + case)."""
+    data = {}
+    for i, (N, C, H, W, OH, OW, aa) in enumerate(RESIZE_BWD_CASES):
+        rng = np.random.RandomState(300 + i)
+        x = t(rng.randn(N, C, H, W)).requires_grad_(True)
+        cot = t(rng.randn(N, C, OH, OW))
+        with torch.enable_grad():
+            y = torch.nn.functional.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=False, antialias=aa)
+            (g,) = torch.autograd.grad((y * cot).sum(), x)
+        stride = 4 if H >= 512 else 1
+        data[f"case{i}.grad"] = g.numpy()[:, :, ::stride, ::stride]
+        data[f"case{i}.grad_sum"] = g.double().sum(dim=(0, 2, 3)).numpy()
+    np.savez_compressed(os.path.join(OUT, "resize_backward.npz"), cases=np.array(RESIZE_BWD_CASES, dtype=np.int64), **data)
+    print("  wrote resize_backward.npz")
+
+
+def gen_sr_backward_r64():
+    """gen_sr_backward at neural_rendering_resolution 64 (BASELINE config 1): the 64^2 feature image goes through the head's
+    antialiased bilinear pre-resize to 128^2 (superresolution.py:283-286), so the input gradient includes that resize's adjoint."""
+    sr = SuperresolutionHybrid8XDC(channels=32, img_resolution=512, sr_num_fp16_res=4, sr_antialias=True,
+                                   channel_base=32768, channel_max=512, fused_modconv_default="inference_only")
+    load(sr, sr_params(41))
+    rng = np.random.RandomState(78)
+    with torch.enable_grad():
+        x = t(rng.randn(1, 32, 64, 64) * 0.5).requires_grad_(True)
+        ws = t(rng.randn(1, 14, 512))
+        cot = t(rng.randn(1, 3, 512, 512))
+        img = sr(x[:, :3], x, ws, noise_mode="none")
+        (g,) = torch.autograd.grad((img * cot).sum(), x)
+    print(f"    sr_backward_r64: |image| max {float(img.abs().max()):.3g}, |grad| max {float(g.abs().max()):.3g}")
+    # inputs are regenerated by the test from RandomState(78): x (x 0.5), ws, cot
+    np.savez_compressed(os.path.join(OUT, "sr_backward_r64.npz"), seed=41, grad=g.numpy(), grad_sum=g.double().sum(dim=(0, 2, 3)).numpy(),
+                        grad_absmax=float(g.abs().max()), image_s8=img.detach()[:, :, ::8, ::8].numpy())
+    print("  wrote sr_backward_r64.npz")
+
+
 def gen_block_backward():
     """One reference SynthesisBlock (skip architecture, up-sampling conv0 + conv1 + ToRGB + upsample2d skip; conv_clamp 256 as the
     SR head's) under autograd: d<cot_x, x_out> + <cot_img, img_out> / d (x_in, img_in).  Small enough (32 -> 64 channels, 32^2 ->
@@ -462,6 +505,8 @@ if __name__ == "__main__":
     gen_synthesis_full()
     gen_sr()
     gen_sr_backward()
+    gen_sr_backward_r64()
+    gen_resize_backward()
     gen_block_backward()
     gen_e2e()
     gen_e2e_full()

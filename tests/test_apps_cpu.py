@@ -71,3 +71,18 @@ def test_camera_samples_and_video_schedule_match_reference():
     assert len(s12) == 12 and np.allclose(cams_of(G, s12), z["video_cams_12"], atol=1e-6)      # default start: no interpolation leg
     s9 = utils.video_camera_schedule(9, 10.0, 20.0, init_pitch=1.2, init_yaw=1.7)
     assert len(s9) == 9 + 9 // 4 and np.allclose(cams_of(G0, s9), z["video_cams_9_interp"], atol=1e-6)
+
+
+def test_sr_gradient_support_table():
+    """decode()['image'] carries plane gradients for SuperresolutionHybrid8XDC at any neural rendering resolution (sr_grad.py);
+    the other head classes fall back to the node that raises in backward (utils._NotDifferentiableImage)."""
+    from nerffaceediting_amd import sr_grad
+
+    class SuperresolutionHybrid8XDC:          # only the class name and the resolution decide
+        input_resolution = 128
+
+    class SuperresolutionHybrid4X:
+        input_resolution = 128
+    assert sr_grad.supported(SuperresolutionHybrid8XDC(), 128) and sr_grad.supported(SuperresolutionHybrid8XDC(), 64)
+    assert sr_grad.supported(SuperresolutionHybrid8XDC(), 512) and not sr_grad.supported(SuperresolutionHybrid8XDC(), 0)
+    assert not sr_grad.supported(SuperresolutionHybrid4X(), 128)

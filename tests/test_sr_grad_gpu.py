@@ -136,6 +136,53 @@ def test_sr_input_gradient_matches_reference_autograd(tag, dev):
     assert es <= 5e-3 * max(float(np.abs(z[f"{tag}.grad_sum"]).max()), 1.0)         # sums over 16 384 entries: the flips do not cancel
 
 
+def test_resize_backward_matches_autograd_and_is_the_adjoint(dev):
+    """nfe_resize_bilinear_backward against the input gradient autograd derives for F.interpolate(bilinear, antialias=...)
+    (tests/golden/resize_backward.npz: up- and down-scaling, odd sizes, both antialias settings, the 512 -> 128 case of config 3),
+    and <resize(x), g> == <x, resize^T(g)> with the package's own forward."""
+    from nerffaceediting_amd import dense_ops as D
+    z = load("resize_backward")
+    for i, (N, C, H, W, OH, OW, aa) in enumerate(z["cases"].tolist()):
+        rng = np.random.RandomState(300 + i)
+        x = t(rng.randn(N, C, H, W), dev).permute(0, 2, 3, 1).contiguous()
+        cot = t(rng.randn(N, C, OH, OW), dev).permute(0, 2, 3, 1).contiguous()
+        g = D.resize_bilinear_backward(cot, H, W, bool(aa))
+        assert g.shape == (N, H, W, C)
+        ref = z[f"case{i}.grad"]
+        stride = 4 if H >= 512 else 1
+        got = g.permute(0, 3, 1, 2)[:, :, ::stride, ::stride].cpu().numpy()
+        assert np.abs(got - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max()), (i, np.abs(got - ref).max())
+        assert np.abs(g.double().sum(dim=(0, 1, 2)).cpu().numpy() - z[f"case{i}.grad_sum"]).max() <= 1e-3
+        lhs = float((D.resize_bilinear(x, OH, OW, bool(aa)).double() * cot.double()).sum())
+        rhs = float((x.double() * g.double()).sum())
+        assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0), (i, lhs, rhs)
+
+
+def test_sr_input_gradient_at_resolution_64(dev):
+    """The head fed a 64^2 feature image (BASELINE config 1): antialiased pre-resize to 128^2, both blocks, and back - against the
+    reference's autograd (gen_sr_backward_r64); same sparse-flip statistics as at 128^2 (see the test above)."""
+    from nerffaceediting_amd import sr_grad
+    z = load("sr_backward_r64")
+    sr = _sr(z, dev)
+    rng = np.random.RandomState(78)
+    x, ws, cot = rng.randn(1, 32, 64, 64) * 0.5, rng.randn(1, 14, 512), rng.randn(1, 3, 512, 512)
+    assert sr_grad.supported(sr, 64)
+    feat = t(x, dev).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    img = sr_grad.SRImage.apply(feat, sr, t(ws, dev), "none")
+    assert float((img.detach().permute(0, 3, 1, 2)[:, :, ::8, ::8].cpu() - torch.from_numpy(z["image_s8"])).abs().max()) <= 1e-3 * max(1.0, float(np.abs(z["image_s8"]).max()))
+    (img * t(cot, dev).permute(0, 2, 3, 1)).sum().backward()
+    grad = feat.grad.permute(0, 3, 1, 2).cpu()
+    amax = float(z["grad_absmax"])
+    ref = torch.from_numpy(z["grad"])
+    err = (grad - ref).abs()
+    rel_l2 = float(((grad - ref).double().square().sum() / ref.double().square().sum()).sqrt())
+    inside = float((err <= 1e-3 * amax).float().mean())
+    print(f"SR input gradient at 64^2: max-abs {float(err.max()):.3e}, median {float(err.median()):.2e} (largest entry {amax:.3g}), "
+          f"{100 * inside:.2f} % within 1e-3 of it, relative L2 {rel_l2:.2e}")
+    assert float(err.median()) <= 1e-4 * amax and inside >= 0.98 and rel_l2 <= 6e-3 and float(err.max()) <= 3e-2 * amax
+    assert np.abs(grad.double().sum(dim=(0, 2, 3)).numpy() - z["grad_sum"]).max() <= 5e-3 * max(float(np.abs(z["grad_sum"]).max()), 1.0)
+
+
 def test_block_backward_with_the_references_slopes(dev):
     """sr_grad.block_backward on one SynthesisBlock against the reference's autograd (gen_block_backward), with the slope of every
     leaky-ReLU unit and every clamp decision PINNED to the reference's forward (the fixture keeps them as bit masks): then every
