@@ -28,10 +28,21 @@ from .training.networks_stylegan2 import _publish, batch_styles, block_layers
 GRAD_MATH = "bf16x3"      # fp32-grade split-bf16 MFMA for every backward convolution
 
 
+HEADS = ("SuperresolutionHybrid8XDC", "SuperresolutionHybrid8X", "SuperresolutionHybrid4X", "SuperresolutionHybrid2X",
+         "SuperresolutionHybridDeepfp32")
+
+
 def supported(sr, resolution):
-    """True where SRImage can run: the 512^2 head of the FFHQ configuration (SuperresolutionHybrid8XDC), fed at any neural
-    rendering resolution (the bilinear / antialiased pre-resize to its 128^2 input has its adjoint in nfe_resize_bilinear_backward)."""
-    return type(sr).__name__ == "SuperresolutionHybrid8XDC" and int(resolution) > 0
+    """True where SRImage can run: every two-block head of the reference (superresolution.py:29-290), fed at any neural rendering
+    resolution (the bilinear / antialiased pre-resize to the head's input has its adjoint in nfe_resize_bilinear_backward)."""
+    return type(sr).__name__ in HEADS and int(resolution) > 0
+
+
+def _resizes(sr, r_in):
+    """Whether the head resizes a feature image of this size before block0 (8XDC / 8X / 2X: whenever it differs; 4X / Deepfp32:
+    only when it is smaller: superresolution.py:80, :145, :283)."""
+    r = sr.input_resolution
+    return (r_in < r) if getattr(sr, "resize_if_smaller_only", False) else (r_in != r)
 
 
 def _act_grad(out, g, gain, clamp):
@@ -101,7 +112,7 @@ def block_forward_saving(blk, x, img, styles, dcoefs, noise_mode, conv_math):
     o0 = blk.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=s0, dcoef=d0)
     o1 = blk.conv1.forward_nhwc(o0, None, noise_mode=noise_mode, conv_math=conv_math, styles=s1, dcoef=d1)
     y = blk.torgb.forward_nhwc(o1, None, skip=None, conv_math=conv_math, styles=st_rgb)              # clamped ToRGB output
-    img = dense_ops.upsample2d(img) + y                                                       # :453-457
+    img = (dense_ops.upsample2d(img) if blk.conv0.up == 2 else img) + y          # networks_stylegan2.py:453-457 / superresolution.py:247-250
     return o1, img, (o0, o1, y, s0, s1, st_rgb, d0, d1)
 
 
@@ -117,18 +128,20 @@ def block_backward(blk, saved, g_img, g_x):
         g_o1 = g_o1 + g_x
     c1, c0 = blk.conv1, blk.conv0
     g_o0 = _conv_bwd_plain(c1, _act_grad(o1, g_o1, c1.act_gain, c1.conv_clamp), s1, d1)
-    g_in = _conv_bwd_up(c0, _act_grad(o0, g_o0, c0.act_gain, c0.conv_clamp), s0, d0)
-    return g_in, dense_ops.upfirdn2d(g_img, down=2, padding=(1, 2), gain=4.0)                     # transpose of upsample2d
+    g_pre0 = _act_grad(o0, g_o0, c0.act_gain, c0.conv_clamp)
+    if c0.up == 2:
+        return _conv_bwd_up(c0, g_pre0, s0, d0), dense_ops.upfirdn2d(g_img, down=2, padding=(1, 2), gain=4.0)      # transpose of upsample2d
+    return _conv_bwd_plain(c0, g_pre0, s0, d0), g_img                             # SynthesisBlockNoUp: conv0 at the same resolution, img + y
 
 
 def sr_forward_saving(sr, feat, ws, noise_mode):
-    """SuperresolutionHybrid8XDC.forward_nhwc layer by layer, keeping what the backward needs.  feat [N,R,R,32] NHWC."""
-    assert type(sr).__name__ == "SuperresolutionHybrid8XDC", "the SR-head gradient is built for SuperresolutionHybrid8XDC"
+    """The head's forward_nhwc (two blocks, superresolution.py:29-290) layer by layer, keeping what the backward needs.  feat [N,R,R,32] NHWC."""
+    assert type(sr).__name__ in HEADS, f"the SR-head gradient is not built for {type(sr).__name__}"
     ws3 = ws[:, -1:, :].repeat(1, 3, 1).to(torch.float32)                                   # superresolution.py:280
     st, dc = batch_styles(block_layers(sr.block0) + block_layers(sr.block1), ws3, [0, 1, 2, 0, 1, 2])
     x, img = feat, feat[..., :3].contiguous()
     r = sr.input_resolution
-    if feat.shape[1] != r:                                                                    # superresolution.py:283-286
+    if _resizes(sr, feat.shape[1]):                                                           # superresolution.py:283-286
         x = dense_ops.resize_bilinear(x, r, r, sr.sr_antialias)
         img = dense_ops.resize_bilinear(img, r, r, sr.sr_antialias)
     saved = [(feat.shape[1], feat.shape[2])]
@@ -139,12 +152,12 @@ def sr_forward_saving(sr, feat, ws, noise_mode):
 
 
 def sr_backward(sr, saved, g_img):
-    """g_img [N,512,512,3] NHWC -> gradient w.r.t. the feature image [N,R,R,32] (its first 3 channels also feed the skip path)."""
+    """g_img [N,out,out,3] NHWC -> gradient w.r.t. the feature image [N,R,R,32] (its first 3 channels also feed the skip path)."""
     g_x = None                                      # gradient w.r.t. the current block's activation from the block after it
     (h_in, w_in), blocks = saved[0], saved[1:]
     for blk, sv in zip((sr.block1, sr.block0), reversed(blocks)):
         g_x, g_img = block_backward(blk, sv, g_img, g_x)
-    if h_in != sr.input_resolution:                 # transpose of the pre-resize of both inputs
+    if _resizes(sr, h_in):                          # transpose of the pre-resize of both inputs
         g_x = dense_ops.resize_bilinear_backward(g_x, h_in, w_in, sr.sr_antialias)
         g_img = dense_ops.resize_bilinear_backward(g_img.contiguous(), h_in, w_in, sr.sr_antialias)
     g_x[..., :3] += g_img                                                                         # rgb = feat[..., :3]

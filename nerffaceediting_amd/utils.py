@@ -59,9 +59,9 @@ class _NotDifferentiableImage(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad):
-        raise RuntimeError("decode(): out['image'] is differentiable with respect to the planes only for SuperresolutionHybrid8XDC "
-                           "(sr_grad.py); for this head build the editing loss on image_raw / image_seg / image_depth, or detach "
-                           "out['image'] explicitly")
+        raise RuntimeError("decode(): out['image'] is differentiable with respect to the planes only for the reference's own "
+                           "super-resolution head classes (sr_grad.HEADS); for this head build the editing loss on image_raw / "
+                           "image_seg / image_depth, or detach out['image'] explicitly")
 
 
 def encode(G, ws, **synthesis_kwargs):

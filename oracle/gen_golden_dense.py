@@ -349,6 +349,39 @@ def gen_sr_variants():
     print("  wrote dense_sr_variants.npz")
 
 
+SR_BWD_VARIANTS = (("SuperresolutionHybrid8X", 512, 64, dict(sr_antialias=True)), ("SuperresolutionHybrid4X", 256, 64, dict(sr_antialias=True)),
+                   ("SuperresolutionHybrid4X", 256, 128, dict(sr_antialias=False)), ("SuperresolutionHybrid2X", 128, 96, dict(sr_antialias=True)),
+                   ("SuperresolutionHybridDeepfp32", 256, 128, dict()))
+
+
+def gen_sr_backward_variants():
+    """Input gradient of the other super-resolution heads by the reference's autograd: heads whose first block does not up-sample
+    (4X, 2X, Deepfp32: SynthesisBlockNoUp), fp32 heads without clamp, inputs smaller / larger than the head's input resolution
+    (4X at its own 128^2: no resize)."""
+    from training import superresolution as ref_sr
+    from oracle.dense_params import params_by_name
+    data = {}
+    for name, res, in_res, kw in SR_BWD_VARIANTS:
+        tag = f"{name}.{in_res}"
+        net = getattr(ref_sr, name)(channels=32, img_resolution=res, sr_num_fp16_res=4, **kw)
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        load(net, params_by_name(81, shapes))
+        rng = np.random.RandomState(zlib_crc("bwd." + tag))
+        with torch.enable_grad():
+            x = t(rng.randn(1, 32, in_res, in_res) * 0.5).requires_grad_(True)
+            ws = t(rng.randn(1, 14, 512))
+            out = net(x[:, :3].clone(), x, ws, noise_mode="none")      # clone: SynthesisBlockNoUp adds to its image in place (:250)
+            cot = t(rng.randn(*out.shape))
+            (g,) = torch.autograd.grad((out * cot).sum(), x)
+        print(f"    reference {tag:36s} out {tuple(out.shape)} |grad| max {float(g.abs().max()):.3g}")
+        # x (x 0.5), ws, cot: regenerated from crc32("bwd." + tag) by the test, in this order
+        st = 4 if in_res >= 128 else 2                       # kept entries: every st-th pixel (the file stays small)
+        data.update({tag + ".stride": st, tag + ".grad_s": g[:, :, ::st, ::st].numpy(), tag + ".grad_sum": g.double().sum(dim=(0, 2, 3)).numpy(),
+                     tag + ".grad_absmax": float(g.abs().max()), tag + ".out_s8": out.detach()[:, :, ::8, ::8].numpy()})
+    np.savez_compressed(os.path.join(OUT, "sr_backward_variants.npz"), seed=81, **data)
+    print("  wrote sr_backward_variants.npz")
+
+
 def zlib_crc(s):
     import zlib
     return zlib.crc32(s.encode()) & 0x7FFFFFFF
@@ -506,6 +539,7 @@ if __name__ == "__main__":
     gen_sr()
     gen_sr_backward()
     gen_sr_backward_r64()
+    gen_sr_backward_variants()
     gen_resize_backward()
     gen_block_backward()
     gen_e2e()

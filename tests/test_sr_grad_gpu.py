@@ -183,6 +183,44 @@ def test_sr_input_gradient_at_resolution_64(dev):
     assert np.abs(grad.double().sum(dim=(0, 2, 3)).numpy() - z["grad_sum"]).max() <= 5e-3 * max(float(np.abs(z["grad_sum"]).max()), 1.0)
 
 
+@pytest.mark.parametrize("tag", ["SuperresolutionHybrid8X.64", "SuperresolutionHybrid4X.64", "SuperresolutionHybrid4X.128",
+                                 "SuperresolutionHybrid2X.96", "SuperresolutionHybridDeepfp32.128"])
+def test_sr_input_gradient_of_the_other_heads(tag, dev):
+    """The two-block heads other than 8XDC (superresolution.py:29-155) against the reference's autograd: a first block without
+    up-sampling (4X, 2X, Deepfp32), fp32 heads without clamp (Deepfp32), plain bilinear and antialiased pre-resizes."""
+    import zlib
+    from oracle.dense_params import params_by_name
+    from nerffaceediting_amd import sr_grad
+    from nerffaceediting_amd.training import superresolution as SR
+    z = load("sr_backward_variants")
+    name, in_res = tag.split(".")
+    in_res = int(in_res)
+    res = {"SuperresolutionHybrid8X": 512, "SuperresolutionHybrid4X": 256, "SuperresolutionHybrid2X": 128, "SuperresolutionHybridDeepfp32": 256}[name]
+    kw = {} if name.endswith("Deepfp32") else dict(sr_antialias=(tag != "SuperresolutionHybrid4X.128"))
+    net = getattr(SR, name)(channels=32, img_resolution=res, sr_num_fp16_res=4, **kw)
+    net = load_module(net, params_by_name(int(z["seed"]), {k: tuple(v.shape) for k, v in net.state_dict().items()}), dev)
+    rng = np.random.RandomState(zlib.crc32(("bwd." + tag).encode()) & 0x7FFFFFFF)
+    x, ws = rng.randn(1, 32, in_res, in_res) * 0.5, rng.randn(1, 14, 512)
+    cot = rng.randn(1, 3, res, res)
+    assert sr_grad.supported(net, in_res)
+    feat = t(x, dev).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    img = sr_grad.SRImage.apply(feat, net, t(ws, dev), "none")
+    ref_img = z[tag + ".out_s8"]
+    assert float((img.detach().permute(0, 3, 1, 2)[:, :, ::8, ::8].cpu() - torch.from_numpy(ref_img)).abs().max()) <= 1e-3 * max(1.0, float(np.abs(ref_img).max()))
+    (img * t(cot, dev).permute(0, 2, 3, 1)).sum().backward()
+    st = int(z[tag + ".stride"])
+    grad = feat.grad.permute(0, 3, 1, 2).cpu()
+    amax, ref = float(z[tag + ".grad_absmax"]), torch.from_numpy(z[tag + ".grad_s"])
+    err = (grad[:, :, ::st, ::st] - ref).abs()
+    rel_l2 = float(((grad[:, :, ::st, ::st] - ref).double().square().sum() / ref.double().square().sum()).sqrt())
+    inside = float((err <= 1e-3 * amax).float().mean())
+    print(f"SR input gradient [{tag}]: max-abs {float(err.max()):.3e}, median {float(err.median()):.2e} (largest entry {amax:.3g}), "
+          f"{100 * inside:.2f} % within 1e-3 of it, relative L2 {rel_l2:.2e}")
+    # (a single flipped unit moves its receptive field by a fixed amount; against the smaller gradients of the 128^2 head that is up to 4.3 %)
+    assert float(err.median()) <= 1e-4 * amax and inside >= 0.98 and rel_l2 <= 6e-3 and float(err.max()) <= 6e-2 * amax
+    assert np.abs(grad.double().sum(dim=(0, 2, 3)).numpy() - z[tag + ".grad_sum"]).max() <= 5e-3 * max(float(np.abs(z[tag + ".grad_sum"]).max()), 1.0)
+
+
 def test_block_backward_with_the_references_slopes(dev):
     """sr_grad.block_backward on one SynthesisBlock against the reference's autograd (gen_block_backward), with the slope of every
     leaky-ReLU unit and every clamp decision PINNED to the reference's forward (the fixture keeps them as bit masks): then every
