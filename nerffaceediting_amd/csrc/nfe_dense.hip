@@ -1745,17 +1745,24 @@ static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st
     hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), grid, dim3(64 * (WV + LW)), bytes, st, K2);
 }
 
-static bool conv3_eligible(int mode, int h, int w, int cin, int cout) {
-    if (cin % 16 != 0 || w < 32 || h < 8) return false;
+// Which layers take the LDS-DMA path.  The tiles are 32 pixels wide; split-bf16 wants images at least that wide (narrower ones waste
+// the MFMA work its K loop is bound by: measured slower), plain bf16 takes everything down to 4 x 4 - the generic kernel has no
+// operand pipeline and spent 79 us per 4^2..16^2 layer at 8 views (tools/r03_small_layers.sh: backbone 2.01 -> 1.83 ms).  The
+// size-only queries of the API (no math argument) answer with the conservative rule.
+static bool conv3_eligible(int mode, int h, int w, int cin, int cout, int math = NFE_CONV_BF16X3) {
+    static const int min_w_env = [] { const char* e = getenv("NFE_C3_MIN_W"); return e ? atoi(e) : 0; }();      // A/B knobs
+    static const int min_h_env = [] { const char* e = getenv("NFE_C3_MIN_H"); return e ? atoi(e) : 0; }();
+    const int min_w = min_w_env ? min_w_env : (math == NFE_CONV_BF16 ? 4 : 32), min_h = min_h_env ? min_h_env : (math == NFE_CONV_BF16 ? 4 : 8);
+    if (cin % 16 != 0 || w < min_w || h < min_h) return false;
     return mode == NFE_CONV_3X3 ? cout % 64 == 0 : (mode == NFE_CONV_3X3_UP2 && cout % 32 == 0);
 }
 
 // Plain 3x3 layers on the LDS-DMA path with too few (tile, M-block group, sample) workgroups to fill the chip twice (32^2 / 64^2
 // layers at small batch): split the K loop over 2 or 4 workgroups, each keeping at least 8 K-groups; partial sums go through
 // splitk_reduce_kernel (deterministic slice order).  0 = no split.
-static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout) {
+static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout, int math = NFE_CONV_BF16X3) {
     static const bool off = [] { const char* e = getenv("NFE_C3_KSPLIT"); return e && e[0] == '0'; }();
-    if (off || mode == NFE_CONV_1X1 || !conv3_eligible(mode, h, w, cin, cout)) return 0;
+    if (off || mode == NFE_CONV_1X1 || !conv3_eligible(mode, h, w, cin, cout, math)) return 0;
     const int G = cin / 16;
     if (mode == NFE_CONV_3X3_UP2) {            // the kernel and the reduce pass support it (NFE_C3_KSPLIT_UP=1), measured without gain at
         static const bool on = [] { const char* e = getenv("NFE_C3_KSPLIT_UP"); return e && e[0] == '1'; }();      // batch 1 and 4: off
@@ -1799,9 +1806,8 @@ extern "C" int nfe_conv_splits_in_epilogue(int mode, int n, int h, int w, int ci
 }
 
 extern "C" int nfe_conv_fuses_rgb(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels) {
-    (void)math;
     if (mode != NFE_CONV_3X3 || rgb_channels < 1 || rgb_channels > 4 || cout > 256 || C3_BIG) return 0;
-    return conv3_eligible(mode, h, w, cin, cout) && conv3_ksplit(mode, n, h, w, cin, cout) == 0 ? 1 : 0;
+    return conv3_eligible(mode, h, w, cin, cout, math) && conv3_ksplit(mode, n, h, w, cin, cout, math) == 0 ? 1 : 0;
 }
 
 extern "C" uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c) {
@@ -1833,10 +1839,10 @@ static int splitk_slices(int mode, int math, int n, int h, int w, int cin, int c
 extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout) {
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
     uint64_t fl = mode == NFE_CONV_3X3_UP2 ? (uint64_t)n * (2 * h + 1) * (2 * w + 1) * cout : 0;     // transposed-conv result
-    if (conv3_eligible(mode, h, w, cin, cout)) {
+    if (conv3_eligible(mode, h, w, cin, cout, math)) {
         const uint64_t elems = (uint64_t)n * h * w * cin;           // bf16 hi (+ lo) image of the modulated input
         fl += math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
-        fl += (uint64_t)conv3_ksplit(mode, n, h, w, cin, cout) * n *
+        fl += (uint64_t)conv3_ksplit(mode, n, h, w, cin, cout, math) * n *
               (mode == NFE_CONV_3X3_UP2 ? (uint64_t)(2 * h + 1) * (2 * w + 1) : (uint64_t)h * w) * cout;          // split-K partial sums
         if (nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, 3)) fl += (uint64_t)(cout / 64) * n * h * w * 4;   // fused-ToRGB partial sums
     } else if (const int ks = splitk_slices(mode, math, n, h, w, cin, cout)) {
@@ -1850,9 +1856,9 @@ extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, in
 extern "C" int nfe_conv_describe(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels, char* buf, int buf_len) {
     NFE_REQUIRE(buf && buf_len > 0, "nfe_conv_describe: no buffer");
     const char* m = math == NFE_CONV_BF16 ? "bf16" : "bf16x3";
-    if (mode != NFE_CONV_1X1 && conv3_eligible(mode, h, w, cin, cout)) {
+    if (mode != NFE_CONV_1X1 && conv3_eligible(mode, h, w, cin, cout, math)) {
         static const char* names[] = {"up2 1x(32x8)/4w", "big 128ch 32x16/4w", "mid 32x16/4w", "x3 32x16/4w (2x4 blocks)", "32x16/8w", "32x8/4w", "128ch 32x16/8w", "32x16/4w compute + 4w loaders"};
-        const int ks = conv3_ksplit(mode, n, h, w, cin, cout);
+        const int ks = conv3_ksplit(mode, n, h, w, cin, cout, math);
         snprintf(buf, (size_t)buf_len, "conv3[%s] %s ksplit=%d fuse_rgb=%d split_in_epilogue=%d%s", names[conv3_variant(mode, math, n, h, w, cout)], m, ks,
                  rgb_channels > 0 ? nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, rgb_channels) : 0,
                  nfe_conv_splits_in_epilogue(mode, n, h, w, cin, cout),
@@ -1902,7 +1908,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         NFE_CHECK_LAUNCH("modsplit_kernel");
         return NFE_OK;
     };
-    const bool fast = a->mode != NFE_CONV_1X1 && a->scratch && conv3_eligible(a->mode, a->h, a->w, a->cin, a->cout) &&
+    const bool fast = a->mode != NFE_CONV_1X1 && a->scratch && conv3_eligible(a->mode, a->h, a->w, a->cin, a->cout, a->math) &&
                       a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout);
     NFE_REQUIRE(!a->x_split || fast, "nfe_modulated_conv: x_split needs the fast path (eligible sizes and nfe_conv_scratch_floats() of scratch)");
     NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || a->out || a->next_split, "nfe_modulated_conv: no output requested");
@@ -1932,7 +1938,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         K.Cin = a->cin; K.Cout = a->cout; K.lrelu = a->lrelu; K.act_gain = a->act_gain; K.clamp = a->clamp; K.out = a->out; K.scratch = a->scratch;
         const int ext = up2 ? 1 : 0;
         const bool bf16 = a->math == NFE_CONV_BF16;
-        const int c3ks = conv3_ksplit(a->mode, a->n, a->h, a->w, a->cin, a->cout);
+        const int c3ks = conv3_ksplit(a->mode, a->n, a->h, a->w, a->cin, a->cout, a->math);
         if (fuse_rgb) {
             K.rgb_w = a->rgb_weight; K.rgb_s = a->rgb_styles; K.rgb_c = a->rgb_channels;
             K.rgb_partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);   // behind the split-image area (no split-K here)
