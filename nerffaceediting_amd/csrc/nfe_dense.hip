@@ -310,21 +310,42 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
             for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.0f;
 
     const int q = tid & 3;                                    // staging: this thread's 4-channel quarter
+    // Register double buffer (round 3): the weights and the input patch of K-group g+1 are requested while K-group g multiplies;
+    // before, every K-group exposed a full global round trip between two barriers (79 us per 4^2..16^2 layer at 8 views).
+    constexpr int A_PER = (TAPS * 2 * 64 + 255) / 256, P_PER = (PUSED * PUSED * 4 + 255) / 256;
+    uint4 ra[A_PER];
+    float4 rp[P_PER], rs4;
+    bool rch_ok;
+    auto request = [&](int g) {
+        const uint4* src = P.packed + ((long long)mb * G + g) * (TAPS * 2 * 64);
+#pragma unroll
+        for (int k = 0; k < A_PER; ++k) { const int i = tid + 256 * k; ra[k] = i < TAPS * 2 * 64 ? src[i] : make_uint4(0, 0, 0, 0); }
+        rch_ok = 16 * g + 4 * q < P.Cin;
+        rs4 = rch_ok ? *reinterpret_cast<const float4*>(P.styles + (long long)n * P.Cin + 16 * g + 4 * q) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < P_PER; ++k) {
+            const int idx = tid + 256 * k;
+            const int pix = idx >> 2, py = pix / PUSED, px = pix % PUSED;
+            const int y = ty0 - HALO + py, x = tx0 - HALO + px;
+            rp[k] = make_float4(0, 0, 0, 0);
+            if (idx < PUSED * PUSED * 4 && rch_ok && y >= 0 && y < P.H && x >= 0 && x < P.W)
+                rp[k] = *reinterpret_cast<const float4*>(P.x + (((long long)n * P.H + y) * P.W + x) * P.Cin + 16 * g + 4 * q);
+        }
+    };
+    if (g_lo < g_hi) request(g_lo);
     for (int g = g_lo; g < g_hi; ++g) {
         __syncthreads();
         // (a) weight fragments of this M-block / K-group: TAPS*2 KiB, contiguous in the packed image
-        const uint4* src = P.packed + ((long long)mb * G + g) * (TAPS * 2 * 64);
-        for (int i = tid; i < TAPS * 2 * 64; i += 256) ldsA[i] = src[i];
+#pragma unroll
+        for (int k = 0; k < A_PER; ++k) { const int i = tid + 256 * k; if (i < TAPS * 2 * 64) ldsA[i] = ra[k]; }
         // (b) input patch * styles -> bf16 hi/lo
-        const bool ch_ok = 16 * g + 4 * q < P.Cin;
-        const float4 s4 = ch_ok ? *reinterpret_cast<const float4*>(P.styles + (long long)n * P.Cin + 16 * g + 4 * q) : make_float4(0, 0, 0, 0);
-        for (int idx = tid; idx < PUSED * PUSED * 4; idx += 256) {
+#pragma unroll
+        for (int k = 0; k < P_PER; ++k) {
+            const int idx = tid + 256 * k;
+            if (idx >= PUSED * PUSED * 4) continue;
             const int pix = idx >> 2, py = pix / PUSED, px = pix % PUSED;
-            const int y = ty0 - HALO + py, x = tx0 - HALO + px;
-            float4 v = make_float4(0, 0, 0, 0);
-            if (ch_ok && y >= 0 && y < P.H && x >= 0 && x < P.W)
-                v = *reinterpret_cast<const float4*>(P.x + (((long long)n * P.H + y) * P.W + x) * P.Cin + 16 * g + 4 * q);
-            v.x *= s4.x; v.y *= s4.y; v.z *= s4.z; v.w *= s4.w;
+            float4 v = rp[k];
+            v.x *= rs4.x; v.y *= rs4.y; v.z *= rs4.z; v.w *= rs4.w;
             unsigned h0, l0, h1, l1;
             split2<TERMS>(v.x, v.y, h0, l0);
             split2<TERMS>(v.z, v.w, h1, l1);
@@ -332,6 +353,7 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
             *reinterpret_cast<uint2*>(ldsP + off) = make_uint2(h0, h1);
             if (TERMS == 3) *reinterpret_cast<uint2*>(ldsP + PATCH_PART_BYTES + off) = make_uint2(l0, l1);
         }
+        if (g + 1 < g_hi) request(g + 1);
         __syncthreads();
 #pragma unroll
         for (int t = 0; t < TAPS; ++t) {
