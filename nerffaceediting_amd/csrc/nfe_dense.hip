@@ -245,11 +245,14 @@ struct ConvK {
 constexpr int PATCH = 18;                                         // 16 + halo
 constexpr int PATCH_PART_BYTES = PATCH * 2 * PATCH * 16;          // one of hi / lo
 
+// bias_act.py:93-125: lrelu(0.2) -> gain -> clamp.  Branch-free and four instructions (round 3; the select / two-compare form was a
+// fifth of the epilogues' arithmetic): max(v, 0.2 v) IS the leaky ReLU (0.2 v > v exactly where v < 0, the same product either
+// way), slope 1 switches it off, the median of (v, -c, c) is the clamp and c = +inf switches that off.  Same bits as the branchy
+// form for every input incl. -0 and NaN (v_med3 returns the minimum when an operand is NaN, as fminf(fmaxf(NaN, -c), c) = -c).
 __device__ __forceinline__ float epilogue_act(float v, int lrelu, float gain, float clamp) {
-    if (lrelu) v = v < 0.0f ? v * 0.2f : v;
-    v *= gain;
-    if (clamp >= 0.0f) v = fminf(fmaxf(v, -clamp), clamp);
-    return v;
+    const float slope = lrelu ? 0.2f : 1.0f, c = clamp >= 0.0f ? clamp : INFINITY;      // uniform: scalar selects
+    v = __builtin_amdgcn_fmed3f(v, v * slope, INFINITY);                                // = max(v, slope * v)
+    return __builtin_amdgcn_fmed3f(v * gain, -c, c);
 }
 
 // upsample2d (upfirdn2d.py:315-350: zero-insert x2, pad (2,1), [1,3,3,1]/8*2 per axis) evaluated at (y,x)
