@@ -949,7 +949,8 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
     // instruction writes full lines (8 pixels x 128 contiguous bytes of fp32, or 32 pixels x 32 bytes = 1 KiB of one 16-channel
     // plane of the consumer's bf16 image) instead of 64 separate 16-byte pieces
     constexpr int ST_STRIDE = 36;
-    float* stile = reinterpret_cast<float*>(lds) + 4 * 32 * MBW + wave * (32 * ST_STRIDE);
+    float* stile = reinterpret_cast<float*>(lds) + 4 * 32 * MBW + wave * (NBW * 32 * ST_STRIDE);      // NBW tiles per wave (one per image row it owns)
+    static_assert(UP2 || (4 * 32 * MBW + WV * NBW * 32 * ST_STRIDE) * 4 <= STAGES * STAGE_BYTES, "epilogue tiles must fit the ring");
     if (KS == 1 || UP2) __syncthreads();               // every wave is done with the last K-group's fragments: LDS is free
     if (fuse_rgb) {
         for (int i = tid; i < P.rgb_c * 32 * MBW; i += 64 * WV) {
@@ -1086,43 +1087,52 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
 #pragma unroll
             for (int c = 0; c < 4; ++c) rgb[nb][c] = 0.0f;
         const int sp = lane >> 1, sh = lane & 1;        // consumer's image: lane = (pixel of 32, 8-channel half of a 16-channel plane)
+        // Loop order m -> channel octet -> row: the per-channel constants of an octet (demodulation, bias, ToRGB weights: 5 LDS reads)
+        // are read ONCE and serve the wave's NBW rows, whose arithmetic covers the next reads' latency; every row has its own
+        // transposition tile.  (Row -> octet re-read them per row: 20 dependent LDS round trips per 32 x 32 block at two to four waves
+        // per SIMD were most of the epilogue's 17 k - 36 k cycles.)
 #pragma unroll
         for (int m = 0; m < MBW; ++m) {
 #pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) {
-                const int y = ty0 + NBW * wave + nb;
-                if (y >= P.H) continue;                 // wave-uniform; lanes beyond the image width compute along and are masked at the store
-                const float nz = nzv[nb];
+            for (int qq = 0; qq < 4; ++qq) {
+                float4 d = make_float4(1, 1, 1, 1), b = make_float4(0.1f, 0.2f, 0.3f, 0.4f), wq[4];
+                if (!((C3_ABM) & 256)) {
+                    d = *reinterpret_cast<const float4*>(ec + 32 * m + 8 * qq + 4 * h);
+                    b = *reinterpret_cast<const float4*>(ec + EC + 32 * m + 8 * qq + 4 * h);
+                }
+                if (fuse_rgb) {
 #pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    // constants from LDS where they are used: held in registers across the (m, nb) blocks they made the 128-register
-                    // variants spill 40 registers into scratch inside the epilogue (32 k cycles per wave, tools/c3_profile.py light form)
-                    float4 d = make_float4(1, 1, 1, 1), b = make_float4(0.1f, 0.2f, 0.3f, 0.4f);
-                    if (!((C3_ABM) & 256)) {
-                        d = *reinterpret_cast<const float4*>(ec + 32 * m + 8 * qq + 4 * h);
-                        b = *reinterpret_cast<const float4*>(ec + EC + 32 * m + 8 * qq + 4 * h);
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (c < P.rgb_c) wq[c] = *reinterpret_cast<const float4*>(wmod + c * 32 * MBW + 32 * m + 8 * qq + 4 * h);
+                }
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb) {
+                    if (ty0 + NBW * wave + nb >= P.H) continue;      // wave-uniform; lanes beyond the image width compute along and are masked at the store
+                    const float nz = nzv[nb];
                     float4 v;
                     v.x = epilogue_act(acc[0][m][nb][4 * qq + 0] * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
                     v.y = epilogue_act(acc[0][m][nb][4 * qq + 1] * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
                     v.z = epilogue_act(acc[0][m][nb][4 * qq + 2] * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
                     v.w = epilogue_act(acc[0][m][nb][4 * qq + 3] * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-                    if (P.out || P.split_hi) *reinterpret_cast<float4*>(stile + j * ST_STRIDE + 8 * qq + 4 * h) = v;
+                    if (P.out || P.split_hi) *reinterpret_cast<float4*>(stile + nb * (32 * ST_STRIDE) + j * ST_STRIDE + 8 * qq + 4 * h) = v;
                     if (fuse_rgb) {
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
-                            if (c < P.rgb_c) {
-                                const float4 wq = *reinterpret_cast<const float4*>(wmod + c * 32 * MBW + 32 * m + 8 * qq + 4 * h);
-                                rgb[nb][c] = fmaf(v.x, wq.x, fmaf(v.y, wq.y, fmaf(v.z, wq.z, fmaf(v.w, wq.w, rgb[nb][c]))));
-                            }
+                            if (c < P.rgb_c) rgb[nb][c] = fmaf(v.x, wq[c].x, fmaf(v.y, wq[c].y, fmaf(v.z, wq[c].z, fmaf(v.w, wq[c].w, rgb[nb][c]))));
                     }
                 }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NBW; ++nb) {
+                const int y = ty0 + NBW * wave + nb;
+                if (y >= P.H) continue;
+                const float* st_nb = stile + nb * (32 * ST_STRIDE);
                 if (P.out) {                    // same-wave LDS operations execute in order: no barrier between the writes above and these reads
                     const long long o_row = (((long long)n * P.H + y) * P.W + tx0) * P.Cout + 32 * (mb0 + m);
 #pragma unroll
                     for (int it = 0; it < 4; ++it) {
                         const int p = 8 * it + (lane >> 3), c = lane & 7;
-                        const float4 v = *reinterpret_cast<const float4*>(stile + p * ST_STRIDE + 4 * c);
+                        const float4 v = *reinterpret_cast<const float4*>(st_nb + p * ST_STRIDE + 4 * c);
                         if ((C3_ABM) & 512) asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
                         else if (tx0 + p < P.W) *reinterpret_cast<float4*>(P.out + o_row + (long long)p * P.Cout + 4 * c) = v;
                     }
@@ -1130,7 +1140,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                 if (P.split_hi) {               // one store instruction = the 32 pixels x 16 channels of one plane of the group-major image:
 #pragma unroll                                  // 1 KiB contiguous (round 3; was 16 pieces of 32 bytes per instruction)
                     for (int gI = 0; gI < 2; ++gI) {
-                        const float* tp = stile + sp * ST_STRIDE + 16 * gI + 8 * sh;
+                        const float* tp = st_nb + sp * ST_STRIDE + 16 * gI + 8 * sh;
                         const float* np_ = ec + 2 * EC + 32 * m + 16 * gI + 8 * sh;
                         const float4 v0 = *reinterpret_cast<const float4*>(tp), v1 = *reinterpret_cast<const float4*>(tp + 4);
                         float4 s0 = make_float4(1, 1, 1, 1), s1 = s0;
