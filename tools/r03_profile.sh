@@ -5,7 +5,7 @@
 export TMPDIR=/tmp
 OUT=gpurun_out/r03_profile
 mkdir -p $OUT
-PMC_KERNEL="render_kernel<false, false, 0, false, false, false, true, false>" bash tools/pmc.sh r03_profile/pmc > $OUT/r03_pmc_render.txt 2>&1
+PMC_KERNEL="render_kernel<false, false, 0, false, false, false, true, false, false>" bash tools/pmc.sh r03_profile/pmc > $OUT/r03_pmc_render.txt 2>&1
 cp $OUT/pmc/issue_floor.json profiles/r03_issue_floor.json
 cp $OUT/pmc/issue_floor.json $OUT/r03_issue_floor.json
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/r03_bench_line.json 2> $OUT/bench.err
