@@ -100,6 +100,14 @@ def test_backward_sweep(seed, dev):
     else:
         for got, want in ((gg, gn), (ga, gd)):
             assert float(np.abs(un(got) - want).max()) <= 1e-3 * float(np.abs(want).max()) + 1e-7, seed
+    # the same gradients from the decoder outputs a split-bf16 forward keeps (tap_sample_colors, ABI v11) instead of the re-evaluation
+    # pass: arbitrary ray counts (untiled ray blocks), broadcast planes, one or two plane sets, absent cotangents
+    out2 = ops.render(pg, pa, ops.decoder_pack(*decp_heads), c["opts"], u_coarse=t(c["u_c"], dev),
+                      u_fine=None if c["u_f"] is None else t(c["u_f"], dev), taps=True, sample_colors=True, **kw)
+    g2, a2 = ops.render_backward(pg, pa, decp_heads, 1.0, c["opts"], out2[4]["depths_all"], cots, sample_colors=out2[4]["sample_colors"], **kw)
+    r2, ra2 = ops.render_backward(pg, pa, decp_heads, 1.0, c["opts"], out2[4]["depths_all"], cots, **kw)
+    for got, ref in ((g2, r2), (a2, ra2)):
+        assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-9, seed
 
 
 @pytest.mark.parametrize("D,Di", [(256, 0), (256, 256), (4, 256), (255, 1), (2, 0)])
