@@ -1345,8 +1345,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK P, long long n
 constexpr int UPFIR_ROWS = NFE_UPFIR_ROWS;     // 2-row output blocks per thread: consecutive blocks share 3 of their 5 filtered rows
 
 #ifndef UPFIR_WAVES
-#define UPFIR_WAVES 3
+#define UPFIR_WAVES 2      // no register cap below what the kernel wants: at 3 waves per SIMD (168 registers) it spilled inside the row loop, and scratch traffic shares the vmcnt queue
 #endif
+// HAS_OUT / PARTS (0: no consumer image, 1: bf16 hi, 2: hi + lo) are compile-time on purpose: with the stores under run-time
+// conditions the compiler cannot count them and waits with `s_waitcnt vmcnt(0)` for the prefetched rows - i.e. for the stores it has
+// just issued as well (loads and stores retire in order on gfx9) - and the read and write streams serialise: 391 us for the SR
+// layer's 1.08 GB, where reads alone take 140 and writes alone 108 (round 3, tools/r03_upfir_ablate.sh).
+template <bool HAS_OUT, int PARTS>
 __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
     // One thread = 4 channels x 2 output columns x 2*UPFIR_ROWS output rows, walking down the image with a sliding
     // window of row-filtered values: 10 loads of T per 4 outputs (separable 4-tap filter per axis) instead of 64,
@@ -1364,7 +1369,7 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
         const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + 4 * c4) : make_float4(1, 1, 1, 1);
         const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
         float4 s2 = make_float4(0, 0, 0, 0);
-        if (P.split_hi) s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
+        if (PARTS) s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
         // row-filtered T row ty: rf[dx] = sum_b F[b] T[ty][X0+dx+b-1].  The five loads are unconditional (clamped address, value
         // zeroed by a select afterwards): with the bounds tests as branches every load sat in its own exec-masked block behind an
         // `s_waitcnt vmcnt(0)` and a thread had one load in flight at a time (round 3: 126 -> see DESIGN 5).
@@ -1412,13 +1417,24 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
             reduce_row(2 * by0 - 1, ta, win[0]); reduce_row(2 * by0, tb, win[1]); reduce_row(2 * by0 + 1, tc, win[2]);
         }
         load_row(2 * by0 + 2, ta); load_row(2 * by0 + 3, tb);
+        // the block's four noise values travel with its rows: read where they are used they were four exposed global round trips
+        // per block (a dependent load behind `s_waitcnt vmcnt(0)` in front of every output pixel)
+        const float* nzp = P.noise ? P.noise + n * P.noise_n_stride + X0 : nullptr;
+        float2 nza = make_float2(0, 0), nzb = make_float2(0, 0);
+        auto load_noise = [&](int Y0_) {
+            if (!nzp) return;
+            nza = *reinterpret_cast<const float2*>(nzp + (long long)Y0_ * OW);          // X0 is even, OW is even: 8-byte aligned
+            nzb = *reinterpret_cast<const float2*>(nzp + (long long)(Y0_ + 1) * OW);
+        };
+        load_noise(2 * by0);
 #pragma unroll 1
         for (int rr = 0; rr < UPFIR_ROWS; ++rr) {
             const int by = by0 + rr;
             if (by >= P.H) break;
             const int Y0 = 2 * by;
             reduce_row(Y0 + 2, ta, win[3]); reduce_row(Y0 + 3, tb, win[4]);
-            if (rr + 1 < UPFIR_ROWS && by + 1 < P.H) { load_row(Y0 + 4, ta); load_row(Y0 + 5, tb); }
+            const float nzv4[2][2] = {{nza.x * P.noise_strength, nza.y * P.noise_strength}, {nzb.x * P.noise_strength, nzb.y * P.noise_strength}};
+            if (rr + 1 < UPFIR_ROWS && by + 1 < P.H) { load_row(Y0 + 4, ta); load_row(Y0 + 5, tb); load_noise(Y0 + 2); }
 #pragma unroll
             for (int dy = 0; dy < 2; ++dy)
 #pragma unroll
@@ -1430,7 +1446,7 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
                         sm.z = fmaf(F[aa], win[dy + aa][dx].z, sm.z); sm.w = fmaf(F[aa], win[dy + aa][dx].w, sm.w);
                     }
                     const int Y = Y0 + dy, X = X0 + dx;
-                    const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
+                    const float nz = nzv4[dy][dx];
                     float4 o;
                     o.x = epilogue_act(sm.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
                     o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
@@ -1441,11 +1457,11 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
                     asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(s2.x));
                     continue;
 #endif
-                    if (P.out) reinterpret_cast<float4*>(P.out)[oi] = o;
-                    if (P.split_hi) {                       // what modsplit_kernel would make of `o` for the next layer (group-major)
+                    if (HAS_OUT) reinterpret_cast<float4*>(P.out)[oi] = o;
+                    if (PARTS) {                            // what modsplit_kernel would make of `o` for the next layer (group-major)
                         unsigned h0, l0, h1, l1;
                         const long long si = split_index(n, C4 >> 2, OH, OW, Y, X, c4);
-                        if (P.split_lo) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
+                        if (PARTS == 2) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
                         else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
                         P.split_hi[si] = make_uint2(h0, h1);
                     }
@@ -1754,6 +1770,15 @@ static int num_cus_dense() {
 #define C3_LC_DEFAULT 0
 #endif
 
+static void launch_upfir(const ConvK& P, long long total, hipStream_t st) {
+    const dim3 grid(grid1d(total, 256, 1 << 15)), block(256);
+    const int parts = P.split_hi ? (P.split_lo ? 2 : 1) : 0;
+#define NFE_UPFIR(O, S) hipLaunchKernelGGL((upfir_kernel<O, S>), grid, block, 0, st, P)
+    if (P.out) { if (parts == 2) NFE_UPFIR(true, 2); else if (parts == 1) NFE_UPFIR(true, 1); else NFE_UPFIR(true, 0); }
+    else { if (parts == 2) NFE_UPFIR(false, 2); else if (parts == 1) NFE_UPFIR(false, 1); else NFE_UPFIR(false, 0); }
+#undef NFE_UPFIR
+}
+
 // Up-sampling layers on the conv3 fast path: FIR + layer epilogue fused into the transposed conv (overlapping 32 x 8 tiles, 1.5x the
 // K-loop work, no fp32 scratch round trip) where that pays: measured per math mode and input width (tools/r03_upfused_ab.sh) -
 // plain bf16 up to 256 input channels; split-bf16, whose K loop is MFMA-bound, only the 32-channel layer at the head's entry.
@@ -2009,7 +2034,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, a->h + ext, a->w + ext_w, st);
             reduce_up();
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
-            hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
+            launch_upfir(P, total, st);
             break;
         }
         case C3V_BIG:       // big tile, one wave per SIMD: 128 channels x 32x16 pixels on 4 waves, as long as the grid still fills the chip twice
@@ -2065,7 +2090,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, up);
         if (up) {
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
-            hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
+            launch_upfir(P, total, st);
         }
         NFE_CHECK_LAUNCH("split-K conv kernels");
         return split_tail();
@@ -2082,7 +2107,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     else {
         launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st);
         const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
-        hipLaunchKernelGGL(upfir_kernel, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, st, P);
+        launch_upfir(P, total, st);
     }
     NFE_CHECK_LAUNCH("conv kernels");
     return split_tail();
