@@ -1267,10 +1267,17 @@ __global__ __launch_bounds__(256, 2) void torgb_kernel(ConvK P) {
         for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
-#pragma unroll 2
+        // the next K-group's 8 input channels and styles are requested before this one's MFMAs (round 3: the loop was
+        // load -> wait -> 3 MFMAs per K-group, one exposed round trip each)
+        float4 nx0 = *reinterpret_cast<const float4*>(xp), nx1 = *reinterpret_cast<const float4*>(xp + 4);
+        float4 ns0 = *reinterpret_cast<const float4*>(sp), ns1 = *reinterpret_cast<const float4*>(sp + 4);
+#pragma unroll 1
         for (int g = 0; g < G; ++g) {
-            const float4 x0 = *reinterpret_cast<const float4*>(xp + 16 * g), x1 = *reinterpret_cast<const float4*>(xp + 16 * g + 4);
-            const float4 s0 = *reinterpret_cast<const float4*>(sp + 16 * g), s1 = *reinterpret_cast<const float4*>(sp + 16 * g + 4);
+            const float4 x0 = nx0, x1 = nx1, s0 = ns0, s1 = ns1;
+            if (g + 1 < G) {
+                nx0 = *reinterpret_cast<const float4*>(xp + 16 * (g + 1)); nx1 = *reinterpret_cast<const float4*>(xp + 16 * (g + 1) + 4);
+                ns0 = *reinterpret_cast<const float4*>(sp + 16 * (g + 1)); ns1 = *reinterpret_cast<const float4*>(sp + 16 * (g + 1) + 4);
+            }
             Frag8 bh, bl;
             split2<TERMS>(x0.x * s0.x, x0.y * s0.y, bh.u[0], bl.u[0]);
             split2<TERMS>(x0.z * s0.z, x0.w * s0.w, bh.u[1], bl.u[1]);
