@@ -293,7 +293,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
                              sample_colors=True)
             e[1].record()
             ops.render_backward(norm, denorm, heads, 1.0, opts, out[4]["depths_all"], cots, cam2world=c2w_t, intrinsics=K_t, resolution=Re,
-                                sample_colors=out[4]["sample_colors"])
+                                sample_colors=out[4]["sample_colors"], sample_colors_resolution=out[4]["sample_colors_resolution"])
             e[2].record()
             ev[i] = e
         dt = timed_steps(args, torch, dist, world, step)
@@ -385,6 +385,7 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
     all-gathered over RCCL while chunk k+1 renders (sharding.ChunkedFrameGather).  Timed like the main loop: barrier +
     synchronize on both sides, MAX over ranks."""
     from nerffaceediting_amd import apps, sharding
+    coll = world > 1 or bool(getattr(args, "force_collective", False))      # one-rank RCCL group: the exchange still runs
     if G is None:
         G = full_generator(torch, dev, D, 0, "bf16")
     G.neural_rendering_resolution = R
@@ -400,7 +401,7 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
         return apps.to_uint8(img)
 
     def one_pass():
-        gat = sharding.ChunkedFrameGather(V, chunk, (G.img_resolution, G.img_resolution, 3), torch.uint8, dev)
+        gat = sharding.ChunkedFrameGather(V, chunk, (G.img_resolution, G.img_resolution, 3), torch.uint8, dev, force_collective=coll)
         ring = apps.StreamRing(dev, getattr(args, "streams", 3))       # chunks rotate over the HIP streams
         for k in range(gat.rounds()):
             sl = gat.local_slice(k)
@@ -411,7 +412,7 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
         G.synthesis(ws_local[:nw].contiguous(), c_all[a:a + nw].contiguous(), noise_mode="const")
     for _ in range(warmup):
         one_pass()
-    if world > 1:
+    if coll:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -419,11 +420,11 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
         out = one_pass()
     torch.cuda.synchronize()
     dt_local = time.perf_counter() - t0         # this rank's own block + its share of the exchanges, before waiting for the others
-    if world > 1:
+    if coll:
         dist.barrier()
     dt = time.perf_counter() - t0
     blocks = [{"rank": rank, "frames": [a, b], "seconds_per_pass_before_barrier": dt_local / max(steps, 1)}]
-    if world > 1:
+    if coll:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -442,10 +443,10 @@ def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, 
 
 def distributed_info(dist, world):
     """What the process group itself reports (not what the command line asked for)."""
-    if world > 1:
+    if world > 1 or dist.is_initialized():      # a one-rank group exists only under --force-collective
         assert dist.is_initialized() and dist.get_world_size() == world, (dist.get_world_size(), world)
         return {"backend": dist.get_backend(), "world_size": dist.get_world_size(),
-                "launcher": os.environ.get("NFE_LAUNCHER", "torch.distributed.run")}
+                "launcher": os.environ.get("NFE_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none (single rank)")}
     return {"backend": None, "world_size": 1, "launcher": None}
 
 
@@ -505,6 +506,9 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the full-synthesis workloads alternate their batches on")
     ap.add_argument("--orbit-frames", type=int, default=512, help="frames of the strong-scaling orbit job (BASELINE config 4)")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the config-4 orbit job reported beside the default line")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="with --gpus 1: still create the (one-rank) RCCL process group and run every frame exchange through it instead of "
+                         "short-circuiting - all of the multi-GPU data path a 1-GPU box can execute (train.py:37-43 precedent)")
     args = ap.parse_args()
 
     from nerffaceediting_amd import launch
@@ -537,8 +541,12 @@ def main():
     from nerffaceediting_amd import ops, sharding
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    coll = world > 1 or args.force_collective
+    if coll:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:                           # no launcher: a one-rank rendezvous of our own
+            os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
+            os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
     dist_info = distributed_info(dist, world)
 
@@ -547,7 +555,7 @@ def main():
         out["distributed"] = dist_info
         if rank == 0:
             print(json.dumps(out))
-        if world > 1:
+        if coll:
             dist.destroy_process_group()
         return
 
@@ -580,11 +588,11 @@ def main():
                                            clock_probe=probes[i] if timed else None)
         if timed:
             ev[i][1].record()
-        if world > 1:                                           # frames of every rank, in view order; the exchange of step i
+        if coll:                                                # frames of every rank, in view order; the exchange of step i
             frames = rgb[:, :3].reshape(VIEWS_PER_GPU, 3, R, R)  # runs under the render of step i+1 (two in flight at most)
             if len(pending) >= 2:
                 pending.pop(0)[0].wait()
-            pending.append(sharding.all_gather_frames_async(frames, n_total))
+            pending.append(sharding.all_gather_frames_async(frames, n_total, force=coll))
         return rgb
 
     for i in range(args.warmup):
@@ -600,7 +608,7 @@ def main():
     drain()
 
     def barrier():
-        if world > 1:
+        if coll:
             dist.barrier()
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -609,7 +617,7 @@ def main():
     drain()                                                     # every frame exchange of the timed steps has completed
     torch.cuda.synchronize(); barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if coll:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -671,7 +679,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:          # reported at N=1 only (host cores are shared by all ranks)
             out["cpu_baseline"] = cpu_baseline(planes_np, dec_np, c2w, K, opts, seed)
         print(json.dumps(out))
-    if world > 1:
+    if coll:
         dist.destroy_process_group()
 
 

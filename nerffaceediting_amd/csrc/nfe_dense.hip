@@ -596,6 +596,9 @@ __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
 // scratch that upfir_kernel filters.
 template <int TERMS, int MBW, int ROWS>
 constexpr int conv3_stage_bytes() { return (MBW * 9 + C3Tile<ROWS>::B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
+// LDS behind the ring for the epilogue constants ec[3][32 * MBW] (demodulation, bias, next styles): the kernel and its launch both
+// size it from here (a fixed + 1024 was 512 bytes short for the MBW = 4 variants, whose third row lay past the allocation)
+template <int MBW> constexpr int conv3_ec_bytes() { return 3 * 32 * MBW * 4 > 1024 ? 3 * 32 * MBW * 4 : 1024; }
 
 // STAGES-deep ring of K-group buffers: the loads of K-group g+STAGES-1 are issued while g is computed, so a
 // load has STAGES-1 K-groups of MFMA time to land.
@@ -743,6 +746,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
     constexpr int EC_OFFSET = STAGES * STAGE_BYTES > FUSED_T_BYTES ? STAGES * STAGE_BYTES : FUSED_T_BYTES;
     float* ec = reinterpret_cast<float*>(lds + EC_OFFSET);
     constexpr int EC = 32 * MBW;
+    static_assert(3 * EC * 4 <= conv3_ec_bytes<MBW>(), "ec[] must fit the bytes launch_conv3 reserves behind the ring");
     const bool own_epilogue = !UP2 && KS == 1;
     if ((own_epilogue || fusedup) && tid < EC && !((C3_ABM) & 256)) {
         const int ch = 32 * mb0 + tid;
@@ -1821,11 +1825,12 @@ static bool up_fused(int math, int ksplit, int cin) {
     return on && !ksplit && cin <= (math == NFE_CONV_BF16 ? max_bf16 : max_x3);
 }
 
+static_assert(conv3_ec_bytes<2>() == 1024 && conv3_ec_bytes<4>() == 1536, "epilogue constants: three float rows of 32 * MBW channels");
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override = 0) {
     constexpr int ROWS = NBW * WV;
     constexpr int ring = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>(), fused_t = UP2 ? 2 * (2 * ROWS) * 64 * 16 : 0;
-    constexpr int bytes = (ring > fused_t ? ring : fused_t) + 1024;                  // ring (or the fused FIR's tile) + the epilogue constants
+    constexpr int bytes = (ring > fused_t ? ring : fused_t) + conv3_ec_bytes<MBW>();  // ring (or the fused FIR's tile) + the epilogue constants
     static bool once = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();

@@ -1118,11 +1118,16 @@ __global__ __launch_bounds__(64) void bwd_accumulate_kernel(BwdK P) {
 #define ACC_V(k) "v[" ACC_STR(ACC_TB) "+" k "]"
 static_assert(BIN_TEXELS == 9, "tap offsets 0, 1, 9, 10 below");
 
-__device__ __forceinline__ void acc_tile_zero() {
+// M0 discipline: s_set_gpr_idx_on / _idx write M0[7:0] and the asm statements below consume it inside the SAME
+// statement, so nothing of ours is live in M0 across a statement boundary; the "m0" clobber tells the compiler that whatever IT
+// kept there is gone (hipcc treats M0 as reserved and answers with -Winline-asm "clobber list contains reserved registers", hence
+// the pragmas).  tests/test_lint_cpu.py::test_accumulate_reg_kernel_register_contract checks the kernel's ISA: no M0 use and no
+// index-mode instruction outside these statements, no scratch, no spills, and the register count that covers the tile.
 #pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"      // "clobber list contains reserved registers": reserving them is the point
+#pragma clang diagnostic ignored "-Winline-asm"
+__device__ __forceinline__ void acc_tile_zero() {
+    // "clobber list contains reserved registers": reserving them is the point
     asm volatile(".set nfe_i, 0\n.rept 81\nv_mov_b32 v[" ACC_STR(ACC_TB) "+nfe_i], 0\n.set nfe_i, nfe_i+1\n.endr" ::: ACC_TOP);
-#pragma clang diagnostic pop
 }
 __device__ __forceinline__ void acc_tile_add(unsigned texel, float w0, float w1, float w2, float w3, float row) {
     asm volatile("s_set_gpr_idx_on %0, 0xc\n" "s_nop 3\n"                       // 0xc: index vdst and src2; wait states: see ACC_NOP_A
@@ -1130,7 +1135,7 @@ __device__ __forceinline__ void acc_tile_add(unsigned texel, float w0, float w1,
                  "v_fma_f32 " ACC_V("1") ", %2, %5, " ACC_V("1") "\n"
                  "v_fma_f32 " ACC_V("9") ", %3, %5, " ACC_V("9") "\n"
                  "v_fma_f32 " ACC_V("10") ", %4, %5, " ACC_V("10") "\n"
-                 "s_set_gpr_idx_off" :: "s"(texel), "s"(w0), "s"(w1), "s"(w2), "s"(w3), "v"(row));
+                 "s_set_gpr_idx_off" :: "s"(texel), "s"(w0), "s"(w1), "s"(w2), "s"(w3), "v"(row) : "m0");
 }
 // four records under one index-mode window (s_set_gpr_idx_idx moves the index; the mode switch is paid once per four)
 __device__ __forceinline__ void acc_tile_add4(const unsigned (&t)[4], const float (&w)[4][4], const float (&r)[4]) {
@@ -1166,9 +1171,10 @@ __device__ __forceinline__ void acc_tile_add4(const unsigned (&t)[4], const floa
                  :: "s"(t[0]), "s"(t[1]), "s"(t[2]), "s"(t[3]),
                     ACC_WC(w[0][0]), ACC_WC(w[0][1]), ACC_WC(w[0][2]), ACC_WC(w[0][3]), ACC_WC(w[1][0]), ACC_WC(w[1][1]), ACC_WC(w[1][2]), ACC_WC(w[1][3]),
                     ACC_WC(w[2][0]), ACC_WC(w[2][1]), ACC_WC(w[2][2]), ACC_WC(w[2][3]), ACC_WC(w[3][0]), ACC_WC(w[3][1]), ACC_WC(w[3][2]), ACC_WC(w[3][3]),
-                    "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]));
+                    "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]) : "m0");
 #undef ACC_FMA4
 }
+#pragma clang diagnostic pop
 #ifndef ACC_GROUP
 #define ACC_GROUP 4
 #endif

@@ -9,6 +9,7 @@ are children, the parent waits for them, forwards rank 0's standard output and r
 waiting in it).  No torch import here: this must stay safe to call before anything initialises HIP.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -38,6 +39,35 @@ def spawn_ranks(script, argv, nprocs, env=None, timeout=None, stdout=None):
                 NFE_LAUNCHER="self")
     base.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this pool (RCCL needs it)
     procs = []
+
+    def stop_all():
+        """terminate, then kill, every rank still alive - by the exact PIDs started here, never by a pattern"""
+        alive = [p for p in procs if p.poll() is None]
+        for p in alive:
+            p.terminate()
+        for p in alive:
+            try:
+                p.wait(10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+
+    # SIGTERM / SIGINT in the parent must not orphan ranks that hold the GPUs (possibly blocked in a collective): turn the signal
+    # into an exception here, and let the finally clause below stop the children.  (Handlers can only be set from the main thread.)
+    restore = {}
+    if threading.current_thread() is threading.main_thread():
+        def on_signal(signum, frame):
+            raise KeyboardInterrupt(f"signal {signum}")
+        for sig in (signal.SIGTERM, signal.SIGINT):
+            restore[sig] = signal.signal(sig, on_signal)
+    try:
+        return _run_ranks(script, argv, nprocs, base, procs, stop_all, timeout, stdout)
+    finally:
+        stop_all()
+        for sig, old in restore.items():
+            signal.signal(sig, old)
+
+
+def _run_ranks(script, argv, nprocs, base, procs, stop_all, timeout, stdout):
     for r in range(nprocs):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=e,
@@ -66,13 +96,7 @@ def spawn_ranks(script, argv, nprocs, env=None, timeout=None, stdout=None):
             if rc == 0:
                 rc = 124
                 print(f"[launch] timeout after {timeout} s; stopping all ranks", file=sys.stderr)
-            for r in live:
-                procs[r].terminate()                               # exact PIDs we started, never a pattern
-            for r in live:
-                try:
-                    procs[r].wait(10)
-                except subprocess.TimeoutExpired:
-                    procs[r].kill()
+            stop_all()                                              # exact PIDs we started, never a pattern
             live.clear()
         else:
             time.sleep(0.05)

@@ -286,6 +286,9 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
                 "sample_colors needs the split-bf16 decoder, no density_noise and no cross decoder"
             tap["sample_colors"] = torch.empty(lib.nfe_render_sample_colors_floats(N, M, D + Di), device=dev)
             a.tap_sample_colors = tap["sample_colors"].data_ptr()
+            # the buffer's ray order follows the launch's ray-block shape (8x4 pixel tiles when resolution % 8 == 0 and resolution^2 ==
+            # n_rays, else 32 consecutive rays): render_backward must be given the same `resolution` and checks it against this
+            tap["sample_colors_resolution"] = int(a.resolution)
     need = lib.nfe_render_workspace_bytes(N, M, D, Di)
     if Di > 0 and a.density_noise > 0:                      # draw index of every merged sample (include/nfe_render.h)
         need += (N * M * (D + Di) * 4 + 255) // 256 * 256
@@ -298,7 +301,7 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
 
 def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, depths_all, grads, *, origins=None, dirs=None,
                     cam2world=None, intrinsics=None, resolution=0, affines=None, channels_first=False, need=(True, True),
-                    sample_colors=None):
+                    sample_colors=None, sample_colors_resolution=None):
     """nfe_render_backward: the vector-Jacobian product of `render` w.r.t. the two plane sets (what autograd does for
     renderer.py:301-363 with the planes as leaves; depths are constants, renderer.py:198,211).
 
@@ -373,6 +376,13 @@ def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, dept
     a.grad_planes_app = ga.data_ptr() if ga is not None else None
     a.grad_view_stride = 0 if bcast else 3 * H * W * 32
     if sample_colors is not None:           # the `sample_colors` tap of the forward call: no re-evaluation pass
+        if sample_colors_resolution is None:
+            raise ValueError("render_backward: sample_colors needs sample_colors_resolution (the `sample_colors_resolution` tap of the "
+                             "forward call): the buffer's ray order depends on the forward launch's resolution")
+        if int(sample_colors_resolution) != int(a.resolution):
+            raise ValueError(f"render_backward: sample_colors were stored by a forward launch with resolution={int(sample_colors_resolution)}, "
+                             f"this call resolves to resolution={int(a.resolution)}: colours would be paired with the wrong rays "
+                             "(pass the same `resolution` to render and render_backward)")
         sample_colors = _dev(sample_colors, "sample_colors", (lib.nfe_render_sample_colors_floats(N, M, S),))
         a.sample_colors = sample_colors.data_ptr()
         keep.append(sample_colors)

@@ -17,12 +17,21 @@ def shard_range(n_views, rank, world_size):
     return start, min(start + per, n_views)
 
 
-def all_gather_frames(local_frames, n_views, group=None):
+def _collective_active(group, force):
+    """A world of one rank normally short-circuits every exchange; `force` keeps the collective (a one-rank RCCL group is all a
+    1-GPU box can offer: it still exercises communicator init, the uint8 all_gather_into_tensor, the staging-buffer reuse and
+    the stream ordering against the render streams - tests/test_rccl_single_gpu.py, bench.py --force-collective)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or bool(force)
+
+
+def all_gather_frames(local_frames, n_views, group=None, force=False):
     """local_frames [v_local, ...] (this rank's block, in order) -> [n_views, ...] on every rank.
 
     Uses one all_gather_into_tensor on padded equal-size blocks (one collective per job or chunk).
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective_active(group, force):
         assert local_frames.shape[0] == n_views
         return local_frames
     world = dist.get_world_size(group)
@@ -36,10 +45,10 @@ def all_gather_frames(local_frames, n_views, group=None):
     return out[:n_views]
 
 
-def all_gather_frames_async(local_frames, n_views, group=None):
+def all_gather_frames_async(local_frames, n_views, group=None, force=False):
     """Same exchange, not waited for: returns (work, frames).  The collective runs on the backend's own stream
     (RCCL: overlapped with whatever the caller launches next); call work.wait() before reading `frames`."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective_active(group, force):
         assert local_frames.shape[0] == n_views
         return None, local_frames
     world = dist.get_world_size(group)
@@ -66,9 +75,9 @@ class ChunkedFrameGather:
     block), and a rank whose block is exhausted submits an empty tensor.
     """
 
-    def __init__(self, n_views, chunk, frame_shape, dtype, device, group=None, max_in_flight=2):
+    def __init__(self, n_views, chunk, frame_shape, dtype, device, group=None, max_in_flight=2, force_collective=False):
         self.n_views, self.chunk, self.group = int(n_views), int(chunk), group
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.active = _collective_active(group, force_collective)
         self.world = dist.get_world_size(group) if self.active else 1
         self.rank = dist.get_rank(group) if self.active else 0
         self.frame_shape, self.dtype, self.device = tuple(frame_shape), dtype, device

@@ -44,6 +44,7 @@ class _RenderWithPlaneGrad(torch.autograd.Function):
                          u_fine=jitter[1], seed=seed, ray_limits=limits, taps=True, decoder_math=renderer.decoder_math, sample_colors=colors)
         ctx.save_for_backward(pg, pa, ray_origins, ray_directions, out[4]["depths_all"])
         ctx.sample_colors = out[4].get("sample_colors")
+        ctx.sample_colors_resolution = out[4].get("sample_colors_resolution")
         ctx.decoder, ctx.options, ctx.same = decoder, dict(options), same
         ctx.shape = tuple(norm_planes.shape)
         if renderer.keep_taps:
@@ -56,7 +57,8 @@ class _RenderWithPlaneGrad(torch.autograd.Function):
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
         gg, ga = ops.render_backward(pg, pg if ctx.same else pa, ctx.decoder.heads(), ctx.decoder.lr_mul, ctx.options, depths_all,
                                      (g_rgb, g_seg, g_depth, g_wsum), origins=o, dirs=d,
-                                     need=(need[0] or (ctx.same and need[1]), need[1] and not ctx.same), sample_colors=ctx.sample_colors)
+                                     need=(need[0] or (ctx.same and need[1]), need[1] and not ctx.same), sample_colors=ctx.sample_colors,
+                                     sample_colors_resolution=ctx.sample_colors_resolution)
         unpack = lambda g: None if g is None else g.permute(0, 1, 4, 2, 3).reshape(ctx.shape)   # gather layout -> [N,3,32,H,W]
         if ctx.same:        # one tensor fed both inputs: its whole gradient goes to whichever slot autograd asked for first
             g = unpack(gg)

@@ -48,10 +48,46 @@ def denormalize_plane(planes, mean, var):
     return out.reshape(N, P, C, H, W)
 
 
+def _make_grid(img, nrow=8, padding=2, pad_value=0.0):
+    """torchvision.utils.make_grid for a [N,C,H,W] batch with N > 1 (the only form utils.render_tensor reaches it in): images left
+    to right, `nrow` per row, `padding` pixels of `pad_value` around every image."""
+    n, c, h, w = img.shape
+    xmaps = min(int(nrow), n)
+    ymaps = -(-n // xmaps)
+    grid = img.new_full((c, (h + padding) * ymaps + padding, (w + padding) * xmaps + padding), pad_value)
+    for k in range(n):
+        y, x = divmod(k, xmaps)
+        grid[:, y * (h + padding) + padding:y * (h + padding) + padding + h, x * (w + padding) + padding:x * (w + padding) + padding + w] = img[k]
+    return grid
+
+
+@torch.no_grad()
+def render_tensor(img, normalize=True, nrow=8):
+    """utils.py:11-30: tensor (or list of [1,C,H,W] tensors) in [-1,1] -> PIL image; a batch becomes a grid of `nrow` columns
+    (torchvision's make_grid layout, restated in _make_grid: torchvision is not a dependency of this package).  Same quirks as the
+    reference: one-channel inputs are broadcast to three, the batch axis of a single image is squeezed away, values are scaled by 255
+    and truncated (not rounded, not clamped) by the uint8 cast."""
+    from PIL import Image
+    if type(img) == list:
+        img = torch.cat(img, dim=0).expand(-1, 3, -1, -1)
+    elif len(img.shape) == 3:
+        img = img.expand(3, -1, -1)
+    elif len(img.shape) == 4:
+        img = img.expand(-1, 3, -1, -1)
+    img = img.squeeze()
+    if normalize:
+        img = img / 2 + .5
+    if len(img.shape) == 3:
+        return Image.fromarray((img.permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8))
+    if len(img.shape) == 2:
+        return Image.fromarray((img.cpu().numpy() * 255).astype(np.uint8))
+    return Image.fromarray((_make_grid(img, nrow=nrow).permute(1, 2, 0).cpu().numpy() * 255).astype(np.uint8))
+
+
 class _NotDifferentiableImage(torch.autograd.Function):
-    """Fallback for the SR configurations sr_grad.py does not cover (heads other than SuperresolutionHybrid8XDC, or a neural
-    rendering resolution that needs the antialiased pre-resize): `image` is tied to the graph through this node so that a loss
-    term on it fails loudly in backward() instead of silently contributing a zero plane gradient."""
+    """Fallback for a super-resolution head class sr_grad.py does not know (sr_grad.supported() accepts every two-block head of the
+    reference at any neural rendering resolution; anything else lands here): `image` is tied to the graph through this node so that
+    a loss term on it fails loudly in backward() instead of silently contributing a zero plane gradient."""
 
     @staticmethod
     def forward(ctx, image, anchor):
@@ -70,9 +106,17 @@ def encode(G, ws, **synthesis_kwargs):
     return planes.view(len(planes), 3, 32, planes.shape[-2], planes.shape[-1])
 
 
-def decode(G, ws, cam, norm_planes, denorm_planes, **synthesis_kwargs):
+def decode(G, ws, cam, norm_planes, denorm_planes, differentiable_image=True, **synthesis_kwargs):
     """utils.py:165-199: render (possibly edited) planes from camera(s) `cam` [N,25].  One plane set may serve
-    several cameras (planes batch 1, N cameras)."""
+    several cameras (planes batch 1, N cameras).
+
+    When a plane tensor requires grad, out['image'] is differentiable as in the reference; that costs memory: the SR head then runs
+    layer by layer and keeps its six activations (about 0.4 GB per 512^2 view) until backward.  An editing loop whose loss never reads
+    out['image'] (e.g. a segmentation loss on image_seg, as optimize_planes) can pass `differentiable_image=False`: the head runs
+    fused, nothing is kept, and out['image'] is a detached tensor (an extension of the reference's signature; the default keeps the
+    reference's behaviour).  The renderer's own kept per-sample colours (192 B per sample) are `G.renderer.keep_sample_colors`.
+    On the differentiable path only `noise_mode` of the synthesis kwargs reaches the head (the reference's other block kwargs -
+    `force_fp32`, `fused_modconv`, `update_emas` - select code paths this package does not have)."""
     cam2world_matrix = cam[:, :16].reshape(-1, 4, 4).contiguous()
     intrinsics = cam[:, 16:25].reshape(-1, 3, 3).contiguous()
     R = G.neural_rendering_resolution
@@ -86,7 +130,7 @@ def decode(G, ws, cam, norm_planes, denorm_planes, **synthesis_kwargs):
         ws = ws.expand(N, -1, -1).contiguous()
     sr_noise = G.rendering_kwargs["superresolution_noise_mode"]
     in_graph = torch.is_grad_enabled() and feature_samples.requires_grad
-    if in_graph and sr_grad.supported(G.superresolution, R):
+    if in_graph and differentiable_image and sr_grad.supported(G.superresolution, R):
         # planes are being optimised: the head runs layer by layer and keeps its activations, `image` carries the gradient
         # back to the feature image through the same MFMA kernels (sr_grad.py), as the reference's decode() does by autograd
         image = sr_grad.SRImage.apply(feat, G.superresolution, ws, sr_noise).permute(0, 3, 1, 2)
@@ -94,7 +138,7 @@ def decode(G, ws, cam, norm_planes, denorm_planes, **synthesis_kwargs):
         sr = G.superresolution.forward_nhwc(rgb, feat, ws, noise_mode=sr_noise,
                                             **{k: v for k, v in synthesis_kwargs.items() if k != "noise_mode"})
         image = dense_ops.nhwc_to_nchw(sr)
-        if in_graph:                             # other SR heads / a pre-resize in front of the head: no backward built
+        if in_graph and differentiable_image:    # an SR head class sr_grad does not know: no backward built
             image = _NotDifferentiableImage.apply(image, feature_samples)
     return {"image_raw": dense_ops.nhwc_to_nchw(rgb), "image": image,
             "image_depth": depth_samples.permute(0, 2, 1).reshape(N, 1, R, R),

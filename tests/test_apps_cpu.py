@@ -89,3 +89,30 @@ def test_sr_gradient_support_table():
     assert sr_grad.supported(SuperresolutionHybrid8XDC(), 128) and sr_grad.supported(SuperresolutionHybrid8XDC(), 64)
     assert sr_grad.supported(SuperresolutionHybrid8XDC(), 512) and not sr_grad.supported(SuperresolutionHybrid8XDC(), 0)
     assert sr_grad.supported(SuperresolutionHybrid4X(), 128) and not sr_grad.supported(SomeOtherHead(), 128)
+
+
+def test_render_tensor_follows_the_reference_conventions():
+    """utils.render_tensor (utils.py:11-30): [-1,1] -> uint8 by x/2 + .5, * 255, truncating cast; one image -> its own size, a
+    batch -> torchvision's make_grid layout (2 px of zero padding around every image, `nrow` images per row), a list of [1,C,H,W]
+    tensors is concatenated, one-channel inputs are broadcast to RGB.  torchvision is not installed here: the grid is checked
+    against make_grid's documented geometry (known-answer)."""
+    from nerffaceediting_amd import utils
+    one = torch.linspace(-1, 1, 3 * 4 * 5).view(1, 3, 4, 5)
+    im = utils.render_tensor(one)
+    assert im.size == (5, 4) and im.mode == "RGB"
+    want = ((one[0] / 2 + .5).permute(1, 2, 0).numpy() * 255).astype(np.uint8)
+    assert np.array_equal(np.asarray(im), want)
+    assert np.asarray(im)[0, 0, 0] == 0 and np.asarray(im)[-1, -1, -1] == 255
+    gray = utils.render_tensor(torch.zeros(1, 1, 4, 5))                           # one channel -> RGB, 0 -> 127 (truncation of 127.5)
+    assert gray.mode == "RGB" and np.asarray(gray).min() == 127 == np.asarray(gray).max()
+    flat = utils.render_tensor(torch.full((4, 5), 0.25), normalize=False)         # a 2-D tensor stays one-channel ('L')
+    assert flat.mode == "L" and flat.size == (5, 4) and int(np.asarray(flat)[0, 0]) == 63
+    batch = [torch.full((1, 3, 4, 5), v) for v in np.linspace(-1, 1, 10)]
+    grid = np.asarray(utils.render_tensor(batch, nrow=8))
+    assert grid.shape == ((4 + 2) * 2 + 2, (5 + 2) * 8 + 2, 3)
+    assert grid[:2].max() == 0 and grid[:, :2].max() == 0                           # padding is pad_value 0 -> 0
+    for k in range(10):
+        y, x = divmod(k, 8)
+        tile = grid[2 + y * 6:2 + y * 6 + 4, 2 + x * 7:2 + x * 7 + 5]
+        assert tile.min() == tile.max() == int((np.float32(np.linspace(-1, 1, 10)[k]) / 2 + .5) * 255), k
+    assert grid[2 + 6:2 + 6 + 4, 2 + 2 * 7:].max() == 0                             # the unused cells of the last row stay empty

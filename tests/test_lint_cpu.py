@@ -15,3 +15,16 @@ def test_no_scalar_combined_lane_mask_selects_in_shipped_kernels():
     assert len(heads) == 4 and all("S1" in l for l in heads), r.stdout[:500]
     for l in heads:
         assert "S1 (select on scalar-combined VALU mask) = 0," in l, l
+
+
+def test_inline_asm_audit_and_accumulate_reg_kernel_register_contract():
+    """tools/asm_audit.py (compile-only): every instruction-bearing `asm` statement of the four .hip files against the hazards hipcc
+    does not pad inside asm strings (cdna_hip_programming.md 5.7) - M0 written and consumed inside ONE statement with its wait
+    states, the VGPR index mode switched off before the statement ends, no VALU-written SGPR feeding an asm VMEM instruction, no
+    MFMA result read by a statement - and the register contract of bwd_accumulate_reg_kernel: no M0 use outside its
+    statements, no scratch, 161 VGPRs (the tile v80..v160 is covered), no compiler instruction inside the reserved range."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_audit.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+    assert "asm audit: 0 violations" in r.stdout
+    assert "s_set_gpr_idx_on" in r.stdout and "M0-1 (4 >= 4 states)" in r.stdout        # the index-mode statements were seen and checked
+    assert "global_load_lds_dwordx4" in r.stdout and "M0-1 (1 >= 1 states)" in r.stdout   # so were conv3_kernel's LDS-DMA statements

@@ -104,7 +104,8 @@ def test_backward_sweep(seed, dev):
     # pass: arbitrary ray counts (untiled ray blocks), broadcast planes, one or two plane sets, absent cotangents
     out2 = ops.render(pg, pa, ops.decoder_pack(*decp_heads), c["opts"], u_coarse=t(c["u_c"], dev),
                       u_fine=None if c["u_f"] is None else t(c["u_f"], dev), taps=True, sample_colors=True, **kw)
-    g2, a2 = ops.render_backward(pg, pa, decp_heads, 1.0, c["opts"], out2[4]["depths_all"], cots, sample_colors=out2[4]["sample_colors"], **kw)
+    g2, a2 = ops.render_backward(pg, pa, decp_heads, 1.0, c["opts"], out2[4]["depths_all"], cots, sample_colors=out2[4]["sample_colors"],
+                                 sample_colors_resolution=out2[4]["sample_colors_resolution"], **kw)
     r2, ra2 = ops.render_backward(pg, pa, decp_heads, 1.0, c["opts"], out2[4]["depths_all"], cots, **kw)
     for got, ref in ((g2, r2), (a2, ra2)):
         assert float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max()) + 1e-9, seed

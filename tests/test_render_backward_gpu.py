@@ -269,7 +269,8 @@ def test_backward_from_kept_sample_colors(N, R, two_pass, dev):
     for a, b in zip(out[:4], plain[:4]):
         assert torch.equal(a, b)                        # keeping the colours does not change the forward's outputs
     ref = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, **kw)
-    got = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, sample_colors=out[4]["sample_colors"], **kw)
+    got = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, sample_colors=out[4]["sample_colors"],
+                              sample_colors_resolution=out[4]["sample_colors_resolution"], **kw)
     for r_, g_ in zip(ref, got):
         scale = float(r_.abs().max())
         assert scale > 0 and float((r_ - g_).abs().max()) <= 1e-6 * scale
@@ -356,3 +357,31 @@ def test_backward_argument_errors(dev):
     with pytest.raises(AssertionError):
         ops.render_backward(packed, packed, heads[:7] + [heads[7][:5]], 1.0, orc.FFHQ_OPTIONS, t(depths, dev), cots,
                             origins=t(o, dev), dirs=t(d, dev))
+
+
+def test_sample_colors_layout_mismatch_is_refused(dev):
+    """the kept per-sample colours are laid out by the forward launch's ray-block shape (8x4 pixel tiles when
+    resolution % 8 == 0, else 32 consecutive rays), and the buffer has the same size either way.  A backward call that resolves to
+    another `resolution` than the forward that filled the buffer must be refused instead of pairing colours with the wrong rays."""
+    from nerffaceediting_amd import ops
+    N, R, D, H = 1, 16, 8, 32
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pn = torch.randn(N, 3, H, H, 32, generator=g).to(dev)
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+    heads = [torch.randn(*s, generator=g).to(dev) * (1.0 if len(s) == 2 else 0.2) for s in shapes]
+    o = torch.zeros(N, R * R, 3, device=dev); o[..., 2] = 2.7
+    d = torch.nn.functional.normalize(torch.randn(N, R * R, 3, generator=g).to(dev) * 0.05 + torch.tensor([0.0, 0.0, -1.0], device=dev), dim=-1)
+    opts = dict(depth_resolution=D, depth_resolution_importance=0, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    out = ops.render(pn, pn, ops.decoder_pack(*heads), opts, origins=o, dirs=d, resolution=R, seed=1, taps=True, sample_colors=True)
+    assert out[4]["sample_colors_resolution"] == R
+    cots = tuple(torch.randn(N, R * R, c, generator=g).to(dev) for c in (32, 15, 1, 1))
+    ok = ops.render_backward(pn, pn, heads, 1.0, opts, out[4]["depths_all"], cots, origins=o, dirs=d, resolution=R,
+                             sample_colors=out[4]["sample_colors"], sample_colors_resolution=out[4]["sample_colors_resolution"])
+    assert torch.isfinite(ok[0]).all()
+    flat = ops.render(pn, pn, ops.decoder_pack(*heads), opts, origins=o[:, :250].contiguous(), dirs=d[:, :250].contiguous(), seed=1, taps=True, sample_colors=True)
+    assert flat[4]["sample_colors_resolution"] == 0                     # 250 rays are no square image: consecutive-ray blocks
+    with pytest.raises(ValueError, match="resolution"):                 # forward tiled at R = 16, backward told the rays are a flat list
+        ops.render_backward(pn, pn, heads, 1.0, opts, out[4]["depths_all"], cots, origins=o, dirs=d, resolution=-1,
+                            sample_colors=out[4]["sample_colors"], sample_colors_resolution=out[4]["sample_colors_resolution"])
+    with pytest.raises(ValueError, match="sample_colors_resolution"):
+        ops.render_backward(pn, pn, heads, 1.0, opts, out[4]["depths_all"], cots, origins=o, dirs=d, resolution=R, sample_colors=out[4]["sample_colors"])

@@ -172,3 +172,44 @@ def test_spawn_ranks_reports_a_failed_rank(tmp_path):
     ok.write_text("import os\nprint('rank', os.environ['RANK'], flush=True)\n")
     rc, text = launch.spawn_ranks(str(ok), [], 2, stdout=io.StringIO())
     assert rc == 0 and text == "rank 0\n"
+
+
+def test_a_terminated_launcher_does_not_orphan_its_ranks(tmp_path):
+    """SIGTERM (or Ctrl-C) in the parent of `spawn_ranks` must stop the rank processes - on a GPU box they hold the
+    devices and may sit in a collective forever.  A launcher process starts two ranks that write their PIDs and sleep; the launcher
+    is sent SIGTERM; both rank PIDs must be gone shortly after."""
+    import signal
+    import time as _t
+    ranks = tmp_path / "sleepers.py"
+    ranks.write_text("import os, time\n"
+                     f"open(os.path.join({str(tmp_path)!r}, 'pid' + os.environ['RANK']), 'w').write(str(os.getpid()))\n"
+                     "time.sleep(120)\n")
+    parent = tmp_path / "parent.py"
+    parent.write_text(f"import sys\nsys.path.insert(0, {ROOT!r})\nfrom nerffaceediting_amd import launch\n"
+                      f"rc, _ = launch.spawn_ranks({str(ranks)!r}, [], 2)\nsys.exit(rc)\n")
+    p = subprocess.Popen([sys.executable, str(parent)], env=_clean_env(), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    try:
+        t0 = _t.time()
+        while not all((tmp_path / f"pid{r}").exists() and (tmp_path / f"pid{r}").read_text() for r in (0, 1)):
+            assert _t.time() - t0 < 60 and p.poll() is None
+            _t.sleep(0.1)
+        pids = [int((tmp_path / f"pid{r}").read_text()) for r in (0, 1)]
+        p.send_signal(signal.SIGTERM)
+        p.wait(30)
+
+        def alive(pid):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                return False
+            try:                                     # a zombie still answers kill(0): look at its state
+                return open(f"/proc/{pid}/stat").read().split(") ")[1][0] != "Z"
+            except OSError:
+                return False
+        t0 = _t.time()
+        while any(alive(pid) for pid in pids) and _t.time() - t0 < 20:
+            _t.sleep(0.1)
+        assert not any(alive(pid) for pid in pids), "rank processes survived their launcher"
+    finally:
+        if p.poll() is None:
+            p.kill()

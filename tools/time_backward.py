@@ -42,10 +42,11 @@ def main():
     out = fwd()
     depths = out[4]["depths_all"]
     colors = out[4].get("sample_colors")
+    colors_res = out[4].get("sample_colors_resolution")
 
     def bwd(need=(True, True)):
         return ops.render_backward(planes_n, planes_d, heads, 1.0, opts, depths, cots, cam2world=c2w, intrinsics=K, resolution=R, need=need,
-                                   sample_colors=colors)
+                                   sample_colors=colors, sample_colors_resolution=colors_res)
 
     def timeit(fn, it=10):
         fn(); torch.cuda.synchronize()
