@@ -103,7 +103,7 @@ struct Axis {
 };
 // Hide a value from the optimiser (no instruction): used where it would otherwise re-combine two per-lane conditions into one
 // scalar-unit mask operation (see above).
-__device__ __forceinline__ float opaque_f(float v) { asm volatile("" : "+v"(v)); return v; }
+__device__ __forceinline__ float opaque_f(float v) { asm volatile("; nfe_launder %0" : "+v"(v)); return v; }
 __device__ __forceinline__ Axis axis_geometry(int size, float g) {
     Axis a;
     const float i = (g + 1.0f) * (0.5f * (float)size) - 0.5f;

@@ -27,7 +27,7 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
         // otherwise fold the multiply into the subtraction below (fma(x, s, -hi): the lo part of the EXACT product) in one producer
         // kernel and not in another, and the consumer's image would depend on which kernel wrote it (round 3: the fused up-sampling
         // epilogue and upfir_kernel differed in the last bit of lo in rare elements).  Defined: hi + lo split the ROUNDED product.
-        asm volatile("" : "+v"(a), "+v"(b));
+        asm volatile("; nfe_launder %0 %1" : "+v"(a), "+v"(b));
         const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
         hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
         bf16x2 p = {(__bf16)(a - __uint_as_float(ua & 0xffff0000u)), (__bf16)(b - __uint_as_float(ub & 0xffff0000u))};

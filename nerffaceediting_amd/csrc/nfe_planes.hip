@@ -37,7 +37,7 @@ __global__ void ray_limits_kernel(const float* __restrict__ origins, const float
         // validity as a chain of selects, each fed by its own compare (no lane masks combined on the scalar unit: lint shape S1)
         float tmin = ((ix < 0 ? half : -half) - ox) * ix, tmax = ((ix < 0 ? -half : half) - ox) * ix;
         const float tymin = ((iy < 0 ? half : -half) - oy) * iy, tymax = ((iy < 0 ? -half : half) - oy) * iy;
-        auto flag = [](bool c) { int v = c ? 1 : 0; asm volatile("" : "+v"(v)); return v; };     // opaque: stays a per-lane integer
+        auto flag = [](bool c) { int v = c ? 1 : 0; asm volatile("; nfe_launder %0" : "+v"(v)); return v; };     // opaque: stays a per-lane integer
         int invalid = flag(tmin > tymax) | flag(tymin > tmax);
         tmin = fmaxf(tmin, tymin); tmax = fminf(tmax, tymax);          // torch.max/min propagate like fmax here
         const float tzmin = ((iz < 0 ? half : -half) - oz) * iz, tzmax = ((iz < 0 ? -half : half) - oz) * iz;

@@ -9,6 +9,9 @@
 // (:288-300).  See DESIGN.md §4 for the lane mapping and the MFMA operand layouts.
 #include "nfe_common.h"
 
+#ifndef NFE_RENDER_WS_DEFAULT
+#define NFE_RENDER_WS_DEFAULT 42    // 0: fused render_kernel; NP * 10 + WPS: render_ws_kernel, NP producer-consumer pairs per workgroup at WPS waves per SIMD
+#endif
 #ifdef NFE_SQUARE_RUNTIME
 #define NFE_SQUARE_RT 1
 #else
@@ -115,10 +118,21 @@ __device__ __forceinline__ float min126_bits(float y) { return __int_as_float(mi
 #ifndef NFE_SOFTPLUS_MINFORM
 #define NFE_SOFTPLUS_MINFORM 0
 #endif
+#ifndef NFE_SOFTPLUS_SCALAR
+#define NFE_SOFTPLUS_SCALAR 0      // 1: plain v_add_f32 instead of v_pk_add_f32 (packed fp32 shares the matrix pipe: it cannot run under an MFMA)
+#endif
+__device__ __forceinline__ float add_f32_plain(float a, float b) {      // an add the SLP vectoriser cannot pair into v_pk_add_f32
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 __device__ __forceinline__ void softplus_log2_x16(f32x16& a) {
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
-#if NFE_SOFTPLUS_MINFORM
+#if NFE_SOFTPLUS_SCALAR
+        const float e0 = add_f32_plain(exp2_fast(-__builtin_fabsf(a[r])), 1.0f), e1 = add_f32_plain(exp2_fast(-__builtin_fabsf(a[r + 1])), 1.0f);
+        a[r] = add_f32_plain(log2_fast(e0), relu_bits(a[r])); a[r + 1] = add_f32_plain(log2_fast(e1), relu_bits(a[r + 1]));
+#elif NFE_SOFTPLUS_MINFORM
         const f32x2 e = f32x2{exp2_fast(min126_bits(a[r])), exp2_fast(min126_bits(a[r + 1]))} + splat(1.0f);
         a[r] = log2_fast(e[0]); a[r + 1] = log2_fast(e[1]);
 #else
@@ -140,7 +154,9 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
 // Launder a value through an empty asm: the optimiser can no longer prove it loop-invariant, so addresses
 // and constants derived from it are recomputed at the point of use (a few VALU ops) instead of being hoisted
 // to the kernel prologue and spilled to scratch (which is what happens at 256 VGPRs otherwise).
-__device__ __forceinline__ int launder(int v) { asm volatile("" : "+v"(v)); return v; }
+// The comment inside the statement names the register in the ISA: tools/asm_audit.py finds the value's real producer and its
+// consumers around the (empty) statement - the hazard recogniser sees the STATEMENT as the producer and pads nothing for it.
+__device__ __forceinline__ int launder(int v) { asm volatile("; nfe_launder %0" : "+v"(v)); return v; }
 
 // ---- quad-cooperative gather ------------------------------------------------------------------------
 // The vector L1 retires one 64-byte request per clock and merges only ADJACENT lanes (4 lanes x 16 contiguous
@@ -196,7 +212,7 @@ template <int I> __device__ __forceinline__ float quad_swizzle(float v) {
     NFE_PIPE_FMA(S, 0, 0) NFE_PIPE_FMA(S, 0, 1) NFE_PIPE_FMA(S, 0, 2) NFE_PIPE_FMA(S, 0, 3)                \
     NFE_PIPE_FMA(S, 1, 0) NFE_PIPE_FMA(S, 1, 1) NFE_PIPE_FMA(S, 1, 2) NFE_PIPE_FMA(S, 1, 3)
 
-template <bool SIGMA_ONLY, int PL, bool DUAL = false>
+template <bool SIGMA_ONLY, int PL, bool DUAL = false, bool INB = false>
 __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, int qoff, const Taps& tp, f32x2 (&sg)[8],
                                                  f32x2 (&qn)[8], f32x2 (&qd)[8], f32x2* sa = nullptr) {
     {
@@ -215,7 +231,7 @@ __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, 
             qd[2 * i + 1] = pk_fma(DUAL ? sa[2 * i + 1] : sg[2 * i + 1], f32x2{sc.z, sc.w}, qd[2 * i + 1]);
         }
     }
-    if (__builtin_amdgcn_ballot_w64(tp.wdef != 0.0f) != 0) {     // rare: some sample of the wave left the plane
+    if (!INB && __builtin_amdgcn_ballot_w64(tp.wdef != 0.0f) != 0) {     // rare: some sample of the wave left the plane
         const float wd[4] = {quad_bcast<0>(tp.wdef), quad_bcast<1>(tp.wdef), quad_bcast<2>(tp.wdef), quad_bcast<3>(tp.wdef)};
         const float4 b = *reinterpret_cast<const float4*>(aff + 1 * 96 + PL * 32 + qoff);
 #pragma unroll
@@ -319,6 +335,93 @@ __device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ 
     plane_affine_acc<false, 2, true>(aff, qoff, tp[2], sg, qn, qd, sa);
 }
 
+// ---- in-bounds fast path of the gather (square planes; round 4) ---------------------------------------------
+// ~90 % of the wave-steps of an FFHQ-like camera have the 2 x 2 footprints of all their 32 samples inside all three planes.  Then
+// nothing of the zeros-padding machinery is needed: no clamped coordinates, no validity selects, no weight deficit (`wdef` == 0
+// exactly), and the four taps of a point sit at fixed distances from the first - +128 bytes (next texel: the load's immediate
+// offset) and +W * 128 bytes (next row: a second scalar base) - so ONE byte offset per (plane, point) goes through the DPP
+// quad-broadcast instead of four.  Saves ~125 vector + 36 DPP instructions of the ~1 000 a wave issues per 32 samples; the kernel
+// is bound by exactly that count.  The arithmetic that produces weights, offsets and sums is the general
+// path's, in the same order: results are bit-identical.  The decision is one ballot -> s_cmp -> s_cbranch_scc per sample (the
+// stable branch form of profiles/experiments/r02_square_branch.md), taken before any load of the sample is in flight.
+#ifndef NFE_INB_FAST
+#define NFE_INB_FAST 1
+#endif
+struct InbAxes { int x0, y0, z0; float fx, fy, fz; };
+// floor coordinate and fraction of the three axes exactly as axis_geometry computes them; true when every lane is inside
+__device__ __forceinline__ bool inb_axes(int size, float gx, float gy, float gz, InbAxes& a) {
+    const float hs = 0.5f * (float)size;
+    const float ix = (gx + 1.0f) * hs - 0.5f, iy = (gy + 1.0f) * hs - 0.5f, iz = (gz + 1.0f) * hs - 0.5f;
+    const float fx0 = floorf(ix), fy0 = floorf(iy), fz0 = floorf(iz);
+    a.fx = ix - fx0; a.fy = iy - fy0; a.fz = iz - fz0;
+    a.x0 = (int)fx0; a.y0 = (int)fy0; a.z0 = (int)fz0;                   // saturating conversion: far-away samples fail the test below
+    const unsigned worst = max(max((unsigned)a.x0, (unsigned)a.y0), (unsigned)a.z0);        // negative -> huge
+    return __builtin_amdgcn_ballot_w64(worst >= (unsigned)(size - 1)) == 0;
+}
+// one 16-byte piece at (uniform base) + (32-bit byte offset) + (compile-time immediate)
+template <int IMM>
+__device__ __forceinline__ float4 texel_piece_imm(const char* __restrict__ base, unsigned byte_off) {
+#ifdef NFE_ABLATE_GATHER
+    return make_float4((float)byte_off, 1.0f, 2.0f, 3.0f);
+#else
+    return *reinterpret_cast<const float4*>(base + byte_off + IMM);
+#endif
+}
+#define NFE_INB_PLANE(PL, A0, B0, FA, FB)          /* plane PL: axis a indexes W (taps a0, a0+1), axis b indexes H */         \
+    off0[PL] = (unsigned)((B0) * W + (A0)) * 128u;                                                                             \
+    { const float ea_ = 1.0f - (FA), eb_ = 1.0f - (FB);                                                                        \
+      wt[PL][0] = ea_ * eb_; wt[PL][1] = (FA) * eb_; wt[PL][2] = ea_ * (FB); wt[PL][3] = (FA) * (FB); }
+#define NFE_INB_VOFF(PL)                                                                                                       \
+    vo[0] = (unsigned)quad_bcast<0>((int)off0[PL]) + qoff_bytes; vo[1] = (unsigned)quad_bcast<1>((int)off0[PL]) + qoff_bytes;  \
+    vo[2] = (unsigned)quad_bcast<2>((int)off0[PL]) + qoff_bytes; vo[3] = (unsigned)quad_bcast<3>((int)off0[PL]) + qoff_bytes;
+#define NFE_INB_ISSUE_I(S, K, I)                                                                                               \
+    vg[S][(K) * 4 + I] = texel_piece_imm<(K) * 128>(b_, vo[I]); wq[S][(K) * 4 + I] = quad_swizzle<I>(wt_[K]);
+#define NFE_INB_ISSUE(S, PL, ROW)                  /* the two taps of row ROW (0 / 1) of plane PL, four points each */          \
+    {                                                                                                                          \
+        const char* b_ = reinterpret_cast<const char*>(pg + (PL) * plane_elems) + ((ROW) ? row_bytes : 0);                     \
+        const float wt_[2] = {wt[PL][2 * (ROW)], wt[PL][2 * (ROW) + 1]};                                                       \
+        NFE_INB_ISSUE_I(S, 0, 0) NFE_INB_ISSUE_I(S, 0, 1) NFE_INB_ISSUE_I(S, 0, 2) NFE_INB_ISSUE_I(S, 0, 3)                    \
+        NFE_INB_ISSUE_I(S, 1, 0) NFE_INB_ISSUE_I(S, 1, 1) NFE_INB_ISSUE_I(S, 1, 2) NFE_INB_ISSUE_I(S, 1, 3)                    \
+    }
+template <bool SIGMA_ONLY>
+__device__ __forceinline__ void gather_pipelined_inb(const float* __restrict__ pg, int W, long long plane_elems,
+                                                     const float* __restrict__ aff, int lane, const InbAxes& a,
+                                                     f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+    unsigned off0[3];
+    float wt[3][4];
+    unsigned vo[4];
+    const long long row_bytes = (long long)W * 128;
+    const int ll = launder(lane);
+    const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
+    const unsigned qoff_bytes = (unsigned)qoff * 4u;
+    float4 vg[2][8];
+    float wq[2][8];
+    f32x2 sg[8];
+    const Taps none{};                                      // plane_affine_acc<.., INB> does not look at it
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
+    NFE_INB_PLANE(0, a.x0, a.y0, a.fx, a.fy)                // project_onto_planes (renderer.py:39-53): p0 = (x, y)
+    NFE_INB_VOFF(0)
+    NFE_INB_ISSUE(0, 0, 0) NFE_INB_ISSUE(1, 0, 1)
+    NFE_INB_PLANE(1, a.x0, a.z0, a.fx, a.fz)                // p1 = (x, z)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(0) NFE_INB_VOFF(1) NFE_INB_ISSUE(0, 1, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(1) NFE_INB_ISSUE(1, 1, 1)
+    plane_affine_acc<SIGMA_ONLY, 0, false, true>(aff, qoff, none, sg, qn, qd);
+    NFE_INB_PLANE(2, a.z0, a.x0, a.fz, a.fx)                // p2 = (z, x)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(0) NFE_INB_VOFF(2) NFE_INB_ISSUE(0, 2, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(1) NFE_INB_ISSUE(1, 2, 1)
+    plane_affine_acc<SIGMA_ONLY, 1, false, true>(aff, qoff, none, sg, qn, qd);
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE_CONSUME(1)
+    plane_affine_acc<SIGMA_ONLY, 2, false, true>(aff, qoff, none, sg, qn, qd);
+}
+
 // experiment helper (NFE_SQUARE_RUNTIME == 6): `H == W` as an integer in an SGPR, opaque to the optimiser
 __device__ __forceinline__ int sq_flag_scc(int H, int W) {
     int f;
@@ -331,6 +434,12 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
                                                  const float* __restrict__ aff, int lane, float gx, float gy, float gz,
                                                  f32x2 (&qn)[8], f32x2 (&qd)[8]) {
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
+#if NFE_INB_FAST && !defined(NFE_SQUARE_RUNTIME)
+    if (SQUARE) {
+        InbAxes ia;
+        if (inb_axes(W, gx, gy, gz, ia)) { gather_pipelined_inb<SIGMA_ONLY>(pg, W, plane_elems, aff, lane, ia, qn, qd); return; }
+    }
+#endif
     Taps tp[3];
     unsigned offs[3][4];
     Axis ax_xw, ax_zh;
@@ -583,6 +692,45 @@ __device__ __forceinline__ void split_hidden(const f32x16& a0, const f32x16& a1,
     }
 }
 
+// Instruction-level interleave of a stage (sched_group_barrier: the scheduler must emit the groups in this order inside the
+// scheduling region that ends at the next sched_barrier(0)).  Without it hipcc clusters a stage's MFMAs at its top and runs the
+// other head's softplus behind them (ISA: "MMMMMM" then 32 x "TTvvPnTTnP"), so the matrix pipe idles under the transcendentals and
+// vice versa; an MFMA holds the SIMD's vector issue for 8 of its 32 cycles only (MI355X_MICROARCH.md, cycle constants), the other
+// 24 take two transcendentals or up to six plain VALU instructions for free.
+#ifndef NFE_MLP_IGLP
+#define NFE_MLP_IGLP 0
+#endif
+#if NFE_MLP_IGLP
+#define NFE_IGLP_MFMA_TRANS(N)                                                                             \
+    _Pragma("unroll") for (int g_ = 0; g_ < (N); ++g_) {                                                   \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                             \
+        __builtin_amdgcn_sched_group_barrier(0x400, NFE_IGLP_T, 0);      /* transcendentals */             \
+        __builtin_amdgcn_sched_group_barrier(0x002, NFE_IGLP_V, 0);      /* other VALU */                  \
+    }
+// a layer-1 stage: every k-step first needs its 8 hidden values split into bf16 pairs (VALU), then issues 3 MFMAs
+#define NFE_IGLP_SPLIT_MFMA_TRANS(KS)                                                                      \
+    _Pragma("unroll") for (int k_ = 0; k_ < (KS); ++k_) {                                                  \
+        __builtin_amdgcn_sched_group_barrier(0x002, NFE_IGLP_SPLIT, 0);  /* split of this k-step */        \
+        _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) {                                                 \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                             \
+            __builtin_amdgcn_sched_group_barrier(0x400, NFE_IGLP_T, 0);                                    \
+            __builtin_amdgcn_sched_group_barrier(0x002, NFE_IGLP_V, 0);                                    \
+        }                                                                                                  \
+    }
+#else
+#define NFE_IGLP_MFMA_TRANS(N)
+#define NFE_IGLP_SPLIT_MFMA_TRANS(KS)
+#endif
+#ifndef NFE_IGLP_SPLIT
+#define NFE_IGLP_SPLIT 20
+#endif
+#ifndef NFE_IGLP_T
+#define NFE_IGLP_T 5
+#endif
+#ifndef NFE_IGLP_V
+#define NFE_IGLP_V 8
+#endif
+
 template <bool CROSS = false>
 __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
                                               int lane, f32x16& og, f32x16& oa) {
@@ -625,6 +773,7 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
     }
     softplus_log2_x16(g0); softplus_log2_x16(g1);
     load_bias1(lds, 0, h, og);
+    NFE_IGLP_MFMA_TRANS(12)
     __builtin_amdgcn_sched_barrier(0);
     // ---- S4
 #pragma unroll
@@ -638,6 +787,7 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
     }
     softplus_log2_x16(p0); softplus_log2_x16(p1);
     load_bias1(lds, 1, h, oa);
+    NFE_IGLP_SPLIT_MFMA_TRANS(4)
     __builtin_amdgcn_sched_barrier(0);
     // ---- S5
 #pragma unroll
@@ -660,6 +810,116 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- the same pairing, interleaved by hand at instruction level (round 4) -------------------------------
+// hipcc schedules a stage of mlp_pair_bf16 as "all MFMAs, then all of the other head's softplus" (sched_group_barrier patterns
+// were honoured for one stage and silently dropped for the other), so the two pipes take turns instead of overlapping.  Here every
+// MFMA is followed by a fixed share of the partner head's vector work and a scheduling fence: the MFMA holds the SIMD's vector
+// issue for 8 of its 32 cycles, the transcendentals behind it run in the other 24.
+#ifndef NFE_MLP_INTERLEAVE
+#define NFE_MLP_INTERLEAVE 0
+#endif
+__device__ __forceinline__ void softplus_pair(f32x16& a0, f32x16& a1, int p) {       // values 2p, 2p + 1 of the 32 hidden units a lane holds
+    f32x16& a = p < 8 ? a0 : a1;
+    const int r = 2 * (p & 7);
+#if NFE_SOFTPLUS_SCALAR
+    const float e0 = add_f32_plain(exp2_fast(-__builtin_fabsf(a[r])), 1.0f), e1 = add_f32_plain(exp2_fast(-__builtin_fabsf(a[r + 1])), 1.0f);
+    a[r] = add_f32_plain(log2_fast(e0), relu_bits(a[r])); a[r + 1] = add_f32_plain(log2_fast(e1), relu_bits(a[r + 1]));
+#else
+    const f32x2 e = f32x2{exp2_fast(-__builtin_fabsf(a[r])), exp2_fast(-__builtin_fabsf(a[r + 1]))} + splat(1.0f);
+    const f32x2 l = f32x2{log2_fast(e[0]), log2_fast(e[1])} + f32x2{relu_bits(a[r]), relu_bits(a[r + 1])};
+    a[r] = l[0]; a[r + 1] = l[1];
+#endif
+}
+// softplus pairs issued behind MFMA i of a 12-MFMA stage (16 pairs in all)
+#define NFE_IL_SHARE(I) (((I) % 3) == 0 ? 2 : 1)
+#define NFE_IL_SOFTPLUS(A0, A1, I)                                                                         \
+    {                                                                                                      \
+        _Pragma("unroll") for (int c_ = 0; c_ < NFE_IL_SHARE(I); ++c_) softplus_pair(A0, A1, pi_++);        \
+        __builtin_amdgcn_sched_barrier(0);                                                                 \
+    }
+
+__device__ __forceinline__ void mlp_pair_bf16_il(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
+                                                 int lane, f32x16& og, f32x16& oa) {
+    lane = launder(lane);
+    const int h = lane >> 5;
+    const uint4* F = reinterpret_cast<const uint4*>(lds) + lane;
+    __builtin_amdgcn_sched_barrier(0);
+    Frag gh[2], gl[2], ah[2], al[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int w = 0; w < 4; ++w) split_pair(fn[4 * s + w][0], fn[4 * s + w][1], gh[s].u[w], gl[s].u[w]);
+    f32x16 g0, g1, p0, p1;
+    load_bias0(lds, 0, h, g0, g1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S2: geometry layer 0 | appearance features -> bf16 pairs (two words behind each of the first eight MFMAs... one per MFMA)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        Frag h0, l0, h1, l1;
+        h0.q = NFE_L0_FRAG(0, 0, s, 0); l0.q = NFE_L0_FRAG(0, 0, s, 1);
+        h1.q = NFE_L0_FRAG(0, 1, s, 0); l1.q = NFE_L0_FRAG(0, 1, s, 1);
+        g0 = NFE_MFMA_BF16(h0, gh[s], g0); split_pair(fd[4 * s + 0][0], fd[4 * s + 0][1], ah[s].u[0], al[s].u[0]); __builtin_amdgcn_sched_barrier(0);
+        g1 = NFE_MFMA_BF16(h1, gh[s], g1); split_pair(fd[4 * s + 1][0], fd[4 * s + 1][1], ah[s].u[1], al[s].u[1]); __builtin_amdgcn_sched_barrier(0);
+        g0 = NFE_MFMA_BF16(h0, gl[s], g0); split_pair(fd[4 * s + 2][0], fd[4 * s + 2][1], ah[s].u[2], al[s].u[2]); __builtin_amdgcn_sched_barrier(0);
+        g1 = NFE_MFMA_BF16(h1, gl[s], g1); split_pair(fd[4 * s + 3][0], fd[4 * s + 3][1], ah[s].u[3], al[s].u[3]); __builtin_amdgcn_sched_barrier(0);
+        g0 = NFE_MFMA_BF16(l0, gh[s], g0); g1 = NFE_MFMA_BF16(l1, gh[s], g1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    load_bias0(lds, 1, h, p0, p1);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S3: appearance layer 0 | softplus of the geometry hidden layer
+    {
+        int pi_ = 0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            Frag h0, l0, h1, l1;
+            h0.q = NFE_L0_FRAG(1, 0, s, 0); l0.q = NFE_L0_FRAG(1, 0, s, 1);
+            h1.q = NFE_L0_FRAG(1, 1, s, 0); l1.q = NFE_L0_FRAG(1, 1, s, 1);
+            p0 = NFE_MFMA_BF16(h0, ah[s], p0); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 0)
+            p1 = NFE_MFMA_BF16(h1, ah[s], p1); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 1)
+            p0 = NFE_MFMA_BF16(h0, al[s], p0); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 2)
+            p1 = NFE_MFMA_BF16(h1, al[s], p1); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 3)
+            p0 = NFE_MFMA_BF16(l0, ah[s], p0); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 4)
+            p1 = NFE_MFMA_BF16(l1, ah[s], p1); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 5)
+        }
+    }
+    load_bias1(lds, 0, h, og);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S4: geometry layer 1 (k-step: split its 8 hidden values, 3 MFMAs) | softplus of the appearance hidden layer
+    {
+        int pi_ = 0;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Frag hh, hl, wh, wl;
+            split_hidden(g0, g1, s, hh, hl);
+            wh.q = NFE_L1_FRAG(0, s, 0); wl.q = NFE_L1_FRAG(0, s, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            og = NFE_MFMA_BF16(wh, hh, og); NFE_IL_SOFTPLUS(p0, p1, 3 * s + 0)
+            og = NFE_MFMA_BF16(wh, hl, og); NFE_IL_SOFTPLUS(p0, p1, 3 * s + 1)
+            og = NFE_MFMA_BF16(wl, hh, og); NFE_IL_SOFTPLUS(p0, p1, 3 * s + 2)
+        }
+    }
+    load_bias1(lds, 1, h, oa);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- S5: appearance layer 1 | appearance hidden -> bf16 pairs (the split of k-step s + 1 runs behind the MFMAs of k-step s)
+    {
+        Frag hh, hl, nh, nl;
+        split_hidden(p0, p1, 0, hh, hl);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            Frag wh, wl;
+            wh.q = NFE_L1_FRAG(1, s, 0); wl.q = NFE_L1_FRAG(1, s, 1);
+            oa = NFE_MFMA_BF16(wh, hh, oa);
+            if (s < 3) split_hidden(p0, p1, s + 1, nh, nl);
+            oa = NFE_MFMA_BF16(wh, hl, oa);
+            oa = NFE_MFMA_BF16(wl, hh, oa);
+            hh = nh; hl = nl;
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // The decoder proper (DisentangledOSGDecoder.forward after the mean over planes, triplane.py:254-270) on features that
 // are already in "own" layout: fn / fd = channels 16h..16h+15 of this lane's point of the geometry / appearance set.
 // Outputs as eval_point documents them.
@@ -676,7 +936,8 @@ __device__ __forceinline__ void decode_features(const float* __restrict__ lds, c
 #endif
     constexpr bool PAIR = NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3;
     static_assert(!CROSS || (NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3), "the cross term lives in the paired split-bf16 decoder");
-    if (PAIR) mlp_pair_bf16<CROSS>(lds, fn, fd, lane, og, oa);
+    if (PAIR && NFE_MLP_INTERLEAVE && !CROSS) mlp_pair_bf16_il(lds, fn, fd, lane, og, oa);
+    else if (PAIR) mlp_pair_bf16<CROSS>(lds, fn, fd, lane, og, oa);
     else if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og);
     else mlp_bf16(lds, fn, 0, lane, og);
     if (!SIGMA_ONLY) {
@@ -1033,6 +1294,478 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
 }
 
 
+// ------------------------------------------------------------------------------------------
+// Wave-specialised form of the single-set, split-bf16 render launch (round 4).
+//
+// render_kernel above is one program per wave: gather (112 VGPRs at its peak), decoder (96 + fragments) and march state (48) add
+// up to 256 registers + spills = two waves per SIMD, and the wave spends half its life not issuing.  Here the two
+// halves of that program run in DIFFERENT waves of one workgroup, so that neither needs more than 128 registers (four waves per
+// SIMD) and the matrix work of one wave runs beside the texture / vector work of another:
+//   producer wave p (waves 0 .. NP-1):   depth schedule, tap geometry, quad-cooperative gather, per-plane affines  ->  the two
+//       32-point x 32-channel feature tiles of its pair in LDS - the very tile exchange_to_own() used for the quad -> own
+//       transposition, so the hand-off costs no LDS traffic the fused kernel did not already have;
+//   consumer wave NP + p:                reads its lane's 16 channels in MFMA-operand order, both decoder heads (split-bf16 MFMA),
+//       sigmoid, mid-point compositing, outputs.
+// Synchronisation is two monotone counters per pair in LDS (`full`: tiles written by the producer, `taken`: tiles read by the
+// consumer; geometry and appearance tiles count separately, so each counter moves twice per sample).  Tiles are single-buffered:
+// the producer works on sample k+1 while the consumer decodes sample k and only blocks at its write if the consumer has not yet
+// read the previous tile - the consumer is the slower role, so that wait is the back-pressure that keeps the pair in step.
+// s_barrier cannot do this (every wave of the block would wait for the slowest), and gfx950 has no named barriers.
+// Waves w and w + 4 of a workgroup share a SIMD (MI355X_MICROARCH.md, "waves go to SIMDs in the cyclic order"), so with NP = 4
+// every SIMD holds a producer and the consumer of the same pair, twice over with two workgroups per CU.
+// Outputs are bit-identical to render_kernel's: same tap order in the bilinear sums, same MFMA order in each head (mlp_bf16), same
+// march arithmetic (tests/test_render_gpu.py::test_wave_specialised_kernel_is_bit_identical).
+// ------------------------------------------------------------------------------------------
+constexpr int WS_T_OFF = 2 * XCHG_FLOATS;                   // per pair, behind the affines: geometry tile, appearance tile,
+constexpr int WS_FLAG_OFF = WS_T_OFF + 32;                  // 32 depths, then {full, taken, abort, -}
+constexpr int WS_PAIR_FLOATS = AFF_FLOATS + WS_FLAG_OFF + 4;
+static_assert(WS_PAIR_FLOATS % 4 == 0 && AFF_FLOATS % 4 == 0, "16-byte aligned tiles");
+template <int NP> constexpr int ws_lds_bytes() { return (DEC_FLOATS + NP * WS_PAIR_FLOATS) * 4; }
+#ifndef WS_SLEEP
+#define WS_SLEEP 2
+#endif
+constexpr int WS_SPIN_LIMIT = 1 << 18;                      // x (s_sleep 1 + an LDS read) ~ 50 ms: a lost partner ends the wait, never the box
+
+// Wait until *flag has reached `need` (wrap-safe).  Returns false when the wait was abandoned: the flag's pair is then marked
+// aborted and every later wait of the pair returns at once - the launch finishes with garbage in that pair's rays and a count in
+// depth_minmax[2] instead of hanging the GPU.
+__device__ __forceinline__ bool ws_wait(unsigned* flags, int which, unsigned need) {
+    int spins = 0;
+    while (true) {
+        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(v - need) >= 0) return true;
+        const unsigned ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (ab != 0u) return false;
+        if (++spins > WS_SPIN_LIMIT) {
+            __hip_atomic_store(flags + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(WS_SLEEP);
+    }
+}
+// Publish: every LDS access this wave issued before is complete (release), then the counter moves.
+__device__ __forceinline__ void ws_signal(unsigned* flags, int which, unsigned value, int lane) {
+    if (lane == 0) __hip_atomic_store(flags + which, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The producer's gather: as gather_pipelined, but a batch is ONE tap of the quad's four points (4 loads) and three batches are in
+// flight (48 data registers instead of 64): the tap order of the bilinear sums is unchanged.
+#define NFE_WS_ISSUE_I(S, I)                                                                               \
+    vg[S][I] = texel_piece(base_, (unsigned)quad_bcast<I>((int)off_) + qoff_bytes); wq[S][I] = quad_swizzle<I>(wk_);
+#define NFE_WS_ISSUE(S, PL, K)                                                                             \
+    {                                                                                                      \
+        const float* base_ = pg + (PL) * plane_elems;                                                      \
+        const unsigned off_ = offs[PL][K];                                                                 \
+        const float wk_ = tp[PL].w[K];                                                                     \
+        NFE_WS_ISSUE_I(S, 0) NFE_WS_ISSUE_I(S, 1) NFE_WS_ISSUE_I(S, 2) NFE_WS_ISSUE_I(S, 3)                \
+    }
+#define NFE_WS_CONSUME(S)                                                                                  \
+    _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                     \
+        const f32x2 w2 = splat(wq[S][i_]);                                                                 \
+        sg[2 * i_ + 0] = pk_fma(w2, f32x2{vg[S][i_].x, vg[S][i_].y}, sg[2 * i_ + 0]);                      \
+        sg[2 * i_ + 1] = pk_fma(w2, f32x2{vg[S][i_].z, vg[S][i_].w}, sg[2 * i_ + 1]);                      \
+    }
+#ifndef NFE_WS_FLIGHT
+#define NFE_WS_FLIGHT 2            // tap batches (4 loads each) in flight in the producer's gather: 2 or 3
+#endif
+// the producer's gather on the in-bounds fast path (see gather_pipelined_inb): one byte offset per (plane, point)
+#define NFE_WSI_ISSUE(S, PL, K)                                                                            \
+    {                                                                                                      \
+        const char* b_ = reinterpret_cast<const char*>(pg + (PL) * plane_elems) + (((K) >> 1) ? row_bytes : 0); \
+        const float wk_ = wt[PL][K];                                                                       \
+        vg[S][0] = texel_piece_imm<((K) & 1) * 128>(b_, vo[PL][0]); wq[S][0] = quad_swizzle<0>(wk_);       \
+        vg[S][1] = texel_piece_imm<((K) & 1) * 128>(b_, vo[PL][1]); wq[S][1] = quad_swizzle<1>(wk_);       \
+        vg[S][2] = texel_piece_imm<((K) & 1) * 128>(b_, vo[PL][2]); wq[S][2] = quad_swizzle<2>(wk_);       \
+        vg[S][3] = texel_piece_imm<((K) & 1) * 128>(b_, vo[PL][3]); wq[S][3] = quad_swizzle<3>(wk_);       \
+    }
+#define NFE_WSI_VOFF(PL)                                                                                   \
+    vo[PL][0] = (unsigned)quad_bcast<0>((int)off0[PL]) + qoff_bytes; vo[PL][1] = (unsigned)quad_bcast<1>((int)off0[PL]) + qoff_bytes; \
+    vo[PL][2] = (unsigned)quad_bcast<2>((int)off0[PL]) + qoff_bytes; vo[PL][3] = (unsigned)quad_bcast<3>((int)off0[PL]) + qoff_bytes;
+__device__ __forceinline__ void gather_pipelined_ws_inb(const float* __restrict__ pg, int W, long long plane_elems,
+                                                        const float* __restrict__ aff, int lane, const InbAxes& a,
+                                                        f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+    unsigned off0[3];
+    float wt[3][4];
+    unsigned vo[3][4];
+    const long long row_bytes = (long long)W * 128;
+    const int ll = launder(lane);
+    const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
+    const unsigned qoff_bytes = (unsigned)qoff * 4u;
+    float4 vg[NFE_WS_FLIGHT][4];
+    float wq[NFE_WS_FLIGHT][4];
+    f32x2 sg[8];
+    const Taps none{};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
+#define NFE_WS_SLOT(N) ((N) % NFE_WS_FLIGHT)
+#define NFE_WSI_STEP(N)                                                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    NFE_WS_CONSUME(NFE_WS_SLOT(N))                                                                         \
+    if ((N) + NFE_WS_FLIGHT < 12) NFE_WSI_ISSUE(NFE_WS_SLOT(N), ((N) + NFE_WS_FLIGHT) / 4, ((N) + NFE_WS_FLIGHT) % 4)
+    NFE_INB_PLANE(0, a.x0, a.y0, a.fx, a.fy)
+    NFE_WSI_VOFF(0)
+    NFE_WSI_ISSUE(0, 0, 0) NFE_WSI_ISSUE(1, 0, 1)
+    if (NFE_WS_FLIGHT == 3) NFE_WSI_ISSUE(2 % NFE_WS_FLIGHT, 0, 2)
+    NFE_INB_PLANE(1, a.x0, a.z0, a.fx, a.fz)
+    NFE_WSI_VOFF(1)
+    NFE_WSI_STEP(0) NFE_WSI_STEP(1) NFE_WSI_STEP(2) NFE_WSI_STEP(3)
+    plane_affine_acc<false, 0, false, true>(aff, qoff, none, sg, qn, qd);
+    NFE_INB_PLANE(2, a.z0, a.x0, a.fz, a.fx)
+    NFE_WSI_VOFF(2)
+    NFE_WSI_STEP(4) NFE_WSI_STEP(5) NFE_WSI_STEP(6) NFE_WSI_STEP(7)
+    plane_affine_acc<false, 1, false, true>(aff, qoff, none, sg, qn, qd);
+    NFE_WSI_STEP(8) NFE_WSI_STEP(9) NFE_WSI_STEP(10) NFE_WSI_STEP(11)
+    plane_affine_acc<false, 2, false, true>(aff, qoff, none, sg, qn, qd);
+#undef NFE_WSI_STEP
+#undef NFE_WS_SLOT
+}
+
+template <bool SQUARE>
+__device__ __forceinline__ void gather_pipelined_ws(const float* __restrict__ pg, int H, int W, long long plane_elems,
+                                                    const float* __restrict__ aff, int lane, float gx, float gy, float gz,
+                                                    f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+#if NFE_INB_FAST
+    if (SQUARE) {
+        InbAxes ia;
+        if (inb_axes(W, gx, gy, gz, ia)) { gather_pipelined_ws_inb(pg, W, plane_elems, aff, lane, ia, qn, qd); return; }
+    }
+#endif
+    Taps tp[3];
+    unsigned offs[3][4];
+    Axis ax_xw, ax_zh;
+    if (SQUARE) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) } else { NFE_PIPE_GEOM(0, gx, gy) }
+    const int ll = launder(lane);
+    const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
+    const unsigned qoff_bytes = (unsigned)qoff * 4u;
+    float4 vg[NFE_WS_FLIGHT][4];
+    float wq[NFE_WS_FLIGHT][4];
+    f32x2 sg[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
+    // tap n = 4 * plane + k goes through slot n % NFE_WS_FLIGHT; consume(n) is followed by issue(n + NFE_WS_FLIGHT)
+#define NFE_WS_SLOT(N) ((N) % NFE_WS_FLIGHT)
+#define NFE_WS_STEP(N)                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                     \
+    NFE_WS_CONSUME(NFE_WS_SLOT(N))                                                                         \
+    if ((N) + NFE_WS_FLIGHT < 12) NFE_WS_ISSUE(NFE_WS_SLOT(N), ((N) + NFE_WS_FLIGHT) / 4, ((N) + NFE_WS_FLIGHT) % 4)
+    NFE_WS_ISSUE(0, 0, 0) NFE_WS_ISSUE(1, 0, 1)
+    if (NFE_WS_FLIGHT == 3) NFE_WS_ISSUE(2 % NFE_WS_FLIGHT, 0, 2)
+    if (SQUARE) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) } else { NFE_PIPE_GEOM(1, gx, gz) }
+    NFE_WS_STEP(0) NFE_WS_STEP(1) NFE_WS_STEP(2) NFE_WS_STEP(3)
+    plane_affine_acc<false, 0>(aff, qoff, tp[0], sg, qn, qd);
+    if (SQUARE) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_PIPE_GEOM(2, gz, gx) }
+    NFE_WS_STEP(4) NFE_WS_STEP(5) NFE_WS_STEP(6) NFE_WS_STEP(7)
+    plane_affine_acc<false, 1>(aff, qoff, tp[1], sg, qn, qd);
+    NFE_WS_STEP(8) NFE_WS_STEP(9) NFE_WS_STEP(10) NFE_WS_STEP(11)
+    plane_affine_acc<false, 2>(aff, qoff, tp[2], sg, qn, qd);
+#undef NFE_WS_STEP
+#undef NFE_WS_SLOT
+}
+
+// quad layout (channels 16h+4c.. of the quad's four points) -> the pair's tile, exchange_to_own()'s write half
+__device__ __forceinline__ void ws_write_tile(float* __restrict__ xp, int lane, const f32x2 (&fq)[8]) {
+    lane = launder(lane);
+    const int Q = lane >> 2, c = lane & 3, h = lane >> 5;
+    const int row0 = 4 * (Q & 7);
+    float* wr = xp + row0 * 32 + 4 * ((4 * h + c) ^ xchg_swz(row0));
+    float* wr2 = xp + row0 * 32 + 4 * ((4 * h + c) ^ xchg_swz(row0 + 2));
+    *reinterpret_cast<float4*>(wr) = make_float4(fq[0][0], fq[0][1], fq[1][0], fq[1][1]);
+    *reinterpret_cast<float4*>(wr + 32) = make_float4(fq[2][0], fq[2][1], fq[3][0], fq[3][1]);
+    *reinterpret_cast<float4*>(wr2 + 64) = make_float4(fq[4][0], fq[4][1], fq[5][0], fq[5][1]);
+    *reinterpret_cast<float4*>(wr2 + 96) = make_float4(fq[6][0], fq[6][1], fq[7][0], fq[7][1]);
+}
+// ... and its read half: channels 16h..16h+15 of this lane's own point
+__device__ __forceinline__ void ws_read_tile(const float* __restrict__ xp, int lane, f32x2 (&fo)[8]) {
+    const int h = lane >> 5, j = lane & 31;
+    const int rd = j * 32 + 4 * ((4 * h) ^ xchg_swz(j));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(xp + (rd ^ (4 * q)));
+        fo[2 * q + 0] = f32x2{v.x, v.y};
+        fo[2 * q + 1] = f32x2{v.z, v.w};
+    }
+}
+
+template <int NP, int WPS, bool SQUARE, bool GENERIC>
+__global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    for (int i = threadIdx.x; i < DEC_B_G0 / 4; i += NP * 128)
+        reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(P.dec + DEC_BF16)[i];
+    for (int i = threadIdx.x; i < (DEC_FLOATS - DEC_B_G0) / 4; i += NP * 128)
+        reinterpret_cast<float4*>(lds + DEC_B_G0)[i] = reinterpret_cast<const float4*>(P.dec + DEC_B_G0)[i];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = wave < NP;
+    const int pair = producer ? wave : wave - NP;
+    const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
+    float* aff = lds + DEC_FLOATS + pair * WS_PAIR_FLOATS;
+    float* tile_g = aff + AFF_FLOATS;
+    float* tile_a = tile_g + XCHG_FLOATS;
+    float* tile_t = tile_g + WS_T_OFF;
+    unsigned* flags = reinterpret_cast<unsigned*>(tile_g + WS_FLAG_OFF);
+    if (producer && lane < 4) flags[lane] = 0u;
+    __syncthreads();
+    const bool probe = P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0;
+    if (probe && lane == 0) { P.clock_probe[0] = __builtin_amdgcn_s_memtime(); P.clock_probe[1] = __builtin_amdgcn_s_memrealtime(); }
+
+    const int S = P.S;
+    const int blocks_per_view = (P.M + 31) >> 5;
+    const long long total_rb = (long long)P.N * blocks_per_view;
+    const long long n_pairs = (long long)gridDim.x * NP;
+    unsigned step = 0;                       // samples handed over so far by this pair (both roles count alike)
+    bool alive = true;
+
+#ifdef WS_ONLY_CONSUMER
+    if (false) {
+#else
+    if (producer) {
+#endif
+        const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
+        int cur_view = -1;
+        float tmin = INFINITY, tmax = -INFINITY;
+#pragma unroll 1
+        for (long long rb = (long long)blockIdx.x * NP + pair; rb < total_rb; rb += n_pairs) {
+            const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
+            if (n != cur_view) {
+                // the consumer never reads the affines, but the previous block's tiles must have left before anything of this
+                // pair's LDS region is rewritten by other lanes than their owners: the affines are private to this wave - no wait
+                stage_affine(P.aff, n, aff, lane); cur_view = n;
+            }
+            int m, px = 0, py = 0;
+            if (P.tiled) {
+                const int tiles_x = P.R >> 3;
+                px = (b % tiles_x) * 8 + (j & 7);
+                py = (b / tiles_x) * 4 + (j >> 3);
+                m = py * P.R + px;
+            } else {
+                m = b * 32 + j;
+                if (P.R > 0) { py = min(m, P.M - 1) / P.R; px = min(m, P.M - 1) % P.R; }
+            }
+            const bool valid = m < P.M;
+            m = min(m, P.M - 1);
+            const long long ray = (long long)n * P.M + m;
+            float ox, oy, oz, dx, dy, dz;
+            if (P.origins) {
+                const float* o = P.origins + ray * 3; const float* d = P.dirs + ray * 3;
+                ox = o[0]; oy = o[1]; oz = o[2]; dx = d[0]; dy = d[1]; dz = d[2];
+            } else {        // RaySampler.forward, ray_sampler.py:35-61 (as render_kernel)
+                const float* c = P.cam2world + n * 16; const float* K = P.intrinsics + n * 9;
+                const float fx = K[0], sk = K[1], cx = K[2], fy = K[4], cy = K[5];
+                const float inv = 1.0f / (float)P.R;
+                const float xc = (float)px * inv + 0.5f * inv, yc = (float)py * inv + 0.5f * inv;
+                const float xl = (xc - cx + cy * sk / fy - sk * yc / fy) / fx;
+                const float yl = (yc - cy) / fy;
+                ox = c[3]; oy = c[7]; oz = c[11];
+                float wx = c[0] * xl + c[1] * yl + c[2] + c[3];
+                float wy = c[4] * xl + c[5] * yl + c[6] + c[7];
+                float wz = c[8] * xl + c[9] * yl + c[10] + c[11];
+                dx = wx - ox; dy = wy - oy; dz = wz - oz;
+                float nrm = fmaxf(sqrtf(dx * dx + dy * dy + dz * dz), 1e-12f);
+                dx /= nrm; dy /= nrm; dz /= nrm;
+            }
+            const float* pg = P.planes_g + (long long)n * P.plane_view_stride;
+            // GENERIC = false (the common launch): stratified depths between scalar limits, jitter from Philox or a buffer - the
+            // schedule's constants are wave-uniform and stay in SGPRs; GENERIC = true adds per-ray limits, disparity, depth buffers
+            float rs = P.ray_start, re = P.ray_end;
+            if (GENERIC && P.depth_mode == DEPTH_PER_RAY) { rs = P.rs_ray[ray]; re = P.re_ray[ray]; }
+            const float inv_dm1 = 1.0f / (float)(S - 1);
+            const float delta = (re - rs) / (float)(S - 1);
+            u32x4 rnd = {0, 0, 0, 0};
+            const long long plane_elems = (long long)P.H * P.W * 32;
+            const unsigned roff = (unsigned)(ray * S);        // the launch guarantees N * M * S < 2^31: 32-bit element offsets
+#pragma unroll 1
+            for (int k = 0; k < S; ++k, ++step) {
+                float t;
+                if (GENERIC && P.depth_mode == DEPTH_BUFFER) {
+                    t = P.depth_buf[roff + (unsigned)k];
+                } else {
+                    float u;
+                    if (P.u) {
+                        u = P.u[roff + (unsigned)k];
+                    } else {
+                        if ((k & 3) == 0)
+                            rnd = philox4x32_10((unsigned)ray, (unsigned)(k >> 2), 0u, 0u, (unsigned)seed, (unsigned)(seed >> 32));
+                        unsigned bits = (k & 3) == 0 ? rnd.x : (k & 3) == 1 ? rnd.y : (k & 3) == 2 ? rnd.z : rnd.w;
+                        u = u01(bits);
+                    }
+                    if (GENERIC && P.depth_mode == DEPTH_DISPARITY) {
+                        float sd = (float)k * inv_dm1 + u * inv_dm1;
+                        t = 1.0f / (1.0f / rs * (1.0f - sd) + 1.0f / re * sd);
+                    } else if (GENERIC && P.depth_mode == DEPTH_PER_RAY) {
+                        t = rs + ((float)k / (float)(S - 1)) * (re - rs) + u * delta;
+                    } else {
+                        t = fmaf((float)k, delta, rs) + u * delta;
+                    }
+                }
+                if (P.out_depths && valid && h == 0) P.out_depths[roff + (unsigned)k] = t;
+                tmin = fminf(tmin, t); tmax = fmaxf(tmax, t);
+                const float gx = P.coord_scale * fmaf(t, dx, ox);
+                const float gy = P.coord_scale * fmaf(t, dy, oy);
+                const float gz = P.coord_scale * fmaf(t, dz, oz);
+                f32x2 qn[8], qd[8];
+                int opq;                                     // opaque zero: the (loop-invariant) affine reads stay inside the loop
+                asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
+                const float* affk = aff + opq;
+                {
+                    const int l0 = launder(lane);
+                    const int qoff0 = (l0 >> 5) * 16 + (l0 & 3) * 4;
+                    const float4 bn = *reinterpret_cast<const float4*>(affk + AFF_BSUM + qoff0);
+                    const float4 bd = *reinterpret_cast<const float4*>(affk + AFF_BSUM + 32 + qoff0);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        qn[2 * i] = f32x2{bn.x, bn.y}; qn[2 * i + 1] = f32x2{bn.z, bn.w};
+                        qd[2 * i] = f32x2{bd.x, bd.y}; qd[2 * i + 1] = f32x2{bd.z, bd.w};
+                    }
+                }
+#if !defined(WS_ABLATE) || WS_ABLATE != 1          // timing experiment: 1 = producer without its gather
+                gather_pipelined_ws<SQUARE>(pg, P.H, P.W, plane_elems, affk, lane, gx, gy, gz, qn, qd);
+#else
+                qn[0][0] += gx; qd[0][0] += gy + gz;
+#endif
+                // geometry tile + depths of sample `step`: the consumer must have read the geometry tile of the previous sample
+                if (alive) alive = ws_wait(flags, 1, 2u * step - 1u);
+                ws_write_tile(tile_g + opq, lane, qn);
+                if (h == 0) tile_t[j + opq] = t;
+                ws_signal(flags, 0, 2u * step + 1u, lane);
+                if (alive) alive = ws_wait(flags, 1, 2u * step);
+                ws_write_tile(tile_a + opq, lane, qd);
+                ws_signal(flags, 0, 2u * step + 2u, lane);
+            }
+        }
+        if (P.depth_minmax) {
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                tmin = fminf(tmin, __shfl_xor(tmin, off));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+            }
+            if (lane == 0 && tmin <= tmax) {
+                atomicMin(P.depth_minmax + 0, f2ord(tmin));
+                atomicMax(P.depth_minmax + 1, f2ord(tmax));
+            }
+            if (lane == 0 && !alive) atomicAdd(P.depth_minmax + 2, 1u);
+        }
+#ifdef WS_ONLY_PRODUCER
+    } else if (false) {
+#else
+    } else {
+#endif
+#pragma unroll 1
+        for (long long rb = (long long)blockIdx.x * NP + pair; rb < total_rb; rb += n_pairs) {
+            const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
+            int m;
+            if (P.tiled) {
+                const int tiles_x = P.R >> 3;
+                m = ((b / tiles_x) * 4 + (j >> 3)) * P.R + (b % tiles_x) * 8 + (j & 7);
+            } else {
+                m = b * 32 + j;
+            }
+            const bool valid = m < P.M;
+            m = min(m, P.M - 1);
+            const long long ray = (long long)n * P.M + m;
+            f32x2 acc_rgb[8], acc_seg[4], prev_rgb[8], prev_seg[4];
+            float acc_d = 0.0f, acc_w = 0.0f, T = 1.0f, prev_t = 0.0f, prev_sig = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) { acc_rgb[c] = splat(0.0f); prev_rgb[c] = splat(0.0f); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { acc_seg[c] = splat(0.0f); prev_seg[c] = splat(0.0f); }
+#pragma unroll 1
+            for (int k = 0; k < S; ++k, ++step) {
+                int opq;                                     // opaque zero: keeps the LDS weight reads inside the loop (render_kernel)
+                asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
+                const float* ldsw = lds + opq;
+                f32x16 og, oa;
+                float t;
+                {
+                    if (alive) alive = ws_wait(flags, 0, 2u * step + 1u);
+                    f32x2 fn[8];
+                    ws_read_tile(tile_g + opq, lane, fn);
+                    t = tile_t[j + opq];
+                    ws_signal(flags, 1, 2u * step + 1u, lane);
+#if !defined(WS_ABLATE) || WS_ABLATE != 2          // timing experiment: 2 = consumer without its decoder
+                    mlp_bf16(ldsw, fn, 0, lane, og);
+#else
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) og[r] = fn[r >> 1][r & 1];
+#endif
+                }
+                {
+                    if (alive) alive = ws_wait(flags, 0, 2u * step + 2u);
+                    f32x2 fd[8];
+                    ws_read_tile(tile_a + opq, lane, fd);
+                    ws_signal(flags, 1, 2u * step + 2u, lane);
+#if !defined(WS_ABLATE) || WS_ABLATE != 2
+                    mlp_bf16(ldsw, fd, 1, lane, oa);
+#else
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oa[r] = fd[r >> 1][r & 1];
+#endif
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {    // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269 (decode_features)
+                    const f32x2 d = f32x2{exp2_fast(-oa[r]), exp2_fast(-oa[r + 1])} + splat(1.0f);
+                    const f32x2 sg = pk_fma(f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])}, splat(1.002f), splat(-0.001f));
+                    oa[r] = sg[0]; oa[r + 1] = sg[1];
+                }
+                {   // SegMipRayMarcher2.run_forward (ray_marcher.py:68-101), as render_kernel
+                    const bool first = k == 0;
+                    const float dlt = t - (first ? t : prev_t);
+                    const float dens = softplus_f((prev_sig + og[0]) * 0.5f - 1.0f);
+                    const float alpha = first ? 0.0f : 1.0f - exp2_fast(-(dens * dlt) * LOG2E);
+                    const float w = alpha * T;
+                    T = T * (1.0f - alpha + 1e-10f);
+                    const f32x2 wh = splat(w * 0.5f);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        acc_rgb[c] = pk_fma(wh, prev_rgb[c] + f32x2{oa[2 * c], oa[2 * c + 1]}, acc_rgb[c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc_seg[c] = pk_fma(wh, prev_seg[c] + f32x2{og[2 + 2 * c], og[3 + 2 * c]}, acc_seg[c]);
+                    acc_d = fmaf(w, (prev_t + t) * 0.5f, acc_d);
+                    acc_w += w;
+                }
+                prev_t = t; prev_sig = og[0];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) prev_rgb[c] = f32x2{oa[2 * c], oa[2 * c + 1]};
+#pragma unroll
+                for (int c = 0; c < 4; ++c) prev_seg[c] = f32x2{og[2 + 2 * c], og[3 + 2 * c]};
+            }
+            if (valid) {
+                const float wb = P.white_back ? (1.0f - acc_w) : 0.0f;
+                float rgbv[16], segv[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    rgbv[2 * c] = (acc_rgb[c][0] + wb) * 2.0f - 1.0f;
+                    rgbv[2 * c + 1] = (acc_rgb[c][1] + wb) * 2.0f - 1.0f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { segv[2 * c] = acc_seg[c][0]; segv[2 * c + 1] = acc_seg[c][1]; }
+                const int nsg = h ? 7 : 8;
+                if (P.channels_first) {
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) P.rgb[((long long)n * 32 + 16 * h + c) * P.M + m] = rgbv[c];
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < nsg) P.seg[((long long)n * 15 + 8 * h + c) * P.M + m] = segv[c];
+                } else {
+                    float4* o = reinterpret_cast<float4*>(P.rgb + ray * 32 + 16 * h);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        o[q] = make_float4(rgbv[4 * q], rgbv[4 * q + 1], rgbv[4 * q + 2], rgbv[4 * q + 3]);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (c < nsg) P.seg[ray * 15 + 8 * h + c] = segv[c];
+                }
+                if (h == 0) {
+                    P.depth[ray] = acc_d / acc_w;
+                    P.wsum[ray] = acc_w;
+                }
+            }
+        }
+        if (P.depth_minmax && lane == 0 && !alive) atomicAdd(P.depth_minmax + 2, 1u);
+    }
+    if (probe && lane == 0) { P.clock_probe[2] = __builtin_amdgcn_s_memtime(); P.clock_probe[3] = __builtin_amdgcn_s_memrealtime(); }
+}
+
+
 // Composite the depth segments of a split launch in order (see PARTIAL_FLOATS) and finish exactly as the kernel's own
 // epilogue does; the coarse pass of a two-pass render (sigma_only) only needs its weights rescaled by the transmittance
 // in front of their segment.  One lane per (ray, output channel group): lanes 0..31 of a 64-lane group take rgb channel,
@@ -1080,7 +1813,7 @@ __global__ void depth_clamp_kernel(float* depth, long long n, const unsigned* mi
 }
 
 __global__ void minmax_init_kernel(unsigned* minmax) {
-    minmax[0] = 0xFFFFFFFFu; minmax[1] = 0u;
+    minmax[0] = 0xFFFFFFFFu; minmax[1] = 0u; minmax[2] = 0u;      // [2]: hand-off waits abandoned by render_ws_kernel (must stay 0)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1390,6 +2123,31 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
     }
 }
 
+// Wave-specialised launch (render_ws_kernel): one plane set, full split-bf16 decoder, no noise / cross / kept colours, and enough
+// ray blocks to fill the chip without the depth split.  NFE_RENDER_WS=0 keeps the fused kernel (A/B, tests).
+static int ws_mode() {
+    static const int v = [] { const char* e = getenv("NFE_RENDER_WS"); return e ? atoi(e) : NFE_RENDER_WS_DEFAULT; }();
+    return v;
+}
+template <int NP, int WPS>
+static void launch_render_ws(const RenderK& P, long long total_rb, hipStream_t st) {
+    constexpr int bytes = ws_lds_bytes<NP>();
+    constexpr int per_cu = (WPS * 4) / (2 * NP);          // workgroups per CU that make WPS waves per SIMD
+    static_assert(per_cu >= 1 && per_cu * bytes <= 160 * 1024, "LDS of the resident workgroups");
+    long long blocks = (total_rb + NP - 1) / NP;
+    const long long cap = (long long)num_cus() * per_cu;
+    if (blocks > cap) blocks = cap;
+    const bool generic = P.depth_mode != DEPTH_STRATIFIED;
+#define NFE_WS_LAUNCH(SQ, GE)                                                                                                    \
+    {                                                                                                                            \
+        allow_lds(render_ws_kernel<NP, WPS, SQ, GE>, bytes);                                                                     \
+        hipLaunchKernelGGL((render_ws_kernel<NP, WPS, SQ, GE>), dim3((unsigned)blocks), dim3(NP * 128), bytes, st, P);           \
+    }
+    if (P.H == P.W) { if (generic) NFE_WS_LAUNCH(true, true) else NFE_WS_LAUNCH(true, false) }
+    else { if (generic) NFE_WS_LAUNCH(false, true) else NFE_WS_LAUNCH(false, false) }
+#undef NFE_WS_LAUNCH
+}
+
 static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math, hipStream_t st) {
     const long long total_rb = (long long)P.N * ((P.M + 31) / 32);
     long long blocks = (total_rb + 3) / 4;
@@ -1439,6 +2197,18 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
         const long long rays = (long long)P.N * P.M;
         hipLaunchKernelGGL(render_combine_kernel, dim3((unsigned)((rays + 3) / 4)), dim3(256), 0, st, Q, sigma_only ? 1 : 0);
         NFE_CHECK_LAUNCH("render_combine_kernel");
+        return NFE_OK;
+    }
+    if (ws_mode() && !dual && !sigma_only && math == NFE_MATH_BF16X3 && P.density_noise == 0.0f && !P.tap_colors && !P.out_weights &&
+        total_rb >= 2048 && (long long)P.N * P.M * P.S < (1ll << 31)) {
+        switch (ws_mode()) {          // pairs per workgroup x 10 + waves per SIMD
+            case 42: launch_render_ws<4, 2>(P, total_rb, st); break;
+            case 63: launch_render_ws<6, 3>(P, total_rb, st); break;
+            case 33: launch_render_ws<3, 3>(P, total_rb, st); break;
+            case 84: launch_render_ws<8, 4>(P, total_rb, st); break;
+            default: launch_render_ws<4, 4>(P, total_rb, st); break;
+        }
+        NFE_CHECK_LAUNCH("render_ws_kernel");
         return NFE_OK;
     }
     if (sigma_only) {

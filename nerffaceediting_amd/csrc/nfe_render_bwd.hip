@@ -534,7 +534,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
     for (int b = 0; b < 2; ++b) {
         {   // the fragment loads are loop invariant: hoisted, all 52 of them would sit in registers (208 VGPRs) for the whole kernel
             unsigned long long fp = reinterpret_cast<unsigned long long>(F);
-            asm volatile("" : "+v"(fp));
+            asm volatile("; nfe_launder %0" : "+v"(fp));
             F = reinterpret_cast<const uint4*>(fp);
         }
         // ---- F0: pre-activations of the 64 hidden units (2 M-blocks), bias first
@@ -859,7 +859,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             unsigned todo_lo = (unsigned)have, todo_hi = (unsigned)(have >> 32);
             for (;;) {
                 todo_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_lo); todo_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_hi);
-                asm volatile("" : "+s"(todo_lo), "+s"(todo_hi));
+                asm volatile("; nfe_launder %0 %1" : "+s"(todo_lo), "+s"(todo_hi));
                 if ((todo_lo | todo_hi) == 0u) break;
                 const int leader = todo_lo ? __builtin_ctz(todo_lo) : 32 + __builtin_ctz(todo_hi);
                 const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);

@@ -50,6 +50,18 @@ def _workspace(device, nbytes):
     return ws
 
 
+def render_handoff_aborts(device=None):
+    """Diagnostic (synchronises): how many producer / consumer waits render_ws_kernel abandoned in the LAST nfe_render call issued
+    from the current stream of `device` (word 2 of the render workspace, zeroed by every call).  Must be 0: a non-zero count means a
+    wave pair lost its partner, finished with garbage in its rays instead of hanging the GPU, and the outputs are invalid."""
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    ws = _workspaces.get((device.index, torch.cuda.current_stream(device).cuda_stream))
+    if ws is None:
+        return 0
+    torch.cuda.synchronize(device)
+    return int(ws[:12].view(torch.int32)[2].item())
+
+
 def ray_sampler(cam2world, intrinsics, resolution):
     """RaySampler.forward (ray_sampler.py:24-62): [N,4,4],[N,3,3] -> origins, dirs [N,R*R,3]."""
     lib = _lib.load()

@@ -411,9 +411,93 @@ print("HASH", h.hexdigest())
     hashes = {}
     detail = {}
     for b in ("1", "2", "3", "4"):
-        env = dict(os.environ, NFE_RENDER_BLOCKS_PER_CU=b, PYTHONPATH=root)
+        # NFE_RENDER_WS=0: the fused kernel at every occupancy (the wave-specialised launch has one fixed geometry: it is covered by
+        # test_wave_specialised_launch_matches_the_fused_kernel and, at its only occupancy, by the "ws" run below)
+        env = dict(os.environ, NFE_RENDER_BLOCKS_PER_CU=b, NFE_RENDER_WS="0", PYTHONPATH=root)
         r = subprocess.run([sys.executable, "-c", prog], cwd=root, env=env, capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-2000:]
         hashes[b] = [l for l in r.stdout.splitlines() if l.startswith("HASH")][0]
         detail[b] = [l for l in r.stdout.splitlines() if l.startswith("CASE")]
     assert hashes["1"] == hashes["2"] == hashes["3"] == hashes["4"], detail
+    ws = []
+    for rep in range(2):                  # default build (wave-specialised launch where it applies): two processes, same bits
+        r = subprocess.run([sys.executable, "-c", prog], cwd=root, env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        ws.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert ws[0] == ws[1]
+
+
+# ---- round 4: the wave-specialised launch (render_ws_kernel) ------------------------------------------------------------------
+_WS_PROG = r"""
+import sys, numpy as np, torch
+from nerffaceediting_amd import ops
+from oracle import render_oracle as orc           # camera construction only
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(11)
+N, H = 2, 256
+raw = torch.randn(N, 96, H, H, generator=g).to(dev)
+packed, aff = ops.plane_pack(raw), ops.make_affine(*ops.plane_stats(raw))
+rawr = torch.randn(N, 96, 192, 320, generator=g).to(dev)                   # non-square planes: the run-time axis geometry
+packedr, affr = ops.plane_pack(rawr), ops.make_affine(*ops.plane_stats(rawr))
+shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+dec = ops.decoder_pack(*[(torch.randn(*s, generator=g) * (1.0 if len(s) == 2 else 0.2)).to(dev) for s in shapes])
+c2w = torch.from_numpy(np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2 + p, [0, 0, 0.2], 2.7).reshape(1, 4, 4) for y, p in ((0.3, -0.2), (-0.9, 0.4))])).to(dev)
+K = torch.from_numpy(np.repeat(orc.fov_to_intrinsics(18.837)[None], N, 0)).to(dev)     # second camera: rays that leave the planes
+outs = []
+def keep(r):
+    outs.extend(x.cpu().numpy() for x in r[:4])
+    assert ops.render_handoff_aborts() == 0
+base = dict(ray_start=2.25, ray_end=3.3, box_warp=1.0, depth_resolution_importance=0)
+R = 512
+keep(ops.render(packed, packed, dec, dict(base, depth_resolution=64), cam2world=c2w, intrinsics=K, resolution=R, affines=aff, seed=5))                       # the headline shape
+keep(ops.render(packed, packed, dec, dict(base, depth_resolution=33, white_back=True), cam2world=c2w, intrinsics=K, resolution=R, affines=aff, seed=6, channels_first=True))
+keep(ops.render(packedr, packedr, dec, dict(base, depth_resolution=48), cam2world=c2w, intrinsics=K, resolution=R, affines=affr, seed=7))                  # non-square
+R2 = 264                                                                    # 264^2 = 69 696 rays: 2 178 ray blocks of 8x4 tiles, ragged grid-stride
+o, d = ops.ray_sampler(c2w, K, R2)
+u = torch.rand(N, R2 * R2, 40, generator=torch.Generator(device=dev).manual_seed(3), device=dev)
+keep(ops.render(packed, packed, dec, dict(base, depth_resolution=40), origins=o, dirs=d, u_coarse=u))                                                     # caller's rays, injected jitter, no affines
+keep(ops.render(packed, packed, dec, dict(base, depth_resolution=40, disparity_space_sampling=True), origins=o, dirs=d, u_coarse=u, affines=aff))           # GENERIC depth schedule
+lim = (torch.full((N, R2 * R2, 1), 2.3, device=dev) + 0.1 * torch.rand(N, R2 * R2, 1, device=dev, generator=torch.Generator(device=dev).manual_seed(4)),
+       torch.full((N, R2 * R2, 1), 3.2, device=dev))
+keep(ops.render(packed, packed, dec, dict(base, depth_resolution=40), origins=o, dirs=d, u_coarse=u, affines=aff, ray_limits=lim))                          # per-ray limits
+M3 = 70001                                                                  # not a square image: 32 consecutive rays per block, ragged last block
+keep(ops.render(packed, packed, dec, dict(base, depth_resolution=24), origins=o[:, :M3].contiguous(), dirs=d[:, :M3].contiguous(), affines=aff, seed=9))
+first = [x.copy() for x in outs[:4]]
+for i in range(int(sys.argv[2])):                                           # repeated launches of the headline shape: bit-identical
+    r = ops.render(packed, packed, dec, dict(base, depth_resolution=64), cam2world=c2w, intrinsics=K, resolution=R, affines=aff, seed=5)
+    if i % 10 == 9:
+        assert all(np.array_equal(x.cpu().numpy(), y) for x, y in zip(r, first)), i
+        assert ops.render_handoff_aborts() == 0
+np.savez(sys.argv[1], *outs)
+"""
+
+
+def test_wave_specialised_launch_matches_the_fused_kernel(dev, tmp_path):
+    """render_ws_kernel (producer waves: depths + gather + affines; consumer waves: decoder + march; hand-off through the LDS
+    exchange tile) against render_kernel on the same inputs, one child interpreter per NFE_RENDER_WS value (read once
+    per process): the headline shape, white_back + channels_first, non-square planes, caller-supplied rays with injected jitter,
+    disparity sampling and per-ray limits (the GENERIC depth schedule), a ray count that is no square image.  Same arithmetic in the
+    same order up to the compiler's contraction choices (the two kernels inline the tap geometry into different surroundings): <= 2e-5
+    (measured 5e-7 on square planes, 9e-6 on non-square ones), the bound of the split-vs-unsplit test; no hand-off wait abandoned; 60 repeated launches of
+    the headline shape bit-identical."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("NFE_RENDER_WS") is not None and os.environ.get("NFE_WS_CHILD"):
+        pytest.skip("this is the child run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for mode in ("0", "42"):
+        out = str(tmp_path / f"ws{mode}.npz")
+        r = subprocess.run([sys.executable, "-c", _WS_PROG, out, "60" if mode != "0" else "0"], cwd=root,
+                           env=dict(os.environ, NFE_RENDER_WS=mode, NFE_WS_CHILD="1", PYTHONPATH=root), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        z = np.load(out)
+        res[mode] = [z[k] for k in z.files]
+    assert len(res["0"]) == len(res["42"]) == 28
+    worst = 0.0
+    for i, (a, b) in enumerate(zip(res["0"], res["42"])):
+        assert a.shape == b.shape and np.isfinite(b).all(), i
+        worst = max(worst, max_abs(a, b))
+        assert max_abs(a, b) <= 2e-5 * max(1.0, float(np.abs(a).max())), (i, max_abs(a, b))
+    print(f"wave-specialised vs fused render kernel: worst difference {worst:.2e} over {len(res['0'])} output tensors")

@@ -19,6 +19,17 @@ every instruction-bearing block, per kernel instance, the rules below are CHECKE
         v_cmp) of that SGPR within the 5 preceding instructions (VALU-writes-SGPR -> VMEM-reads: 5 wait states).
   MFMA  no statement contains or directly follows an MFMA whose result it reads (none of the statements takes an MFMA result
         as an operand: checked as "no v_mfma within 12 instructions before a block that reads one of its D registers").
+  LAUN  the "launder" statements (`asm volatile("; nfe_launder %0" : "+v"(x))`: no instruction, they only hide a value from the
+        optimiser).  For hipcc's hazard recogniser the STATEMENT is now the writer of x, so it pads nothing between the value's real
+        producer and its consumers.  Checked on the ISA around every such statement (the comment names the register): the real
+        producer within the 4 preceding instructions and the consumers within the 4 following ones must not form a pair that needs
+        wait states on gfx940-class hardware - transcendental -> non-transcendental VALU (1), VALU -> DPP / v_readlane /
+        v_readfirstlane / v_permlane (2 / 1), MFMA -> anything (many), VALU -> MFMA A/B operand (2), VALU-written SGPR -> VMEM (5) /
+        lane select (4) - unless that many states separate them.  (Found the hard way in round 4: an `asm("v_add_f32 ...")` that
+        consumed a v_exp_f32 result gave run-dependent results, profiles/experiments/r04_asm_trans_hazard.md.)
+  TRNS  a VALU instruction INSIDE a statement that reads a register a transcendental (v_exp / v_log / v_rcp / ...) wrote in the
+        instruction right before it, with no wait state between (gfx940 "trans forwarding" hazard: hipcc pads it for its own
+        instructions only).  Same check for MFMA results read inside a statement (rule MFMA).
   WAIT  statements that only wait (s_waitcnt) are listed; they order the COMPILER's counted loads (LDS-DMA is issued by asm and
         counted by hand: conv3_kernel's vmcnt ladder).
 
@@ -103,6 +114,92 @@ def regs(ops, kind):
     return found
 
 
+TRANS = ("v_exp_", "v_log_", "v_rcp_", "v_rsq_", "v_sqrt_", "v_sin_", "v_cos_")
+LANE_X = ("v_readlane", "v_readfirstlane", "v_permlane", "v_writelane")
+
+
+def launder_sites(lines):
+    """-> list of (instruction index the statement sits in front of, kind 'v'/'s', set of registers) for the annotated statements"""
+    out, n, in_blk = [], 0, False
+    for ln in lines:
+        if ";;#ASMSTART" in ln:
+            in_blk = True
+            continue
+        if ";;#ASMEND" in ln:
+            in_blk = False
+            continue
+        m = re.search(r";\s*nfe_launder\s+(.*)$", ln)
+        if in_blk and m:
+            txt = m.group(1)
+            rv, rs = regs(txt, "v"), regs(txt, "s")
+            if rv:
+                out.append((n, "v", rv))
+            if rs:
+                out.append((n, "s", rs))
+            continue
+        if re.match(r"^\s*\.", ln) or re.match(r"^[.\w$]+:", ln):
+            continue
+        if INST.match(ln) and not in_blk:
+            n += 1
+        elif INST.match(ln) and in_blk:
+            n += 1
+    return out
+
+
+def check_launder(name, lines, errors, stats):
+    ins = [(m, o) for m, o, _ in parse(lines)]
+    for at, kind, rset in launder_sites(lines):
+        stats["launder"] = stats.get("launder", 0) + 1
+        # the real producer: the closest earlier instruction whose destination (first operand) holds one of the registers
+        prod, states = None, 0
+        for k in range(at - 1, max(-1, at - 5), -1):
+            mn, ops = ins[k]
+            n = nop_states(mn, ops)
+            if n:
+                states += n
+                continue
+            if mn.startswith(("s_waitcnt",)):
+                continue
+            dst = ops.split(",")[0]
+            if regs(dst, kind) & rset and not mn.startswith(("global_store", "ds_write", "buffer_store", "s_cmp", "v_cmp")):
+                prod = (mn, at - 1 - k)
+                break
+            states += 1
+        if prod is None:
+            continue
+        pm = prod[0]
+        for k in range(at, min(len(ins), at + 4)):
+            mn, ops = ins[k]
+            n = nop_states(mn, ops)
+            if n:
+                states += n
+                continue
+            srcs = ",".join(ops.split(",")[1:]) if not mn.startswith(("global_store", "ds_write", "buffer_store")) else ops
+            if regs(srcs, kind) & rset:
+                need = 0
+                if kind == "v":
+                    if pm.startswith("v_mfma"):
+                        need = 12
+                    elif pm.startswith(TRANS) and mn.startswith("v_") and not mn.startswith(TRANS):
+                        need = 1
+                    elif pm.startswith("v_") and ("dpp" in mn or "quad_perm" in ops or "row_" in ops):
+                        need = 2
+                    elif pm.startswith("v_") and mn.startswith(LANE_X):
+                        need = 1
+                    elif pm.startswith("v_") and mn.startswith("v_mfma"):
+                        need = 2
+                else:
+                    if pm.startswith("v_") and mn.startswith(("global_", "buffer_", "scratch_")):
+                        need = 5
+                    elif pm.startswith("v_") and mn.startswith(("v_readlane", "v_writelane")):
+                        need = 4
+                if need:
+                    stats["launder_pairs"] = stats.get("launder_pairs", 0) + 1
+                    if states < need:
+                        errors.append("%s: LAUN: %s -> [launder] -> %s with %d wait states (< %d)" % (name, pm, mn, states, need))
+            states += 1
+
+
 def audit_kernel(name, lines, meta, report, errors):
     ins = parse(lines)
     blocks = {}
@@ -170,6 +267,23 @@ def audit_kernel(name, lines, meta, report, errors):
             pm, po, _ = ins[k]
             if pm.startswith("v_mfma") and regs(po.split(",")[0], "v") & reads:
                 errors.append("%s: MFMA: a statement reads the result of %s %d instructions after it" % (name, pm, first - k))
+        # ---- TRNS: transcendental result consumed by a VALU instruction of the statement without a wait state
+        for i in ix:
+            mn, ops, _ = ins[i]
+            if not mn.startswith("v_") or mn.startswith(TRANS):
+                continue
+            srcs = regs(",".join(ops.split(",")[1:]), "v")
+            states = 0
+            for k in range(i - 1, max(-1, i - 3), -1):
+                pm, po, _ = ins[k]
+                n = nop_states(pm, po)
+                if n:
+                    states += n
+                    continue
+                if pm.startswith(TRANS) and regs(po.split(",")[0], "v") & srcs and states < 1:
+                    errors.append("%s: TRNS: %s reads the result of %s %d instruction(s) earlier with %d wait states" % (name, mn, pm, i - k, states))
+                    entry["rules"].add("TRNS")
+                states += 1
         if any(re.search(r"v\[80\+|\bv(8\d|9\d|1[0-5]\d|160)\b", ins[i][1]) and ins[i][0].startswith("v_") and
                re.search(r"nfe_i|\+", ins[i][1]) for i in ix):
             fixed_tile = True
@@ -196,13 +310,17 @@ def main():
     outdir = os.path.join(L.ROOT, "nerffaceediting_amd", "csrc", "build", "lint")
     os.makedirs(outdir, exist_ok=True)
     errors, rows = [], []
+    extra = tuple(os.environ.get("ASM_AUDIT_FLAGS", "").split())          # e.g. -DNFE_SOFTPLUS_SCALAR=1: audit an experiment build
     for f in L.ALL:
-        text = open(L.assemble(os.path.join(L.CSRC, f), outdir)).read()
+        text = open(L.assemble(os.path.join(L.CSRC, f), outdir, extra)).read()
         report, nk, nb, nr = {}, 0, 0, 0
+        stats = {}
         for name, lines, meta in kernels(text):
             a, b = audit_kernel(name, lines, meta, report, errors)
+            check_launder(name, lines, errors, stats)
             nk, nb, nr = nk + 1, nb + a, nr + b
-        print("%s: %d kernels, %d asm statements in the ISA, %d carry instructions, %d distinct" % (f, nk, nb, nr, len(report)))
+        print("%s: %d kernels, %d asm statements in the ISA, %d carry instructions, %d distinct; %d launder statements, %d of them between a "
+              "hazard-prone producer / consumer pair" % (f, nk, nb, nr, len(report), stats.get("launder", 0), stats.get("launder_pairs", 0)))
         for sig, e in sorted(report.items(), key=lambda kv: -kv[1]["count"]):
             rows.append((f, sig, e["count"], len(e["kernels"]), ", ".join(sorted(e["rules"])) or "-"))
             print("   x%-5d in %3d kernels  [%s]  %s" % (e["count"], len(e["kernels"]), ", ".join(sorted(e["rules"])) or "no hazard rule applies", sig[:150]))

@@ -8,7 +8,7 @@ contains the kernel's MFMA instructions (the per-sample loop of render_kernel), 
     vector memory, scalar, waits.
 The cycle column prices each class with the single-wave issue costs of tools/microbench/valu_rate.hip (profiles/r02_valu_rate.txt).
 
-usage: isa_census.py <file.s> <mangled-kernel-substring> [--json out.json]
+usage: isa_census.py <file.s> <mangled-kernel-substring> [--json out.json] [--anchor global_load_dwordx4]
 """
 import json
 import re
@@ -101,7 +101,8 @@ def main():
         m = re.match(r"^\s+([a-z_0-9]+)\s*(.*)$", ln)
         if m and not m.group(1).startswith("."):
             insts.append((m.group(1), m.group(2), cur[0], cur[1]))
-    mf = [k for k, it in enumerate(insts) if it[0].startswith("v_mfma")]
+    anchor = sys.argv[sys.argv.index("--anchor") + 1] if "--anchor" in sys.argv else "v_mfma"      # the loop is found around these
+    mf = [k for k, it in enumerate(insts) if it[0].startswith(anchor)]
     # innermost loop around the MFMAs: the backward branch after the last MFMA whose target precedes the first one, closest fit
     best = None
     for k, it in enumerate(insts):
