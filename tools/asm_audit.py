@@ -311,6 +311,9 @@ def main():
     os.makedirs(outdir, exist_ok=True)
     errors, rows = [], []
     extra = tuple(os.environ.get("ASM_AUDIT_FLAGS", "").split())          # e.g. -DNFE_SOFTPLUS_SCALAR=1: audit an experiment build
+    if extra:                                                             # ... into its own directory: build/lint holds the shipped build's ISA
+        outdir = os.path.join(L.ROOT, "nerffaceediting_amd", "csrc", "build", "lint_experiment")
+        os.makedirs(outdir, exist_ok=True)
     for f in L.ALL:
         text = open(L.assemble(os.path.join(L.CSRC, f), outdir, extra)).read()
         report, nk, nb, nr = {}, 0, 0, 0
