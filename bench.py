@@ -44,9 +44,12 @@ HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
 PEAK_CLOCK_GHZ = 2.4                         # MI355X shader clock (hipDeviceProp clockRate); the chip holds 1.9-2.2 GHz under this load
 N_CU, N_SIMD = 256, 1024
 # Per-launch hardware counters of the dominant kernel, from rocprofv3 --pmc passes of THIS command on the shipped build
-# (tools/r03_profile.sh: tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed).  PMC cannot be collected
+# (tools/r04_profile2.sh: tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed).  PMC cannot be collected
 # inside the timed process.
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_issue_floor.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_issue_floor.json")
+# Static instruction mix of the kernels' per-sample loops (tools/isa_census.py) and the SIMD cycles one wave-instruction of each
+# class costs (tools/microbench/valu_rate.hip at two waves per SIMD): the `simd_pipes` ceiling below.
+CENSUS_FILE = os.path.join(ROOT, "profiles", "r04_isa_census.json")
 
 
 def backward_roofline(bwd_ms, samples, logical_gbs):
@@ -79,6 +82,36 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
                     "gather + scatter bytes / time is quoted for reference only (planes and gradients are cache resident)"}
 
 
+def pmc_fractions(name, share_of_ms=None, total_ms=None, steps_per_launch=None):
+    """Ceilings of a kernel from its committed counter file profiles/<name> (one rocprofv3 --pmc record per launch, tools/pmc.sh):
+    busy cycles of each unit / kernel cycles.  The kernel cycles are the PROFILED launch's (GRBM_GUI_ACTIVE / 8 XCDs) unless the
+    caller gives this run's time of the whole multi-kernel step (`total_ms`) and the kernel's share of it under the profiler
+    (`share_of_ms`): then the profiled clock x (share x total_ms).  simd_pipes: the no-overlap SIMD execution time of the retired
+    instructions (issue_model's docstring); without a census of this variant the non-transcendental VALU instructions are priced at
+    the fused kernel's average (3.55 cycles) and the transcendentals at 163 per 32-sample step (`steps_per_launch`), 0 if unknown."""
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        c = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["avg_ns_profiled"] * 1e-9)
+    ms = share_of_ms * total_ms if (share_of_ms and total_ms) else c["avg_ns_profiled"] * 1e-6
+    cycles = ms * 1e-3 * clk
+    hbm = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0
+    mfma_cost = c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c["SQ_INSTS_MFMA"], 1.0)                 # 32 (bf16 32x32x16) or 64 (f32 32x32x2)
+    trans = 163.0 * steps_per_launch if steps_per_launch else 0.0
+    other = max(c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"] - trans, 0.0)
+    fr = {"ta_busy": c["TA_TA_BUSY"] / N_CU / cycles, "l1_request": c["TCP_TOTAL_CACHE_ACCESSES"] / N_CU / cycles,
+          "matrix_pipe": c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / cycles,
+          "simd_pipes": (other * 3.55 + trans * 8.29 + c["SQ_INSTS_MFMA"] * mfma_cost) / N_SIMD / cycles,
+          "hbm": hbm / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)}
+    bound = max(fr, key=fr.get)
+    return {"kernel": c["kernel"], "kernel_ms": ms, "kernel_ms_profiled": c["avg_ns_profiled"] * 1e-6, "clock_ghz_profiled": clk / 1e9,
+            "bound": bound, "frac": fr[bound], "fractions": fr, "hbm_bytes": hbm, "counters_file": "profiles/" + name,
+            "wave_life_split": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
+                                "waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]}}
+
+
 def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD, clock_ghz=None):
     """The ceilings that can bind render_kernel, each as (cycles this resource is busy per launch) / (kernel cycles), with the
     kernel cycles = the kernel time measured HERE x the effective shader clock of the profiled run (GRBM_GUI_ACTIVE / 8 XCDs /
@@ -94,6 +127,17 @@ def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD, clock_ghz=Non
       hbm          (2 x FETCH_SIZE + WRITE_SIZE) bytes against 8 TB/s  (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md);
       logical_gather  SURVEY 8(d)'s algorithmic gather bytes against 8 TB/s - NOT a physical bound (the 25 MB plane set of a
                    view is L2 / Infinity-Cache resident): kept because north_star quotes it; it exceeds 1.
+      simd_pipes   (round 4) the SIMD's execution time for the instructions the launch retires: measured instruction counts
+                   (SQ_INSTS_VALU, SQ_INSTS_MFMA, per launch) x the SIMD cycles one wave-instruction of its class occupies when two
+                   or more waves share the SIMD (plain VALU 2.47, packed fp32 4.53, transcendental 8.29, DPP / v_perm / v_cvt_pk
+                   4.45, v_mfma_f32_32x32x16_bf16 32: tools/microbench/valu_rate.hip, profiles/r02_valu_rate.txt), the VALU classes in
+                   the proportion of the kernel's static instruction census (profiles/r04_isa_census.json), summed as if nothing
+                   overlapped, per SIMD.  That no-overlap sum is 0.79-0.84 of the measured kernel time for the builds of this
+                   kernel (fused / wave-specialised, with / without the in-bounds gather path), and three or four waves per SIMD,
+                   or a hand-interleaved MFMA / transcendental order, shorten nothing (profiles/experiments/r04_render_ws.md): the
+                   SIMD executes this instruction mix essentially back to back; the remainder is LDS / L1 latency that the two
+                   waves of a SIMD do not cover.  It is the binding ceiling; rounds 1-3 read the same state as "no unit above
+                   0.5: latency-bound at two waves per SIMD".
     Returns (bound name, dict of fractions, detail)."""
     try:
         with open(PMC_FILE) as f:
@@ -112,6 +156,30 @@ def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD, clock_ghz=Non
             "l1_request": c["TCP_TOTAL_CACHE_ACCESSES"] / N_CU / cycles,
             "ta_busy": c["TA_TA_BUSY"] / N_CU / cycles,
             "hbm": hbm_bytes / t / (HBM_PEAK_GBS * 1e9), "logical_gather": logical_bytes / t / (HBM_PEAK_GBS * 1e9)}
+    census = None
+    try:
+        with open(CENSUS_FILE) as f:
+            census = json.load(f)
+        cost = census["simd_cycles_per_instruction"]
+        ws = "render_ws_kernel" in c.get("kernel", "")
+        fin = census.get("inbounds_fraction_config2", 0.9)
+        k = census["kernels"]
+
+        def mix(parts):                       # class counts per sample step of the dominant kernel, in-bounds / general steps weighted
+            out = {}
+            for name, wgt in parts:
+                for cls, n in k[name]["by_class"].items():
+                    out[cls] = out.get(cls, 0.0) + wgt * n
+            return out
+        m = mix([("render_ws_kernel.consumer", 1.0), ("render_ws_kernel.producer.inbounds", fin), ("render_ws_kernel.producer.general", 1.0 - fin)] if ws
+                else [("render_kernel.inbounds", fin), ("render_kernel.general", 1.0 - fin)])
+        valu_cls = ["valu", "valu_pk", "valu_trans", "valu_dpp/perm"]
+        static_valu = sum(m.get(x, 0.0) for x in valu_cls)
+        dyn_valu = c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]            # SQ_INSTS_VALU counts the MFMAs too (census: 1 085 + 48 against 1 117 measured)
+        simd_cycles = sum(m.get(x, 0.0) / static_valu * dyn_valu * cost[x] for x in valu_cls) + c["SQ_INSTS_MFMA"] * cost["mfma"]
+        frac["simd_pipes"] = simd_cycles / N_SIMD / cycles
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        census = None
     physical = {k: v for k, v in frac.items() if k != "logical_gather"}
     bound = max(physical, key=physical.get)
     detail = {"counters_file": os.path.relpath(PMC_FILE, ROOT), "kernel_profiled": c.get("kernel"), "kernel_ms_profiled": c["avg_ns_profiled"] / 1e6,
@@ -121,6 +189,9 @@ def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD, clock_ghz=Non
               "wave_life_split": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
                                   "waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
               "l2_hit_rate": c["TCC_HIT"] / max(c["TCC_HIT"] + c["TCC_MISS"], 1.0)}
+    if census is not None:
+        detail["census_file"] = os.path.relpath(CENSUS_FILE, ROOT)
+        detail["simd_cycles_per_instruction"] = census["simd_cycles_per_instruction"]
     return bound, frac, detail
 
 
@@ -251,17 +322,34 @@ def extra_workload(args, torch, dist, dev, rank, world):
         n_total, M = world * VIEWS_PER_GPU, R * R
         bytes_ray = (Dc + Dc) * 2 * 1536 + Dc * 1536 + 196      # final pass: 192 samples x 2 plane sets; coarse pass: 96 x geometry set
         ach = VIEWS_PER_GPU * M * bytes_ray / (ms * 1e-3) / 1e9
+        # counter-derived ceilings of the three kernels of the step (profiles/r04_issue_floor_twopass_*.json, tools/r04_profile1.sh);
+        # each kernel's time in THIS run = its share of the step under the profiler x this run's step time
+        rb = VIEWS_PER_GPU * (M // 32)
+        recs = {"final": ("r04_issue_floor_twopass_final.json", rb * 2 * Dc), "sigma": ("r04_issue_floor_twopass_sigma.json", rb * Dc * 64.0 / 163.0),
+                "importance": ("r04_issue_floor_twopass_importance.json", None)}
+        prof = {k: pmc_fractions(v[0]) for k, v in recs.items()}
+        kern = None
+        if all(prof.values()):
+            tot = sum(p["kernel_ms_profiled"] for p in prof.values())
+            kern = {k: pmc_fractions(recs[k][0], share_of_ms=prof[k]["kernel_ms_profiled"] / tot, total_ms=ms, steps_per_launch=recs[k][1]) for k in recs}
+        dom = kern["final"] if kern else None
         return dict(base, metric="rays/s, 512^2 x (96+96)-sample two-pass dual-plane render", value=n_total * M * args.steps / dt,
                     unit="rays/s", ms_per_step=dt / args.steps * 1e3, scaling="weak", dtype="f32",
                     config={"workload": "BASELINE config 5: render core through the (norm, denorm) entry, appearance statistics swapped "
                                         "between views, 4 views/GPU/step, 512^2 rays, 96 coarse + 96 importance samples",
                             "views_per_step": n_total, "parallelism": f"views-dp{world}"},
-                    roofline={"bound": "wave_issue", "achieved": None, "peak": None, "unit": None, "frac": None,
-                              "traffic": None, "kernel": "sigma-only pass + importance_kernel + nfe::render_kernel<DUAL>",
-                              "kernel_ms": ms, "logical_gather_gbs": ach,
-                              "note": "same per-wave issue bound as the headline kernel (no counter file for this workload, so no frac); "
-                                      "logical_gather_gbs = SURVEY 8(d) gather bytes of all three passes / their time, not a physical rate "
-                                      "(planes are cache resident)"})
+                    roofline={"bound": dom["bound"] if dom else None, "frac": dom["frac"] if dom else None,
+                              "achieved": dom["frac"] * dom["clock_ghz_profiled"] if dom else None, "peak": dom["clock_ghz_profiled"] if dom else None,
+                              "unit": "G busy-cycles/s per unit" if dom else None, "traffic": dom["hbm_bytes"] if dom else None,
+                              "kernel": dom["kernel"] if dom else "nfe::render_kernel<DUAL> (final pass)", "kernel_ms": dom["kernel_ms"] if dom else None,
+                              "step_ms": ms, "kernels": kern, "logical_gather_gbs": ach,
+                              "note": "dominant kernel = the final pass over the 192 merged samples with both plane sets (70 % of the step): "
+                                      "texture addresser 0.78 and L1 request rate 0.75 busy beside a SIMD that is 0.7 busy by the no-overlap "
+                                      "instruction model - co-limited, no single unit saturated; `kernels` lists the same ceilings for the "
+                                      "sigma-only coarse pass and importance_kernel (instruction-bound: one wave per ray); every fraction = "
+                                      "busy cycles from the committed rocprofv3 --pmc record of that kernel / (its share of this run's step "
+                                      "time x the profiled clock); logical_gather_gbs = SURVEY 8(d) gather bytes of all three passes / "
+                                      "their time, not a physical rate (planes are cache resident)"})
 
     if args.workload == "editstep":          # forward + backward of the renderer w.r.t. both plane sets, FFHQ rendering config
         Re, Dc = 128, 48
@@ -365,17 +453,48 @@ def extra_workload(args, torch, dist, dev, rank, world):
                             "parallelism": f"views-dp{world}"},
                     roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv3_kernel<*> + upfir/torgb (backbone + SR stages)",
-                              "kernel_ms": dense_ms, "note": "289.1 GFLOP per view (SURVEY 8d) / single-stream time of the backbone + SR stages (stage_ms); "
-                                                             "split-bf16 issues 3 MFMAs per product, so the matrix pipe does 3x these flops in that mode"})
+                              "kernel_ms": dense_ms,
+                              "kernels": DENSE_KERNEL_PMC["bf16x3" if ffhq else "bf16"],
+                              "render_stage": pmc_fractions("r04_issue_floor.json") if not ffhq else None,
+                              "note": "289.1 GFLOP per view (SURVEY 8d) / single-stream time of the backbone + SR stages (stage_ms); "
+                                      "split-bf16 issues 3 MFMAs per product, so the matrix pipe does 3x these flops in that mode.  `kernels`: "
+                                      "matrix-pipe busy fraction of each conv kernel variant = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel "
+                                      "cycles) from the committed rocprofv3 --pmc passes of this command (the dense kernels are unchanged since); "
+                                      "`render_stage`: the ceilings of the render kernel that takes the stats_render stage (config 3 only)"})
 
     out = orbit_job(args, torch, dist, dev, rank, world, frames=args.orbit_frames, G=G, steps=args.steps, warmup=args.warmup)
     return dict(base, metric="512^2 views/s, 512-frame orbit (gen_videos camera path)", value=out["views_per_s"], unit="views/s",
                 ms_per_step=out["seconds_per_pass"] * 1e3, scaling="strong", dtype="bf16",
                 config={"workload": out["workload"], "frames": out["frames"], "frames_per_rank": out["frames_per_rank"],
                         "chunk": out["chunk"], "parallelism": f"frames-dp{world}"},
-                roofline={"bound": "mfma", "achieved": out["dense_tflops"], "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                          "frac": out["dense_tflops"] / MFMA_BF16_PEAK_TFLOPS, "traffic": None,
-                          "kernel": "whole step (dense flops of this rank / wall time)", "kernel_ms": None})
+                roofline=orbit_roofline(out))
+
+
+# matrix-pipe busy fraction of the conv kernel variants (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), over all launches
+# of a `tools/time_full.py` run under rocprofv3 --pmc: profiles/r03_pmc_dense_*.txt; the dense kernels have not changed since)
+DENSE_KERNEL_PMC = {
+    "bf16": {"source": "profiles/r03_pmc_dense_bf16.txt",
+             "conv3_kernel<1,2,false,2,8,2> (plain 3x3, 8 waves)": {"matrix_pipe": 0.57, "tflops_whole_kernel": 1240},
+             "conv3_kernel<1,1,true,2,4,2> (up-sampling, fused FIR epilogue)": {"matrix_pipe": 0.25, "share_of_conv_time": 0.48, "share_of_conv_macs": 0.23}},
+    "bf16x3": {"source": "profiles/r03_pmc_dense_x3.txt",
+               "conv3_kernel<3,2,false,1,4,4> (plain 3x3, split-bf16)": {"matrix_pipe": 0.85, "note": "K loop; three MFMAs per product"}},
+}
+
+
+def orbit_roofline(out):
+    """The orbit job is 77 % render kernel (8-view launches of the headline kernel, 1.56 ms per 512^2 x 64 view): its roofline block is
+    that kernel's, from the same committed counter record as the headline line; the dense stages' aggregate stays beside it."""
+    r = pmc_fractions("r04_issue_floor.json")
+    if r is None:
+        return {"bound": None, "frac": None, "achieved": None, "peak": None, "unit": None, "traffic": None, "kernel": None, "kernel_ms": None}
+    per_view_ms = r["kernel_ms_profiled"] / VIEWS_PER_GPU
+    return {"bound": r["bound"], "frac": r["frac"], "achieved": r["frac"] * r["clock_ghz_profiled"], "peak": r["clock_ghz_profiled"],
+            "unit": "G busy-cycles/s per unit", "traffic": r["hbm_bytes"], "kernel": r["kernel"], "kernel_ms": r["kernel_ms_profiled"],
+            "fractions": r["fractions"], "render_share_of_pass": per_view_ms * 1e-3 * out["frames_per_rank"] / out["seconds_per_pass"],
+            "dense_tflops": out["dense_tflops"], "dense_frac_of_bf16_peak": out["dense_tflops"] / MFMA_BF16_PEAK_TFLOPS,
+            "note": "dominant kernel = the render kernel (render_share_of_pass of this rank's wall time, from its profiled 4-view launch "
+                    "time); fractions = busy cycles / kernel cycles of the committed rocprofv3 --pmc record of the headline command "
+                    "(profiles/r04_issue_floor.json), not re-measured by this run; dense_tflops = this rank's conv flops / wall time"}
 
 
 def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, warmup=0, chunk=8, return_frames=False):
@@ -664,14 +783,16 @@ def main():
             "distributed": dist_info,
             "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                          "frac": frac.get(bound) if bound else None, "traffic": detail.get("hbm_bytes"),
-                         "kernel": "nfe::render_kernel<DUAL=0,SIGMA_ONLY=0,BF16X3,...,SQUARE=1>", "kernel_ms": kern_ms,
-                         "kernel_ms_fp32_exact": fp32_ms, "fractions": frac,
+                         "kernel": detail.get("kernel_profiled") or "nfe::render_ws_kernel<4,2,SQUARE=1,GENERIC=0>", "kernel_ms": kern_ms,
+                         "kernel_ms_fp32_exact": fp32_ms, "fp32_exact": pmc_fractions("r04_issue_floor_fp32.json", share_of_ms=1.0, total_ms=fp32_ms, steps_per_launch=VIEWS_PER_GPU * (M // 32) * D),
+                         "fractions": frac,
                          "algorithmic_bytes_per_launch": launch_bytes, "detail": detail,
                          "note": "frac = busy cycles of the binding resource per launch (hardware counters of this build, profiles/) / "
                                  "kernel cycles (kernel time measured here with HIP events x effective clock); `fractions` lists every "
                                  "ceiling: per-wave instruction issue, matrix pipe, L1 request rate, TA, true HBM traffic, and SURVEY "
-                                 "8(d)'s logical gather bytes (not physical: planes are cache resident, so it exceeds 1); no unit is "
-                                 "saturated: the kernel is latency-bound at the 2 waves per SIMD its 256 VGPRs allow (DESIGN.md 6); "
+                                 "8(d)'s logical gather bytes (not physical: planes are cache resident, so it exceeds 1), and simd_pipes = the "
+                                 "SIMD's own execution time for the retired instruction mix (the binding one: more waves per SIMD or a "
+                                 "different instruction order do not shorten the kernel, fewer / cheaper instructions do, DESIGN.md 6.1); "
                                  "traffic = HBM bytes per launch"},
         }
         if strong is not None:

@@ -356,7 +356,12 @@ __device__ __forceinline__ bool inb_axes(int size, float gx, float gy, float gz,
     a.fx = ix - fx0; a.fy = iy - fy0; a.fz = iz - fz0;
     a.x0 = (int)fx0; a.y0 = (int)fy0; a.z0 = (int)fz0;                   // saturating conversion: far-away samples fail the test below
     const unsigned worst = max(max((unsigned)a.x0, (unsigned)a.y0), (unsigned)a.z0);        // negative -> huge
+#if NFE_INB_FAST == 2          // instruction census only (tools/isa_census.py): the fast path unconditionally, no general path in the loop
+    (void)worst;
+    return true;
+#else
     return __builtin_amdgcn_ballot_w64(worst >= (unsigned)(size - 1)) == 0;
+#endif
 }
 // one 16-byte piece at (uniform base) + (32-bit byte offset) + (compile-time immediate)
 template <int IMM>

@@ -224,3 +224,51 @@ def test_orbit_job_frames_equal_direct_synthesis():
         assert worst <= 2 and differing <= 0.15 * frames.numel()
     finally:
         del G.synthesis
+
+
+def test_soak_500_launches_on_three_streams():
+    """500 launches under --streams 3 load for render_kernel / render_ws_kernel, conv3_kernel and importance_kernel.
+    (a) 500 synthesis() calls of the FFHQ configuration in split-bf16 rotating over three HIP streams (per call: ~40 conv3 / conv /
+    torgb / upfir launches, the sigma-only pass of render_kernel, importance_kernel, the wave-specialised final pass with its depth
+    buffer, the SR head), every output compared bit for bit with the first call and dropped; (b) 500 launches of the headline
+    render shape (render_ws_kernel, 512^2 x 64, 2 views) on the same ring with the dense calls of (a) still in flight around them.
+    No hand-off wait of the wave-specialised kernel may be abandoned."""
+    from nerffaceediting_amd import apps, ops
+    dev = torch.device("cuda:0")
+    z = load("dense_e2e_cfg1")
+    G = _full_generator(dev, int(z["seed"]), 48, 48)
+    G.backbone.synthesis.conv_math = G.superresolution.conv_math = "bf16x3"
+    N, R = 4, 128
+    g = torch.Generator(device="cpu").manual_seed(22)
+    zs = torch.randn(N, 512, generator=g).to(dev)
+    c = apps.orbit_cameras(N, dev)
+    ws = G.mapping(zs, c, truncation_psi=0.7, truncation_cutoff=14)
+    G.renderer.seed_tensor = torch.tensor([987654321], dtype=torch.int64, device=dev)
+    raw = torch.randn(2, 96, 256, 256, generator=g).to(dev)
+    packed, aff = ops.plane_pack(raw), ops.make_affine(*ops.plane_stats(raw))
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+    dec = ops.decoder_pack(*[(torch.randn(*s, generator=g) * (1.0 if len(s) == 2 else 0.2)).to(dev) for s in shapes])
+    opts = dict(depth_resolution=64, depth_resolution_importance=0, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    headline = lambda: ops.render(packed, packed, dec, opts, cam2world=c[:2, :16].reshape(2, 4, 4).contiguous(),
+                                  intrinsics=c[:2, 16:].reshape(2, 3, 3).contiguous(), resolution=512, affines=aff, seed=77)
+    try:
+        first = G.synthesis(ws, c, neural_rendering_resolution=R, noise_mode="const")
+        first_r = headline()
+        torch.cuda.synchronize()
+        ring = apps.StreamRing(dev, 3)
+        bad = []
+        for i in range(500):
+            o = ring.take(*ring.run(lambda: G.synthesis(ws, c, neural_rendering_resolution=R, noise_mode="const")))
+            r = ring.take(*ring.run(headline))
+            for t_ in r:                          # a tuple: StreamRing.take() records only tensors / dict values on the consumer stream
+                t_.record_stream(torch.cuda.current_stream())
+            if not all(torch.equal(o[k], first[k]) for k in KEYS):
+                bad.append(("synthesis", i))
+            if not all(torch.equal(a, b) for a, b in zip(r, first_r)):
+                bad.append(("render", i))
+        ring.drain()
+        torch.cuda.synchronize()
+    finally:
+        G.renderer.seed_tensor = None
+    assert not bad, bad[:8]
+    assert ops.render_handoff_aborts() == 0

@@ -103,13 +103,15 @@ def main():
             insts.append((m.group(1), m.group(2), cur[0], cur[1]))
     anchor = sys.argv[sys.argv.index("--anchor") + 1] if "--anchor" in sys.argv else "v_mfma"      # the loop is found around these
     mf = [k for k, it in enumerate(insts) if it[0].startswith(anchor)]
-    # innermost loop around the MFMAs: the backward branch after the last MFMA whose target precedes the first one, closest fit
+    # innermost loop around the anchors: the backward branch with the smallest span that still holds most of them (anchors may also
+    # occur in the prologue - the decoder staging loads - so "all" would find no loop)
     best = None
     for k, it in enumerate(insts):
-        if it[0].startswith(("s_cbranch", "s_branch")) and k > mf[-1]:
+        if it[0].startswith(("s_cbranch", "s_branch")):
             tgt = labels.get(it[1].strip())
-            if tgt is not None and tgt <= mf[0]:
-                if best is None or (k - tgt) < (best[1] - best[0]):
+            if tgt is not None and tgt < k:
+                inside = sum(1 for a in mf if tgt <= a <= k)
+                if 2 * inside >= len(mf) and (best is None or (k - tgt) < (best[1] - best[0])):
                     best = (tgt, k)
     lo, hi = best
     body = insts[lo:hi + 1]
