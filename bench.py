@@ -401,7 +401,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     roofline=backward_roofline(bwd_ms, VIEWS_PER_GPU * Me * S2, ach))
 
     ffhq = args.workload == "ffhq"
-    conv_math = "bf16x3" if ffhq else "bf16"
+    conv_math = ("bf16x3" if ffhq else "bf16") if getattr(args, "conv_math", "auto") == "auto" else args.conv_math
     G = full_generator(torch, dev, 48 if ffhq else D, 48 if ffhq else 0, conv_math)
     if args.workload in ("full", "ffhq"):    # config 3, or the FFHQ inference configuration
         NV = 4 if ffhq else 8
@@ -440,12 +440,12 @@ def extra_workload(args, torch, dist, dev, rank, world):
         flops = GFLOP_DENSE_PER_VIEW * NV * 1e9
         ach = flops / (dense_ms * 1e-3) / 1e12
         what = ("FFHQ inference configuration (train.py:306-307): a1-a14, 4 views/GPU/step, neural render 128^2 x (48+48) -> "
-                "SuperresolutionHybrid8XDC to 512^2, split-bf16 (fp32-grade) MFMA convs, fp32 render") if ffhq else (
+                "SuperresolutionHybrid8XDC to 512^2, %s MFMA convs, fp32 render" % MATH_NAME[conv_math]) if ffhq else (
                 "BASELINE config 3: a1-a14, 8 views/GPU/step, neural render 512^2 x 64 -> antialias resize -> "
-                "SuperresolutionHybrid8XDC to 512^2, bf16 MFMA convs (fp32 accumulate), fp32 render")
+                "SuperresolutionHybrid8XDC to 512^2, %s MFMA convs (fp32 accumulate), fp32 render" % MATH_NAME[conv_math])
         return dict(base, metric="512^2 views/s, full synthesis (mapping + backbone + %s render + SR)" % ("128^2 x (48+48)" if ffhq else "512^2 x 64"),
                     value=n_total * args.steps / dt, unit="views/s", ms_per_step=dt / args.steps * 1e3, scaling="weak",
-                    dtype="bf16x3" if ffhq else "bf16",
+                    dtype=conv_math,
                     config={"workload": what,
                             "views_per_step": n_total, "synthesis_ms": syn_ms, "stage_ms": stage, "streams": args.streams,
                             "stage_ms_note": "HIP-event times of three extra steps issued on one stream after the timed region (inside it "
@@ -454,7 +454,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv3_kernel<*> + upfir/torgb (backbone + SR stages)",
                               "kernel_ms": dense_ms,
-                              "kernels": DENSE_KERNEL_PMC["bf16x3" if ffhq else "bf16"],
+                              "kernels": DENSE_KERNEL_PMC["bf16x3" if conv_math == "bf16x3" else "bf16"], "conv_math": conv_math,
                               "render_stage": pmc_fractions("r04_issue_floor.json") if not ffhq else None,
                               "note": "289.1 GFLOP per view (SURVEY 8d) / single-stream time of the backbone + SR stages (stage_ms); "
                                       "split-bf16 issues 3 MFMAs per product, so the matrix pipe does 3x these flops in that mode.  `kernels`: "
@@ -479,6 +479,9 @@ DENSE_KERNEL_PMC = {
     "bf16x3": {"source": "profiles/r03_pmc_dense_x3.txt",
                "conv3_kernel<3,2,false,1,4,4> (plain 3x3, split-bf16)": {"matrix_pipe": 0.85, "note": "K loop; three MFMAs per product"}},
 }
+
+
+MATH_NAME = {"bf16x3": "split-bf16 (fp32-grade, 3 MFMAs per product)", "bf16": "bf16", "fp16": "fp16-operand (the reference's GPU arithmetic, 1 MFMA per product)"}
 
 
 def orbit_roofline(out):
@@ -625,6 +628,10 @@ def main():
     ap.add_argument("--streams", type=int, default=3, help="HIP streams the full-synthesis workloads alternate their batches on")
     ap.add_argument("--orbit-frames", type=int, default=512, help="frames of the strong-scaling orbit job (BASELINE config 4)")
     ap.add_argument("--no-strong-scaling", action="store_true", help="skip the config-4 orbit job reported beside the default line")
+    ap.add_argument("--conv-math", choices=["auto", "bf16x3", "bf16", "fp16"], default="auto",
+                    help="operand arithmetic of the convolutions in --workload full / ffhq / orbit: auto = the workload's own (bf16 for config "
+                         "3 and the orbit, split-bf16 for ffhq); fp16 = one v_mfma_f32_32x32x16_f16 per product, the reference's GPU arithmetic for "
+                         "its fp16 layers (train.py:183, networks_stylegan2.py:421-423)")
     ap.add_argument("--force-collective", action="store_true",
                     help="with --gpus 1: still create the (one-rank) RCCL process group and run every frame exchange through it instead of "
                          "short-circuiting - all of the multi-GPU data path a 1-GPU box can execute (train.py:37-43 precedent)")

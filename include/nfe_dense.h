@@ -27,6 +27,10 @@ extern "C" {
 
 #define NFE_CONV_BF16X3 0
 #define NFE_CONV_BF16 1
+#define NFE_CONV_F16 2        /* ABI v12: fp16 MFMA operands (v_mfma_f32_32x32x16_f16), fp32 accumulate and fp32 activations between layers -
+                               * the reference's own GPU arithmetic for its fp16 layers (networks_stylegan2.py:421-423, superresolution.py:271-277
+                               * with train.py:183 sr_num_fp16_res = 4).  Needs weights packed by nfe_conv_pack_f16; same sizes, scratch and
+                               * kernel variants as NFE_CONV_BF16, 8x finer operand rounding (11 significand bits against 8). */
 
 /* conv modes */
 #define NFE_CONV_3X3 0        /* SynthesisLayer up=1: 3x3, pad 1 (networks_stylegan2.py:311-330) */
@@ -81,6 +85,8 @@ int nfe_broadcast_truncate(const float* w, const float* w_avg, int n, int w_dim,
  * packed must hold nfe_conv_packed_words(cout,cin,k) 4-byte words; wsq is [Cout,Cin]. */
 uint64_t nfe_conv_packed_words(int cout, int cin, int k);
 int nfe_conv_pack(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream);
+/* the same image with fp16 operand words (hi part; the lo part is zero): for math = NFE_CONV_F16 only */
+int nfe_conv_pack_f16(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream);
 
 /* demodulation coefficients: dcoef[n,o] = rsqrt(sum_i styles[n,i]^2 * wsq[o,i] + 1e-8)  (:64-65) */
 int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int cout, float* dcoef, nfe_stream_t stream);
@@ -88,7 +94,7 @@ int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int co
 typedef struct nfe_conv_args {
     uint32_t struct_size;
     int32_t mode;                 /* NFE_CONV_3X3 / _3X3_UP2 / _1X1 */
-    int32_t math;                 /* NFE_CONV_BF16X3 / NFE_CONV_BF16 */
+    int32_t math;                 /* NFE_CONV_BF16X3 / NFE_CONV_BF16 / NFE_CONV_F16 */
     const float* x;               /* [N,H,W,Cin] */
     const float* styles;          /* [N,Cin] (ToRGB: already times weight_gain) */
     const float* packed;          /* from nfe_conv_pack */

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 11
+NFE_ABI_VERSION = 12
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_DECODER_CROSS_FLOATS = 2048
@@ -92,7 +92,7 @@ class DemodGroup(ctypes.Structure):
 
 
 NFE_MAX_GROUPS = 32
-NFE_CONV_BF16X3, NFE_CONV_BF16 = 0, 1
+NFE_CONV_BF16X3, NFE_CONV_BF16, NFE_CONV_F16 = 0, 1, 2
 NFE_CONV_3X3, NFE_CONV_3X3_UP2, NFE_CONV_1X1 = 0, 1, 2
 
 _SIGNATURES = {
@@ -124,6 +124,7 @@ _SIGNATURES = {
     "nfe_broadcast_truncate": (c_int, [FP, FP, c_int, c_int, c_int, c_float, c_int, FP, c_void_p]),
     "nfe_conv_packed_words": (c_uint64, [c_int, c_int, c_int]),
     "nfe_conv_pack": (c_int, [FP, c_int, c_int, c_int, FP, FP, c_void_p]),
+    "nfe_conv_pack_f16": (c_int, [FP, c_int, c_int, c_int, FP, FP, c_void_p]),
     "nfe_conv_demod": (c_int, [FP, FP, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_modulated_conv": (c_int, [POINTER(ConvArgs), c_void_p]),
     "nfe_conv_scratch_floats": (c_uint64, [c_int] * 7),

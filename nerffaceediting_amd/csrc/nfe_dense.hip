@@ -13,6 +13,25 @@ namespace nfe {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 union Frag8 { bf16x8 v; uint4 q; unsigned u[4]; };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// Operand formats of the implicit GEMMs, the TERMS template argument of every kernel below:
+//   3  split-bf16 (hi + lo, three MFMAs per product, fp32-grade)      NFE_CONV_BF16X3
+//   1  bf16 (one MFMA per product)                                    NFE_CONV_BF16
+//   2  fp16 (one MFMA per product, v_mfma_f32_32x32x16_f16)           NFE_CONV_F16: the arithmetic the reference's GPU path uses
+//      for its fp16 layers (networks_stylegan2.py:421-423: fp16 operands, clamp +-256) - 11 significand bits against bf16's 8 at the
+//      same MFMA rate; accumulation stays fp32 and the activations between layers stay fp32 (only the MFMA operands are rounded).
+// Everything that is "one part or two" asks TERMS == 3; TERMS 1 and 2 differ only in the conversion and the MFMA opcode.
+template <int TERMS>
+__device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
+    if constexpr (TERMS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ unsigned f16_pair(float a, float b) {           // round to nearest even; beyond +-65504 -> +-inf (clamped layers never get there)
+    f16x2 p = {(_Float16)a, (_Float16)b};
+    return __builtin_bit_cast(unsigned, p);
+}
 
 __device__ __forceinline__ unsigned bf16_rne(float v) {
     bf16x2 p = {(__bf16)v, (__bf16)0.0f};
@@ -32,11 +51,19 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& hi, unsigned&
         hi = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
         bf16x2 p = {(__bf16)(a - __uint_as_float(ua & 0xffff0000u)), (__bf16)(b - __uint_as_float(ub & 0xffff0000u))};
         lo = *reinterpret_cast<unsigned*>(&p);
+    } else if (TERMS == 2) {
+        hi = f16_pair(a, b);
+        lo = 0;
     } else {
         bf16x2 p = {(__bf16)a, (__bf16)b};
         hi = *reinterpret_cast<unsigned*>(&p);
         lo = 0;
     }
+}
+// single-part split whose format is known at run time only (the HBM-bound passes that are not templated on the operand format)
+__device__ __forceinline__ void split2_single(int f16, float a, float b, unsigned& hi) {
+    unsigned lo;
+    if (f16) split2<2>(a, b, hi, lo); else split2<1>(a, b, hi, lo);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -201,7 +228,7 @@ __global__ __launch_bounds__(256) void demod_grouped_kernel(DemodGroups G, int n
 // weights -> MFMA A-fragment image: [Cout/32][Cin/16][taps][part][lane 64][4 words]; word w of lane l
 // holds elements e = 2w, 2w+1 of the 8-vector: out channel 32*mb + (l&31), in channel 16g + 8(l>>5) + e.
 // ------------------------------------------------------------------------------------------------
-__global__ void conv_pack_kernel(const float* __restrict__ weight, int cout, int cin, int taps, float* __restrict__ packed, float* __restrict__ wsq) {
+__global__ void conv_pack_kernel(const float* __restrict__ weight, int cout, int cin, int taps, float* __restrict__ packed, float* __restrict__ wsq, int f16) {
     const int G = (cin + 15) / 16, MB = (cout + 31) / 32;
     const long long total = (long long)MB * G * taps * 2 * 256;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -215,7 +242,7 @@ __global__ void conv_pack_kernel(const float* __restrict__ weight, int cout, int
             const int ch = 16 * g + 8 * h + 2 * word + k;
             const float v = (o < cout && ch < cin) ? weight[((long long)o * cin + ch) * taps + t] : 0.0f;
             const unsigned hi = bf16_rne(v);
-            bits[k] = part == 0 ? hi : bf16_rne(v - __uint_as_float(hi << 16));
+            bits[k] = f16 ? (part == 0 ? (f16_pair(v, 0.0f) & 0xffffu) : 0u) : (part == 0 ? hi : bf16_rne(v - __uint_as_float(hi << 16)));
         }
         packed[i] = __uint_as_float(bits[0] | (bits[1] << 16));
     }
@@ -240,6 +267,7 @@ struct ConvK {
     float* out; float* scratch;
     const float* next_styles; uint2* split_hi; uint2* split_lo;      // up-conv: modulated bf16 image for the consuming layer
     float* partial; int ksplit;                                       // split-K: raw partial sums [ksplit][...], reduced by splitk_reduce_kernel
+    int f16;                                                          // single-part operand images are fp16 (NFE_CONV_F16), not bf16
 };
 
 constexpr int PATCH = 18;                                         // 16 + halo
@@ -398,11 +426,11 @@ __global__ __launch_bounds__(256, 2) void conv_kernel(ConvK P) {
                 const int off = ((py * 2 + h) * PATCH + px) * 16;
                 Frag8 bh, bl;
                 bh.q = *reinterpret_cast<const uint4*>(ldsP + off);
-                acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[a][nb], 0, 0, 0);
+                acc[a][nb] = mfma16<TERMS>(ah.v, bh.v, acc[a][nb], 0, 0, 0);
                 if (TERMS == 3) {
                     bl.q = *reinterpret_cast<const uint4*>(ldsP + PATCH_PART_BYTES + off);
-                    acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[a][nb], 0, 0, 0);
-                    acc[a][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[a][nb], 0, 0, 0);
+                    acc[a][nb] = mfma16<TERMS>(ah.v, bl.v, acc[a][nb], 0, 0, 0);
+                    acc[a][nb] = mfma16<TERMS>(al.v, bh.v, acc[a][nb], 0, 0, 0);
                 }
             }
         }
@@ -495,7 +523,7 @@ __device__ __forceinline__ long long split_index(int n, int G, int H, int W, int
 }
 
 __global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict__ x, const float* __restrict__ styles, long long n_vec,
-                                                       long long hw_vec, int c4, uint2* __restrict__ hi, uint2* __restrict__ lo) {
+                                                       long long hw_vec, int c4, uint2* __restrict__ hi, uint2* __restrict__ lo, int f16) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += (long long)gridDim.x * blockDim.x) {
         const int q = (int)(i % c4);
         const long long n = i / hw_vec;
@@ -506,7 +534,7 @@ __global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict_
         const long long pix = i / c4;                                  // (n, y, x) flattened; hw_vec / c4 pixels per sample
         const long long o = ((n * (c4 >> 2) + (q >> 2)) * (hw_vec / c4) + (pix - n * (hw_vec / c4))) * 4 + (q & 3);
         if (lo) { split2<3>(v.x, v.y, h0, l0); split2<3>(v.z, v.w, h1, l1); lo[o] = make_uint2(l0, l1); }
-        else { split2<1>(v.x, v.y, h0, l0); split2<1>(v.z, v.w, h1, l1); }
+        else { split2_single(f16, v.x, v.y, h0); split2_single(f16, v.z, v.w, h1); }
         hi[o] = make_uint2(h0, h1);
     }
 }
@@ -555,6 +583,7 @@ struct Conv3K {
     int ksplit;         // > 1: blockIdx.z = n * ksplit + ks; this workgroup sums K-groups [ks*G/ksplit, (ks+1)*G/ksplit) and writes
     float* partial;     //      raw partial sums [ksplit][N,H,W,Cout] that splitk_reduce_kernel adds in slice order (+ epilogue)
     const float* next_styles; uint2* split_hi; uint2* split_lo;     // plain 3x3, no split-K: the consuming layer's modulated bf16 image
+    int f16;            // host-side only: launch the TERMS = 2 (fp16 operand) instantiation of the bf16 variant
 };                                                                  // (what modsplit_kernel would make of `out`), written by the epilogue
 
 #ifndef C3_XCD_ALL
@@ -799,7 +828,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
         const unsigned char* ldsB = base + A_CHUNKS * 1024;
-        if constexpr (LW > 0 && TERMS == 1 && !UP2 && NBW == 4 && !C3_LC_GENERIC_LOOP) {
+        if constexpr (LW > 0 && TERMS != 3 && !UP2 && NBW == 4 && !C3_LC_GENERIC_LOOP) {
             // Compute wave of the loader / compute split, plain bf16: this wave is alone on its SIMD's matrix pipe, so the LDS latency
             // of a fragment read must be covered by its own MFMAs.  All 18 weight fragments of the K-group stay in registers (72
             // VGPRs; each is used by 4 rows), the 18 patch fragments (6 patch rows x 3 columns) stream through a ring of four,
@@ -823,7 +852,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                     if (kh >= 0 && kh <= 2) {
 #pragma unroll
                         for (int m = 0; m < MBW; ++m)
-                            acc[0][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[m][kh * 3 + dx].v, Bq[f & 3].v, acc[0][m][nb], 0, 0, 0);
+                            acc[0][m][nb] = mfma16<TERMS>(A[m][kh * 3 + dx].v, Bq[f & 3].v, acc[0][m][nb], 0, 0, 0);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
@@ -867,10 +896,10 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                 acc[a][m][nb][0] += __builtin_bit_cast(float, ah[t & 1][m].u[0] ^ bh[s_ & 1].u[0]);
                 if (TERMS == 3) acc[a][m][nb][1] += __builtin_bit_cast(float, al[t & 1][m].u[0] ^ bl[s_ & 1].u[0]);
 #else
-                acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
+                acc[a][m][nb] = mfma16<TERMS>(ah[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
                 if (TERMS == 3) {
-                    acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, bl[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
-                    acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
+                    acc[a][m][nb] = mfma16<TERMS>(ah[t & 1][m].v, bl[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
+                    acc[a][m][nb] = mfma16<TERMS>(al[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
                 }
 #endif
             }
@@ -881,10 +910,10 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                 if (TERMS == 3) el.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brde[dy]);
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) {
-                    acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, eh.v, acce[kh & 1][m], 0, 0, 0);
+                    acce[kh & 1][m] = mfma16<TERMS>(ah[t & 1][m].v, eh.v, acce[kh & 1][m], 0, 0, 0);
                     if (TERMS == 3) {
-                        acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t & 1][m].v, el.v, acce[kh & 1][m], 0, 0, 0);
-                        acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t & 1][m].v, eh.v, acce[kh & 1][m], 0, 0, 0);
+                        acce[kh & 1][m] = mfma16<TERMS>(ah[t & 1][m].v, el.v, acce[kh & 1][m], 0, 0, 0);
+                        acce[kh & 1][m] = mfma16<TERMS>(al[t & 1][m].v, eh.v, acce[kh & 1][m], 0, 0, 0);
                     }
                 }
             }
@@ -909,10 +938,10 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                 if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brd[nb + dy][dx]);
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) {
-                    acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
+                    acc[a][m][nb] = mfma16<TERMS>(ah[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
                     if (TERMS == 3) {
-                        acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bl.v, acc[a][m][nb], 0, 0, 0);
-                        acc[a][m][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
+                        acc[a][m][nb] = mfma16<TERMS>(ah[m].v, bl.v, acc[a][m][nb], 0, 0, 0);
+                        acc[a][m][nb] = mfma16<TERMS>(al[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
                     }
                 }
             }
@@ -923,10 +952,10 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                 if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brde[dy]);
 #pragma unroll
                 for (int m = 0; m < MBW; ++m) {
-                    acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bh.v, acce[kh & 1][m], 0, 0, 0);
+                    acce[kh & 1][m] = mfma16<TERMS>(ah[m].v, bh.v, acce[kh & 1][m], 0, 0, 0);
                     if (TERMS == 3) {
-                        acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[m].v, bl.v, acce[kh & 1][m], 0, 0, 0);
-                        acce[kh & 1][m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[m].v, bh.v, acce[kh & 1][m], 0, 0, 0);
+                        acce[kh & 1][m] = mfma16<TERMS>(ah[m].v, bl.v, acce[kh & 1][m], 0, 0, 0);
+                        acce[kh & 1][m] = mfma16<TERMS>(al[m].v, bh.v, acce[kh & 1][m], 0, 0, 0);
                     }
                 }
             }
@@ -1058,7 +1087,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                         unsigned h0, l0, h1, l1;
                         const long long si = split_index(n, P.Cout >> 4, OH, OW, Y, X, c4);
                         if (TERMS == 3) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
-                        else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
+                        else { split2<TERMS>(o.x * s2.x, o.y * s2.y, h0, l0); split2<TERMS>(o.z * s2.z, o.w * s2.w, h1, l1); }
                         P.split_hi[si] = make_uint2(h0, h1);
                     }
                 }
@@ -1291,11 +1320,11 @@ __global__ __launch_bounds__(256, 2) void torgb_kernel(ConvK P) {
             for (int mb = 0; mb < MB; ++mb) {
                 Frag8 ah, al;
                 ah.q = ldsA[((mb * G + g) * PARTS + 0) * 64 + lane];
-                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, acc[mb], 0, 0, 0);
+                acc[mb] = mfma16<TERMS>(ah.v, bh.v, acc[mb], 0, 0, 0);
                 if (TERMS == 3) {
                     al.q = ldsA[((mb * G + g) * PARTS + 1) * 64 + lane];
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, acc[mb], 0, 0, 0);
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al.v, bh.v, acc[mb], 0, 0, 0);
+                    acc[mb] = mfma16<TERMS>(ah.v, bl.v, acc[mb], 0, 0, 0);
+                    acc[mb] = mfma16<TERMS>(al.v, bh.v, acc[mb], 0, 0, 0);
                 }
             }
         }
@@ -1330,7 +1359,14 @@ __global__ __launch_bounds__(256, 2) void torgb_kernel(ConvK P) {
 }
 
 template <int TERMS, int MB>
+static void launch_torgb_t(const ConvK& P, hipStream_t st);
+template <int TERMS, int MB>
 static void launch_torgb(const ConvK& P, hipStream_t st) {
+    if constexpr (TERMS == 1) { if (P.f16) { launch_torgb_t<2, MB>(P, st); return; } }
+    launch_torgb_t<TERMS, MB>(P, st);
+}
+template <int TERMS, int MB>
+static void launch_torgb_t(const ConvK& P, hipStream_t st) {
     const int bytes = MB * (P.Cin / 16) * (TERMS == 3 ? 2 : 1) * 1024;
     static int allowed = 0;
     if (bytes > allowed) {
@@ -1497,7 +1533,7 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
                         unsigned h0, l0, h1, l1;
                         const long long si = split_index(n, C4 >> 2, OH, OW, Y, X, c4);
                         if (PARTS == 2) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
-                        else { split2<1>(o.x * s2.x, o.y * s2.y, h0, l0); split2<1>(o.z * s2.z, o.w * s2.w, h1, l1); }
+                        else { split2_single(P.f16, o.x * s2.x, o.y * s2.y, h0); split2_single(P.f16, o.z * s2.z, o.w * s2.w, h1); }
                         P.split_hi[si] = make_uint2(h0, h1);
                     }
                 }
@@ -1752,13 +1788,19 @@ extern "C" uint64_t nfe_conv_packed_words(int cout, int cin, int k) {
     if (cout <= 0 || cin <= 0 || cin % 4 != 0 || (k != 1 && k != 3)) return 0;
     return (uint64_t)((cout + 31) / 32) * ((cin + 15) / 16) * (k * k) * 2 * 256;
 }
-extern "C" int nfe_conv_pack(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream) {
+static int conv_pack_any(const float* weight, int cout, int cin, int k, float* packed, float* wsq, int f16, nfe_stream_t stream) {
     NFE_REQUIRE(weight && packed && wsq, "nfe_conv_pack: null pointer");
     NFE_REQUIRE(cout > 0 && cin > 0 && cin % 4 == 0 && (k == 1 || k == 3), "nfe_conv_pack: need cin %% 4 == 0 and k in {1,3} (cout=%d cin=%d k=%d)", cout, cin, k);
     hipLaunchKernelGGL(conv_pack_kernel, dim3(grid1d((long long)nfe_conv_packed_words(cout, cin, k), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       weight, cout, cin, k * k, packed, wsq);
+                       weight, cout, cin, k * k, packed, wsq, f16);
     NFE_CHECK_LAUNCH("conv_pack_kernel");
     return NFE_OK;
+}
+extern "C" int nfe_conv_pack(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream) {
+    return conv_pack_any(weight, cout, cin, k, packed, wsq, 0, stream);
+}
+extern "C" int nfe_conv_pack_f16(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream) {
+    return conv_pack_any(weight, cout, cin, k, packed, wsq, 1, stream);
 }
 extern "C" int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int cout, float* dcoef, nfe_stream_t stream) {
     NFE_REQUIRE(styles && wsq && dcoef && n > 0 && cin > 0 && cout > 0, "nfe_conv_demod: bad arguments");
@@ -1770,7 +1812,8 @@ extern "C" int nfe_conv_demod(const float* styles, const float* wsq, int n, int 
 
 template <int MODE>
 static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
-    if (math == NFE_CONV_BF16) hipLaunchKernelGGL((conv_kernel<MODE, 1>), grid, dim3(256), 0, st, P);
+    if (math == NFE_CONV_F16) hipLaunchKernelGGL((conv_kernel<MODE, 2>), grid, dim3(256), 0, st, P);
+    else if (math == NFE_CONV_BF16) hipLaunchKernelGGL((conv_kernel<MODE, 1>), grid, dim3(256), 0, st, P);
     else hipLaunchKernelGGL((conv_kernel<MODE, 3>), grid, dim3(256), 0, st, P);
 }
 
@@ -1819,6 +1862,7 @@ static void launch_upfir(const ConvK& P, long long total, hipStream_t st) {
 // plain bf16 up to 256 input channels; split-bf16, whose K loop is MFMA-bound, only the 32-channel layer at the head's entry.
 // NFE_UP_FUSED=0 switches it off, NFE_UP_FUSED_CIN_BF16 / NFE_UP_FUSED_CIN_X3 move the thresholds (A/B knobs).
 static bool up_fused(int math, int ksplit, int cin) {
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     static const bool on = [] { const char* e = getenv("NFE_UP_FUSED"); return !e || e[0] != '0'; }();
     static const int max_x3 = [] { const char* e = getenv("NFE_UP_FUSED_CIN_X3"); return e ? atoi(e) : 32; }();
     static const int max_bf16 = [] { const char* e = getenv("NFE_UP_FUSED_CIN_BF16"); return e ? atoi(e) : 256; }();
@@ -1827,7 +1871,15 @@ static bool up_fused(int math, int ksplit, int cin) {
 
 static_assert(conv3_ec_bytes<2>() == 1024 && conv3_ec_bytes<4>() == 1536, "epilogue constants: three float rows of 32 * MBW channels");
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
+static void launch_conv3_t(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override);
+// the bf16 variant table serves fp16 too: same tiles, stages and thresholds, the kernel instantiated with TERMS = 2
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override = 0) {
+    if constexpr (TERMS == 1) { if (K.f16) { launch_conv3_t<2, MBW, UP2, STAGES, WV, NBW, LW>(K, mode_h, mode_w, st, tiles_override); return; } }
+    launch_conv3_t<TERMS, MBW, UP2, STAGES, WV, NBW, LW>(K, mode_h, mode_w, st, tiles_override);
+}
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW, int LW>
+static void launch_conv3_t(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override) {
     constexpr int ROWS = NBW * WV;
     constexpr int ring = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>(), fused_t = UP2 ? 2 * (2 * ROWS) * 64 * 16 : 0;
     constexpr int bytes = (ring > fused_t ? ring : fused_t) + conv3_ec_bytes<MBW>();  // ring (or the fused FIR's tile) + the epilogue constants
@@ -1846,6 +1898,7 @@ static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st
 // operand pipeline and spent 79 us per 4^2..16^2 layer at 8 views (tools/r03_small_layers.sh: backbone 2.01 -> 1.83 ms).  The
 // size-only queries of the API (no math argument) answer with the conservative rule.
 static bool conv3_eligible(int mode, int h, int w, int cin, int cout, int math = NFE_CONV_BF16X3) {
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     static const int min_w_env = [] { const char* e = getenv("NFE_C3_MIN_W"); return e ? atoi(e) : 0; }();      // A/B knobs
     static const int min_h_env = [] { const char* e = getenv("NFE_C3_MIN_H"); return e ? atoi(e) : 0; }();
     const int min_w = min_w_env ? min_w_env : (math == NFE_CONV_BF16 ? 4 : 32), min_h = min_h_env ? min_h_env : (math == NFE_CONV_BF16 ? 4 : 8);
@@ -1857,6 +1910,7 @@ static bool conv3_eligible(int mode, int h, int w, int cin, int cout, int math =
 // layers at small batch): split the K loop over 2 or 4 workgroups, each keeping at least 8 K-groups; partial sums go through
 // splitk_reduce_kernel (deterministic slice order).  0 = no split.
 static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout, int math = NFE_CONV_BF16X3) {
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     static const bool off = [] { const char* e = getenv("NFE_C3_KSPLIT"); return e && e[0] == '0'; }();
     if (off || mode == NFE_CONV_1X1 || !conv3_eligible(mode, h, w, cin, cout, math)) return 0;
     const int G = cin / 16;
@@ -1878,6 +1932,7 @@ static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout, int ma
 // Which conv3_kernel instantiation a fast-path layer runs (one place: the launcher and nfe_conv_describe both ask here).
 enum { C3V_UP = 0, C3V_BIG, C3V_MID, C3V_X3_TALL4, C3V_TALL8, C3V_BASE, C3V_WIDE8, C3V_LC };
 static int conv3_variant(int mode, int math, int n, int h, int w, int cout) {
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     const bool bf16 = math == NFE_CONV_BF16;
     if (mode == NFE_CONV_3X3_UP2) return C3V_UP;
     const bool tall = h >= 16 * C3_TALL_MIN_TILES;
@@ -1902,11 +1957,13 @@ extern "C" int nfe_conv_splits_in_epilogue(int mode, int n, int h, int w, int ci
 }
 
 extern "C" int nfe_conv_fuses_rgb(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels) {
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     if (mode != NFE_CONV_3X3 || rgb_channels < 1 || rgb_channels > 4 || cout > 256 || C3_BIG) return 0;
     return conv3_eligible(mode, h, w, cin, cout, math) && conv3_ksplit(mode, n, h, w, cin, cout, math) == 0 ? 1 : 0;
 }
 
 extern "C" uint64_t nfe_conv_split_floats(int math, int n, int h, int w, int c) {
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     if (n <= 0 || h <= 0 || w <= 0 || c <= 0) return 0;
     const uint64_t elems = (uint64_t)n * h * w * c;
     return math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems;
@@ -1918,6 +1975,7 @@ extern "C" int nfe_conv_accepts_split(int mode, int h, int w, int cin, int cout)
 // layers up to 128^2 whose weights do not fit the LDS-resident torgb_kernel (512 / 256 input channels) when the batch is too
 // small to fill the chip with (tile, M-block) workgroups alone: 73 us -> 15 us for the 64^2 x 512 -> 96 layer at batch 1.
 static int splitk_slices(int mode, int math, int n, int h, int w, int cin, int cout) {
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     if (cout % 4 != 0) return 0;
     const int G = (cin + 15) / 16;
     const int ks = G >= 16 ? 8 : (G >= 8 ? 4 : 0);
@@ -1933,6 +1991,7 @@ static int splitk_slices(int mode, int math, int n, int h, int w, int cin, int c
 }
 
 extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int cin, int cout) {
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     if (n <= 0 || h <= 0 || w <= 0 || cin <= 0 || cout <= 0) return 0;
     uint64_t fl = mode == NFE_CONV_3X3_UP2 ? (uint64_t)n * (2 * h + 1) * (2 * w + 1) * cout : 0;     // transposed-conv result
     if (conv3_eligible(mode, h, w, cin, cout, math)) {
@@ -1950,8 +2009,10 @@ extern "C" uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, in
 // Text description of the kernels nfe_modulated_conv would launch for a layer of these sizes (tests log it so that a parity
 // failure names the variant; batch-dependent: split-K, fused ToRGB, epilogue split and the tile shape all depend on n).
 extern "C" int nfe_conv_describe(int mode, int math, int n, int h, int w, int cin, int cout, int rgb_channels, char* buf, int buf_len) {
+    const bool f16_ = math == NFE_CONV_F16;
+    if (f16_) math = NFE_CONV_BF16;
     NFE_REQUIRE(buf && buf_len > 0, "nfe_conv_describe: no buffer");
-    const char* m = math == NFE_CONV_BF16 ? "bf16" : "bf16x3";
+    const char* m = f16_ ? "fp16" : (math == NFE_CONV_BF16 ? "bf16" : "bf16x3");
     if (mode != NFE_CONV_1X1 && conv3_eligible(mode, h, w, cin, cout, math)) {
         static const char* names[] = {"up2 1x(32x8)/4w", "big 128ch 32x16/4w", "mid 32x16/4w", "x3 32x16/4w (2x4 blocks)", "32x16/8w", "32x8/4w", "128ch 32x16/8w", "32x16/4w compute + 4w loaders"};
         const int ks = conv3_ksplit(mode, n, h, w, cin, cout, math);
@@ -1974,7 +2035,9 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a != nullptr, "nfe_modulated_conv: args is null");
     NFE_REQUIRE(a->struct_size == sizeof(nfe_conv_args), "nfe_modulated_conv: struct_size %u != %zu (ABI mismatch)", a->struct_size, sizeof(nfe_conv_args));
     NFE_REQUIRE(a->mode >= 0 && a->mode <= 2, "nfe_modulated_conv: unknown mode %d", a->mode);
-    NFE_REQUIRE(a->math == NFE_CONV_BF16X3 || a->math == NFE_CONV_BF16, "nfe_modulated_conv: unknown math %d", a->math);
+    NFE_REQUIRE(a->math == NFE_CONV_BF16X3 || a->math == NFE_CONV_BF16 || a->math == NFE_CONV_F16, "nfe_modulated_conv: unknown math %d", a->math);
+    const int f16 = a->math == NFE_CONV_F16 ? 1 : 0;
+    const int math = f16 ? NFE_CONV_BF16 : a->math;      // fp16: bf16's sizes, variants and thresholds; the launches pick the TERMS = 2 kernels
     NFE_REQUIRE((a->x || a->x_split) && a->styles && a->packed && a->bias && (a->out || a->next_split || a->rgb_weight), "nfe_modulated_conv: null pointer");
     NFE_REQUIRE(!a->next_split || (a->next_styles && a->mode != NFE_CONV_1X1), "nfe_modulated_conv: next_split needs next_styles and a 3x3 mode");
     NFE_REQUIRE(a->n > 0 && a->h > 0 && a->w > 0 && a->cin > 0 && a->cout > 0 && a->cin % 4 == 0, "nfe_modulated_conv: bad sizes n=%d h=%d w=%d cin=%d cout=%d", a->n, a->h, a->w, a->cin, a->cout);
@@ -1983,6 +2046,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(!a->skip || (a->mode == NFE_CONV_1X1 && a->h % 2 == 0 && a->w % 2 == 0), "nfe_modulated_conv: skip needs mode 1x1 and even size");
     NFE_REQUIRE(!a->out_planes || (a->mode == NFE_CONV_1X1 && a->cout == 96), "nfe_modulated_conv: out_planes needs mode 1x1 and cout 96");
     ConvK P{};
+    P.f16 = f16;
     P.x = a->x; P.styles = a->styles; P.packed = reinterpret_cast<const uint4*>(a->packed); P.dcoef = a->dcoef; P.noise = a->noise; P.noise_n_stride = a->noise_n_stride;
     P.noise_strength = a->noise_strength; P.bias = a->bias; P.N = a->n; P.H = a->h; P.W = a->w; P.Cin = a->cin; P.Cout = a->cout;
     P.lrelu = a->lrelu; P.act_gain = a->act_gain; P.clamp = a->clamp; P.skip = a->skip; P.out_planes = a->out_planes; P.out = a->out; P.scratch = a->scratch;
@@ -1991,7 +2055,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     const long long out_elems = (long long)a->n * a->h * upf * a->w * upf * a->cout;
     if (a->next_split && a->mode == NFE_CONV_3X3_UP2) {            // fused into the FIR epilogue
         P.next_styles = a->next_styles; P.split_hi = reinterpret_cast<uint2*>(a->next_split);
-        P.split_lo = a->math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a->next_split) + out_elems) : nullptr;
+        P.split_lo = math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a->next_split) + out_elems) : nullptr;
     }
     // plain 3x3 with a consumer image: one extra elementwise pass over the fp32 output
     auto split_tail = [&]() -> int {
@@ -2000,18 +2064,18 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         unsigned short* sh = reinterpret_cast<unsigned short*>(a->next_split);
         hipLaunchKernelGGL(modsplit_kernel, dim3(grid1d(out_elems / 4, 256, 1 << 15)), dim3(256), 0, st, reinterpret_cast<const float4*>(a->out), a->next_styles,
                            out_elems / 4, (long long)a->h * a->w * (a->cout / 4), a->cout / 4, reinterpret_cast<uint2*>(sh),
-                           a->math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(sh + out_elems) : nullptr);
+                           math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(sh + out_elems) : nullptr, f16);
         NFE_CHECK_LAUNCH("modsplit_kernel");
         return NFE_OK;
     };
-    const bool fast = a->mode != NFE_CONV_1X1 && a->scratch && conv3_eligible(a->mode, a->h, a->w, a->cin, a->cout, a->math) &&
-                      a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout);
+    const bool fast = a->mode != NFE_CONV_1X1 && a->scratch && conv3_eligible(a->mode, a->h, a->w, a->cin, a->cout, math) &&
+                      a->scratch_floats >= nfe_conv_scratch_floats(a->mode, math, a->n, a->h, a->w, a->cin, a->cout);
     NFE_REQUIRE(!a->x_split || fast, "nfe_modulated_conv: x_split needs the fast path (eligible sizes and nfe_conv_scratch_floats() of scratch)");
     NFE_REQUIRE(a->mode != NFE_CONV_3X3_UP2 || a->out || a->next_split, "nfe_modulated_conv: no output requested");
     const bool fuse_rgb = a->rgb_weight != nullptr;
     if (fuse_rgb) {
         NFE_REQUIRE(a->rgb_styles && a->rgb_bias && a->rgb_out, "nfe_modulated_conv: rgb_weight needs rgb_styles, rgb_bias and rgb_out");
-        NFE_REQUIRE(fast && nfe_conv_fuses_rgb(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout, a->rgb_channels),
+        NFE_REQUIRE(fast && nfe_conv_fuses_rgb(a->mode, math, a->n, a->h, a->w, a->cin, a->cout, a->rgb_channels),
                     "nfe_modulated_conv: this layer cannot evaluate ToRGB in its epilogue (ask nfe_conv_fuses_rgb first)");
         NFE_REQUIRE(!a->rgb_skip || (a->h % 2 == 0 && a->w % 2 == 0), "nfe_modulated_conv: rgb_skip needs even sizes");
     }
@@ -2024,29 +2088,30 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         const long long elems = (long long)a->n * a->h * a->w * a->cin;
         float* tail = a->scratch + (up2 ? (long long)a->n * (2 * a->h + 1) * (2 * a->w + 1) * a->cout : 0);   // split image sits after the FIR scratch
         unsigned short* xh = reinterpret_cast<unsigned short*>(a->x_split ? const_cast<float*>(a->x_split) : tail);
-        unsigned short* xl = a->math == NFE_CONV_BF16X3 ? xh + elems : nullptr;
+        unsigned short* xl = math == NFE_CONV_BF16X3 ? xh + elems : nullptr;
         if (!a->x_split)
             hipLaunchKernelGGL(modsplit_kernel, dim3(grid1d(elems / 4, 256, 1 << 15)), dim3(256), 0, st, reinterpret_cast<const float4*>(a->x), a->styles,
-                               elems / 4, (long long)a->h * a->w * (a->cin / 4), a->cin / 4, reinterpret_cast<uint2*>(xh), reinterpret_cast<uint2*>(xl));
+                               elems / 4, (long long)a->h * a->w * (a->cin / 4), a->cin / 4, reinterpret_cast<uint2*>(xh), reinterpret_cast<uint2*>(xl), f16);
         Conv3K K{};
+        K.f16 = f16;
         K.xh = xh; K.xl = xl; K.packed = reinterpret_cast<const uint4*>(a->packed); K.dcoef = a->dcoef; K.noise = a->noise;
         K.noise_n_stride = a->noise_n_stride; K.noise_strength = a->noise_strength; K.bias = a->bias; K.N = a->n; K.H = a->h; K.W = a->w;
         K.Cin = a->cin; K.Cout = a->cout; K.lrelu = a->lrelu; K.act_gain = a->act_gain; K.clamp = a->clamp; K.out = a->out; K.scratch = a->scratch;
         const int ext = up2 ? 1 : 0;
-        const bool bf16 = a->math == NFE_CONV_BF16;
-        const int c3ks = conv3_ksplit(a->mode, a->n, a->h, a->w, a->cin, a->cout, a->math);
+        const bool bf16 = math == NFE_CONV_BF16;
+        const int c3ks = conv3_ksplit(a->mode, a->n, a->h, a->w, a->cin, a->cout, math);
         if (fuse_rgb) {
             K.rgb_w = a->rgb_weight; K.rgb_s = a->rgb_styles; K.rgb_c = a->rgb_channels;
-            K.rgb_partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);   // behind the split-image area (no split-K here)
+            K.rgb_partial = tail + (math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);   // behind the split-image area (no split-K here)
         }
         if (c3ks) {
             K.ksplit = c3ks;
-            K.partial = tail + (a->math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);       // behind the (possibly unused) split-image area
+            K.partial = tail + (math == NFE_CONV_BF16 ? (elems + 1) / 2 : elems);       // behind the (possibly unused) split-image area
         }
         const bool split_in_epilogue = a->next_split && !up2 && !c3ks && a->cout % 4 == 0;   // else: split_tail() re-reads `out`
         if (split_in_epilogue) {
             K.next_styles = a->next_styles; K.split_hi = reinterpret_cast<uint2*>(a->next_split);
-            K.split_lo = a->math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a->next_split) + out_elems) : nullptr;
+            K.split_lo = math == NFE_CONV_BF16X3 ? reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(a->next_split) + out_elems) : nullptr;
         }
         auto reduce_up = [&]() {                    // slices of the transposed-conv result -> a->scratch, in order, before the FIR
             if (!(c3ks && up2)) return;
@@ -2055,10 +2120,10 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, 1);
         };
         int rgb_groups = a->cout / 64;               // M-block groups (workgroups along Cout) that leave a fused-ToRGB partial sum
-        switch (conv3_variant(a->mode, a->math, a->n, a->h, a->w, a->cout)) {
+        switch (conv3_variant(a->mode, math, a->n, a->h, a->w, a->cout)) {
         case C3V_UP: {
             // (round 2 measured, without gain: a double-buffered stage (C3_STAGES_X3_UP = 2) and the 32 x 16 tile on 8 waves: DESIGN.md 5)
-            if (up_fused(a->math, c3ks, a->cin)) {                 // FIR and layer epilogue inside the conv kernel, overlapping tiles
+            if (up_fused(math, c3ks, a->cin)) {                 // FIR and layer epilogue inside the conv kernel, overlapping tiles
                 K.up_fused = 1; K.next_styles = P.next_styles; K.split_hi = P.split_hi; K.split_lo = P.split_lo;
                 const unsigned tiles = (unsigned)((a->h + 5) / 6) * (unsigned)((a->w + 29) / 30);      // ROWS = 8: 6 x 30 new extended-input pixels per tile
                 if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, 0, 0, st, tiles);
@@ -2115,14 +2180,14 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
     const int up = a->mode == NFE_CONV_3X3_UP2;
     const int gh = a->h + up, gw = a->w + up;
     dim3 grid(((gh + 15) / 16) * ((gw + 15) / 16), (a->cout + 31) / 32, a->n);
-    const int ks = a->out_planes ? 0 : splitk_slices(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout);
-    if (ks && a->scratch && a->scratch_floats >= nfe_conv_scratch_floats(a->mode, a->math, a->n, a->h, a->w, a->cin, a->cout)) {
+    const int ks = a->out_planes ? 0 : splitk_slices(a->mode, math, a->n, a->h, a->w, a->cin, a->cout);
+    if (ks && a->scratch && a->scratch_floats >= nfe_conv_scratch_floats(a->mode, math, a->n, a->h, a->w, a->cin, a->cout)) {
         const long long slice = (long long)a->n * (up ? (long long)(2 * a->h + 1) * (2 * a->w + 1) : (long long)a->h * a->w) * a->cout;
         P.ksplit = ks; P.partial = a->scratch + (up ? slice : 0);      // after the transposed-conv scratch
         grid.x *= ks;
-        if (up) launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st);
-        else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, a->math, grid, st);
-        else launch_conv<NFE_CONV_3X3>(P, a->math, grid, st);
+        if (up) launch_conv<NFE_CONV_3X3_UP2>(P, f16 ? NFE_CONV_F16 : math, grid, st);
+        else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, f16 ? NFE_CONV_F16 : math, grid, st);
+        else launch_conv<NFE_CONV_3X3>(P, f16 ? NFE_CONV_F16 : math, grid, st);
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid1d(slice / 4, 256, 1 << 14)), dim3(256), 0, st, P, slice / 4, up);
         if (up) {
             const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
@@ -2131,17 +2196,17 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
         NFE_CHECK_LAUNCH("split-K conv kernels");
         return split_tail();
     }
-    const int mb1 = (a->cout + 31) / 32, parts1 = a->math == NFE_CONV_BF16 ? 1 : 2;
+    const int mb1 = (a->cout + 31) / 32, parts1 = math == NFE_CONV_BF16 ? 1 : 2;
     const bool torgb_fast = a->mode == NFE_CONV_1X1 && a->cin % 16 == 0 && (mb1 == 1 || mb1 == 3) && a->lrelu == 0 && !a->dcoef && !a->noise &&
                             (long long)mb1 * (a->cin / 16) * parts1 * 1024 <= 64 * 1024 && (long long)a->h * a->w >= 1024;
-    if (a->mode == NFE_CONV_3X3) launch_conv<NFE_CONV_3X3>(P, a->math, grid, st);
+    if (a->mode == NFE_CONV_3X3) launch_conv<NFE_CONV_3X3>(P, f16 ? NFE_CONV_F16 : math, grid, st);
     else if (torgb_fast) {
         if (mb1 == 1) { if (parts1 == 1) launch_torgb<1, 1>(P, st); else launch_torgb<3, 1>(P, st); }
         else { if (parts1 == 1) launch_torgb<1, 3>(P, st); else launch_torgb<3, 3>(P, st); }
     }
-    else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, a->math, grid, st);
+    else if (a->mode == NFE_CONV_1X1) launch_conv<NFE_CONV_1X1>(P, f16 ? NFE_CONV_F16 : math, grid, st);
     else {
-        launch_conv<NFE_CONV_3X3_UP2>(P, a->math, grid, st);
+        launch_conv<NFE_CONV_3X3_UP2>(P, f16 ? NFE_CONV_F16 : math, grid, st);
         const long long total = (long long)a->n * ((a->h + UPFIR_ROWS - 1) / UPFIR_ROWS) * a->w * (a->cout / 4);
         launch_upfir(P, total, st);
     }

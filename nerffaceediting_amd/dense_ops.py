@@ -7,8 +7,8 @@ import torch
 from . import _lib
 from .ops import _dev, _ptr, _stream
 
-MATH = {None: _lib.NFE_CONV_BF16X3, "bf16x3": _lib.NFE_CONV_BF16X3, "bf16": _lib.NFE_CONV_BF16,
-        _lib.NFE_CONV_BF16X3: _lib.NFE_CONV_BF16X3, _lib.NFE_CONV_BF16: _lib.NFE_CONV_BF16}
+MATH = {None: _lib.NFE_CONV_BF16X3, "bf16x3": _lib.NFE_CONV_BF16X3, "bf16": _lib.NFE_CONV_BF16, "fp16": _lib.NFE_CONV_F16,
+        _lib.NFE_CONV_BF16X3: _lib.NFE_CONV_BF16X3, _lib.NFE_CONV_BF16: _lib.NFE_CONV_BF16, _lib.NFE_CONV_F16: _lib.NFE_CONV_F16}
 
 
 def _call(dev, rc_fn, what):
@@ -142,8 +142,9 @@ def broadcast_truncate(w, w_avg, num_ws, psi=1.0, cutoff=None):
     return ws
 
 
-def conv_pack(weight):
-    """[Cout,Cin,k,k] -> (packed MFMA fragment image, wsq [Cout,Cin])."""
+def conv_pack(weight, math=None):
+    """[Cout,Cin,k,k] -> (packed MFMA fragment image, wsq [Cout,Cin]).  math='fp16' packs fp16 operand words (for layers run with
+    math='fp16' only); every other mode shares the bf16 hi + lo image."""
     lib = _lib.load()
     weight = _dev(weight, "weight", (None, None, None, None))
     cout, cin, k, _ = weight.shape
@@ -152,7 +153,8 @@ def conv_pack(weight):
         raise RuntimeError(f"conv_pack: unsupported weight shape {list(weight.shape)}")
     packed = torch.empty(words, device=weight.device)
     wsq = torch.empty(cout, cin, device=weight.device)
-    _call(weight.device, lambda: lib.nfe_conv_pack(_ptr(weight), cout, cin, k, _ptr(packed), _ptr(wsq), _stream()), "nfe_conv_pack")
+    fn = lib.nfe_conv_pack_f16 if MATH[math] == _lib.NFE_CONV_F16 else lib.nfe_conv_pack
+    _call(weight.device, lambda: fn(_ptr(weight), cout, cin, k, _ptr(packed), _ptr(wsq), _stream()), "nfe_conv_pack")
     return packed, wsq
 
 

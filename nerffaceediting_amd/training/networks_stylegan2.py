@@ -17,14 +17,17 @@ import torch
 from .. import _lib, dense_ops
 
 
-def _pack_cached(module, weight):
-    """Packed MFMA image of a conv weight, rebuilt only when the parameter changes."""
+def _pack_cached(module, weight, conv_math=None):
+    """Packed MFMA image of a conv weight, rebuilt only when the parameter changes.  conv_math='fp16' has its own image (fp16
+    operand words); the bf16 modes share one."""
+    f16 = dense_ops.MATH[conv_math] == _lib.NFE_CONV_F16
     key = (weight.data_ptr(), weight._version, tuple(weight.shape))
-    if getattr(module, "_packed_key", None) != key:
-        module._packed = dense_ops.conv_pack(weight.detach())
+    attr = "_packed_f16" if f16 else "_packed"
+    if getattr(module, attr + "_key", None) != key:
+        setattr(module, attr, dense_ops.conv_pack(weight.detach(), "fp16" if f16 else None))
         _publish()
-        module._packed_key = key
-    return module._packed
+        setattr(module, attr + "_key", key)
+    return getattr(module, attr)
 
 
 def _publish():
@@ -134,7 +137,7 @@ class SynthesisLayer(torch.nn.Module):
         assert tuple(x.shape[1:]) == (in_res, in_res, self.in_channels), f"wrong input shape {list(x.shape)}"       # misc.assert_shape :314
         if styles is None:
             styles = self.affine(w)
-        packed, wsq = _pack_cached(self, self.weight)
+        packed, wsq = _pack_cached(self, self.weight, conv_math)
         if dcoef is None:
             dcoef = dense_ops.conv_demod(styles, wsq)
         noise, strength = None, 0.0
@@ -171,7 +174,7 @@ class ToRGBLayer(torch.nn.Module):
         if styles is None:
             styles = dense_ops.fully_connected(w, lin.weight.detach(), lin.bias.detach(), lin.weight_gain * self.weight_gain,
                                                lin.bias_gain * self.weight_gain)      # affine(w) * weight_gain
-        packed, _ = _pack_cached(self, self.weight)
+        packed, _ = _pack_cached(self, self.weight, conv_math)
         return dense_ops.modulated_conv(x, styles, packed, self.out_channels, _lib.NFE_CONV_1X1, self.bias.detach(), lrelu=False,
                                         act_gain=1.0, clamp=self.conv_clamp, skip=skip, out_planes=out_planes, math=conv_math)
 

@@ -68,7 +68,7 @@ def test_mapping_network(dev):
         assert maxerr(ws, z["ws." + tag]) <= 2e-5, tag
 
 
-@pytest.mark.parametrize("math", ["bf16x3", "bf16"])
+@pytest.mark.parametrize("math", ["bf16x3", "bf16", "fp16"])
 @pytest.mark.parametrize("tag", LAYERS)
 def test_modulated_conv_layers(tag, math, dev):
     from nerffaceediting_amd import dense_ops
@@ -86,8 +86,9 @@ def test_modulated_conv_layers(tag, math, dev):
     ref = z[tag + ".out"]
     e = maxerr(dense_ops.nhwc_to_nchw(y), ref)
     print(tag, math, e, float(np.abs(ref).max()))
-    # bf16x3: fp32-grade.  bf16: 8-bit mantissa operands, K up to 432 terms -> ~1e-2 of the output scale
-    assert e <= (1e-4 if math == "bf16x3" else 3e-2 * float(np.abs(ref).max()))
+    # bf16x3: fp32-grade.  bf16: 8-bit mantissa operands, K up to 432 terms -> ~1e-2 of the output scale.  fp16 (round 4): 11-bit
+    # operands, 8 x finer
+    assert e <= {"bf16x3": 1e-4, "bf16": 3e-2 * float(np.abs(ref).max()), "fp16": 4e-3 * float(np.abs(ref).max())}[math]
 
 
 def test_torgb_skip_matches_upsample2d(dev):
