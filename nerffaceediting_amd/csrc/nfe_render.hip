@@ -1321,8 +1321,12 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
 // Outputs are bit-identical to render_kernel's: same tap order in the bilinear sums, same MFMA order in each head (mlp_bf16), same
 // march arithmetic (tests/test_render_gpu.py::test_wave_specialised_kernel_is_bit_identical).
 // ------------------------------------------------------------------------------------------
-constexpr int WS_T_OFF = 2 * XCHG_FLOATS;                   // per pair, behind the affines: geometry tile, appearance tile,
-constexpr int WS_FLAG_OFF = WS_T_OFF + 32;                  // 32 depths, then {full, taken, abort, -}
+#ifndef WS_BUFS
+#define WS_BUFS 1                                           // tile sets per pair: 2 lets the producer run one sample further ahead (measured: no gain, 6.13 vs 6.12 ms)
+#endif
+constexpr int WS_SET_FLOATS = 2 * XCHG_FLOATS + 32;         // one set: geometry tile, appearance tile, 32 depths
+constexpr int WS_T_OFF = 2 * XCHG_FLOATS;
+constexpr int WS_FLAG_OFF = WS_BUFS * WS_SET_FLOATS;        // behind the sets: {full, taken, abort, -}
 constexpr int WS_PAIR_FLOATS = AFF_FLOATS + WS_FLAG_OFF + 4;
 static_assert(WS_PAIR_FLOATS % 4 == 0 && AFF_FLOATS % 4 == 0, "16-byte aligned tiles");
 template <int NP> constexpr int ws_lds_bytes() { return (DEC_FLOATS + NP * WS_PAIR_FLOATS) * 4; }
@@ -1503,10 +1507,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
     const int pair = producer ? wave : wave - NP;
     const int lane = threadIdx.x & 63, j = lane & 31, h = lane >> 5;
     float* aff = lds + DEC_FLOATS + pair * WS_PAIR_FLOATS;
-    float* tile_g = aff + AFF_FLOATS;
-    float* tile_a = tile_g + XCHG_FLOATS;
-    float* tile_t = tile_g + WS_T_OFF;
-    unsigned* flags = reinterpret_cast<unsigned*>(tile_g + WS_FLAG_OFF);
+    float* tile_g0 = aff + AFF_FLOATS;
+    unsigned* flags = reinterpret_cast<unsigned*>(tile_g0 + WS_FLAG_OFF);
     if (producer && lane < 4) flags[lane] = 0u;
     __syncthreads();
     const bool probe = P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0;
@@ -1626,13 +1628,15 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
 #else
                 qn[0][0] += gx; qd[0][0] += gy + gz;
 #endif
-                // geometry tile + depths of sample `step`: the consumer must have read the geometry tile of the previous sample
-                if (alive) alive = ws_wait(flags, 1, 2u * step - 1u);
-                ws_write_tile(tile_g + opq, lane, qn);
-                if (h == 0) tile_t[j + opq] = t;
+                // geometry tile + depths of sample `step` go to set step % WS_BUFS: the consumer must have read that set's previous
+                // content, the geometry tile of sample step - WS_BUFS
+                float* tile_g = tile_g0 + (int)(step % WS_BUFS) * WS_SET_FLOATS + opq;
+                if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 1u);
+                ws_write_tile(tile_g, lane, qn);
+                if (h == 0) tile_g[WS_T_OFF + j] = t;
                 ws_signal(flags, 0, 2u * step + 1u, lane);
-                if (alive) alive = ws_wait(flags, 1, 2u * step);
-                ws_write_tile(tile_a + opq, lane, qd);
+                if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 2u);
+                ws_write_tile(tile_g + XCHG_FLOATS, lane, qd);
                 ws_signal(flags, 0, 2u * step + 2u, lane);
             }
         }
@@ -1677,13 +1681,14 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 int opq;                                     // opaque zero: keeps the LDS weight reads inside the loop (render_kernel)
                 asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
                 const float* ldsw = lds + opq;
+                const float* tile_g = tile_g0 + (int)(step % WS_BUFS) * WS_SET_FLOATS + opq;
                 f32x16 og, oa;
                 float t;
                 {
                     if (alive) alive = ws_wait(flags, 0, 2u * step + 1u);
                     f32x2 fn[8];
-                    ws_read_tile(tile_g + opq, lane, fn);
-                    t = tile_t[j + opq];
+                    ws_read_tile(tile_g, lane, fn);
+                    t = tile_g[WS_T_OFF + j];
                     ws_signal(flags, 1, 2u * step + 1u, lane);
 #if !defined(WS_ABLATE) || WS_ABLATE != 2          // timing experiment: 2 = consumer without its decoder
                     mlp_bf16(ldsw, fn, 0, lane, og);
@@ -1695,7 +1700,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 {
                     if (alive) alive = ws_wait(flags, 0, 2u * step + 2u);
                     f32x2 fd[8];
-                    ws_read_tile(tile_a + opq, lane, fd);
+                    ws_read_tile(tile_g + XCHG_FLOATS, lane, fd);
                     ws_signal(flags, 1, 2u * step + 2u, lane);
 #if !defined(WS_ABLATE) || WS_ABLATE != 2
                     mlp_bf16(ldsw, fd, 1, lane, oa);
@@ -2206,13 +2211,19 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
     }
     if (ws_mode() && !dual && !sigma_only && math == NFE_MATH_BF16X3 && P.density_noise == 0.0f && !P.tap_colors && !P.out_weights &&
         total_rb >= 2048 && (long long)P.N * P.M * P.S < (1ll << 31)) {
-        switch (ws_mode()) {          // pairs per workgroup x 10 + waves per SIMD
-            case 42: launch_render_ws<4, 2>(P, total_rb, st); break;
+        // pairs per workgroup x 10 + waves per SIMD.  Shipped: 42.  The 3- and 4-waves-per-SIMD geometries (63, 33, 84, 44) were built and
+        // measured slower (profiles/experiments/r04_render_ws.md); they need -DWS_BUFS=1 to fit their tiles into 160 KB of LDS
+#if WS_BUFS == 1
+        switch (ws_mode()) {
             case 63: launch_render_ws<6, 3>(P, total_rb, st); break;
             case 33: launch_render_ws<3, 3>(P, total_rb, st); break;
             case 84: launch_render_ws<8, 4>(P, total_rb, st); break;
-            default: launch_render_ws<4, 4>(P, total_rb, st); break;
+            case 44: launch_render_ws<4, 4>(P, total_rb, st); break;
+            default: launch_render_ws<4, 2>(P, total_rb, st); break;
         }
+#else
+        launch_render_ws<4, 2>(P, total_rb, st);
+#endif
         NFE_CHECK_LAUNCH("render_ws_kernel");
         return NFE_OK;
     }

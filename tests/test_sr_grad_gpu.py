@@ -94,7 +94,7 @@ def test_modulated_conv_backward_is_the_adjoint(up, cin, cout, r, dev):
 
 def _case(z, tag):
     rng = np.random.RandomState(77)                                        # gen_sr_backward's draw order: x, ws, cot per case
-    for case in ("plain", "clamped"):
+    for case in ("plain", "clamped", "clamped8"):
         x = rng.randn(1, 32, 128, 128) * float(z[f"{case}.scale"])
         ws = rng.randn(1, 14, 512)
         cot = rng.randn(1, 3, 512, 512)
@@ -108,7 +108,7 @@ def _sr(z, dev):
                                                  channel_max=512, fused_modconv_default="inference_only"), sr_params(int(z["seed"])), dev)
 
 
-@pytest.mark.parametrize("tag", ["plain", "clamped"])
+@pytest.mark.parametrize("tag", ["plain", "clamped", "clamped8"])
 def test_sr_input_gradient_matches_reference_autograd(tag, dev):
     """Against the reference's autograd.  The head holds ~1e8 leaky-ReLU units per view; a unit whose pre-activation is within the
     forward's rounding (split-bf16, ~1e-5) of zero can take the other slope than in the reference's fp32 forward, and each such
