@@ -287,54 +287,6 @@ __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, 
         sa[2 * i_ + 1] = pk_fma(w2, f32x2{vg[S][4 + i_].z, vg[S][4 + i_].w}, sa[2 * i_ + 1]);              \
     }
 
-template <bool SQUARE>
-__device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ pg, const float* __restrict__ pa, int H, int W,
-                                                      long long plane_elems, const float* __restrict__ aff, int lane,
-                                                      float gx, float gy, float gz, f32x2 (&qn)[8], f32x2 (&qd)[8]) {
-    Taps tp[3];
-    unsigned offs[3][4];
-    Axis ax_xw, ax_zh;
-    if (SQUARE) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) } else { NFE_PIPE_GEOM(0, gx, gy) }
-    const int ll = launder(lane);
-    const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
-    const unsigned qoff_bytes = (unsigned)qoff * 4u;
-    float4 vg[2][8];
-    float wq[2][4];
-    f32x2 sg[8], sa[8];
-#pragma unroll
-    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); sa[c] = splat(0.0f); }
-    NFE_PIPE2_ISSUE(0, 0, 0) NFE_PIPE2_ISSUE(1, 0, 1)
-    if (SQUARE) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) } else { NFE_PIPE_GEOM(1, gx, gz) }
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 0, 2)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 0, 3)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 1, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 1, 1)
-    plane_affine_acc<false, 0, true>(aff, qoff, tp[0], sg, qn, qd, sa);
-    if (SQUARE) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_PIPE_GEOM(2, gz, gx) }
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 1, 2)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 1, 3)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 2, 0)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 2, 1)
-    plane_affine_acc<false, 1, true>(aff, qoff, tp[1], sg, qn, qd, sa);
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 2, 2)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 2, 3)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(0)
-    __builtin_amdgcn_sched_barrier(0);
-    NFE_PIPE2_CONSUME(1)
-    plane_affine_acc<false, 2, true>(aff, qoff, tp[2], sg, qn, qd, sa);
-}
-
 // ---- in-bounds fast path of the gather (square planes; round 4) ---------------------------------------------
 // ~90 % of the wave-steps of an FFHQ-like camera have the 2 x 2 footprints of all their 32 samples inside all three planes.  Then
 // nothing of the zeros-padding machinery is needed: no clamped coordinates, no validity selects, no weight deficit (`wdef` == 0
@@ -425,6 +377,121 @@ __device__ __forceinline__ void gather_pipelined_inb(const float* __restrict__ p
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(1)
     plane_affine_acc<SIGMA_ONLY, 2, false, true>(aff, qoff, none, sg, qn, qd);
+}
+
+// the same for two plane sets (norm_planes != normalised denorm_planes): twelve batches of one tap = 4 + 4 loads, two in flight
+#define NFE_INB2_ISSUE_I(S, I, IMM)                                                                                            \
+    vg[S][I] = texel_piece_imm<IMM>(bg_, vo[I]); vg[S][4 + I] = texel_piece_imm<IMM>(ba_, vo[I]); wq[S][I] = quad_swizzle<I>(wk_);
+#define NFE_INB2_ISSUE(S, PL, K)                                                                                               \
+    {                                                                                                                          \
+        const char* bg_ = reinterpret_cast<const char*>(pg + (PL) * plane_elems) + (((K) >> 1) ? row_bytes : 0);               \
+        const char* ba_ = reinterpret_cast<const char*>(pa + (PL) * plane_elems) + (((K) >> 1) ? row_bytes : 0);               \
+        const float wk_ = wt[PL][K];                                                                                           \
+        NFE_INB2_ISSUE_I(S, 0, ((K) & 1) * 128) NFE_INB2_ISSUE_I(S, 1, ((K) & 1) * 128)                                        \
+        NFE_INB2_ISSUE_I(S, 2, ((K) & 1) * 128) NFE_INB2_ISSUE_I(S, 3, ((K) & 1) * 128)                                        \
+    }
+__device__ __forceinline__ void gather_pipelined_dual_inb(const float* __restrict__ pg, const float* __restrict__ pa, int W, long long plane_elems,
+                                                          const float* __restrict__ aff, int lane, const InbAxes& a,
+                                                          f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+    unsigned off0[3];
+    float wt[3][4];
+    unsigned vo[4];
+    const long long row_bytes = (long long)W * 128;
+    const int ll = launder(lane);
+    const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
+    const unsigned qoff_bytes = (unsigned)qoff * 4u;
+    float4 vg[2][8];
+    float wq[2][4];
+    f32x2 sg[8], sa[8];
+    const Taps none{};
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); sa[c] = splat(0.0f); }
+    NFE_INB_PLANE(0, a.x0, a.y0, a.fx, a.fy)
+    NFE_INB_VOFF(0)
+    NFE_INB2_ISSUE(0, 0, 0) NFE_INB2_ISSUE(1, 0, 1)
+    NFE_INB_PLANE(1, a.x0, a.z0, a.fx, a.fz)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_INB2_ISSUE(0, 0, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_INB2_ISSUE(1, 0, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_INB_VOFF(1) NFE_INB2_ISSUE(0, 1, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_INB2_ISSUE(1, 1, 1)
+    plane_affine_acc<false, 0, true, true>(aff, qoff, none, sg, qn, qd, sa);
+    NFE_INB_PLANE(2, a.z0, a.x0, a.fz, a.fx)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_INB2_ISSUE(0, 1, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_INB2_ISSUE(1, 1, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_INB_VOFF(2) NFE_INB2_ISSUE(0, 2, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_INB2_ISSUE(1, 2, 1)
+    plane_affine_acc<false, 1, true, true>(aff, qoff, none, sg, qn, qd, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_INB2_ISSUE(0, 2, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_INB2_ISSUE(1, 2, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1)
+    plane_affine_acc<false, 2, true, true>(aff, qoff, none, sg, qn, qd, sa);
+}
+
+template <bool SQUARE>
+__device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ pg, const float* __restrict__ pa, int H, int W,
+                                                      long long plane_elems, const float* __restrict__ aff, int lane,
+                                                      float gx, float gy, float gz, f32x2 (&qn)[8], f32x2 (&qd)[8]) {
+#if NFE_INB_FAST && !defined(NFE_SQUARE_RUNTIME)
+    if (SQUARE) {
+        InbAxes ia;
+        if (inb_axes(W, gx, gy, gz, ia)) { gather_pipelined_dual_inb(pg, pa, W, plane_elems, aff, lane, ia, qn, qd); return; }
+    }
+#endif
+    Taps tp[3];
+    unsigned offs[3][4];
+    Axis ax_xw, ax_zh;
+    if (SQUARE) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) } else { NFE_PIPE_GEOM(0, gx, gy) }
+    const int ll = launder(lane);
+    const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
+    const unsigned qoff_bytes = (unsigned)qoff * 4u;
+    float4 vg[2][8];
+    float wq[2][4];
+    f32x2 sg[8], sa[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) { sg[c] = splat(0.0f); sa[c] = splat(0.0f); }
+    NFE_PIPE2_ISSUE(0, 0, 0) NFE_PIPE2_ISSUE(1, 0, 1)
+    if (SQUARE) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) } else { NFE_PIPE_GEOM(1, gx, gz) }
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 0, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 0, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 1, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 1, 1)
+    plane_affine_acc<false, 0, true>(aff, qoff, tp[0], sg, qn, qd, sa);
+    if (SQUARE) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_PIPE_GEOM(2, gz, gx) }
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 1, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 1, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 2, 0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 2, 1)
+    plane_affine_acc<false, 1, true>(aff, qoff, tp[1], sg, qn, qd, sa);
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0) NFE_PIPE2_ISSUE(0, 2, 2)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1) NFE_PIPE2_ISSUE(1, 2, 3)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(0)
+    __builtin_amdgcn_sched_barrier(0);
+    NFE_PIPE2_CONSUME(1)
+    plane_affine_acc<false, 2, true>(aff, qoff, tp[2], sg, qn, qd, sa);
 }
 
 // experiment helper (NFE_SQUARE_RUNTIME == 6): `H == W` as an integer in an SGPR, opaque to the optimiser
@@ -1390,6 +1457,7 @@ __device__ __forceinline__ void ws_signal(unsigned* flags, int which, unsigned v
 #define NFE_WSI_VOFF(PL)                                                                                   \
     vo[PL][0] = (unsigned)quad_bcast<0>((int)off0[PL]) + qoff_bytes; vo[PL][1] = (unsigned)quad_bcast<1>((int)off0[PL]) + qoff_bytes; \
     vo[PL][2] = (unsigned)quad_bcast<2>((int)off0[PL]) + qoff_bytes; vo[PL][3] = (unsigned)quad_bcast<3>((int)off0[PL]) + qoff_bytes;
+template <bool SIGMA_ONLY>
 __device__ __forceinline__ void gather_pipelined_ws_inb(const float* __restrict__ pg, int W, long long plane_elems,
                                                         const float* __restrict__ aff, int lane, const InbAxes& a,
                                                         f32x2 (&qn)[8], f32x2 (&qd)[8]) {
@@ -1418,25 +1486,25 @@ __device__ __forceinline__ void gather_pipelined_ws_inb(const float* __restrict_
     NFE_INB_PLANE(1, a.x0, a.z0, a.fx, a.fz)
     NFE_WSI_VOFF(1)
     NFE_WSI_STEP(0) NFE_WSI_STEP(1) NFE_WSI_STEP(2) NFE_WSI_STEP(3)
-    plane_affine_acc<false, 0, false, true>(aff, qoff, none, sg, qn, qd);
+    plane_affine_acc<SIGMA_ONLY, 0, false, true>(aff, qoff, none, sg, qn, qd);
     NFE_INB_PLANE(2, a.z0, a.x0, a.fz, a.fx)
     NFE_WSI_VOFF(2)
     NFE_WSI_STEP(4) NFE_WSI_STEP(5) NFE_WSI_STEP(6) NFE_WSI_STEP(7)
-    plane_affine_acc<false, 1, false, true>(aff, qoff, none, sg, qn, qd);
+    plane_affine_acc<SIGMA_ONLY, 1, false, true>(aff, qoff, none, sg, qn, qd);
     NFE_WSI_STEP(8) NFE_WSI_STEP(9) NFE_WSI_STEP(10) NFE_WSI_STEP(11)
-    plane_affine_acc<false, 2, false, true>(aff, qoff, none, sg, qn, qd);
+    plane_affine_acc<SIGMA_ONLY, 2, false, true>(aff, qoff, none, sg, qn, qd);
 #undef NFE_WSI_STEP
 #undef NFE_WS_SLOT
 }
 
-template <bool SQUARE>
+template <bool SQUARE, bool SIGMA_ONLY>
 __device__ __forceinline__ void gather_pipelined_ws(const float* __restrict__ pg, int H, int W, long long plane_elems,
                                                     const float* __restrict__ aff, int lane, float gx, float gy, float gz,
                                                     f32x2 (&qn)[8], f32x2 (&qd)[8]) {
 #if NFE_INB_FAST
     if (SQUARE) {
         InbAxes ia;
-        if (inb_axes(W, gx, gy, gz, ia)) { gather_pipelined_ws_inb(pg, W, plane_elems, aff, lane, ia, qn, qd); return; }
+        if (inb_axes(W, gx, gy, gz, ia)) { gather_pipelined_ws_inb<SIGMA_ONLY>(pg, W, plane_elems, aff, lane, ia, qn, qd); return; }
     }
 #endif
     Taps tp[3];
@@ -1461,12 +1529,12 @@ __device__ __forceinline__ void gather_pipelined_ws(const float* __restrict__ pg
     if (NFE_WS_FLIGHT == 3) NFE_WS_ISSUE(2 % NFE_WS_FLIGHT, 0, 2)
     if (SQUARE) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) } else { NFE_PIPE_GEOM(1, gx, gz) }
     NFE_WS_STEP(0) NFE_WS_STEP(1) NFE_WS_STEP(2) NFE_WS_STEP(3)
-    plane_affine_acc<false, 0>(aff, qoff, tp[0], sg, qn, qd);
+    plane_affine_acc<SIGMA_ONLY, 0>(aff, qoff, tp[0], sg, qn, qd);
     if (SQUARE) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_PIPE_GEOM(2, gz, gx) }
     NFE_WS_STEP(4) NFE_WS_STEP(5) NFE_WS_STEP(6) NFE_WS_STEP(7)
-    plane_affine_acc<false, 1>(aff, qoff, tp[1], sg, qn, qd);
+    plane_affine_acc<SIGMA_ONLY, 1>(aff, qoff, tp[1], sg, qn, qd);
     NFE_WS_STEP(8) NFE_WS_STEP(9) NFE_WS_STEP(10) NFE_WS_STEP(11)
-    plane_affine_acc<false, 2>(aff, qoff, tp[2], sg, qn, qd);
+    plane_affine_acc<SIGMA_ONLY, 2>(aff, qoff, tp[2], sg, qn, qd);
 #undef NFE_WS_STEP
 #undef NFE_WS_SLOT
 }
@@ -1495,8 +1563,11 @@ __device__ __forceinline__ void ws_read_tile(const float* __restrict__ xp, int l
     }
 }
 
-template <int NP, int WPS, bool SQUARE, bool GENERIC>
+// DUAL: two plane sets (the producer runs the fused kernel's dual gather); SIGMA_ONLY: the coarse pass of a two-pass render (geometry
+// set and geometry head only; the consumer writes the compositing weights, the producer the depths).
+template <int NP, int WPS, bool SQUARE, bool GENERIC, bool DUAL = false, bool SIGMA_ONLY = false>
 __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
+    static_assert(!(DUAL && SIGMA_ONLY), "a sigma-only pass reads one plane set");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     for (int i = threadIdx.x; i < DEC_B_G0 / 4; i += NP * 128)
         reinterpret_cast<float4*>(lds)[i] = reinterpret_cast<const float4*>(P.dec + DEC_BF16)[i];
@@ -1570,6 +1641,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 dx /= nrm; dy /= nrm; dz /= nrm;
             }
             const float* pg = P.planes_g + (long long)n * P.plane_view_stride;
+            const float* pa = P.planes_a + (long long)n * P.plane_view_stride;
             // GENERIC = false (the common launch): stratified depths between scalar limits, jitter from Philox or a buffer - the
             // schedule's constants are wave-uniform and stay in SGPRs; GENERIC = true adds per-ray limits, disparity, depth buffers
             float rs = P.ray_start, re = P.ray_end;
@@ -1624,7 +1696,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                     }
                 }
 #if !defined(WS_ABLATE) || WS_ABLATE != 1          // timing experiment: 1 = producer without its gather
-                gather_pipelined_ws<SQUARE>(pg, P.H, P.W, plane_elems, affk, lane, gx, gy, gz, qn, qd);
+                if (DUAL) gather_pipelined_dual<SQUARE>(pg, pa, P.H, P.W, plane_elems, affk, lane, gx, gy, gz, qn, qd);
+                else gather_pipelined_ws<SQUARE, SIGMA_ONLY>(pg, P.H, P.W, plane_elems, affk, lane, gx, gy, gz, qn, qd);
 #else
                 qn[0][0] += gx; qd[0][0] += gy + gz;
 #endif
@@ -1634,10 +1707,14 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 1u);
                 ws_write_tile(tile_g, lane, qn);
                 if (h == 0) tile_g[WS_T_OFF + j] = t;
-                ws_signal(flags, 0, 2u * step + 1u, lane);
-                if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 2u);
-                ws_write_tile(tile_g + XCHG_FLOATS, lane, qd);
-                ws_signal(flags, 0, 2u * step + 2u, lane);
+                if (SIGMA_ONLY) {                     // no appearance tile: both halves of the sample's count move at once
+                    ws_signal(flags, 0, 2u * step + 2u, lane);
+                } else {
+                    ws_signal(flags, 0, 2u * step + 1u, lane);
+                    if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 2u);
+                    ws_write_tile(tile_g + XCHG_FLOATS, lane, qd);
+                    ws_signal(flags, 0, 2u * step + 2u, lane);
+                }
             }
         }
         if (P.depth_minmax) {
@@ -1689,7 +1766,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                     f32x2 fn[8];
                     ws_read_tile(tile_g, lane, fn);
                     t = tile_g[WS_T_OFF + j];
-                    ws_signal(flags, 1, 2u * step + 1u, lane);
+                    ws_signal(flags, 1, 2u * step + (SIGMA_ONLY ? 2u : 1u), lane);
 #if !defined(WS_ABLATE) || WS_ABLATE != 2          // timing experiment: 2 = consumer without its decoder
                     mlp_bf16(ldsw, fn, 0, lane, og);
 #else
@@ -1697,7 +1774,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                     for (int r = 0; r < 16; ++r) og[r] = fn[r >> 1][r & 1];
 #endif
                 }
-                {
+                if (!SIGMA_ONLY) {
                     if (alive) alive = ws_wait(flags, 0, 2u * step + 2u);
                     f32x2 fd[8];
                     ws_read_tile(tile_g + XCHG_FLOATS, lane, fd);
@@ -1710,7 +1787,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
 #endif
                 }
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {    // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269 (decode_features)
+                for (int r = 0; r < (SIGMA_ONLY ? 0 : 16); r += 2) {    // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269 (decode_features)
                     const f32x2 d = f32x2{exp2_fast(-oa[r]), exp2_fast(-oa[r + 1])} + splat(1.0f);
                     const f32x2 sg = pk_fma(f32x2{__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])}, splat(1.002f), splat(-0.001f));
                     oa[r] = sg[0]; oa[r + 1] = sg[1];
@@ -1722,23 +1799,28 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                     const float alpha = first ? 0.0f : 1.0f - exp2_fast(-(dens * dlt) * LOG2E);
                     const float w = alpha * T;
                     T = T * (1.0f - alpha + 1e-10f);
-                    const f32x2 wh = splat(w * 0.5f);
+                    if (P.out_weights && valid && h == 0 && !first) P.out_weights[ray * (S - 1) + (k - 1)] = w;
+                    if (!SIGMA_ONLY) {
+                        const f32x2 wh = splat(w * 0.5f);
 #pragma unroll
-                    for (int c = 0; c < 8; ++c)
-                        acc_rgb[c] = pk_fma(wh, prev_rgb[c] + f32x2{oa[2 * c], oa[2 * c + 1]}, acc_rgb[c]);
+                        for (int c = 0; c < 8; ++c)
+                            acc_rgb[c] = pk_fma(wh, prev_rgb[c] + f32x2{oa[2 * c], oa[2 * c + 1]}, acc_rgb[c]);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        acc_seg[c] = pk_fma(wh, prev_seg[c] + f32x2{og[2 + 2 * c], og[3 + 2 * c]}, acc_seg[c]);
-                    acc_d = fmaf(w, (prev_t + t) * 0.5f, acc_d);
-                    acc_w += w;
+                        for (int c = 0; c < 4; ++c)
+                            acc_seg[c] = pk_fma(wh, prev_seg[c] + f32x2{og[2 + 2 * c], og[3 + 2 * c]}, acc_seg[c]);
+                        acc_d = fmaf(w, (prev_t + t) * 0.5f, acc_d);
+                        acc_w += w;
+                    }
                 }
                 prev_t = t; prev_sig = og[0];
+                if (!SIGMA_ONLY) {
 #pragma unroll
-                for (int c = 0; c < 8; ++c) prev_rgb[c] = f32x2{oa[2 * c], oa[2 * c + 1]};
+                    for (int c = 0; c < 8; ++c) prev_rgb[c] = f32x2{oa[2 * c], oa[2 * c + 1]};
 #pragma unroll
-                for (int c = 0; c < 4; ++c) prev_seg[c] = f32x2{og[2 + 2 * c], og[3 + 2 * c]};
+                    for (int c = 0; c < 4; ++c) prev_seg[c] = f32x2{og[2 + 2 * c], og[3 + 2 * c]};
+                }
             }
-            if (valid) {
+            if (valid && !SIGMA_ONLY) {
                 const float wb = P.white_back ? (1.0f - acc_w) : 0.0f;
                 float rgbv[16], segv[8];
 #pragma unroll
@@ -2127,8 +2209,8 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
         if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else if (P.tap_colors && !SIGMA_ONLY)
             hipLaunchKernelGGL((render_kernel<DUAL, false, NFE_MATH_BF16X3, false, false, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
-        else if (P.H == P.W && !DUAL && !NFE_SQUARE_RT)      // shared axis geometry: measured faster with one plane set (-2.5 %), not with two (+0.8 %)
-            hipLaunchKernelGGL((render_kernel<false, SIGMA_ONLY, NFE_MATH_BF16X3, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+        else if (P.H == P.W && !NFE_SQUARE_RT)               // shared axis geometry + the in-bounds gather path (round 4: pays with two plane sets too)
+            hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
     }
 }
@@ -2139,7 +2221,7 @@ static int ws_mode() {
     static const int v = [] { const char* e = getenv("NFE_RENDER_WS"); return e ? atoi(e) : NFE_RENDER_WS_DEFAULT; }();
     return v;
 }
-template <int NP, int WPS>
+template <int NP, int WPS, bool DUAL = false, bool SIGMA_ONLY = false>
 static void launch_render_ws(const RenderK& P, long long total_rb, hipStream_t st) {
     constexpr int bytes = ws_lds_bytes<NP>();
     constexpr int per_cu = (WPS * 4) / (2 * NP);          // workgroups per CU that make WPS waves per SIMD
@@ -2150,8 +2232,8 @@ static void launch_render_ws(const RenderK& P, long long total_rb, hipStream_t s
     const bool generic = P.depth_mode != DEPTH_STRATIFIED;
 #define NFE_WS_LAUNCH(SQ, GE)                                                                                                    \
     {                                                                                                                            \
-        allow_lds(render_ws_kernel<NP, WPS, SQ, GE>, bytes);                                                                     \
-        hipLaunchKernelGGL((render_ws_kernel<NP, WPS, SQ, GE>), dim3((unsigned)blocks), dim3(NP * 128), bytes, st, P);           \
+        allow_lds(render_ws_kernel<NP, WPS, SQ, GE, DUAL, SIGMA_ONLY>, bytes);                                                   \
+        hipLaunchKernelGGL((render_ws_kernel<NP, WPS, SQ, GE, DUAL, SIGMA_ONLY>), dim3((unsigned)blocks), dim3(NP * 128), bytes, st, P); \
     }
     if (P.H == P.W) { if (generic) NFE_WS_LAUNCH(true, true) else NFE_WS_LAUNCH(true, false) }
     else { if (generic) NFE_WS_LAUNCH(false, true) else NFE_WS_LAUNCH(false, false) }
@@ -2159,6 +2241,7 @@ static void launch_render_ws(const RenderK& P, long long total_rb, hipStream_t s
 }
 
 static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math, hipStream_t st) {
+    if (sigma_only && !P.dec_cross) dual = false;      // a sigma-only pass reads the geometry set only: the one-set variants (SQUARE, in-bounds path) serve it
     const long long total_rb = (long long)P.N * ((P.M + 31) / 32);
     long long blocks = (total_rb + 3) / 4;
     static const int blocks_per_cu = [] {                // tuning/diagnostic knob; default 2 blocks (8 waves) per CU
@@ -2209,11 +2292,11 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
         NFE_CHECK_LAUNCH("render_combine_kernel");
         return NFE_OK;
     }
-    if (ws_mode() && !dual && !sigma_only && math == NFE_MATH_BF16X3 && P.density_noise == 0.0f && !P.tap_colors && !P.out_weights &&
+    if (ws_mode() && math == NFE_MATH_BF16X3 && P.density_noise == 0.0f && !P.tap_colors && (sigma_only || !P.out_weights) &&
         total_rb >= 2048 && (long long)P.N * P.M * P.S < (1ll << 31)) {
         // pairs per workgroup x 10 + waves per SIMD.  Shipped: 42.  The 3- and 4-waves-per-SIMD geometries (63, 33, 84, 44) were built and
-        // measured slower (profiles/experiments/r04_render_ws.md); they need -DWS_BUFS=1 to fit their tiles into 160 KB of LDS
-#if WS_BUFS == 1
+        // measured slower (profiles/experiments/r04_render_ws.md); they are compiled only with -DNFE_WS_GEOMETRIES (and need WS_BUFS = 1 to fit their tiles into 160 KB of LDS)
+#if WS_BUFS == 1 && defined(NFE_WS_GEOMETRIES)       // experiment builds only
         switch (ws_mode()) {
             case 63: launch_render_ws<6, 3>(P, total_rb, st); break;
             case 33: launch_render_ws<3, 3>(P, total_rb, st); break;
@@ -2222,7 +2305,9 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
             default: launch_render_ws<4, 2>(P, total_rb, st); break;
         }
 #else
-        launch_render_ws<4, 2>(P, total_rb, st);
+        if (sigma_only) launch_render_ws<4, 2, false, true>(P, total_rb, st);
+        else if (dual) launch_render_ws<4, 2, true, false>(P, total_rb, st);
+        else launch_render_ws<4, 2>(P, total_rb, st);
 #endif
         NFE_CHECK_LAUNCH("render_ws_kernel");
         return NFE_OK;

@@ -462,6 +462,13 @@ lim = (torch.full((N, R2 * R2, 1), 2.3, device=dev) + 0.1 * torch.rand(N, R2 * R
 keep(ops.render(packed, packed, dec, dict(base, depth_resolution=40), origins=o, dirs=d, u_coarse=u, affines=aff, ray_limits=lim))                          # per-ray limits
 M3 = 70001                                                                  # not a square image: 32 consecutive rays per block, ragged last block
 keep(ops.render(packed, packed, dec, dict(base, depth_resolution=24), origins=o[:, :M3].contiguous(), dirs=d[:, :M3].contiguous(), affines=aff, seed=9))
+packed2 = ops.plane_pack((raw * 0.8 + 0.1).contiguous())                  # two-pass renders: the sigma-only and the (dual-set) final pass
+two = dict(base, depth_resolution=24, depth_resolution_importance=24)
+uc = torch.rand(N, 256 * 256, 24, generator=torch.Generator(device=dev).manual_seed(5), device=dev)
+uf = torch.rand(N * 256 * 256, 24, generator=torch.Generator(device=dev).manual_seed(6), device=dev)
+keep(ops.render(packed, packed2, dec, two, cam2world=c2w, intrinsics=K, resolution=256, u_coarse=uc, u_fine=uf))                 # dual sets, no affines
+keep(ops.render(packed, packed, dec, dict(two, white_back=True), cam2world=c2w, intrinsics=K, resolution=256, affines=aff, u_coarse=uc, u_fine=uf))
+keep(ops.render(packedr, packedr, dec, two, cam2world=c2w, intrinsics=K, resolution=256, affines=affr, u_coarse=uc, u_fine=uf))   # non-square planes
 first = [x.copy() for x in outs[:4]]
 for i in range(int(sys.argv[2])):                                           # repeated launches of the headline shape: bit-identical
     r = ops.render(packed, packed, dec, dict(base, depth_resolution=64), cam2world=c2w, intrinsics=K, resolution=R, affines=aff, seed=5)
@@ -476,7 +483,8 @@ def test_wave_specialised_launch_matches_the_fused_kernel(dev, tmp_path):
     """render_ws_kernel (producer waves: depths + gather + affines; consumer waves: decoder + march; hand-off through the LDS
     exchange tile) against render_kernel on the same inputs, one child interpreter per NFE_RENDER_WS value (read once
     per process): the headline shape, white_back + channels_first, non-square planes, caller-supplied rays with injected jitter,
-    disparity sampling and per-ray limits (the GENERIC depth schedule), a ray count that is no square image.  Same arithmetic in the
+    disparity sampling and per-ray limits (the GENERIC depth schedule), a ray count that is no square image, and three two-pass renders
+    (sigma-only coarse pass + depth-buffer final pass: two plane sets, one set with white_back, non-square planes).  Same arithmetic in the
     same order up to the compiler's contraction choices (the two kernels inline the tap geometry into different surroundings): <= 2e-5
     (measured 5e-7 on square planes, 9e-6 on non-square ones), the bound of the split-vs-unsplit test; no hand-off wait abandoned; 60 repeated launches of
     the headline shape bit-identical."""
@@ -494,10 +502,12 @@ def test_wave_specialised_launch_matches_the_fused_kernel(dev, tmp_path):
         assert r.returncode == 0, r.stderr[-3000:]
         z = np.load(out)
         res[mode] = [z[k] for k in z.files]
-    assert len(res["0"]) == len(res["42"]) == 28
+    assert len(res["0"]) == len(res["42"]) == 40
     worst = 0.0
     for i, (a, b) in enumerate(zip(res["0"], res["42"])):
         assert a.shape == b.shape and np.isfinite(b).all(), i
         worst = max(worst, max_abs(a, b))
-        assert max_abs(a, b) <= 2e-5 * max(1.0, float(np.abs(a).max())), (i, max_abs(a, b))
+        # two-pass renders (tensors 28..39): the importance samples are drawn from the coarse weights, which carries a last-bit
+        # difference of the coarse pass into the fine depths: measured 2.9e-5 on the non-square case, bound 1e-4
+        assert max_abs(a, b) <= (2e-5 if i < 28 else 1e-4) * max(1.0, float(np.abs(a).max())), (i, max_abs(a, b))
     print(f"wave-specialised vs fused render kernel: worst difference {worst:.2e} over {len(res['0'])} output tensors")
