@@ -1940,6 +1940,42 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
     return v;
 }
 
+// Ascending bitonic sort of 64 * R order-preserving depth keys held R per lane (element i = lane + 64 r), round 4.  Only the sorted
+// depths leave the kernel, so the keys carry no index and ties need no order.  Stage (k, j): element i keeps the smaller of (itself,
+// element i ^ j) iff ((i & k) == 0) == ((i & j) == 0).  j >= 64 pairs two registers of one lane; j < 64 is a lane exchange
+// (ds_bpermute through __shfl_xor; the LDS crossbar, no VALU issue slot for the data movement).
+template <int R>
+__device__ __forceinline__ void bitonic_sort_keys(unsigned (&v)[R], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j >= 1; j >>= 1) {
+            if (j >= 64) {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const int q = r ^ (j >> 6);
+                    if (q > r) {                                   // registers r < q: element index of r is the smaller one
+                        const bool asc = ((64 * r) & k) == 0;      // compile-time: (i & k) for k >= 128 depends on r only
+                        const unsigned lo = min(v[r], v[q]), hi = max(v[r], v[q]);
+                        v[r] = asc ? lo : hi; v[q] = asc ? hi : lo;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    const unsigned o = (unsigned)__shfl_xor((int)v[r], j);
+                    const int i = lane + 64 * r;
+                    const bool keep_min = ((i & k) == 0) == ((i & j) == 0);
+                    v[r] = keep_min ? min(v[r], o) : max(v[r], o);
+                }
+            }
+        }
+    }
+}
+
+// R = number of 64-sample chunks that hold D and Di (1, 2 or 4: <= 64, <= 128, <= 256 samples); WITH_SRC: the draw index of every
+// merged sample is wanted too (density noise only): that path keeps the (depth, index) rank counting of rounds 1-3.
+template <int R, bool WITH_SRC>
 __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1960,10 +1996,10 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
         wave_lds_fence();
         // smoothed weights a_i, i=0..D-2 (max_pool1d(k2,s1,p1) then avg_pool1d(k2,s1), +0.01): :205-207
         // only a[1..D-3] are used; q_i = a_{i+1} + 1e-5, i = 0..B-1 (:210, :228)
-        float qv[NFE_MAX_SAMPLES / 64];
+        float qv[R];
         float part = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+        for (int c = 0; c < R; ++c) {
             const int i = c * 64 + lane;
             float q = 0.0f;
             if (i < B) {
@@ -1981,7 +2017,7 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
         // cdf knots: cdf[0] = 0, cdf[i+1] = cumsum(pdf)[i]  (:229-232)
         float carry = 0.0f;
 #pragma unroll
-        for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+        for (int c = 0; c < R; ++c) {
             const int i = c * 64 + lane;
             float pdf = qv[c] / total;
             float sc = wave_incl_scan(pdf, lane) + carry;
@@ -1991,15 +2027,28 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
         if (lane == 0) cdf[0] = 0.0f;
         wave_lds_fence();
         // inverse-CDF sampling (:236-252)
-        for (int e = lane; e < Di; e += 64) {
+        unsigned fkey[R];                                  // this lane's fine depths as ordered keys (element lane + 64 c), +inf padding
+#pragma unroll
+        for (int c = 0; c < R; ++c) fkey[c] = 0xFFFFFFFFu;
+        u32x4 rb = {0, 0, 0, 0};
+        if (!P.u_fine) {
+            const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
+            rb = philox4x32_10((unsigned)ray, (unsigned)lane, 1u, 0u, (unsigned)seed, (unsigned)(seed >> 32));
+        }
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int e = c * 64 + lane;
+            const bool live = e < Di;            // no early `continue`: the lane exchanges below involve every lane
             float u;
             if (P.u_fine) {
-                u = P.u_fine[ray * Di + e];
+                u = live ? P.u_fine[ray * Di + e] : 0.0f;
             } else {
-                const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
-                u32x4 r = philox4x32_10((unsigned)ray, (unsigned)(e >> 2), 1u, 0u,
-                                        (unsigned)seed, (unsigned)(seed >> 32));
-                unsigned bits = (e & 3) == 0 ? r.x : (e & 3) == 1 ? r.y : (e & 3) == 2 ? r.z : r.w;
+                // Philox block b yields the draws of samples 4b .. 4b + 3: lane b computed it once (rb, below the loop header), sample e
+                // fetches word e & 3 of lane e >> 2 (same stream as one Philox call per sample, a quarter of the work)
+                const int src = 16 * c + (lane >> 2);
+                const unsigned bx = (unsigned)__shfl((int)rb.x, src), by = (unsigned)__shfl((int)rb.y, src);
+                const unsigned bz = (unsigned)__shfl((int)rb.z, src), bw = (unsigned)__shfl((int)rb.w, src);
+                const unsigned bits = (e & 3) == 0 ? bx : (e & 3) == 1 ? by : (e & 3) == 2 ? bz : bw;
                 u = u01(bits);
             }
             // searchsorted(cdf[0..B], u, right=True): number of knots <= u
@@ -2012,22 +2061,30 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
             float den = ca - cb;
             if (den < 1e-5f) den = 1.0f;
             const float t = bb + (u - cb) / den * (ba - bb);
-            keys[e] = make_uint2((unsigned)e, f2ord(t));
-            if (P.tap_fine) P.tap_fine[ray * Di + e] = t;
+            if (live) fkey[c] = f2ord(t);
+            if (WITH_SRC && live) keys[e] = make_uint2((unsigned)e, f2ord(t));
+            if (P.tap_fine && live) P.tap_fine[ray * Di + e] = t;
         }
-        for (int e = Di + lane; e < DiP; e += 64) keys[e] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-        wave_lds_fence();
+        if (WITH_SRC) {
+            for (int e = Di + lane; e < DiP; e += 64) keys[e] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            wave_lds_fence();
+        }
         // merge (unify_samples, renderer.py:288-300: only the sorted depths leave this kernel, so ties need no order).
         // 1. rank of each fine depth among the fine depths by counting: the number of (depth, draw index) keys below its own - every
         //    lane walks the whole key list (two keys per LDS read, broadcast) with one 64-bit compare and one add-with-carry per key;
         //    no sorting network, no intermediate barriers.  The ranked depths go to tf[], which is therefore ascending.
         // 2. position of each fine depth = its rank + #coarse <= it (binary search: coarse depths are ascending),
         //    position of each coarse depth = its index + #fine < it (binary search in tf[]).
-        {
-            unsigned long long mine[NFE_MAX_SAMPLES / 64];
-            unsigned rank[NFE_MAX_SAMPLES / 64];
+        if (!WITH_SRC) {            // round 4: sort the keys in registers (28 compare-exchange stages for 128 keys against 98 x 2 compares per lane)
+            bitonic_sort_keys<R>(fkey, lane);
 #pragma unroll
-            for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+            for (int c = 0; c < R; ++c)
+                if (c * 64 + lane < Di) tf[c * 64 + lane] = ord2f(fkey[c]);
+        } else {
+            unsigned long long mine[R];
+            unsigned rank[R];
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
                 const int e = c * 64 + lane;
                 const uint2 k = keys[min(e, DiP - 1)];
                 mine[c] = (unsigned long long)k.y << 32 | k.x;
@@ -2038,14 +2095,14 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
                 const uint4 q = kp[j];
                 const unsigned long long k0 = (unsigned long long)q.y << 32 | q.x, k1 = (unsigned long long)q.w << 32 | q.z;
 #pragma unroll
-                for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+                for (int c = 0; c < R; ++c) {
                     if (c * 64 >= Di) break;
                     rank[c] += (k0 < mine[c]) ? 1u : 0u;
                     rank[c] += (k1 < mine[c]) ? 1u : 0u;
                 }
             }
 #pragma unroll
-            for (int c = 0; c < NFE_MAX_SAMPLES / 64; ++c) {
+            for (int c = 0; c < R; ++c) {
                 const int e = c * 64 + lane;
                 if (e < Di) tf[rank[c]] = ord2f((unsigned)(mine[c] >> 32));
             }
@@ -2530,7 +2587,13 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         const int lds_bytes = 4 * ((((3 * D + 3) & ~3) + 2 * ((Di + 2) & ~1) + Di + 3) & ~3) * 4;      // four waves, importance_kernel's layout
         long long blocks = ((long long)nr + 3) / 4;
         if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
-        hipLaunchKernelGGL(importance_kernel, dim3((unsigned)blocks), dim3(256), lds_bytes, st, I);
+        {
+            const int mx = D > Di ? D : Di;
+#define NFE_IMP(RR) { if (src_all) hipLaunchKernelGGL((importance_kernel<RR, true>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, I); \
+                      else hipLaunchKernelGGL((importance_kernel<RR, false>), dim3((unsigned)blocks), dim3(256), lds_bytes, st, I); }
+            if (mx <= 64) NFE_IMP(1) else if (mx <= 128) NFE_IMP(2) else NFE_IMP(4)
+#undef NFE_IMP
+        }
         NFE_CHECK_LAUNCH("importance_kernel");
         // pass 3: march the merged samples
         RenderK F = P;
