@@ -81,7 +81,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 union Frag { bf16x8 v; uint4 q; unsigned u[4]; };
 
-__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#ifndef NFE_PK_SCALAR
+#define NFE_PK_SCALAR 0      // experiment (with -fno-slp-vectorize): two v_fma_f32 instead of one v_pk_fma_f32 - packed fp32 shares the matrix
+#endif                       // pipe and cannot execute beside another wave's MFMA; plain VALU can (SQ_VALU_MFMA_COEXEC_CYCLES)
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+#if NFE_PK_SCALAR
+    return f32x2{__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])};
+#else
+    return __builtin_elementwise_fma(a, b, c);
+#endif
+}
 __device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
 
 // Raw v_exp_f32 / v_log_f32 (base 2, 1 ulp, no denormal-range fix-up code: the differences are far
@@ -2289,7 +2298,7 @@ static void launch_render_ws(const RenderK& P, long long total_rb, hipStream_t s
     const bool generic = P.depth_mode != DEPTH_STRATIFIED;
 #define NFE_WS_LAUNCH(SQ, GE)                                                                                                    \
     {                                                                                                                            \
-        allow_lds(render_ws_kernel<NP, WPS, SQ, GE, DUAL, SIGMA_ONLY>, bytes);                                                   \
+        static const bool once_ = (allow_lds(render_ws_kernel<NP, WPS, SQ, GE, DUAL, SIGMA_ONLY>, bytes), true); (void)once_;    \
         hipLaunchKernelGGL((render_ws_kernel<NP, WPS, SQ, GE, DUAL, SIGMA_ONLY>), dim3((unsigned)blocks), dim3(NP * 128), bytes, st, P); \
     }
     if (P.H == P.W) { if (generic) NFE_WS_LAUNCH(true, true) else NFE_WS_LAUNCH(true, false) }

@@ -14,6 +14,7 @@ pass() {
 }
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES
 pass sq2 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_SALU SQ_INSTS_MFMA SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE
+pass sq3 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_CVT SQ_VALU_MFMA_COEXEC_CYCLES SQ_INST_CYCLES_SALU
 pass mem1 FETCH_SIZE TCC_HIT GRBM_GUI_ACTIVE TA_TA_BUSY TCP_TOTAL_CACHE_ACCESSES
 pass mem2 WRITE_SIZE TCC_MISS TCC_REQ TCP_TCC_READ_REQ TA_FLAT_READ_WAVEFRONTS
 python3 tools/pmc_summary.py $OUT > $OUT/summary.txt 2>&1
