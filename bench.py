@@ -791,6 +791,7 @@ def main():
             "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit,
                          "frac": frac.get(bound) if bound else None, "traffic": detail.get("hbm_bytes"),
                          "kernel": detail.get("kernel_profiled") or "nfe::render_ws_kernel<4,2,SQUARE=1,GENERIC=0>", "kernel_ms": kern_ms,
+                         "kernel_mcycles": kern_ms * 1e-3 * detail["effective_clock_ghz"] * 1e3 if detail.get("effective_clock_ghz") else None,   # shader cycles per launch (x 1e6): the box-independent figure (clocks differ by +-4 % between boxes)
                          "kernel_ms_fp32_exact": fp32_ms, "fp32_exact": pmc_fractions("r04_issue_floor_fp32.json", share_of_ms=1.0, total_ms=fp32_ms, steps_per_launch=VIEWS_PER_GPU * (M // 32) * D),
                          "fractions": frac,
                          "algorithmic_bytes_per_launch": launch_bytes, "detail": detail,
