@@ -128,8 +128,10 @@ __device__ __forceinline__ float min126_bits(float y) { return __int_as_float(mi
 #define NFE_SOFTPLUS_MINFORM 0
 #endif
 #ifndef NFE_SOFTPLUS_SCALAR
-#define NFE_SOFTPLUS_SCALAR 0      // 1: plain v_add_f32 instead of v_pk_add_f32 (packed fp32 shares the matrix pipe: it cannot run under an MFMA)
-#endif
+#define NFE_SOFTPLUS_SCALAR 0      // 1: EXPERIMENT ONLY, KNOWN WRONG - plain v_add_f32 through inline asm instead of v_pk_add_f32.  The asm
+#endif                             // instruction reads a v_exp_f32 / v_log_f32 result one instruction after it was written, without the wait state
+                                   // hipcc inserts only for its own instructions: run-dependent results on MI355X.  Kept as the reproducer of
+                                   // profiles/experiments/r04_asm_trans_hazard.md; tools/asm_audit.py (rule TRNS) flags all 36 sites.
 __device__ __forceinline__ float add_f32_plain(float a, float b) {      // an add the SLP vectoriser cannot pair into v_pk_add_f32
     float r;
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
