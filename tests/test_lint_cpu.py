@@ -28,3 +28,16 @@ def test_inline_asm_audit_and_accumulate_reg_kernel_register_contract():
     assert "asm audit: 0 violations" in r.stdout
     assert "s_set_gpr_idx_on" in r.stdout and "M0-1 (4 >= 4 states)" in r.stdout        # the index-mode statements were seen and checked
     assert "global_load_lds_dwordx4" in r.stdout and "M0-1 (1 >= 1 states)" in r.stdout   # so were conv3_kernel's LDS-DMA statements
+
+
+def test_asm_audit_detects_the_reproduced_hazard():
+    """The detector must see what the hardware punished: the experiment build -DNFE_SOFTPLUS_SCALAR=1 (an inline-asm v_add_f32 that
+    reads a v_exp_f32 / v_log_f32 result without the wait state: run-dependent results on MI355X,
+    profiles/experiments/r04_asm_trans_hazard.md) has to fail rule TRNS, in every render kernel that contains the statement."""
+    env = dict(os.environ, ASM_AUDIT_FLAGS="-DNFE_SOFTPLUS_SCALAR=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_audit.py"), "--files", "nfe_render.hip"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 1, r.stdout[-2000:]
+    hits = [l for l in r.stdout.splitlines() if l.startswith("VIOLATION") and "TRNS" in l]
+    assert len(hits) >= 100 and all("v_add_f32 reads the result of v_" in l for l in hits), hits[:3]
+    kernels = {l.split(":")[0] for l in hits}
+    assert any("render_ws_kernel" in k for k in kernels) and any("render_kernel" in k for k in kernels)

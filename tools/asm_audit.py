@@ -33,7 +33,8 @@ every instruction-bearing block, per kernel instance, the rules below are CHECKE
   WAIT  statements that only wait (s_waitcnt) are listed; they order the COMPILER's counted loads (LDS-DMA is issued by asm and
         counted by hand: conv3_kernel's vmcnt ladder).
 
-usage: asm_audit.py [--md OUT.md]     exit code 1 on any violated rule
+usage: asm_audit.py [--md OUT.md] [--files a.hip,b.hip]     exit code 1 on any violated rule
+       ASM_AUDIT_FLAGS="-DNFE_SOFTPLUS_SCALAR=1" asm_audit.py --files nfe_render.hip     audits an experiment build (own ISA directory)
 """
 import os
 import re
@@ -314,7 +315,8 @@ def main():
     if extra:                                                             # ... into its own directory: build/lint holds the shipped build's ISA
         outdir = os.path.join(L.ROOT, "nerffaceediting_amd", "csrc", "build", "lint_experiment")
         os.makedirs(outdir, exist_ok=True)
-    for f in L.ALL:
+    files = sys.argv[sys.argv.index("--files") + 1].split(",") if "--files" in sys.argv else L.ALL
+    for f in files:
         text = open(L.assemble(os.path.join(L.CSRC, f), outdir, extra)).read()
         report, nk, nb, nr = {}, 0, 0, 0
         stats = {}
