@@ -552,6 +552,9 @@ __device__ uint4 nfe_zero16[4];                                  // source of th
 #ifndef C3_DMA_BUILTIN
 #define C3_DMA_BUILTIN 0                                         // 1: the round-2 form (compiler-tracked LDS-DMA), kept for A/B
 #endif
+#ifndef C3_UP_BCACHE
+#define C3_UP_BCACHE 1                                           // up-sampling K loop: the six distinct patch fragments of a K-group in registers
+#endif
 #ifndef C3_FRAG_PIPE
 #define C3_FRAG_PIPE 1                                           // A/B switch of the fragment-read pipeline in conv3_kernel
 #endif
@@ -854,6 +857,41 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
                         for (int m = 0; m < MBW; ++m)
                             acc[0][m][nb] = mfma16<TERMS>(A[m][kh * 3 + dx].v, Bq[f & 3].v, acc[0][m][nb], 0, 0, 0);
                     }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else if constexpr (UP2 && TERMS != 3 && C3_UP_BCACHE) {
+            // Up-sampling layers, single-part operands (round 4).  The nine taps of the transposed convolution read only 2 x 2
+            // input offsets (dy, dx = 1 - (k >> 1)), i.e. (NBW + 1) x 2 = 6 distinct patch fragments per K-group for the wave's NBW
+            // rows - the tap loop above fetches one per (tap, row): 18.  With MBW = 1 (four phase accumulators fill the register
+            // budget) every MFMA also needs its own weight fragment, so the loop ran at 1.5 LDS fragment reads per MFMA with all
+            // four SIMDs sharing one 256 B/clk LDS: the K loop was LDS-read bound (matrix pipe 0.22-0.25 busy over the kernel).
+            // Here the six patch fragments of the K-group sit in registers (24 VGPRs): 9 + 6 = 15 reads per 18 MFMAs.
+            Frag8 Bc[NBW + 1][2];
+#pragma unroll
+            for (int rr = 0; rr <= NBW; ++rr)
+#pragma unroll
+                for (int dx = 0; dx < 2; ++dx) Bc[rr][dx].q = *reinterpret_cast<const uint4*>(ldsB + brd[rr][dx]);
+            Frag8 ah[2][MBW];
+#pragma unroll
+            for (int m = 0; m < MBW; ++m) ah[0][m].q = ldsA[((m * 9 + 0) * PARTS) * 64];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int kh = t / 3, kw = t % 3, dy = 1 - (kh >> 1), dx = 1 - (kw >> 1), a = (kh & 1) * 2 + (kw & 1);
+                if (t + 1 < 9) {
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) ah[(t + 1) & 1][m].q = ldsA[((m * 9 + t + 1) * PARTS) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nb = 0; nb < NBW; ++nb)
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) acc[a][m][nb] = mfma16<TERMS>(ah[t & 1][m].v, Bc[nb + dy][dx].v, acc[a][m][nb], 0, 0, 0);
+                if (kw == 2 && edge_tile && wave == 0) {   // wave-uniform: the extra column of the unfused form
+                    Frag8 eh;
+                    eh.q = *reinterpret_cast<const uint4*>(ldsB + brde[dy]);
+#pragma unroll
+                    for (int m = 0; m < MBW; ++m) acce[kh & 1][m] = mfma16<TERMS>(ah[t & 1][m].v, eh.v, acce[kh & 1][m], 0, 0, 0);
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
