@@ -552,6 +552,11 @@ __device__ uint4 nfe_zero16[4];                                  // source of th
 #ifndef C3_DMA_BUILTIN
 #define C3_DMA_BUILTIN 0                                         // 1: the round-2 form (compiler-tracked LDS-DMA), kept for A/B
 #endif
+#ifndef C3_UP_DBUF
+#define C3_UP_DBUF 0                                             // 1: fused up-sampling epilogue with two FIR slice buffers (5 barriers per tile instead of 8): measured no gain (3.27 vs 3.27 ms FFHQ fp16 step), twice the LDS
+#endif
+// LDS of the fused up-sampling epilogue: C3_UP_DBUF + 1 slice buffers of [2 halves][2 ROWS][64] float4
+constexpr int conv3_fused_t_bytes(int rows) { return (C3_UP_DBUF ? 2 : 1) * 2 * (2 * rows) * 64 * 16; }
 #ifndef C3_UP_BCACHE
 #define C3_UP_BCACHE 1                                           // up-sampling K loop: the six distinct patch fragments of a K-group in registers
 #endif
@@ -774,7 +779,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
     // Per-channel epilogue constants of this workgroup's 32 * MBW channels go to LDS now (1 KiB behind the ring): loaded in the
     // epilogue they were a dependent global round trip with nothing to hide it (8 % of the kernel, tools/r03_abm_stats.sh).
     // [0] demodulation coefficients, [1] bias, [2] the consuming layer's styles.  Visible after the first barrier of the K loop.
-    constexpr int FUSED_T_BYTES = UP2 ? 2 * (2 * ROWS) * 64 * 16 : 0;          // the fused up-sampling epilogue's scratch slice (8 channels)
+    constexpr int FUSED_T_BYTES = UP2 ? conv3_fused_t_bytes(ROWS) : 0;         // the fused up-sampling epilogue's scratch slices (8 channels each)
     constexpr int EC_OFFSET = STAGES * STAGE_BYTES > FUSED_T_BYTES ? STAGES * STAGE_BYTES : FUSED_T_BYTES;
     float* ec = reinterpret_cast<float*>(lds + EC_OFFSET);
     constexpr int EC = 32 * MBW;
@@ -1077,20 +1082,27 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
             const int Y = 2 * ty0 + y0 + r;
             nzs[r] = (P.noise && xok && Y >= 0 && Y < OH) ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
         }
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
+        // slice qq (accumulator registers 4 qq .. 4 qq + 3 of both lane halves) -> slice buffer qq & 1 (C3_UP_DBUF) or the only one
+        constexpr int SLICE = 2 * TYL * XS;                    // float4 elements of one slice buffer
+        auto put_slice = [&](int qq) {
+            float4* dst = Tl + (C3_UP_DBUF ? (qq & 1) * SLICE : 0);
 #pragma unroll
             for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                 for (int a = 0; a < NACC; ++a)
-                    Tl[(h * TYL + 2 * (NBW * wave + nb) + (a >> 1)) * XS + 2 * j + (a & 1)] =
+                    dst[(h * TYL + 2 * (NBW * wave + nb) + (a >> 1)) * XS + 2 * j + (a & 1)] =
                         make_float4(acc[a][0][nb][4 * qq], acc[a][0][nb][4 * qq + 1], acc[a][0][nb][4 * qq + 2], acc[a][0][nb][4 * qq + 3]);
-            __syncthreads();
+        };
+        if (C3_UP_DBUF) { put_slice(0); __syncthreads(); }
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+            if (C3_UP_DBUF) { if (qq + 1 < 4) put_slice(qq + 1); }      // the other buffer: its readers finished before the last barrier
+            else { put_slice(qq); __syncthreads(); }
             if (active) {
                 const float4 d = *reinterpret_cast<const float4*>(ec + 8 * qq + 4 * hs);
                 const float4 b = *reinterpret_cast<const float4*>(ec + EC + 8 * qq + 4 * hs);
                 const float4 s2 = *reinterpret_cast<const float4*>(ec + 2 * EC + 8 * qq + 4 * hs);
-                const float4* col = Tl + (hs * TYL) * XS + Xl - 1;
+                const float4* col = Tl + (C3_UP_DBUF ? (qq & 1) * SLICE : 0) + (hs * TYL) * XS + Xl - 1;
                 auto hrow = [&](int yl) {
                     const float4* rp = col + yl * XS;
                     const float4 t0 = rp[0], t1 = rp[1], t2 = rp[2], t3 = rp[3];
@@ -1919,7 +1931,7 @@ static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st
 template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW, int LW>
 static void launch_conv3_t(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override) {
     constexpr int ROWS = NBW * WV;
-    constexpr int ring = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>(), fused_t = UP2 ? 2 * (2 * ROWS) * 64 * 16 : 0;
+    constexpr int ring = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>(), fused_t = UP2 ? conv3_fused_t_bytes(ROWS) : 0;
     constexpr int bytes = (ring > fused_t ? ring : fused_t) + conv3_ec_bytes<MBW>();  // ring (or the fused FIR's tile) + the epilogue constants
     static bool once = [] {
         return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
