@@ -60,7 +60,7 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
     import json
     import os
     rec = None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_backward_counters.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_backward_counters.json")
     if os.path.exists(path):
         rec = json.load(open(path))
     ach = rec["hbm_bytes_per_launch"] / rec["avg_ns_profiled"] if rec else None            # GB/s
@@ -72,10 +72,11 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
             "kernel_ms": rec["avg_ns_profiled"] * 1e-6 if rec else None, "backward_ms": bwd_ms,
             "hbm_bytes_per_sample_model": 1240, "hbm_model_gbs": samples * 1240 / (bwd_ms * 1e-3) / 1e9,
             "logical_gather_scatter_gbs": logical_gbs,
-            "note": "achieved / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r03_backward_counters.json "
-                    "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE, rocprofv3 duration under the counters), not re-measured by this "
-                    "run; peak = the 8 TB/s HBM figure (a read-only stream reaches 6.3 TB/s on this machine, tools/microbench/read_bw.hip, so "
-                    "the kernel is at 0.96 of what reads can get); backward_ms is this run's HIP-event time of the whole backward.  Per sample "
+            "note": "achieved / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r04_backward_counters.json "
+                    "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE; duration = rocprofv3 kernel trace of the both-sets mode, which "
+                    "agrees with the duration under the counters to 0.6 %), not re-measured by this run; peak = the 8 TB/s HBM figure (a "
+                    "read-only stream reaches 6.3 TB/s on this machine, tools/microbench/read_bw.hip, so the kernel is at 0.87 of what reads "
+                    "can get); backward_ms is this run's HIP-event time of the whole backward.  Per sample "
                     "the decoder-backward kernel writes a 256-byte feature-gradient row and three 32-byte records, the fill pass sorts a 4-byte "
                     "index per record, the accumulate pass (one wave owns an 8x8 texel tile in registers) reads index, record and row once per "
                     "plane; the forward keeps the decoders' per-sample outputs (192 B per sample) so that no sample is re-evaluated.  logical "
