@@ -1409,7 +1409,7 @@ constexpr int WS_PAIR_FLOATS = AFF_FLOATS + WS_FLAG_OFF + 4;
 static_assert(WS_PAIR_FLOATS % 4 == 0 && AFF_FLOATS % 4 == 0, "16-byte aligned tiles");
 template <int NP> constexpr int ws_lds_bytes() { return (DEC_FLOATS + NP * WS_PAIR_FLOATS) * 4; }
 #ifndef WS_SLEEP
-#define WS_SLEEP 2
+#define WS_SLEEP 2                                          // s_sleep argument of the hand-off poll (measured 0 / 2 / 8: 6.50 / 6.47 / 6.44 ms - polling is not the cost)
 #endif
 constexpr int WS_SPIN_LIMIT = 1 << 18;                      // x (s_sleep 1 + an LDS read) ~ 50 ms: a lost partner ends the wait, never the box
 
@@ -1603,6 +1603,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
     unsigned step = 0;                       // samples handed over so far by this pair (both roles count alike)
     bool alive = true;
 
+    // -DWS_ONLY_CONSUMER / -DWS_ONLY_PRODUCER: compile-only builds that drop the other role, for the per-role register census
+    // (hipcc -Rpass-analysis: consumer 152 VGPRs, producer 169-203); their launches would wait for a partner that never signals.
 #ifdef WS_ONLY_CONSUMER
     if (false) {
 #else
