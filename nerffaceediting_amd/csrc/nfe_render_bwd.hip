@@ -47,6 +47,9 @@ struct BwdK {
     const float* g_rgb; const float* g_seg; const float* g_depth; const float* g_wsum; int channels_first;
     float* grad_g; float* grad_a; long long grad_view_stride;
     float* rec_sig; float* rec_a; float* rec_T;      // [N*M*S] each: (sigma, a, T) then (dL/dsigma, omega, -)
+    // what the scatter pass reads per sample, in ITS order: [3: dL/dsigma, omega, depth][view][64-ray tile][sample][lane], written by
+    // bwd_ray_kernel (a wave of either kernel = one 64-ray tile, tile_ray()).  Null: the direct form reads rec_sig / rec_a in place.
+    float* til; int T; long long til_n;              // ray tiles per view, floats per array (N * T * S * 64)
     const uint4* bfrag;                // split-bf16 MFMA fragments of the decoder and its transposes (bwd_frag_kernel), or null
     // binned scatter (one chunk of views x 64-ray tiles): feature gradients, bin records and their sorted list
     float* df; uint2* rec_key; float4* rec_w; uint2* binrank; unsigned* counts; unsigned* offsets; unsigned* perm;
@@ -273,12 +276,34 @@ __device__ __forceinline__ void segment(float s0, float s1, float t0, float t1, 
     dalpha_dsmid = dlt * e * (x > 20.0f ? 1.0f : sigmoid_t(x));
 }
 
+// Ray m of lane `lane` of 64-ray tile t: an 8 x 8 pixel tile of a square image whose side is a multiple of 8, else 64 consecutive
+// rays (dead lanes of the last tile repeat the view's last ray).  bwd_ray_kernel and bwd_scatter_sorted_kernel share it.
+__device__ __forceinline__ int tile_ray(const BwdK& P, int t, int lane, bool& live) {
+    live = true;
+    if (P.R > 0 && (P.R & 7) == 0 && (long long)P.R * P.R == P.M) {
+        const int tiles_x = P.R >> 3;
+        return ((t / tiles_x) * 8 + (lane >> 3)) * P.R + (t % tiles_x) * 8 + (lane & 7);
+    }
+    const int m = t * 64 + lane;
+    live = m < P.M;
+    return min(m, P.M - 1);
+}
+
 constexpr int RAY_CH = 16;     // samples per batch of bwd_ray_kernel: their loads are issued together, one memory round trip per batch
 
 __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
-    const long long ray = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (ray >= (long long)P.N * P.M) return;
+    const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);          // = (view, 64-ray tile)
+    if (wave >= (long long)P.N * P.T) return;
+    const int lane = threadIdx.x & 63;
+    bool live;
+    const int m_of_lane = tile_ray(P, (int)(wave % P.T), lane, live);
+    if (!live) return;
+    const long long ray = (wave / P.T) * P.M + m_of_lane;
     const int S = P.S;
+    // outputs in the scatter pass's order (coalesced 256-byte rows here and there) or, for the direct form, in place
+    float* __restrict__ o_sig = P.til ? P.til + (size_t)wave * S * 64 + lane : nullptr;
+    float* __restrict__ o_a = P.til ? o_sig + P.til_n : nullptr;
+    float* __restrict__ o_t = P.til ? o_a + P.til_n : nullptr;
     const float* __restrict__ t = P.depths + ray * S;
     float* sig = P.rec_sig + ray * S; float* av = P.rec_a + ray * S; float* __restrict__ Tv = P.rec_T + ray * S;
     // forward: transmittance of every segment, sum of weights, weighted depth.  A lane walks its own ray (stride S between lanes),
@@ -286,6 +311,7 @@ __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
     // step's loads, and the kernel spent one memory latency per sample.
     float T = 1.0f, wtot = 0.0f, dnum = 0.0f;
     float s0 = sig[0], t0 = t[0];
+    if (o_t) o_t[0] = t0;
     for (int j0 = 0; j0 + 1 < S; j0 += RAY_CH) {
         float sc[RAY_CH], tc[RAY_CH], To[RAY_CH];
 #pragma unroll
@@ -303,7 +329,7 @@ __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < RAY_CH; ++u) if (j0 + 1 + u < S) Tv[j0 + u] = To[u];
+        for (int u = 0; u < RAY_CH; ++u) if (j0 + 1 + u < S) { Tv[j0 + u] = To[u]; if (o_t) o_t[(size_t)(j0 + 1 + u) * 64] = tc[u]; }
     }
     const float d0 = dnum / wtot;
     const bool ok = wtot != 0.0f && isfinite(d0);                   // nan_to_num + clamp (:93-94) pass nothing otherwise
@@ -340,9 +366,13 @@ __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < RAY_CH; ++u) if (jh - u >= 0) { sig[jh - u + 1] = gso[u]; av[jh - u + 1] = omo[u]; }
+        for (int u = 0; u < RAY_CH; ++u) if (jh - u >= 0) {
+            if (o_sig) { o_sig[(size_t)(jh - u + 1) * 64] = gso[u]; o_a[(size_t)(jh - u + 1) * 64] = omo[u]; }
+            else { sig[jh - u + 1] = gso[u]; av[jh - u + 1] = omo[u]; }
+        }
     }
-    sig[0] = gs_hi; av[0] = om_hi;
+    if (o_sig) { o_sig[0] = gs_hi; o_a[0] = om_hi; }
+    else { sig[0] = gs_hi; av[0] = om_hi; }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -496,6 +526,11 @@ __device__ __forceinline__ void bsplit(float a, float b, unsigned& hi, unsigned&
     bwd_bf16x2 p = {(__bf16)(a - __uint_as_float(ua & 0xffff0000u)), (__bf16)(b - __uint_as_float(ub & 0xffff0000u))};
     lo = *reinterpret_cast<unsigned*>(&p);
 }
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 9      // timing experiment 9: fragments made up in registers (no fragment traffic)
+#define NFE_BFRAG(F, i) make_uint4((unsigned)(i) * 0x01010101u + (unsigned)lane, 0x3c003c00u, (unsigned)lane << 7, 0x3c003c00u)
+#else
+#define NFE_BFRAG(F, i) (F)[(i) * 64]
+#endif
 __device__ __forceinline__ f32x16 mfma3(const BFrag& ah, const BFrag& al, const BFrag& bh, const BFrag& bl, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, c, 0, 0, 0);
@@ -551,7 +586,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 BFrag ah, al;
-                ah.q = F[(BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 0) * 64]; al.q = F[(BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 1) * 64];
+                ah.q = NFE_BFRAG(F, BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 0); al.q = NFE_BFRAG(F, BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 1);
                 pre[mb] = mfma3(ah, al, b == 0 ? bh[0][s] : bh[1][s], b == 0 ? bl[0][s] : bl[1][s], pre[mb]);
             }
         f32x16 dh[2];
@@ -574,7 +609,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
                 for (int r = 0; r < 8; ++r) hv[8 * (s & 1) + r] = softplus_t(pre[s >> 1][8 * (s & 1) + r]);
                 BFrag hh, hl, ah, al;
                 acc_operand(hv, s & 1, hh, hl);
-                ah.q = F[(BF_F1A + s * 2 + 0) * 64]; al.q = F[(BF_F1A + s * 2 + 1) * 64];
+                ah.q = NFE_BFRAG(F, BF_F1A + s * 2 + 0); al.q = NFE_BFRAG(F, BF_F1A + s * 2 + 1);
                 y = mfma3(ah, al, hh, hl, y);
             }
             dout_app(b, y);                                       // y[r] <- cotangent of app output channel 16h + r
@@ -586,7 +621,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     BFrag ah, al;
-                    ah.q = F[(BF_DHA + (mb * 2 + s) * 2 + 0) * 64]; al.q = F[(BF_DHA + (mb * 2 + s) * 2 + 1) * 64];
+                    ah.q = NFE_BFRAG(F, BF_DHA + (mb * 2 + s) * 2 + 0); al.q = NFE_BFRAG(F, BF_DHA + (mb * 2 + s) * 2 + 1);
                     dh[mb] = mfma3(ah, al, dhh, dhl, dh[mb]);
                 }
             }
@@ -600,7 +635,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 BFrag ah, al;
-                ah.q = F[(BF_DHG + mb * 2 + 0) * 64]; al.q = F[(BF_DHG + mb * 2 + 1) * 64];
+                ah.q = NFE_BFRAG(F, BF_DHG + mb * 2 + 0); al.q = NFE_BFRAG(F, BF_DHG + mb * 2 + 1);
                 dh[mb] = mfma3(ah, al, dhh, dhl, dh[mb]);
             }
         }
@@ -618,7 +653,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
             }
             BFrag ph, pl, ah, al;
             acc_operand(dp, s & 1, ph, pl);
-            ah.q = F[(BF_DF + (head * 4 + s) * 2 + 0) * 64]; al.q = F[(BF_DF + (head * 4 + s) * 2 + 1) * 64];
+            ah.q = NFE_BFRAG(F, BF_DF + (head * 4 + s) * 2 + 0); al.q = NFE_BFRAG(F, BF_DF + (head * 4 + s) * 2 + 1);
             df = mfma3(ah, al, ph, pl, df);
         }
         float* row = tile + (32 * b + j) * stride + col0 + 16 * h;
@@ -639,6 +674,9 @@ constexpr unsigned KEY_INVALID = 0xFFFFFFFFu;
 constexpr int BIN_SHIFT = 3, BIN_MASK = 7, BIN_TEXELS = 9;       // plane tiles of the binned form: 8 x 8 texels + the far taps' row/column
 #ifndef NFE_BIN_SEGMENT
 #define NFE_BIN_SEGMENT 4096
+#endif
+#ifndef NFE_BWD_DEPTH_FAST
+#define NFE_BWD_DEPTH_FAST 0       // A/B: block order of the decoder-backward launch (1 = the depths of one ray tile are neighbours)
 #endif
 constexpr int BIN_SEGMENT = NFE_BIN_SEGMENT;                                // records per workgroup before a bin is split (at most BIN_SPLIT ways)
 constexpr int BIN_SPLIT = 4;
@@ -731,7 +769,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     __shared__ __attribute__((aligned(16))) float tile[64 * SORT_TILE_STRIDE];       // [sample][0..31 geometry-set gradient, 32..63 appearance-set]
     __shared__ float wtab[BINNED ? 1 : 64 * 12];        // tap weights [sample][plane*4 + tap]
     const int lane = threadIdx.x;
-    const int n = blockIdx.z + (BINNED ? P.n0 : 0), kdepth = blockIdx.y, t = blockIdx.x + (BINNED ? P.t0 : 0);
+    // grid = (ray tiles, depths, views), or with NFE_BWD_DEPTH_FAST (depths, ray tiles, views): which neighbours run together
+    const int bx = NFE_BWD_DEPTH_FAST ? blockIdx.y : blockIdx.x;
+    const int n = blockIdx.z + (BINNED ? P.n0 : 0), kdepth = NFE_BWD_DEPTH_FAST ? blockIdx.x : blockIdx.y, t = bx + (BINNED ? P.t0 : 0);
     int m; bool live = true;
     if (P.R > 0 && (P.R & 7) == 0 && (long long)P.R * P.R == P.M) {       // 8x8 pixel tile
         const int tiles_x = P.R >> 3;
@@ -739,10 +779,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     } else {
         m = t * 64 + lane; live = m < P.M; m = min(m, P.M - 1);
     }
-    const long long g = ((long long)n * P.M + m) * P.S + kdepth;
+    // dL/dsigma, omega and the depth of this wave's 64 samples: one 256-byte row each (bwd_ray_kernel wrote them in this order)
+    const float* til = P.til + (((size_t)n * P.T + t) * P.S + kdepth) * 64 + lane;
+    const float t_sample = til[2 * P.til_n];
     SampleGeo geo;
-    sample_geometry(P, n, m, P.depths[g], geo);
-    const float gsig = P.rec_sig[g], omega = P.rec_a[g];
+    sample_geometry(P, n, m, t_sample, geo);
+    const float gsig = til[0], omega = til[P.til_n];
     const long long pv = (long long)n * P.plane_view_stride;
     const long long gv = (long long)n * P.grad_view_stride;
     const float* dec = P.dec;
@@ -830,7 +872,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
     if (BINNED) {       // feature gradients to the chunk buffer, one bin record per (sample, plane); bwd_accumulate_kernel adds them up
         __builtin_amdgcn_wave_barrier();
-        const unsigned wave = ((unsigned)blockIdx.z * (unsigned)P.t_count + blockIdx.x) * (unsigned)P.S + (unsigned)kdepth;
+        const unsigned wave = ((unsigned)blockIdx.z * (unsigned)P.t_count + (unsigned)bx) * (unsigned)P.S + (unsigned)kdepth;
         float* dst = P.df + (size_t)wave * 4096 + lane;
 #pragma unroll 8
         for (int sidx = 0; sidx < 64; ++sidx) dst[sidx * 64] = tile[sidx * SORT_TILE_STRIDE + lane];
@@ -838,7 +880,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
         float ro[3], rd[3];                 // tap geometry again (cheaper than 24 registers kept across the decoder)
         ray_of(P, n, m, ro, rd);
-        const float tt = P.depths[g];
+        const float tt = t_sample;
         const float cx = P.coord_scale * fmaf(tt, rd[0], ro[0]), cy = P.coord_scale * fmaf(tt, rd[1], ro[1]), cz = P.coord_scale * fmaf(tt, rd[2], ro[2]);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
@@ -868,7 +910,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
             }
             unsigned base = 0;
+#if !defined(NFE_BWD_ABLATE) || NFE_BWD_ABLATE != 8     // timing experiment 8: no rank atomics
             if (first_lane == lane) base = __hip_atomic_fetch_add(P.counts + bin, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
             rank += (unsigned)__shfl((int)base, first_lane & 63);
             const size_t slot = (size_t)p * ((size_t)gridDim.z * P.t_count * P.S * 64) + idx;
             P.binrank[slot] = make_uint2(bin, rank);
@@ -1299,6 +1343,11 @@ static uint64_t chunk_slots(int n_views, int n_rays, int n_samples) {
     const uint64_t views = cap / per_view < (uint64_t)n_views ? cap / per_view : (uint64_t)n_views;
     return views * per_view;
 }
+// floats of one array of BwdK::til: whole 64-ray tiles
+static uint64_t tiled_floats(int n_views, int n_rays, int n_samples) {
+    if (n_views <= 0 || n_rays <= 0 || n_samples <= 0) return 0;
+    return (uint64_t)n_views * (((uint64_t)n_rays + 63) / 64) * 64ull * (uint64_t)n_samples;
+}
 // df rows + (key, weights) records + (bin, rank) + sorted record indices + counts and offsets
 static uint64_t binned_bytes(uint64_t slots) {
     return align256(slots * 256) + align256(slots * 3 * 8) + align256(slots * 3 * 16) + align256(slots * 3 * 8) + align256(slots * 3 * 4) +
@@ -1312,7 +1361,7 @@ using namespace nfe;
 extern "C" uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples) {
     const uint64_t ns = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0) * (uint64_t)(n_samples > 0 ? n_samples : 0);
     return BWD_DEC_BYTES + 3 * align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES) +
-           binned_bytes(chunk_slots(n_views, n_rays, n_samples));
+           binned_bytes(chunk_slots(n_views, n_rays, n_samples)) + 3 * align256(tiled_floats(n_views, n_rays, n_samples) * 4);
 }
 
 extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream_t stream) {
@@ -1366,6 +1415,11 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     P.rec_sig = (float*)ws; ws += align256(ns * 4);
     P.rec_a = (float*)ws; ws += align256(ns * 4);
     P.rec_T = (float*)ws;
+    static const char scatter_mode = [] { const char* e = getenv("NFE_BWD_SCATTER"); return e ? e[0] : 'b'; }();     // A/B knob: "direct", "sorted", default binned
+    const bool direct = scatter_mode == 'd' || (long long)a->plane_h * a->plane_w > (1ll << 24);                    // sort keys carry a 24-bit texel index
+    P.T = (a->n_rays + 63) / 64;
+    P.til_n = (long long)tiled_floats(a->n_views, a->n_rays, a->n_samples);
+    P.til = direct ? nullptr : (float*)((char*)a->workspace + need - 3 * align256((uint64_t)P.til_n * 4));          // (the workspace's tail)
 
     const long long per_view = (long long)a->n_rays * a->n_samples;
     const dim3 sgrid((unsigned)((per_view + 255) / 256), (unsigned)a->n_views);
@@ -1384,14 +1438,12 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
         rc = render_eval_pass(a, packed, P.rec_sig, P.rec_a, st);
         if (rc) return rc;
     }
-    const long long rays = (long long)a->n_views * a->n_rays;
-    hipLaunchKernelGGL(bwd_ray_kernel, dim3((unsigned)((rays + 255) / 256)), dim3(256), 0, st, P);
+    hipLaunchKernelGGL(bwd_ray_kernel, dim3((unsigned)(((long long)a->n_views * P.T + 3) / 4)), dim3(256), 0, st, P);
     NFE_CHECK_LAUNCH("bwd_ray_kernel");
-    static const char scatter_mode = [] { const char* e = getenv("NFE_BWD_SCATTER"); return e ? e[0] : 'b'; }();     // A/B knob: "direct", "sorted", default binned
     static const bool valu_dec = [] { const char* e = getenv("NFE_BWD_DECODER"); return e && e[0] == 'v'; }();      // A/B knob: "valu"
     static const bool acc_lds = [] { const char* e = getenv("NFE_BWD_ACC"); return e && e[0] == 'l'; }();            // A/B knob: "lds" = tile in LDS
     unsigned* frags = (unsigned*)((char*)P.rec_T + align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4));
-    if (scatter_mode == 'd' || (long long)a->plane_h * a->plane_w > (1ll << 24)) {      // sort keys carry a 24-bit texel index
+    if (direct) {
         hipLaunchKernelGGL(bwd_scatter_kernel, sgrid, dim3(256), 0, st, P);
         NFE_CHECK_LAUNCH("bwd_scatter_kernel");
         return NFE_OK;
@@ -1404,7 +1456,7 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     P.bins_x = (a->plane_w + BIN_MASK) >> BIN_SHIFT; P.bins_y = (a->plane_h + BIN_MASK) >> BIN_SHIFT;
     const uint64_t bins_per_view = 3ull * P.bins_x * P.bins_y;
     if (scatter_mode == 's' || bins_per_view > BWD_MAX_BINS) {
-        const dim3 tgrid(ray_tiles, (unsigned)a->n_samples, (unsigned)a->n_views);
+        const dim3 tgrid = NFE_BWD_DEPTH_FAST ? dim3((unsigned)a->n_samples, ray_tiles, (unsigned)a->n_views) : dim3(ray_tiles, (unsigned)a->n_samples, (unsigned)a->n_views);
         if (valu_dec) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<false, false>), tgrid, dim3(64), 0, st, P);
         else hipLaunchKernelGGL((bwd_scatter_sorted_kernel<true, false>), tgrid, dim3(64), 0, st, P);
         NFE_CHECK_LAUNCH("bwd_scatter_sorted_kernel");
@@ -1433,7 +1485,7 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
             const unsigned nbins = nv * (unsigned)bins_per_view;
             const unsigned long long slots = (unsigned long long)nv * nt * per_tile;
             if (hipMemsetAsync(P.counts, 0, (size_t)nbins * 4, st) != hipSuccess) return fail(NFE_ELAUNCH, "nfe_render_backward: hipMemsetAsync failed");
-            const dim3 tgrid(nt, (unsigned)a->n_samples, nv);
+            const dim3 tgrid = NFE_BWD_DEPTH_FAST ? dim3((unsigned)a->n_samples, nt, nv) : dim3(nt, (unsigned)a->n_samples, nv);
             if (valu_dec) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<false, true>), tgrid, dim3(64), 0, st, P);
             else hipLaunchKernelGGL((bwd_scatter_sorted_kernel<true, true>), tgrid, dim3(64), 0, st, P);
             NFE_CHECK_LAUNCH("bwd_scatter_sorted_kernel<binned>");
