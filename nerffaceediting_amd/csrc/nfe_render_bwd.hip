@@ -675,6 +675,12 @@ constexpr int BIN_SHIFT = 3, BIN_MASK = 7, BIN_TEXELS = 9;       // plane tiles 
 #ifndef NFE_BIN_SEGMENT
 #define NFE_BIN_SEGMENT 4096
 #endif
+#ifndef NFE_BWD_BATCH_ATOMICS
+#define NFE_BWD_BATCH_ATOMICS 1    // the three planes' rank atomics of a wave in flight together (0: one round trip after the other)
+#endif
+#ifndef NFE_BWD_DF_DEPTH_MAJOR
+#define NFE_BWD_DF_DEPTH_MAJOR 0
+#endif
 #ifndef NFE_BWD_DEPTH_FAST
 #define NFE_BWD_DEPTH_FAST 0       // A/B: block order of the decoder-backward launch (1 = the depths of one ray tile are neighbours)
 #endif
@@ -738,6 +744,8 @@ __device__ __forceinline__ void gather_pair_coop(const BwdK& P, int n, const Sam
             for (int k = 0; k < 4; ++k) {
 #if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 5      // timing experiment: every tap reads texel row 0 (no gather traffic)
                 const int off = __shfl(geo.off[4 * p + k], src) & 0;
+#elif defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 10   // timing experiment: eight different, always cache-resident rows per load (same request count, no misses)
+                const int off = (__shfl(geo.off[4 * p + k], src) & 0) + s8 * 32 + (4 * p + k) * 256;
 #else
                 const int off = __shfl(geo.off[4 * p + k], src);
 #endif
@@ -872,7 +880,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
     if (BINNED) {       // feature gradients to the chunk buffer, one bin record per (sample, plane); bwd_accumulate_kernel adds them up
         __builtin_amdgcn_wave_barrier();
+#if NFE_BWD_DF_DEPTH_MAJOR        // A/B: order of the chunk's df rows and records (which waves' rows are neighbours in memory)
+        const unsigned wave = ((unsigned)blockIdx.z * (unsigned)P.S + (unsigned)kdepth) * (unsigned)P.t_count + (unsigned)bx;
+#else
         const unsigned wave = ((unsigned)blockIdx.z * (unsigned)P.t_count + (unsigned)bx) * (unsigned)P.S + (unsigned)kdepth;
+#endif
         float* dst = P.df + (size_t)wave * 4096 + lane;
 #pragma unroll 8
         for (int sidx = 0; sidx < 64; ++sidx) dst[sidx * 64] = tile[sidx * SORT_TILE_STRIDE + lane];
@@ -882,6 +894,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         ray_of(P, n, m, ro, rd);
         const float tt = t_sample;
         const float cx = P.coord_scale * fmaf(tt, rd[0], ro[0]), cy = P.coord_scale * fmaf(tt, rd[1], ro[1]), cz = P.coord_scale * fmaf(tt, rd[2], ro[2]);
+        // Three phases so that the planes' rank atomics (a round trip to memory each) are in flight together:
+        // records and their position inside the wave's share of each bin, then the three atomics, then the stores.
+        unsigned bin3[3], rank3[3], group3[3], loc3[3];
+        int first3[3];
+        float4 w3[3];
+        bool any3[3];
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const Taps tp = tap_geometry(P.H, P.W, p == 2 ? cz : cx, p == 0 ? cy : (p == 1 ? cz : cx));      // as sample_geometry
@@ -890,11 +908,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const bool any = (live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
             const unsigned bin = any ? ((unsigned)blockIdx.z * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
                                      : KEY_INVALID;
-            // rank inside the bin.  Pass 1 (registers only): for every distinct bin of the wave its first lane, the lanes' position
-            // among the wave's records of that bin and their number.  Pass 2: ONE returning atomic instruction, executed by the first
-            // lanes of all bins together - the bins' round trips to memory overlap instead of following each other.  The loop
-            // condition is made with scalar compares on purpose: the lane-mask form (v_cmp -> vcc, s_cbranch_vccz) of a uniform branch
-            // is not reliable in a 256-register kernel at two waves per SIMD (profiles/experiments/r02_square_branch.md).
+            // rank inside the bin: for every distinct bin of the wave its first lane, the lanes' position among the wave's records
+            // of that bin and their number (registers only); ONE returning atomic instruction per plane, executed by the first lanes
+            // of all its bins together, fetches the bases.  The loop condition is made with scalar compares on purpose: the lane-mask
+            // form (v_cmp -> vcc, s_cbranch_vccz) of a uniform branch is not reliable in a 256-register kernel at two waves per SIMD
+            // (profiles/experiments/r02_square_branch.md).
             unsigned rank = 0, group = 0;
             int first_lane = -1;                      // stays -1 on lanes without a record
             const unsigned long long have = __ballot(any);
@@ -909,23 +927,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 if (bin == b) { rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull)); group = (unsigned)__popcll(same); first_lane = leader; }
                 todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
             }
-            unsigned base = 0;
-#if !defined(NFE_BWD_ABLATE) || NFE_BWD_ABLATE != 8     // timing experiment 8: no rank atomics
-            if (first_lane == lane) base = __hip_atomic_fetch_add(P.counts + bin, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // The accumulate pass adds the four taps of a record at local texels l0, l0 + 1, l0 + row, l0 + row + 1 with plain
+            // read-modify-writes, so they must be four different texels.  Where clamping makes two taps the same texel (x1 == x0
+            // at a plane edge: one of the pair is out of range and carries weight 0) their weights are folded into the first.
+            const int sx = x1 - x0, sy = y1 - y0;
+            float w0 = tp.w[0], w1 = tp.w[1], w2 = tp.w[2], w3v = tp.w[3];
+            if (sx == 0) { w0 += w1; w2 += w3v; w1 = 0.0f; w3v = 0.0f; }
+            if (sy == 0) { w0 += w2; w1 += w3v; w2 = 0.0f; w3v = 0.0f; }
+#if !NFE_BWD_BATCH_ATOMICS
+            {
+                unsigned base = 0;
+                if (first_lane == lane) base = __hip_atomic_fetch_add(P.counts + bin, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                rank += (unsigned)__shfl((int)base, first_lane & 63);
+            }
 #endif
-            rank += (unsigned)__shfl((int)base, first_lane & 63);
+            bin3[p] = bin; rank3[p] = rank; group3[p] = group; first3[p] = first_lane; any3[p] = any;
+            loc3[p] = (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK));
+            w3[p] = make_float4(w0, w1, w2, w3v);
+        }
+        unsigned base3[3] = {0u, 0u, 0u};
+#if NFE_BWD_BATCH_ATOMICS && (!defined(NFE_BWD_ABLATE) || NFE_BWD_ABLATE != 8)     // timing experiment 8: no rank atomics
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (first3[p] == lane) base3[p] = __hip_atomic_fetch_add(P.counts + bin3[p], group3[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned rank = rank3[p] + (unsigned)__shfl((int)base3[p], first3[p] & 63);
             const size_t slot = (size_t)p * ((size_t)gridDim.z * P.t_count * P.S * 64) + idx;
-            P.binrank[slot] = make_uint2(bin, rank);
-            if (any) {
-                // The accumulate pass adds the four taps of a record at local texels l0, l0 + 1, l0 + row, l0 + row + 1 with plain
-                // read-modify-writes, so they must be four different texels.  Where clamping makes two taps the same texel (x1 == x0
-                // at a plane edge: one of the pair is out of range and carries weight 0) their weights are folded into the first.
-                const int sx = x1 - x0, sy = y1 - y0;
-                float w0 = tp.w[0], w1 = tp.w[1], w2 = tp.w[2], w3 = tp.w[3];
-                if (sx == 0) { w0 += w1; w2 += w3; w1 = 0.0f; w3 = 0.0f; }
-                if (sy == 0) { w0 += w2; w1 += w3; w2 = 0.0f; w3 = 0.0f; }
-                P.rec_key[slot] = make_uint2(idx, (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK)));
-                P.rec_w[slot] = make_float4(w0, w1, w2, w3);
+            P.binrank[slot] = make_uint2(bin3[p], rank);
+            if (any3[p]) {
+                P.rec_key[slot] = make_uint2(idx, loc3[p]);
+                P.rec_w[slot] = w3[p];
             }
         }
         return;
