@@ -80,9 +80,10 @@ struct Taps { int xc0, xc1, yc0, yc1; float w[4]; float wdef; };   // wdef = (su
 // taps are inside (as 1.0 / 0.0).  The 2-D weights are separable ((vx ? ex : 0) * (vy ? ey : 0) == (vx && vy) ? ex * ey : 0,
 // bit for bit: the factors are in [0, 1]), so on SQUARE planes the three projections (x,y), (x,z), (z,x) of a sample share
 // their axes: three axis computations instead of six.
-// Every per-lane condition here is consumed by the v_cndmask that follows its v_cmp; none is combined with another one.  The
-// combined form `(vx && vy) ? w : 0` compiles to v_cmp -> SGPR pair, s_and_b64 vcc, v_cndmask, and that SALU step has returned
-// a stale mask for lanes 48-63 in a 256-register kernel at two waves per SIMD (profiles/experiments/r02_lane_mask.md).
+// Every per-lane condition here is consumed by the v_cndmask that follows its v_cmp; none is combined with another one.  Rounds
+// 2-3 blamed the combined form `(vx && vy) ? w : 0` for zeros in lanes 48-63 (r02_lane_mask.md); the cause was the packed multiply
+// the vectoriser made of the weight products in BOTH forms (v_pk_mul_f32 ... op_sel:[0,1]: profiles/experiments/r04_pk_opsel_hazard.md),
+// which the build's assembly pass (csrc/pk_opsel_fix.py) now commutes.  -DNFE_TAPS_COMBINED=1 keeps the old form as a reproducer.
 #ifndef NFE_WAR_PAD
 #define NFE_WAR_PAD ""
 #endif

@@ -695,9 +695,10 @@ constexpr uint64_t BWD_MAX_BINS = 1ull << 19;
 // path is priced by (the lane = sample form of gather_set spends more than half of this kernel there).  Tap offsets and weights
 // live in the lane = sample layout and are fetched by ds_bpermute.  Results go through the tile: row = sample, columns 0..31 the
 // geometry set, 32..63 the appearance set, already scaled by 1/3; same operation order per channel as gather_set.
-// "pointer is not null" as an integer in an SGPR, opaque to the optimiser: branches on it are s_cmp + s_cbranch_scc, never the
-// lane-mask form (s_and_b64 vcc, exec, mask; s_cbranch_vccz) that has gone the wrong way in 256-register kernels at two waves
-// per SIMD (profiles/experiments/r02_square_branch.md, r02_lane_mask.md)
+// "pointer is not null" as an integer in an SGPR, opaque to the optimiser: branches on it are s_cmp + s_cbranch_scc instead of the
+// lane-mask form (s_and_b64 vcc, exec, mask; s_cbranch_vccz).  Written in rounds 2-3 as a guard against the run-dependent results
+// of this kernel; their cause turned out to be a packed-fp32 operand form (profiles/experiments/r04_pk_opsel_hazard.md, removed by
+// the build's assembly pass), not lane masks.  Kept: it costs nothing.
 __device__ __forceinline__ int sgpr_nonnull(const void* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
     int f;
@@ -904,15 +905,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         for (int p = 0; p < 3; ++p) {
             const Taps tp = tap_geometry(P.H, P.W, p == 2 ? cz : cx, p == 0 ? cy : (p == 1 ? cz : cx));      // as sample_geometry
             const int x0 = tp.xc0, x1 = tp.xc1, y0 = tp.yc0, y1 = tp.yc1;
-            // (one compare per decision, no lane masks combined on the scalar unit: profiles/experiments/r02_lane_mask.md)
+            // (one compare per decision: a round-2 precaution, see sgpr_nonnull)
             const bool any = (live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
             const unsigned bin = any ? ((unsigned)blockIdx.z * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
                                      : KEY_INVALID;
             // rank inside the bin: for every distinct bin of the wave its first lane, the lanes' position among the wave's records
             // of that bin and their number (registers only); ONE returning atomic instruction per plane, executed by the first lanes
-            // of all its bins together, fetches the bases.  The loop condition is made with scalar compares on purpose: the lane-mask
-            // form (v_cmp -> vcc, s_cbranch_vccz) of a uniform branch is not reliable in a 256-register kernel at two waves per SIMD
-            // (profiles/experiments/r02_square_branch.md).
+            // of all its bins together, fetches the bases.  The loop condition is made with scalar compares (a round-2 precaution, see
+            // sgpr_nonnull; the failures it was meant to avoid were profiles/experiments/r04_pk_opsel_hazard.md).
             unsigned rank = 0, group = 0;
             int first_lane = -1;                      // stays -1 on lanes without a record
             const unsigned long long have = __ballot(any);
