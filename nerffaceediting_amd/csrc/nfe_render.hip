@@ -527,10 +527,10 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     unsigned offs[3][4];
     Axis ax_xw, ax_zh;
     // Experiment switch (profiles/experiments/r02_square_branch.md; never defined in the shipped build): decide SQUARE at run time.
-    //   1: `H == W` as the compiler lowers it (lane mask in an SGPR pair, s_and_b64 vcc, exec, mask + s_cbranch_vccz): branch
-    //      direction is unreliable when two waves share a SIMD -> run-dependent wrong pixels;
-    //   6: the condition re-made by s_cmp at every site (s_cbranch_scc): stable;   10: as 1, but both arms compute the square
-    //      geometry: stable, i.e. the failure of 1 is the branch going the wrong way, not corrupted data.
+    //   1: `H == W` as the compiler lowers it: run-dependent wrong pixels at two workgroups per CU FROM HIPCC'S ASSEMBLY - round 2 read
+    //      that as the branch going the wrong way; it is the packed multiplies of the tap_geometry arm (56 x v_pk_mul_f32 ... op_sel:[0,1],
+    //      profiles/experiments/r04_pk_opsel_hazard.md): through the build's assembly pass the same source is stable;
+    //   6: the condition re-made by s_cmp at every site;   10: as 1, but both arms compute the square geometry (both stable either way).
 #ifdef NFE_SQUARE_RUNTIME
     const bool SQ_RT = (H == W);
 #if NFE_SQUARE_RUNTIME == 6
