@@ -49,6 +49,16 @@ static_assert(DEC_TOTAL == NFE_DECODER_PACKED_FLOATS, "decoder blob size");
 constexpr float LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
 
 // order-preserving float <-> uint map for atomicMin/atomicMax on depths
+// Per-sample records of the backward (sigma / dL/dsigma, a / omega, T, depth copy) live in the order its kernels walk them:
+// [view][64-ray tile][sample][lane of the tile], a tile being 8 x 8 pixels of a square image whose side is a multiple of 8, else 64
+// consecutive rays - a wave of bwd_ray_kernel / bwd_scatter_sorted_kernel reads and writes 256-byte rows.  Slot of sample 0 of ray m;
+// sample k is 64 * k further.
+__device__ __forceinline__ long long bwd_slot_base(int R, int M, int S, int n, int m) {
+    int t, l;
+    if (R > 0 && (R & 7) == 0 && (long long)R * R == M) { const int px = m % R, py = m / R; t = (py >> 3) * (R >> 3) + (px >> 3); l = (py & 7) * 8 + (px & 7); }
+    else { t = m >> 6; l = m & 63; }
+    return (((long long)n * ((M + 63) >> 6) + t) * S) * 64 + l;
+}
 __device__ __forceinline__ unsigned f2ord(float f) {
     unsigned b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);

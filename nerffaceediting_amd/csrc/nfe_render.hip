@@ -1272,7 +1272,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) a = fmaf(ev_cs[c], og[2 + c], a);
                 a += __shfl_xor(a, 32);                                   // the two channel halves of the point
-                if (valid && h == 0) { P.ev_sig[ray * S + k] = og[0]; P.ev_a[ray * S + k] = a; }
+                if (valid && h == 0) { const long long e = bwd_slot_base(P.R, P.M, S, n, m) + 64ll * k; P.ev_sig[e] = og[0]; P.ev_a[e] = a; }
                 continue;
             }
             {   // Branch-free: the first sample of a march (or of a depth segment) composites with a zero-length interval, i.e.
@@ -2443,6 +2443,7 @@ __global__ __launch_bounds__(256) void color_dot_kernel(RenderK P, const float* 
         else m = b * 32 + j;
         if (m >= P.M) continue;
         const long long ray = (long long)n * P.M + m;
+        const long long ev0 = bwd_slot_base(P.R, P.M, S, n, m);            // the records' tile order (nfe_common.h)
         float gr[32], gs[16];
 #pragma unroll
         for (int c = 0; c < 32; ++c)
@@ -2464,8 +2465,8 @@ __global__ __launch_bounds__(256) void color_dot_kernel(RenderK P, const float* 
                 for (int cc = 0; cc < 8; ++cc) a = fmaf(gs[8 * h + cc], (8 * h + cc < 15) ? cb[(32 + 8 * h + cc) * 32] : 0.0f, a);
                 a2[h] = a;
             }
-            P.ev_sig[ray * S + k] = cb[47 * 32];
-            P.ev_a[ray * S + k] = a2[0] + a2[1];
+            P.ev_sig[ev0 + 64ll * k] = cb[47 * 32];
+            P.ev_a[ev0 + 64ll * k] = a2[0] + a2[1];
         }
     }
 }

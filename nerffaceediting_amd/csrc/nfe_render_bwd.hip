@@ -46,10 +46,9 @@ struct BwdK {
     int S; const float* depths; float coord_scale; int white_back;
     const float* g_rgb; const float* g_seg; const float* g_depth; const float* g_wsum; int channels_first;
     float* grad_g; float* grad_a; long long grad_view_stride;
-    float* rec_sig; float* rec_a; float* rec_T;      // [N*M*S] each: (sigma, a, T) then (dL/dsigma, omega, -)
-    // what the scatter pass reads per sample, in ITS order: [3: dL/dsigma, omega, depth][view][64-ray tile][sample][lane], written by
-    // bwd_ray_kernel (a wave of either kernel = one 64-ray tile, tile_ray()).  Null: the direct form reads rec_sig / rec_a in place.
-    float* til; int T; long long til_n;              // ray tiles per view, floats per array (N * T * S * 64)
+    // per-sample records, each [view][64-ray tile][sample][lane of the tile] (bwd_slot_base, nfe_common.h): (sigma, a, T) from the
+    // evaluation pass and the march, overwritten in place by (dL/dsigma, omega, -); rec_t: the depths in the same order
+    float* rec_sig; float* rec_a; float* rec_T; float* rec_t; int T;      // T: ray tiles per view
     const uint4* bfrag;                // split-bf16 MFMA fragments of the decoder and its transposes (bwd_frag_kernel), or null
     // binned scatter (one chunk of views x 64-ray tiles): feature gradients, bin records and their sorted list
     float* df; uint2* rec_key; float4* rec_w; uint2* binrank; unsigned* counts; unsigned* offsets; unsigned* perm;
@@ -260,8 +259,9 @@ __global__ __launch_bounds__(256, BWD_WAVES) void bwd_eval_kernel(BwdK P) {
 #pragma unroll
         for (int c = 0; c < 32; ++c) a = fmaf(cot_rgb(P, n, m, c), sigmoid_t(oa[c >> 1][c & 1]) * 1.002f - 0.001f, a);    // triplane.py:269
     }
-    P.rec_sig[g] = sigma;
-    P.rec_a[g] = a;
+    const long long e = bwd_slot_base(P.R, P.M, P.S, n, m) + 64ll * (i - (long long)m * P.S);
+    P.rec_sig[e] = sigma;
+    P.rec_a[e] = a;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -300,22 +300,20 @@ __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
     if (!live) return;
     const long long ray = (wave / P.T) * P.M + m_of_lane;
     const int S = P.S;
-    // outputs in the scatter pass's order (coalesced 256-byte rows here and there) or, for the direct form, in place
-    float* __restrict__ o_sig = P.til ? P.til + (size_t)wave * S * 64 + lane : nullptr;
-    float* __restrict__ o_a = P.til ? o_sig + P.til_n : nullptr;
-    float* __restrict__ o_t = P.til ? o_a + P.til_n : nullptr;
     const float* __restrict__ t = P.depths + ray * S;
-    float* sig = P.rec_sig + ray * S; float* av = P.rec_a + ray * S; float* __restrict__ Tv = P.rec_T + ray * S;
-    // forward: transmittance of every segment, sum of weights, weighted depth.  A lane walks its own ray (stride S between lanes),
-    // so every load is its own cache line: the loop is batched by hand - a store per step kept the compiler from hoisting the next
+    // the records of this wave's tile: sample i of this lane is element 64 * i (256-byte rows per sample: coalesced)
+    const size_t tb = (size_t)wave * S * 64 + lane;
+    float* sig = P.rec_sig + tb; float* av = P.rec_a + tb; float* __restrict__ Tv = P.rec_T + tb; float* __restrict__ o_t = P.rec_t + tb;
+    // forward: transmittance of every segment, sum of weights, weighted depth.  The depths come in [ray][sample] order (a lane's
+    // loads are its own cache lines): the loop is batched by hand - a store per step kept the compiler from hoisting the next
     // step's loads, and the kernel spent one memory latency per sample.
     float T = 1.0f, wtot = 0.0f, dnum = 0.0f;
     float s0 = sig[0], t0 = t[0];
-    if (o_t) o_t[0] = t0;
+    o_t[0] = t0;
     for (int j0 = 0; j0 + 1 < S; j0 += RAY_CH) {
         float sc[RAY_CH], tc[RAY_CH], To[RAY_CH];
 #pragma unroll
-        for (int u = 0; u < RAY_CH; ++u) { const int i = min(j0 + 1 + u, S - 1); sc[u] = sig[i]; tc[u] = t[i]; }
+        for (int u = 0; u < RAY_CH; ++u) { const int i = min(j0 + 1 + u, S - 1); sc[u] = sig[(size_t)i * 64]; tc[u] = t[i]; }
 #pragma unroll
         for (int u = 0; u < RAY_CH; ++u) {
             To[u] = T;
@@ -329,7 +327,7 @@ __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < RAY_CH; ++u) if (j0 + 1 + u < S) { Tv[j0 + u] = To[u]; if (o_t) o_t[(size_t)(j0 + 1 + u) * 64] = tc[u]; }
+        for (int u = 0; u < RAY_CH; ++u) if (j0 + 1 + u < S) { Tv[(size_t)(j0 + u) * 64] = To[u]; o_t[(size_t)(j0 + 1 + u) * 64] = tc[u]; }
     }
     const float d0 = dnum / wtot;
     const bool ok = wtot != 0.0f && isfinite(d0);                   // nan_to_num + clamp (:93-94) pass nothing otherwise
@@ -344,12 +342,12 @@ __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
     // reverse: R_j = sum_{k>j} g_k alpha_k prod_{j<m<k} (1 - alpha_m + 1e-10).  Batches again: the loads of samples jh-7 .. jh first,
     // then the recurrence, then the stores (to samples jh-6 .. jh+1: never a sample a later batch still has to read)
     float R = 0.0f;
-    float s1 = sig[S - 1], a1 = av[S - 1], t1 = t[S - 1];
+    float s1 = sig[(size_t)(S - 1) * 64], a1 = av[(size_t)(S - 1) * 64], t1 = t[S - 1];
     float gs_hi = 0.0f, om_hi = 0.0f;          // contributions of segment j to sample j+1
     for (int jh = S - 2; jh >= 0; jh -= RAY_CH) {
         float sc[RAY_CH], ac[RAY_CH], tc[RAY_CH], Tc[RAY_CH], gso[RAY_CH], omo[RAY_CH];
 #pragma unroll
-        for (int u = 0; u < RAY_CH; ++u) { const int i = max(jh - u, 0); sc[u] = sig[i]; ac[u] = av[i]; tc[u] = t[i]; Tc[u] = Tv[i]; }
+        for (int u = 0; u < RAY_CH; ++u) { const int i = max(jh - u, 0); sc[u] = sig[(size_t)i * 64]; ac[u] = av[(size_t)i * 64]; tc[u] = o_t[(size_t)i * 64]; Tc[u] = Tv[(size_t)i * 64]; }
 #pragma unroll
         for (int u = 0; u < RAY_CH; ++u) {
             gso[u] = 0.0f; omo[u] = 0.0f;
@@ -366,13 +364,9 @@ __global__ __launch_bounds__(256) void bwd_ray_kernel(BwdK P) {
             }
         }
 #pragma unroll
-        for (int u = 0; u < RAY_CH; ++u) if (jh - u >= 0) {
-            if (o_sig) { o_sig[(size_t)(jh - u + 1) * 64] = gso[u]; o_a[(size_t)(jh - u + 1) * 64] = omo[u]; }
-            else { sig[jh - u + 1] = gso[u]; av[jh - u + 1] = omo[u]; }
-        }
+        for (int u = 0; u < RAY_CH; ++u) if (jh - u >= 0) { sig[(size_t)(jh - u + 1) * 64] = gso[u]; av[(size_t)(jh - u + 1) * 64] = omo[u]; }
     }
-    if (o_sig) { o_sig[0] = gs_hi; o_a[0] = om_hi; }
-    else { sig[0] = gs_hi; av[0] = om_hi; }
+    sig[0] = gs_hi; av[0] = om_hi;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -425,7 +419,8 @@ __global__ __launch_bounds__(256, BWD_WAVES) void bwd_scatter_kernel(BwdK P) {
     const long long g = (long long)n * per_view + i;
     SampleGeo geo;
     sample_geometry(P, n, m, P.depths[g], geo);
-    const float gsig = P.rec_sig[g], omega = P.rec_a[g];
+    const long long e = bwd_slot_base(P.R, P.M, P.S, n, m) + 64ll * (i - (long long)m * P.S);
+    const float gsig = P.rec_sig[e], omega = P.rec_a[e];
     const long long pv = (long long)n * P.plane_view_stride;
     const long long gv = (long long)n * P.grad_view_stride;
     const float* dec = P.dec;
@@ -789,11 +784,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         m = t * 64 + lane; live = m < P.M; m = min(m, P.M - 1);
     }
     // dL/dsigma, omega and the depth of this wave's 64 samples: one 256-byte row each (bwd_ray_kernel wrote them in this order)
-    const float* til = P.til + (((size_t)n * P.T + t) * P.S + kdepth) * 64 + lane;
-    const float t_sample = til[2 * P.til_n];
+    // (dead lanes of a view's last tile repeat its last ray, whose slot is m & 63 of the same tile: nobody wrote theirs)
+    const size_t rec = (((size_t)n * P.T + t) * P.S + kdepth) * 64 + (live ? lane : (m & 63));
+    const float t_sample = P.rec_t[rec];
     SampleGeo geo;
     sample_geometry(P, n, m, t_sample, geo);
-    const float gsig = til[0], omega = til[P.til_n];
+    const float gsig = P.rec_sig[rec], omega = P.rec_a[rec];
     const long long pv = (long long)n * P.plane_view_stride;
     const long long gv = (long long)n * P.grad_view_stride;
     const float* dec = P.dec;
@@ -1392,9 +1388,8 @@ static uint64_t binned_bytes(uint64_t slots) {
 using namespace nfe;
 
 extern "C" uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples) {
-    const uint64_t ns = (uint64_t)(n_views > 0 ? n_views : 0) * (uint64_t)(n_rays > 0 ? n_rays : 0) * (uint64_t)(n_samples > 0 ? n_samples : 0);
-    return BWD_DEC_BYTES + 3 * align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES) +
-           binned_bytes(chunk_slots(n_views, n_rays, n_samples)) + 3 * align256(tiled_floats(n_views, n_rays, n_samples) * 4);
+    return BWD_DEC_BYTES + 4 * align256(tiled_floats(n_views, n_rays, n_samples) * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES) +
+           binned_bytes(chunk_slots(n_views, n_rays, n_samples));
 }
 
 extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream_t stream) {
@@ -1423,7 +1418,6 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     const uint64_t need = nfe_render_backward_workspace_bytes(a->n_views, a->n_rays, a->n_samples);
     if (a->workspace_bytes < need) return fail(NFE_EWORKSPACE, "nfe_render_backward: workspace %llu < %llu bytes",
                                                (unsigned long long)a->workspace_bytes, (unsigned long long)need);
-    const uint64_t ns = (uint64_t)a->n_views * a->n_rays * a->n_samples;
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)a->workspace;
     float* dec = (float*)ws; ws += BWD_DEC_BYTES;
@@ -1445,14 +1439,14 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     P.g_rgb = a->grad_rgb; P.g_seg = a->grad_seg; P.g_depth = a->grad_depth; P.g_wsum = a->grad_wsum;
     P.channels_first = a->channels_first;
     P.grad_g = a->grad_planes_geo; P.grad_a = a->grad_planes_app; P.grad_view_stride = a->grad_view_stride;
-    P.rec_sig = (float*)ws; ws += align256(ns * 4);
-    P.rec_a = (float*)ws; ws += align256(ns * 4);
-    P.rec_T = (float*)ws;
+    const uint64_t rec_bytes = align256(tiled_floats(a->n_views, a->n_rays, a->n_samples) * 4);
+    P.rec_sig = (float*)ws; ws += rec_bytes;
+    P.rec_a = (float*)ws; ws += rec_bytes;
+    P.rec_T = (float*)ws; ws += rec_bytes;
+    P.rec_t = (float*)ws;
+    P.T = (a->n_rays + 63) / 64;
     static const char scatter_mode = [] { const char* e = getenv("NFE_BWD_SCATTER"); return e ? e[0] : 'b'; }();     // A/B knob: "direct", "sorted", default binned
     const bool direct = scatter_mode == 'd' || (long long)a->plane_h * a->plane_w > (1ll << 24);                    // sort keys carry a 24-bit texel index
-    P.T = (a->n_rays + 63) / 64;
-    P.til_n = (long long)tiled_floats(a->n_views, a->n_rays, a->n_samples);
-    P.til = direct ? nullptr : (float*)((char*)a->workspace + need - 3 * align256((uint64_t)P.til_n * 4));          // (the workspace's tail)
 
     const long long per_view = (long long)a->n_rays * a->n_samples;
     const dim3 sgrid((unsigned)((per_view + 255) / 256), (unsigned)a->n_views);
@@ -1465,7 +1459,7 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
         hipLaunchKernelGGL(bwd_eval_kernel, sgrid, dim3(256), 0, st, P);
         NFE_CHECK_LAUNCH("bwd_eval_kernel");
     } else {
-        float* packed = (float*)((char*)P.rec_T + align256(ns * 4));
+        float* packed = (float*)((char*)P.rec_t + rec_bytes);
         int rc = nfe_decoder_pack(a->geo_w0, a->geo_b0, a->geo_w1, a->geo_b1, a->app_w0, a->app_b0, a->app_w1, a->app_b1, a->lr_mul, packed, stream);
         if (rc) return rc;
         rc = render_eval_pass(a, packed, P.rec_sig, P.rec_a, st);
@@ -1475,7 +1469,7 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     NFE_CHECK_LAUNCH("bwd_ray_kernel");
     static const bool valu_dec = [] { const char* e = getenv("NFE_BWD_DECODER"); return e && e[0] == 'v'; }();      // A/B knob: "valu"
     static const bool acc_lds = [] { const char* e = getenv("NFE_BWD_ACC"); return e && e[0] == 'l'; }();            // A/B knob: "lds" = tile in LDS
-    unsigned* frags = (unsigned*)((char*)P.rec_T + align256(ns * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4));
+    unsigned* frags = (unsigned*)((char*)P.rec_t + rec_bytes + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4));
     if (direct) {
         hipLaunchKernelGGL(bwd_scatter_kernel, sgrid, dim3(256), 0, st, P);
         NFE_CHECK_LAUNCH("bwd_scatter_kernel");

@@ -124,13 +124,13 @@ def test_ops_refuse_cpu_tensors():
 
 
 def test_backward_workspace_is_bounded():
-    """nfe_render_backward_workspace_bytes: three floats per sample for the march records, three more per sample slot of whole
-    64-ray tiles for the copy the scatter pass reads in its own order (round 4), plus the binned scatter's chunk buffers, which stop
-    growing once a chunk holds 2^23 sample slots (256-byte feature-gradient row + 68 bytes of records per slot)."""
+    """nfe_render_backward_workspace_bytes: four floats per sample slot of whole 64-ray tiles for the march records (round 4: kept in
+    the tile order the kernels walk), plus the binned scatter's chunk buffers, which stop growing once a chunk holds 2^23 sample
+    slots (256-byte feature-gradient row + 68 bytes of records per slot)."""
     from nerffaceediting_amd import _lib
     lib = _lib.load()
     align = lambda x: (x + 255) & ~255
-    fixed = lambda n, m, s: lib.nfe_render_backward_workspace_bytes(n, m, s) - 3 * 4 * n * m * s - 3 * align(4 * n * ((m + 63) // 64) * 64 * s)
+    fixed = lambda n, m, s: lib.nfe_render_backward_workspace_bytes(n, m, s) - 4 * align(4 * n * ((m + 63) // 64) * 64 * s)
     per_slot = 256 + 3 * (8 + 16 + 8 + 4)
     small = fixed(3, 70, 12)                       # three views x two 64-ray tiles x 12 samples = 4608 slots
     assert 4608 * per_slot <= small <= 4608 * per_slot + (6 << 20)

@@ -68,7 +68,7 @@ def main():
     wb, gb, nb = run(lb)
     ns = N * M * S
     slots = N * ((M + 63) // 64) * 64 * S
-    regions = [("dec", 32768)] + [(n, align256(ns * 4)) for n in ("rec_sig", "rec_a", "rec_T")] + \
+    regions = [("dec", 32768)] + [(n, align256(slots * 4)) for n in ("rec_sig", "rec_a", "rec_T", "rec_t")] + \
               [("packed", align256(_lib.NFE_DECODER_PACKED_FLOATS * 4)), ("frags", align256(52 * 64 * 16)), ("df", align256(slots * 256)),
                ("rec_key", align256(slots * 3 * 8)), ("rec_w", align256(slots * 3 * 16)), ("binrank", align256(slots * 3 * 8)),
                ("perm", align256(slots * 3 * 4)), ("counts", align256((1 << 19) * 4)), ("offsets", align256((1 << 19) * 4))]
