@@ -2428,7 +2428,13 @@ int render_eval_pass(const nfe_render_backward_args* a, const float* decoder_pac
 // The same two quantities from the colours the forward kept (nfe_render_args.tap_sample_colors): one pass over 192 bytes per sample
 // instead of the gathers and both decoder heads.  Thread = (ray block, sample, lane of the block); the sums run in the evaluation
 // pass's order (16 colour features and 8 logits per channel half, halves added last).
-constexpr int DOT_K = 8;              // samples per thread: the ray's 47 cotangents are loaded once per DOT_K samples
+#ifndef NFE_DOT_K
+#define NFE_DOT_K 8
+#endif
+#ifndef NFE_DOT_UNROLL
+#define NFE_DOT_UNROLL 2
+#endif
+constexpr int DOT_K = NFE_DOT_K;      // samples per thread: the ray's 47 cotangents are loaded once per DOT_K samples
 __global__ __launch_bounds__(256) void color_dot_kernel(RenderK P, const float* __restrict__ colors) {
     const int S = P.S, blocks_per_view = (P.M + 31) >> 5, ksegs = (S + DOT_K - 1) / DOT_K;
     const long long total = (long long)P.N * blocks_per_view * ksegs * 32;
@@ -2452,7 +2458,7 @@ __global__ __launch_bounds__(256) void color_dot_kernel(RenderK P, const float* 
         for (int c = 0; c < 16; ++c)
             gs[c] = (P.ev_g_seg && c < 15) ? (P.ev_channels_first ? P.ev_g_seg[((long long)n * 15 + c) * P.M + m] : P.ev_g_seg[ray * 15 + c]) : 0.0f;
         const int k1 = min(S, (ks + 1) * DOT_K);
-#pragma unroll 2
+#pragma unroll NFE_DOT_UNROLL
         for (int k = ks * DOT_K; k < k1; ++k) {
             const float* cb = colors + ((rb * S + k) * 48) * 32 + j;
             float a2[2];
