@@ -219,12 +219,21 @@ __device__ __forceinline__ void head_backward(const float* __restrict__ w0, cons
     }
 }
 
+// (Round 4, profiles/experiments/r04_bwd_ab1.txt: the decoder-backward kernel without these loads is 0.34 ms faster per 4 views - they are
+// ~500 of its ~4 700 cache-line requests per wave on a texture addresser that is 0.67 busy; issuing them before the gather instead of
+// inside the MFMA chains made it 0.06 ms SLOWER, so it is their number, not their latency.)
 __device__ __forceinline__ float cot_rgb(const BwdK& P, int n, int m, int c) {      // includes the *2 of rgb*2-1
     if (!P.g_rgb) return 0.0f;
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 11     // timing experiment: no cotangent loads
+    return 0.01f * (float)(c + (m & 3));
+#endif
     return 2.0f * (P.channels_first ? P.g_rgb[((long long)n * 32 + c) * P.M + m] : P.g_rgb[((long long)n * P.M + m) * 32 + c]);
 }
 __device__ __forceinline__ float cot_seg(const BwdK& P, int n, int m, int c) {
     if (!P.g_seg) return 0.0f;
+#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 11
+    return 0.02f * (float)(c + (m & 3));
+#endif
     return P.channels_first ? P.g_seg[((long long)n * 15 + c) * P.M + m] : P.g_seg[((long long)n * P.M + m) * 15 + c];
 }
 
