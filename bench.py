@@ -578,7 +578,7 @@ def exchange_check(args, torch, dist, rank, world):
     block of a synthetic frame list (frame f = all bytes f % 251) and the blocks travel through sharding.ChunkedFrameGather
     exactly as orbit_job's frames do.  Runs on the gloo backend on CPU tensors (tests/test_sharding_cpu.py starts it through the
     self-launch path) or on RCCL with device tensors.  Not a benchmark: it times nothing that BASELINE.json names."""
-    from nerffaceediting_amd import sharding
+    from nerffaceediting_amd import launch, sharding
     if args.backend == "nccl":
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
@@ -586,7 +586,7 @@ def exchange_check(args, torch, dist, rank, world):
         dev = torch.device("cpu")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
+        launch.init_process_group(dist, args.backend, **({"device_id": dev} if args.backend == "nccl" else {}))
     info = distributed_info(dist, world)
     V, chunk, shape = int(args.orbit_frames), 3, (8, 8, 3)
     t0 = time.perf_counter()
@@ -674,7 +674,7 @@ def main():
         if world == 1:                           # no launcher: a one-rank rendezvous of our own
             os.environ.setdefault("MASTER_PORT", str(launch.free_port()))
             os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        launch.init_process_group(dist, "nccl", device_id=dev)
     dist_info = distributed_info(dist, world)
 
     if args.workload != "render":

@@ -23,6 +23,24 @@ def free_port():
         return s.getsockname()[1]
 
 
+RENDEZVOUS_BUSY = 98          # exit code of a rank whose rendezvous found the port taken (EADDRINUSE): spawn_ranks retries on another port
+
+
+def init_process_group(dist, backend, **kw):
+    """dist.init_process_group for a rank started by spawn_ranks: free_port() has released the port before rank 0 binds it again, so
+    another process can take it in between.  That shows as 'address already in use' in rank 0; the rank then exits with
+    RENDEZVOUS_BUSY and the parent starts all ranks again on a fresh port (three attempts)."""
+    try:
+        dist.init_process_group(backend, **kw)
+    except Exception as e:          # torch raises DistNetworkError / RuntimeError depending on the store
+        text = str(e).lower()
+        if os.environ.get("NFE_LAUNCHER") == "self" and ("address already in use" in text or "eaddrinuse" in text):
+            print(f"[launch] rank {os.environ.get('RANK')}: rendezvous port {os.environ.get('MASTER_PORT')} is taken", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(RENDEZVOUS_BUSY)
+        raise
+
+
 def launched_by_a_launcher(env=None):
     """True inside a rank process (torch.distributed.run or spawn_ranks has set WORLD_SIZE)."""
     env = os.environ if env is None else env
@@ -60,7 +78,14 @@ def spawn_ranks(script, argv, nprocs, env=None, timeout=None, stdout=None):
         for sig in (signal.SIGTERM, signal.SIGINT):
             restore[sig] = signal.signal(sig, on_signal)
     try:
-        return _run_ranks(script, argv, nprocs, base, procs, stop_all, timeout, stdout)
+        for attempt in range(3):
+            rc, text = _run_ranks(script, argv, nprocs, base, procs, stop_all, timeout, stdout)
+            if rc != RENDEZVOUS_BUSY or attempt == 2:
+                return rc, text
+            stop_all()
+            del procs[:]
+            base["MASTER_PORT"] = str(free_port())
+            print(f"[launch] rendezvous port was taken; retrying on {base['MASTER_PORT']}", file=sys.stderr)
     finally:
         stop_all()
         for sig, old in restore.items():

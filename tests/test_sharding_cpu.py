@@ -213,3 +213,26 @@ def test_a_terminated_launcher_does_not_orphan_its_ranks(tmp_path):
     finally:
         if p.poll() is None:
             p.kill()
+
+
+def test_self_launcher_retries_when_the_rendezvous_port_was_taken(tmp_path):
+    """launch.free_port() releases its port before rank 0 binds it again; a rank that finds it taken exits with RENDEZVOUS_BUSY
+    (launch.init_process_group) and spawn_ranks starts every rank again on a fresh port."""
+    import io
+    from nerffaceediting_amd import launch
+    flag = tmp_path / "first_attempt_done"
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import os, sys\n"
+        f"flag = {str(flag)!r}\n"
+        "if not os.path.exists(flag):\n"
+        "    if os.environ['RANK'] == '0':\n"
+        "        open(flag, 'w').write(os.environ['MASTER_PORT'])\n"
+        f"        os._exit({launch.RENDEZVOUS_BUSY})\n"
+        "    import time; time.sleep(30)\n"                       # the other rank would wait in the rendezvous: the parent must stop it
+        "print('port', os.environ['MASTER_PORT'], 'rank', os.environ['RANK'])\n")
+    out = io.StringIO()
+    rc, text = launch.spawn_ranks(str(script), [], 2, timeout=60, stdout=out)
+    assert rc == 0, (rc, text)
+    first = flag.read_text()
+    assert "rank 0" in text and f"port {first} " not in text          # second attempt, different port
