@@ -679,6 +679,9 @@ constexpr int BIN_SHIFT = 3, BIN_MASK = 7, BIN_TEXELS = 9;       // plane tiles 
 #ifndef NFE_BIN_SEGMENT
 #define NFE_BIN_SEGMENT 4096
 #endif
+#ifndef NFE_BWD_COT_STAGED
+#define NFE_BWD_COT_STAGED 1       // decoder-backward kernel: output cotangents fetched coalesced and handed over through the tile (0: per-lane loads)
+#endif
 #ifndef NFE_BWD_BATCH_ATOMICS
 #define NFE_BWD_BATCH_ATOMICS 1    // the three planes' rank atomics of a wave in flight together (0: one round trip after the other)
 #endif
@@ -811,12 +814,38 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         if (sets == 3) gather_pair_coop<true, true>(P, n, geo, lane, tile);          // (no run-time switch inside the pipelined loop)
         else if (sets == 1) gather_pair_coop<true, false>(P, n, geo, lane, tile);
         else gather_pair_coop<false, true>(P, n, geo, lane, tile);
+        // Output cotangents through the tile (round 4).  Lane (jj, hh) of N-block b needs 8 / 16 consecutive cotangents of sample
+        // 32b + jj; fetched in that layout every load instruction touched 32 rays' cache lines, ~500 line requests per wave on a texture
+        // addresser that is the kernel's busiest unit (without them the kernel is 0.34 ms faster per 4 views).  For the [view, ray,
+        // channel] layout they are now fetched with 8 (4) consecutive lanes per ray row - every line requested once, ~110 requests - into
+        // the columns of the tile the head's features have just left (sample s: row s; N-block b overwrites rows 32b.. only after
+        // it has read them), and the lanes pick their values up with two / four ds_read_b128.
+        const bool staged = NFE_BWD_COT_STAGED && !P.channels_first;
         if (do_g) {
             tile_row(tile, lane, 0, f);
+            if (staged) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {                 // column o = 1 + seg channel (column 0: sigma's slot, not read)
+                    const int ss = 4 * i + (lane >> 4), c = lane & 15;
+                    const int ms = __shfl(m, ss);
+                    const float v = (P.g_seg && c < 15) ? P.g_seg[((long long)n * P.M + ms) * 15 + c] : 0.0f;
+                    if (c < 15) tile[ss * SORT_TILE_STRIDE + 1 + c] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
             head_mfma<false>(F, dec, f, lane, tile, SORT_TILE_STRIDE, 0,
                              [&](int b, float (&d)[8]) {          // outputs 8h..8h+7 of sample 32b + j: sigma = 0, seg = 1..15 (triplane.py:260-261)
                                  const int src = 32 * b + jj;
                                  const float gs = __shfl(gsig, src), om = __shfl(omega, src);
+                                 if (staged) {
+                                     const float4 c0 = *reinterpret_cast<const float4*>(tile + src * SORT_TILE_STRIDE + 8 * hh);
+                                     const float4 c1 = *reinterpret_cast<const float4*>(tile + src * SORT_TILE_STRIDE + 8 * hh + 4);
+                                     const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                                     for (int e = 0; e < 8; ++e) d[e] = (8 * hh + e) == 0 ? gs : om * cv[e];
+                                     return;
+                                 }
                                  const int mm = __shfl(m, src);
 #pragma unroll
                                  for (int e = 0; e < 8; ++e) {
@@ -831,10 +860,35 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         if (do_a) {
             tile_row(tile, lane, 32, f);
+            if (staged) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+                for (int i = 0; i < 8; ++i) {                  // eight lanes per ray row of 128 bytes; the * 2 of rgb * 2 - 1 here (cot_rgb)
+                    const int ss = 8 * i + (lane >> 3), c4 = (lane & 7) * 4;
+                    const int ms = __shfl(m, ss);
+                    const float4 v = *reinterpret_cast<const float4*>(P.g_rgb + ((long long)n * P.M + ms) * 32 + c4);      // do_a: g_rgb is not null
+                    *reinterpret_cast<float4*>(tile + ss * SORT_TILE_STRIDE + 32 + c4) = make_float4(2.0f * v.x, 2.0f * v.y, 2.0f * v.z, 2.0f * v.w);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
             head_mfma<true>(F, dec, f, lane, tile, SORT_TILE_STRIDE, 32, [](int, float (&)[8]) {},
                             [&](int b, f32x16& y) {               // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269), channel 16h + r
                                 const int src = 32 * b + jj;
                                 const float om = __shfl(omega, src);
+                                if (staged) {
+                                    const float* cr = tile + src * SORT_TILE_STRIDE + 32 + 16 * hh;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const float4 cv = *reinterpret_cast<const float4*>(cr + 4 * q);
+                                        const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                                        for (int u = 0; u < 4; ++u) {
+                                            const float sg = sigmoid_t(y[4 * q + u]);
+                                            y[4 * q + u] = om * c4[u] * 1.002f * sg * (1.0f - sg);
+                                        }
+                                    }
+                                    return;
+                                }
                                 const int mm = __shfl(m, src);
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) {
