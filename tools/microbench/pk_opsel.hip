@@ -58,6 +58,10 @@ SEQ(seq11, "v_pk_mul_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,1] op_sel_hi:[1,0]\n
 SEQ(seq12, "v_pk_mul_f32 v[8:9], v[6:7], v[10:11]", "v9")                                                // default op_sel, high result wx1 * fy
 SEQ(seq13, "v_pk_mul_f32 v[8:9], v[10:11], v[10:11] op_sel:[0,1] op_sel_hi:[1,0]", "v8")                 // both sources the SAME pair (render_kernel's site): wy0 * fy
 SEQ(seq14, "v_pk_fma_f32 v[8:9], v[6:7], v[10:11], v[12:13] op_sel:[0,1,1] op_sel_hi:[1,0,0]", "v8")    // lo = wx0 * fy + wy0
+SEQ(seq15, "v_pk_mov_b32 v[8:9], v[6:7], v[10:11] op_sel:[1,0]", "v8")                                   // v_pk_mov_b32: lo = src0.hi (wx1): the library's two instances
+SEQ(seq16, "v_pk_mov_b32 v[8:9], v[6:7], v[10:11] op_sel:[1,0]", "v9")                                   //               hi = src1.lo (wy0)
+SEQ(seq17, "v_pk_mov_b32 v[8:9], v[6:7], v[10:11] op_sel:[0,1]", "v8")                                   //               lo = src0.lo (wx0)
+SEQ(seq18, "v_pk_mov_b32 v[8:9], v[6:7], v[10:11] op_sel:[0,1]", "v9")                                   //               hi = src1.hi (fy)
 
 template <int FORM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void probe(const float* __restrict__ in, unsigned* __restrict__ bad,
@@ -111,7 +115,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     case 11: got = seq11(wx0, wx1, wy0, fy, y1, H); asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want) : "v"(wx1), "v"(wy0)); break;
                     case 12: got = seq12(wx0, wx1, wy0, fy, y1, H); asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want) : "v"(wx1), "v"(fy)); break;
                     case 13: got = seq13(wx0, wx1, wy0, fy, y1, H); asm volatile("v_mul_f32 %0, %1, %2" : "=v"(want) : "v"(wy0), "v"(fy)); break;
-                    default: got = seq14(wx0, wx1, wy0, fy, y1, H); asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want) : "v"(wx0), "v"(fy), "v"(wy0)); break;
+                    case 14: got = seq14(wx0, wx1, wy0, fy, y1, H); asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(want) : "v"(wx0), "v"(fy), "v"(wy0)); break;
+                    case 15: got = seq15(wx0, wx1, wy0, fy, y1, H); want = wx1; break;
+                    case 16: got = seq16(wx0, wx1, wy0, fy, y1, H); want = wy0; break;
+                    case 17: got = seq17(wx0, wx1, wy0, fy, y1, H); want = wx0; break;
+                    default: got = seq18(wx0, wx1, wy0, fy, y1, H); want = fy; break;
                 }
                 if (__float_as_uint(got) != __float_as_uint(want)) {
                     ++mism;
@@ -141,7 +149,7 @@ int main(int argc, char** argv) {
     const int blocks = 256 * 8 * 24, rounds = 64;
     for (int l = 0; l < launches; ++l) {
 #define LAUNCH(F) case F: hipLaunchKernelGGL(probe<F>, dim3(blocks), dim3(64), 0, 0, in, bad, rounds, mb, tb, 256u); break;
-        switch (form) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) default: hipLaunchKernelGGL(probe<14>, dim3(blocks), dim3(64), 0, 0, in, bad, rounds, mb, tb, 256u); }
+        switch (form) { LAUNCH(0) LAUNCH(1) LAUNCH(2) LAUNCH(3) LAUNCH(4) LAUNCH(5) LAUNCH(6) LAUNCH(7) LAUNCH(8) LAUNCH(9) LAUNCH(10) LAUNCH(11) LAUNCH(12) LAUNCH(13) LAUNCH(14) LAUNCH(15) LAUNCH(16) LAUNCH(17) default: hipLaunchKernelGGL(probe<18>, dim3(blocks), dim3(64), 0, 0, in, bad, rounds, mb, tb, 256u); }
     }
     CK(hipDeviceSynchronize());
     std::vector<unsigned> hb(128);
