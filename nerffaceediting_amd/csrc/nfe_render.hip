@@ -765,6 +765,60 @@ __device__ __forceinline__ void load_bias1(const float* __restrict__ lds, int ne
         out[4 * q + 0] = x.x; out[4 * q + 1] = x.y; out[4 * q + 2] = x.z; out[4 * q + 3] = x.w;
     }
 }
+
+// ---- sigma only (the coarse pass of a two-pass render): the geometry head's second layer reduced to its first row ----
+// Of the head's 16 outputs the coarse pass uses sigma, i.e. row 0 of layer 1: 64 multiply-adds per point instead of a 32-row MFMA
+// block (12 MFMAs = 384 matrix cycles) plus the hi / lo split of the 32 hidden values a lane holds (96 vector instructions).  A lane
+// of half h holds the hidden units of K positions 16 s + 8 h + e (s = k-step 0..3, e = 0..7: mlp_bf16's operand order), whose row-0
+// weights are the hi + lo bf16 pairs in lane 32 h of the layer-1 fragments - constants of the launch, fetched once per wave
+// (sigma_row_weights) and kept in 32 registers.  fp32 products of unsplit activations: not less exact than the split-bf16 form.
+#ifndef NFE_SIGMA_ROW
+#define NFE_SIGMA_ROW 1
+#endif
+__device__ __forceinline__ void sigma_row_weights(const float* __restrict__ lds, int lane, float (&w)[32]) {
+    const uint4* F = reinterpret_cast<const uint4*>(lds) + 32 * (lane >> 5);         // row 0 lives in lane 32 h of every fragment
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+        const uint4 hi = F[(16 + s * 2 + 0) * 64], lo = F[(16 + s * 2 + 1) * 64];
+        const unsigned hw[4] = {hi.x, hi.y, hi.z, hi.w}, lw[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w[8 * s + 2 * q] = __uint_as_float(hw[q] << 16) + __uint_as_float(lw[q] << 16);
+            w[8 * s + 2 * q + 1] = __uint_as_float(hw[q] & 0xffff0000u) + __uint_as_float(lw[q] & 0xffff0000u);
+        }
+    }
+}
+// geometry head of one point, sigma only: out[0] = sigma (both lane halves), the other outputs are not computed
+__device__ __forceinline__ void mlp_bf16_sigma(const float* __restrict__ lds, const f32x2 (&f)[8], int lane, const float (&w)[32], f32x16& out) {
+    lane = launder(lane);
+    const int h = lane >> 5;
+    const uint4* F = reinterpret_cast<const uint4*>(lds) + lane;
+    __builtin_amdgcn_sched_barrier(0);
+    Frag fh[2], fl[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split_pair(f[4 * s + q][0], f[4 * s + q][1], fh[s].u[q], fl[s].u[q]);
+    f32x16 a0, a1;
+    load_bias0(lds, 0, h, a0, a1);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        Frag h0, l0, h1, l1;
+        h0.q = NFE_L0_FRAG(0, 0, s, 0); l0.q = NFE_L0_FRAG(0, 0, s, 1);
+        h1.q = NFE_L0_FRAG(0, 1, s, 0); l1.q = NFE_L0_FRAG(0, 1, s, 1);
+        a0 = NFE_MFMA_BF16(h0, fh[s], a0); a1 = NFE_MFMA_BF16(h1, fh[s], a1);
+        a0 = NFE_MFMA_BF16(h0, fl[s], a0); a1 = NFE_MFMA_BF16(h1, fl[s], a1);
+        a0 = NFE_MFMA_BF16(l0, fh[s], a0); a1 = NFE_MFMA_BF16(l1, fh[s], a1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    softplus_log2_x16(a0); softplus_log2_x16(a1);
+    float p0 = 0.0f, p1 = 0.0f;               // two chains: K positions of k-steps 0, 1 (M-block 0) and 2, 3 (M-block 1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { p0 = fmaf(w[r], a0[r], p0); p1 = fmaf(w[16 + r], a1[r], p1); }
+    const float part = p0 + p1;
+    out[0] = lds[DEC_B_G1] + (part + __shfl_xor(part, 32));
+}
+
 // hidden registers 8(s&1)..+7 of M-block s>>1 -> B operand of layer-1 k-step s
 __device__ __forceinline__ void split_hidden(const f32x16& a0, const f32x16& a1, int s, Frag& hh, Frag& hl) {
 #pragma unroll
@@ -1747,6 +1801,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
 #else
     } else {
 #endif
+        float wsig[32];                          // sigma-only pass: row 0 of the geometry head's second layer (mlp_bf16_sigma)
+        if (SIGMA_ONLY && NFE_SIGMA_ROW) sigma_row_weights(lds, lane, wsig);
 #pragma unroll 1
         for (long long rb = (long long)blockIdx.x * NP + pair; rb < total_rb; rb += n_pairs) {
             const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
@@ -1781,7 +1837,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                     t = tile_g[WS_T_OFF + j];
                     ws_signal(flags, 1, 2u * step + (SIGMA_ONLY ? 2u : 1u), lane);
 #if !defined(WS_ABLATE) || WS_ABLATE != 2          // timing experiment: 2 = consumer without its decoder
-                    mlp_bf16(ldsw, fn, 0, lane, og);
+                    if (SIGMA_ONLY && NFE_SIGMA_ROW) mlp_bf16_sigma(ldsw, fn, lane, wsig, og);
+                    else mlp_bf16(ldsw, fn, 0, lane, og);
 #else
 #pragma unroll
                     for (int r = 0; r < 16; ++r) og[r] = fn[r >> 1][r & 1];
