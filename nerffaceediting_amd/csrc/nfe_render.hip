@@ -1062,7 +1062,7 @@ __device__ __forceinline__ void mlp_pair_bf16_il(const float* __restrict__ lds, 
 // Outputs as eval_point documents them.
 template <bool SIGMA_ONLY, int MATH, bool CROSS>
 __device__ __forceinline__ void decode_features(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
-                                                int lane, f32x16& og, f32x16& oa) {
+                                                int lane, f32x16& og, f32x16& oa, const float (&wsig)[32]) {
 #ifdef NFE_ABLATE_MLP      // timing experiment only (tools/ablate.sh): no decoder
 #pragma unroll
     for (int r = 0; r < 16; ++r) { og[r] = fn[r >> 1][r & 1]; oa[r] = fd[r >> 1][r & 1]; }
@@ -1076,6 +1076,7 @@ __device__ __forceinline__ void decode_features(const float* __restrict__ lds, c
     if (PAIR && NFE_MLP_INTERLEAVE && !CROSS) mlp_pair_bf16_il(lds, fn, fd, lane, og, oa);
     else if (PAIR) mlp_pair_bf16<CROSS>(lds, fn, fd, lane, og, oa);
     else if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og);
+    else if (SIGMA_ONLY && NFE_SIGMA_ROW) mlp_bf16_sigma(lds, fn, lane, wsig, og);      // wsig: sigma_row_weights(), once per wave
     else mlp_bf16(lds, fn, 0, lane, og);
     if (!SIGMA_ONLY) {
         if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa);
@@ -1100,7 +1101,7 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
                                            int H, int W, const float* __restrict__ lds,
                                            const float* __restrict__ aff, float* __restrict__ xp,
                                            float gx, float gy, float gz,
-                                           int lane, f32x16& og, f32x16& oa) {
+                                           int lane, f32x16& og, f32x16& oa, const float (&wsig)[32]) {
     f32x2 qn[8], qd[8];          // quad layout: [2i], [2i+1] = channels 16h+4c.. of quad point i
     const int l0 = launder(lane);
     const int qoff0 = (l0 >> 5) * 16 + (l0 & 3) * 4;
@@ -1120,7 +1121,7 @@ __device__ __forceinline__ void eval_point(const float* __restrict__ pg, const f
     f32x2 fn[8], fd[8];          // own layout: channels 16h..16h+15 of this lane's point
     exchange_to_own(xp, lane, qn, fn);
     if (!SIGMA_ONLY) exchange_to_own(xp, lane, qd, fd);
-    decode_features<SIGMA_ONLY, MATH, CROSS>(lds, fn, fd, lane, og, oa);
+    decode_features<SIGMA_ONLY, MATH, CROSS>(lds, fn, fd, lane, og, oa, wsig);
 }
 
 // Copy the decoder image for this math mode into LDS words [0, DEC_FLOATS): fragments then biases.
@@ -1184,6 +1185,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     // ends of the launch (the grid is persistent: workgroup 0 lives as long as the kernel).  Nothing is stamped inside the loop.
     const bool probe = P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0;
     if (probe && lane == 0) { P.clock_probe[0] = __builtin_amdgcn_s_memtime(); P.clock_probe[1] = __builtin_amdgcn_s_memrealtime(); }
+    float wsig[32] = {};                     // sigma-only pass, split-bf16: row 0 of the geometry head's second layer (mlp_bf16_sigma)
+    if (SIGMA_ONLY && MATH == NFE_MATH_BF16X3 && NFE_SIGMA_ROW) sigma_row_weights(lds, lane, wsig);
 
     const int S = P.S;
     const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
@@ -1304,7 +1307,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
             // would pin >200 VGPRs per lane and spill.
             int opq;
             asm volatile("s_mov_b32 %0, 0" : "=s"(opq));
-            eval_point<DUAL, SIGMA_ONLY, MATH, CROSS, SQUARE>(pg, pa, P.H, P.W, lds + opq, aff + opq, xp + opq, gx, gy, gz, lane, og, oa);
+            eval_point<DUAL, SIGMA_ONLY, MATH, CROSS, SQUARE>(pg, pa, P.H, P.W, lds + opq, aff + opq, xp + opq, gx, gy, gz, lane, og, oa, wsig);
 
             if (NOISE) {
                 const unsigned draw = (P.depth_mode == DEPTH_BUFFER && P.src_buf) ? (unsigned)P.src_buf[ray * S + k] : (unsigned)k;
@@ -2231,9 +2234,10 @@ __global__ __launch_bounds__(256, 2) void point_kernel(PointK P) {
         const long long pt = (long long)n * P.Pn + m;
         const float* c = P.coords + pt * 3;
         f32x16 og, oa;
+        const float no_wsig[32] = {};                 // (sigma-row weights: only the sigma-only render pass has them)
         eval_point<DUAL, false, MATH, CROSS>(P.planes_g + (long long)n * P.plane_view_stride,
                                 P.planes_a + (long long)n * P.plane_view_stride, P.H, P.W, lds, aff, xp,
-                                P.coord_scale * c[0], P.coord_scale * c[1], P.coord_scale * c[2], lane, og, oa);
+                                P.coord_scale * c[0], P.coord_scale * c[1], P.coord_scale * c[2], lane, og, oa, no_wsig);
         if (valid) {
             float4* o = reinterpret_cast<float4*>(P.rgb + pt * 32 + 16 * h);
 #pragma unroll
@@ -2292,7 +2296,8 @@ __global__ __launch_bounds__(256, 2) void decoder_kernel(DecoderK P) {
 #pragma unroll
         for (int c = 0; c < 8; ++c) { fn[c] = fn[c] * splat(inv_planes); fd[c] = fd[c] * splat(inv_planes); }
         f32x16 og, oa;
-        decode_features<false, MATH, CROSS>(lds, fn, fd, lane, og, oa);
+        const float no_wsig[32] = {};
+        decode_features<false, MATH, CROSS>(lds, fn, fd, lane, og, oa, no_wsig);
         if (valid) {
             const long long pt = (long long)n * P.Pn + m;
             float4* o = reinterpret_cast<float4*>(P.rgb + pt * 32 + 16 * h);

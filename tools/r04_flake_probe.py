@@ -1,0 +1,34 @@
+"""Round 4: is a flaky backward test a race or summation order?  Runs sweep cases of tests/test_random_sweep_gpu.py 300 times with the
+workspace poisoned (NaN / 1e30) before every call: unwritten workspace reads would show as non-finite or huge deviations; what remains is
+the launch-to-launch spread of the float atomics.    python tools/r04_flake_probe.py [seeds...]"""
+import sys, numpy as np, torch
+sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+import importlib.util
+spec = importlib.util.spec_from_file_location("sw", "/root/repo/tests/test_random_sweep_gpu.py"); m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+from nerffaceediting_amd import ops
+dev = torch.device("cuda:0")
+t = m.t
+for seed in [int(a) for a in sys.argv[1:]] or [6]:
+    c = m.draw_case(seed, backward=True)
+    N, M, rng = c["N"], c["M"], c["rng"]
+    heads = [t(c["dec"][k], dev) for k in m.NAMES]
+    pg = ops.plane_pack(t(c["pn"], dev)); pa = pg if c["same"] else ops.plane_pack(t(c["pd"], dev))
+    kw = dict(origins=t(c["o"], dev), dirs=t(c["d"], dev))
+    cot = [rng.randn(N, M, 32).astype(np.float32), rng.randn(N, M, 15).astype(np.float32), rng.randn(N, M, 1).astype(np.float32), rng.randn(N, M, 1).astype(np.float32)]
+    drop = seed % 4
+    cots = tuple(None if (i == drop and i > 0) else t(x, dev) for i, x in enumerate(cot))
+    dec = ops.decoder_pack(*heads)
+    first = None; worst = 0.0; nans = 0; worst_kr = 0.0
+    for it in range(int(300)):
+        for ws in ops._workspaces.values(): ws.view(torch.float32)[: ws.numel() // 4].fill_(float("nan") if it % 2 else 1e30)
+        out2 = ops.render(pg, pa, dec, c["opts"], u_coarse=t(c["u_c"], dev), u_fine=None if c["u_f"] is None else t(c["u_f"], dev), taps=True, sample_colors=True, **kw)
+        for ws in ops._workspaces.values(): ws.view(torch.float32)[: ws.numel() // 4].fill_(float("nan") if it % 2 else 1e30)
+        g2, a2 = ops.render_backward(pg, pa, heads, 1.0, c["opts"], out2[4]["depths_all"], cots, sample_colors=out2[4]["sample_colors"], sample_colors_resolution=out2[4]["sample_colors_resolution"], **kw)
+        for ws in ops._workspaces.values(): ws.view(torch.float32)[: ws.numel() // 4].fill_(float("nan") if it % 2 else 1e30)
+        r2, ra2 = ops.render_backward(pg, pa, heads, 1.0, c["opts"], out2[4]["depths_all"], cots, **kw)
+        cur = [x.clone() for x in (g2, a2, r2, ra2) if x is not None]
+        if any(not torch.isfinite(x).all() for x in cur): nans += 1
+        worst_kr = max(worst_kr, float((g2 - r2).abs().max() / r2.abs().max()))
+        if first is None: first = cur
+        else: worst = max(worst, max(float((x - y).abs().max() / y.abs().max()) for x, y in zip(cur, first)))
+    print(f"seed {seed}: 300 runs, non-finite results in {nans}, worst deviation from run 0: {worst:.3e}, worst kept-vs-reeval: {worst_kr:.3e}")
