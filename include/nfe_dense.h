@@ -174,6 +174,16 @@ int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int
 int nfe_resize_bilinear_backward(const float* grad_out, int n, int h, int w, int c, int oh, int ow, int antialias, float* grad_in,
                                  nfe_stream_t stream);
 
+/* ---- backward of bias_act('lrelu', gain, clamp) with the ToRGB branch folded in (ABI v13; the SR-head gradient, sr_grad.py) ----
+ * One pass over a layer's saved output `out` [N,H,W,C] (bias_act.py:93-125: the derivative is taken from the OUTPUT):
+ *   g_total = (grad ? grad : 0) + (grad_rgb ? sum_k grad_rgb[n,y,x,k] * rgb_w[k][c] * rgb_s[n][c] : 0)
+ *   dst     = g_total * gain * (out < 0 ? 0.2 : 1) * (clamp > 0 ? (|out| < clamp) : 1) * (scale ? scale[n][c] : 1)
+ * grad: gradient arriving from the next conv layer (or null); grad_rgb [N,H,W,rgb_k] with rgb_w [rgb_k][C], rgb_s [N][C]: the transposed
+ * 1x1 ToRGB of the block (networks_stylegan2.py:455; rgb_k <= 4), or null; scale: a per-(view, channel) factor for the consumer (the
+ * demodulation coefficients of an up-sampling layer's backward-data form), or null.  C % 4 == 0.  dst may alias grad. */
+int nfe_bias_act_backward(const float* out, const float* grad, const float* grad_rgb, const float* rgb_w, const float* rgb_s, int rgb_k,
+                          const float* scale, float gain, float clamp, int n, long long pixels, int c, float* dst, nfe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NFE_ABI_VERSION 12
+#define NFE_ABI_VERSION 13
 
 #define NFE_OK 0
 #define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 12
+NFE_ABI_VERSION = 13
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_DECODER_CROSS_FLOATS = 2048
@@ -136,6 +136,7 @@ _SIGNATURES = {
     "nfe_upfirdn2d": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, FP, c_void_p]),
     "nfe_resize_bilinear": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_resize_bilinear_backward": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_bias_act_backward": (c_int, [FP, FP, FP, FP, FP, c_int, FP, c_float, c_float, c_int, c_int64, c_int, FP, c_void_p]),
     "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
                                 FP, FP, FP, c_float, c_uint64, FP, c_void_p]),
 }

@@ -2324,6 +2324,53 @@ __global__ __launch_bounds__(256) void resize_bwd_kernel(const float* __restrict
 }
 }  // namespace nfe
 
+namespace nfe {
+// nfe_bias_act_backward: thread = (pixel, 4 channels); HBM-bound (reads out, grad, 3 floats of grad_rgb; writes dst)
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float4* __restrict__ out, const float4* __restrict__ grad, const float* __restrict__ grad_rgb,
+                                                           const float* __restrict__ rgb_w, const float* __restrict__ rgb_s, int rgb_k,
+                                                           const float* __restrict__ scale, float gain, float clamp, long long pixels, int c4, long long total,
+                                                           float4* __restrict__ dst) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int q = (int)(i % c4);
+        const long long p = i / c4;
+        const int n = (int)(p / pixels);
+        const int C = 4 * c4;
+        float4 g = grad ? grad[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (grad_rgb) {
+            const float4 s = *reinterpret_cast<const float4*>(rgb_s + (long long)n * C + 4 * q);
+            float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            for (int k = 0; k < rgb_k; ++k) {
+                const float gy = grad_rgb[p * rgb_k + k];
+                const float4 w = *reinterpret_cast<const float4*>(rgb_w + (long long)k * C + 4 * q);
+                t.x = fmaf(gy, w.x, t.x); t.y = fmaf(gy, w.y, t.y); t.z = fmaf(gy, w.z, t.z); t.w = fmaf(gy, w.w, t.w);
+            }
+            g.x = fmaf(t.x, s.x, g.x); g.y = fmaf(t.y, s.y, g.y); g.z = fmaf(t.z, s.z, g.z); g.w = fmaf(t.w, s.w, g.w);
+        }
+        const float4 o = out[i];
+        const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + (long long)n * C + 4 * q) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        auto d = [&](float ov, float gv, float sv) {
+            const float slope = ov < 0.0f ? 0.2f * gain : gain;
+            const float keep = (clamp > 0.0f && !(fabsf(ov) < clamp)) ? 0.0f : 1.0f;
+            return gv * slope * keep * sv;
+        };
+        dst[i] = make_float4(d(o.x, g.x, sc.x), d(o.y, g.y, sc.y), d(o.z, g.z, sc.z), d(o.w, g.w, sc.w));
+    }
+}
+}  // namespace nfe
+
+extern "C" int nfe_bias_act_backward(const float* out, const float* grad, const float* grad_rgb, const float* rgb_w, const float* rgb_s, int rgb_k,
+                                     const float* scale, float gain, float clamp, int n, long long pixels, int c, float* dst, nfe_stream_t stream) {
+    NFE_REQUIRE(out && dst && n > 0 && pixels > 0 && c > 0 && c % 4 == 0, "nfe_bias_act_backward: bad arguments (n=%d pixels=%lld c=%d)", n, pixels, c);
+    NFE_REQUIRE(grad || grad_rgb, "nfe_bias_act_backward: no incoming gradient");
+    NFE_REQUIRE(!grad_rgb || (rgb_w && rgb_s && rgb_k > 0 && rgb_k <= 4), "nfe_bias_act_backward: the ToRGB branch needs rgb_w, rgb_s and 1 <= rgb_k <= 4");
+    const long long total = (long long)n * pixels * (c / 4);
+    hipLaunchKernelGGL(nfe::bias_act_bwd_kernel, dim3(nfe::grid1d(total, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float4*>(out), reinterpret_cast<const float4*>(grad), grad_rgb, rgb_w, rgb_s, rgb_k, scale, gain, clamp,
+                       pixels, c / 4, total, reinterpret_cast<float4*>(dst));
+    NFE_CHECK_LAUNCH("bias_act_bwd_kernel");
+    return NFE_OK;
+}
+
 extern "C" int nfe_resize_bilinear_backward(const float* grad_out, int n, int h, int w, int c, int oh, int ow, int antialias, float* grad_in,
                                             nfe_stream_t stream) {
     NFE_REQUIRE(grad_out && grad_in && n > 0 && h > 0 && w > 0 && c > 0 && oh > 0 && ow > 0, "nfe_resize_bilinear_backward: bad arguments");

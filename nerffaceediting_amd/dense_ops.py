@@ -308,6 +308,31 @@ def resize_bilinear_backward(g, h, w, antialias=True):
     return out
 
 
+def bias_act_backward(out, grad=None, grad_rgb=None, rgb_w=None, rgb_s=None, scale=None, gain=1.0, clamp=None):
+    """Backward of bias_act('lrelu', gain, clamp) (bias_act.py:93-125) at a layer's saved output `out` [N,H,W,C], in ONE pass, with the
+    block's transposed ToRGB folded in (include/nfe_dense.h: nfe_bias_act_backward):
+    ((grad or 0) + (grad_rgb @ rgb_w) * rgb_s) * gain * (0.2 if out < 0 else 1) * (|out| < clamp) * (scale or 1).
+    grad [N,H,W,C] or None; grad_rgb [N,H,W,K] with rgb_w [K,C], rgb_s [N,C] or None; scale [N,C] or None."""
+    lib = _lib.load()
+    out = _dev(out, "out", (None, None, None, None))
+    N, H, W, C = out.shape
+    if grad is not None:
+        grad = _dev(grad.contiguous(), "grad", (N, H, W, C))
+    K = 0
+    if grad_rgb is not None:
+        K = int(grad_rgb.shape[-1])
+        grad_rgb = _dev(grad_rgb.contiguous(), "grad_rgb", (N, H, W, K))
+        rgb_w = _dev(rgb_w.contiguous(), "rgb_w", (K, C))
+        rgb_s = _dev(rgb_s.contiguous(), "rgb_s", (N, C))
+    if scale is not None:
+        scale = _dev(scale.contiguous(), "scale", (N, C))
+    dst = torch.empty_like(out)
+    _call(out.device, lambda: lib.nfe_bias_act_backward(_ptr(out), _ptr(grad), _ptr(grad_rgb), _ptr(rgb_w), _ptr(rgb_s), K, _ptr(scale), float(gain),
+                                                        float(clamp) if clamp is not None else 0.0, N, H * W, C, _ptr(dst), _stream()),
+          "nfe_bias_act_backward")
+    return dst
+
+
 def resize_bilinear(x, oh, ow, antialias=True):
     """F.interpolate(mode='bilinear', align_corners=False, antialias=...) on NHWC."""
     lib = _lib.load()

@@ -45,12 +45,12 @@ def _resizes(sr, r_in):
     return (r_in < r) if getattr(sr, "resize_if_smaller_only", False) else (r_in != r)
 
 
-def _act_grad(out, g, gain, clamp):
-    """d bias_act('lrelu', gain, clamp) / d pre-activation, applied to the incoming gradient (bias_act.py:93-125)."""
-    g = g * torch.where(out < 0, 0.2 * gain, gain)
-    if clamp is not None:
-        g = g * (out.abs() < clamp)
-    return g
+def _act_grad(out, g, gain, clamp, rgb=None, scale=None):
+    """d bias_act('lrelu', gain, clamp) / d pre-activation, applied to the incoming gradient (bias_act.py:93-125) - one HIP pass
+    (nfe_bias_act_backward) that also adds the block's transposed ToRGB branch (rgb = (g_y [N,H,W,3], W^T [3,C], styles [N,C])) and
+    applies a per-(view, channel) factor for the consumer; g may be None when only the ToRGB branch feeds the layer."""
+    g_rgb, w_rgb, s_rgb = rgb if rgb is not None else (None, None, None)
+    return dense_ops.bias_act_backward(out, grad=g, grad_rgb=g_rgb, rgb_w=w_rgb, rgb_s=s_rgb, scale=scale, gain=gain, clamp=clamp)
 
 
 def _bwd_plain(layer):
@@ -90,10 +90,12 @@ def _conv_bwd_plain(layer, g_pre, s, d):
                                     lrelu=False, act_gain=1.0, clamp=None, math=GRAD_MATH)
 
 
-def _conv_bwd_up(layer, g_pre, s, d):
-    N, H2, _, Co = g_pre.shape
+def _conv_bwd_up(layer, g_pre_d, s):
+    """g_pre_d = d . g_pre (the demodulation factor is applied by the activation-gradient pass that produced it)."""
+    N, H2, _, Co = g_pre_d.shape
     H = H2 // 2
-    gT = dense_ops.upfirdn2d((g_pre * d[:, None, None, :]).contiguous(), padding=(2, 2), gain=4.0)          # [N,2H+1,2H+1,Co]
+    g_pre = g_pre_d
+    gT = dense_ops.upfirdn2d(g_pre_d.contiguous(), padding=(2, 2), gain=4.0)          # [N,2H+1,2H+1,Co]
     pad = torch.zeros(N, 2 * H + 2, 2 * H + 2, Co, device=g_pre.device)
     pad[:, :2 * H + 1, :2 * H + 1] = gT
     stack = pad.view(N, H + 1, 2, H + 1, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(N, H + 1, H + 1, 4 * Co).contiguous()
@@ -123,14 +125,14 @@ def block_backward(blk, saved, g_img, g_x):
     clamp = blk.torgb.conv_clamp
     g_y = g_img * (y.abs() < clamp) if clamp is not None else g_img
     Wt = blk.torgb.weight.detach().reshape(blk.torgb.out_channels, blk.torgb.in_channels)
-    g_o1 = torch.matmul(g_y, Wt) * st_rgb[:, None, None, :]                                       # ToRGB: K = 3
-    if g_x is not None:
-        g_o1 = g_o1 + g_x
     c1, c0 = blk.conv1, blk.conv0
-    g_o0 = _conv_bwd_plain(c1, _act_grad(o1, g_o1, c1.act_gain, c1.conv_clamp), s1, d1)
-    g_pre0 = _act_grad(o0, g_o0, c0.act_gain, c0.conv_clamp)
+    # conv1's output gradient = ToRGB^T (K = 3) + what the next block sent, through conv1's activation: one pass
+    g_pre1 = _act_grad(o1, g_x, c1.act_gain, c1.conv_clamp, rgb=(g_y, Wt.contiguous(), st_rgb))
+    g_o0 = _conv_bwd_plain(c1, g_pre1, s1, d1)
     if c0.up == 2:
-        return _conv_bwd_up(c0, g_pre0, s0, d0), dense_ops.upfirdn2d(g_img, down=2, padding=(1, 2), gain=4.0)      # transpose of upsample2d
+        g_pre0 = _act_grad(o0, g_o0, c0.act_gain, c0.conv_clamp, scale=d0)
+        return _conv_bwd_up(c0, g_pre0, s0), dense_ops.upfirdn2d(g_img, down=2, padding=(1, 2), gain=4.0)          # transpose of upsample2d
+    g_pre0 = _act_grad(o0, g_o0, c0.act_gain, c0.conv_clamp)
     return _conv_bwd_plain(c0, g_pre0, s0, d0), g_img                             # SynthesisBlockNoUp: conv0 at the same resolution, img + y
 
 

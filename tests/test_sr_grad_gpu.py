@@ -85,8 +85,10 @@ def test_modulated_conv_backward_is_the_adjoint(up, cin, cout, r, dev):
     d = dense_ops.conv_demod(s, _pack_cached(layer, layer.weight)[1])
     out = layer.forward_nhwc(x, None, noise_mode="none", conv_math="bf16x3", styles=s, dcoef=d)
     # y = act(L x) with L linear and zero bias: act is positively homogeneous piecewise linear -> y = D L x with D = diag(slope*gain)
-    g_pre = sr_grad._act_grad(out, cot, layer.act_gain, layer.conv_clamp)
-    gx = (sr_grad._conv_bwd_up if up == 2 else sr_grad._conv_bwd_plain)(layer, g_pre, s, d)
+    if up == 2:        # the up-sampling form takes d . g_pre (the activation-gradient pass applies the demodulation factor)
+        gx = sr_grad._conv_bwd_up(layer, sr_grad._act_grad(out, cot, layer.act_gain, layer.conv_clamp, scale=d), s)
+    else:
+        gx = sr_grad._conv_bwd_plain(layer, sr_grad._act_grad(out, cot, layer.act_gain, layer.conv_clamp), s, d)
     lhs = float((out.double() * cot.double()).sum())                     # <D L x, g>
     rhs = float((x.double() * gx.double()).sum())                         # <x, L^T D g>
     assert abs(lhs - rhs) <= 2e-4 * max(abs(lhs), 1.0), (lhs, rhs)
@@ -260,3 +262,32 @@ def test_block_backward_with_the_references_slopes(dev):
         e = float((got.permute(0, 3, 1, 2).cpu() - torch.from_numpy(want)).abs().max())
         print(f"  {name}: max-abs error {e:.3e} of largest entry {float(np.abs(want).max()):.3g}")
         assert e <= 1e-3 * float(np.abs(want).max()), (name, e)
+
+
+@pytest.mark.parametrize("with_grad,with_rgb,with_scale,clamp", [(True, True, False, 256.0), (False, True, False, 0.4), (True, False, True, 0.4), (True, False, False, None)])
+def test_bias_act_backward_is_the_lrelu_clamp_derivative_with_torgb_folded_in(with_grad, with_rgb, with_scale, clamp, dev):
+    """nfe_bias_act_backward (ABI v13) against the formula the reference's autograd applies (bias_act.py:93-125: slope and clamp mask
+    from the OUTPUT; the ToRGB branch is a K = 3 matmul, networks_stylegan2.py:455) with every optional input present / absent, values
+    on both sides of zero and of the clamp."""
+    from nerffaceediting_amd import dense_ops
+    g = torch.Generator(device="cpu").manual_seed(11)
+    N, H, W, C, gain = 2, 9, 7, 32, float(np.sqrt(2))
+    out = (torch.randn(N, H, W, C, generator=g) * 0.5).to(dev)
+    grad = torch.randn(N, H, W, C, generator=g).to(dev) if with_grad else None
+    g_rgb = torch.randn(N, H, W, 3, generator=g).to(dev) if with_rgb else None
+    w = torch.randn(3, C, generator=g).to(dev)
+    s = (torch.randn(N, C, generator=g) * 0.3 + 1).to(dev)
+    sc = (torch.rand(N, C, generator=g) + 0.5).to(dev) if with_scale else None
+    got = dense_ops.bias_act_backward(out, grad=grad, grad_rgb=g_rgb, rgb_w=w if with_rgb else None, rgb_s=s if with_rgb else None, scale=sc, gain=gain, clamp=clamp)
+    tot = torch.zeros_like(out)
+    if with_grad:
+        tot = tot + grad
+    if with_rgb:
+        tot = tot + torch.matmul(g_rgb, w) * s[:, None, None, :]
+    want = tot * torch.where(out < 0, 0.2 * gain, gain)
+    if clamp is not None:
+        assert 0.02 < float((out.abs() >= clamp).float().mean()) < 0.9 or clamp > 100          # the mask is exercised
+        want = want * (out.abs() < clamp)
+    if with_scale:
+        want = want * sc[:, None, None, :]
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
