@@ -2348,9 +2348,10 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(const float4* __restr
         }
         const float4 o = out[i];
         const float4 sc = scale ? *reinterpret_cast<const float4*>(scale + (long long)n * C + 4 * q) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        const float lim = clamp > 0.0f ? clamp : INFINITY;                 // one compare per decision (tools/lint_lane_masks.py)
         auto d = [&](float ov, float gv, float sv) {
             const float slope = ov < 0.0f ? 0.2f * gain : gain;
-            const float keep = (clamp > 0.0f && !(fabsf(ov) < clamp)) ? 0.0f : 1.0f;
+            const float keep = fabsf(ov) < lim ? 1.0f : 0.0f;
             return gv * slope * keep * sv;
         };
         dst[i] = make_float4(d(o.x, g.x, sc.x), d(o.y, g.y, sc.y), d(o.z, g.z, sc.z), d(o.w, g.w, sc.w));
