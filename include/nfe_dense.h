@@ -165,6 +165,11 @@ uint64_t nfe_conv_scratch_floats(int mode, int math, int n, int h, int w, int ci
 int nfe_upfirdn2d(const float* in, int n, int h, int w, int c, int up, int down, int pad0, int pad1, float gain, float* out,
                   nfe_stream_t stream);
 
+/* nfe_upfirdn2d(up = 1, down = 1) whose result [N,OH,OW,C] (OH = h + pad0 + pad1 - 3) leaves as its four polyphase images stacked along
+ * the channels (ABI v13): out [N, ceil(OH / 2), ceil(OW / 2), 4 C], out[n][Y/2][X/2][((Y&1)*2 + (X&1)) * C + c], zeros where Y >= OH or
+ * X >= OW.  The operand of the up-sampling layers' backward-data convolution (sr_grad.py). */
+int nfe_upfirdn2d_polyphase(const float* in, int n, int h, int w, int c, int pad0, int pad1, float gain, float* out, nfe_stream_t stream);
+
 /* ---- F.interpolate(mode='bilinear', align_corners=False, antialias=...) (superresolution.py:283-286)
  * NHWC [N,H,W,C] -> [N,OH,OW,C] */
 int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, int oh, int ow, int antialias, float* out,

@@ -136,6 +136,7 @@ _SIGNATURES = {
     "nfe_upfirdn2d": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_float, FP, c_void_p]),
     "nfe_resize_bilinear": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_resize_bilinear_backward": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_upfirdn2d_polyphase": (c_int, [FP, c_int, c_int, c_int, c_int, c_int, c_int, c_float, FP, c_void_p]),
     "nfe_bias_act_backward": (c_int, [FP, FP, FP, FP, FP, c_int, FP, c_float, c_float, c_int, c_int64, c_int, FP, c_void_p]),
     "nfe_point_query": (c_int, [FP, FP, c_int, c_int, c_int64, FP, FP, FP, FP, FP, c_int, FP, c_int, c_int, c_float,
                                 FP, FP, FP, c_float, c_uint64, FP, c_void_p]),

@@ -1702,15 +1702,24 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_small_kernel(const float* __
 //   upsample2d(x)            = upfirdn2d(x, up=2, pad=(2,1), gain=4)         upfirdn2d.py:341-350
 //   its transpose            = upfirdn2d(g, down=2, pad=(1,2), gain=4)
 //   up-conv FIR (pad 1,1)^T  = upfirdn2d(g, pad=(2,2), gain=4)                conv2d_resample.py:114-128
+// POLY (nfe_upfirdn2d_polyphase): the result leaves as the four polyphase images stacked along the channels,
+// out[n][Y / 2][X / 2][((Y & 1) * 2 + (X & 1)) * C + c] over the even-sized grid (OH + 1 & ~1) x (OW + 1 & ~1), zeros beyond OH / OW - the
+// operand layout of the up-sampling layer's backward-data convolution (sr_grad.py: four torch passes before).
+template <bool POLY>
 __global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ in, int N, int H, int W, int C, int up, int down, int pad0,
                                                       float gain, int OH, int OW, float* __restrict__ out) {
     const float F[4] = {0.125f, 0.375f, 0.375f, 0.125f};
-    const long long total = (long long)N * OH * OW * C;
+    const int GH = POLY ? (OH + 1) & ~1 : OH, GW = POLY ? (OW + 1) & ~1 : OW;
+    const long long total = (long long)N * GH * GW * C;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C); long long r = i / C;
-        const int X = (int)(r % OW); r /= OW;
-        const int Y = (int)(r % OH); const int n = (int)(r / OH);
+        const int X = (int)(r % GW); r /= GW;
+        const int Y = (int)(r % GH); const int n = (int)(r / GH);
         float acc = 0.0f;
+        if (POLY && (Y >= OH || X >= OW)) {
+            out[(((long long)n * (GH / 2) + Y / 2) * (GW / 2) + X / 2) * (4 * C) + ((Y & 1) * 2 + (X & 1)) * C + c] = 0.0f;
+            continue;
+        }
 #pragma unroll
         for (int a = 0; a < 4; ++a) {
             const int u = Y * down + a - pad0;                 // row of the zero-inserted image
@@ -1724,7 +1733,8 @@ __global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ 
             }
             acc = fmaf(F[a], rowv, acc);
         }
-        out[i] = acc * gain;
+        if (POLY) out[(((long long)n * (GH / 2) + Y / 2) * (GW / 2) + X / 2) * (4 * C) + ((Y & 1) * 2 + (X & 1)) * C + c] = acc * gain;
+        else out[i] = acc * gain;
     }
 }
 
@@ -2270,9 +2280,20 @@ extern "C" int nfe_upfirdn2d(const float* in, int n, int h, int w, int c, int up
     NFE_REQUIRE((up == 1 || up == 2) && (down == 1 || down == 2) && pad0 >= 0 && pad1 >= 0, "nfe_upfirdn2d: up / down must be 1 or 2, pads >= 0");
     const int oh = (h * up + pad0 + pad1 - 4) / down + 1, ow = (w * up + pad0 + pad1 - 4) / down + 1;
     NFE_REQUIRE(oh > 0 && ow > 0, "nfe_upfirdn2d: empty output");
-    hipLaunchKernelGGL(upfirdn_kernel, dim3(grid1d((long long)n * oh * ow * c, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(upfirdn_kernel<false>, dim3(grid1d((long long)n * oh * ow * c, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream,
                        in, n, h, w, c, up, down, pad0, gain, oh, ow, out);
     NFE_CHECK_LAUNCH("upfirdn_kernel");
+    return NFE_OK;
+}
+
+extern "C" int nfe_upfirdn2d_polyphase(const float* in, int n, int h, int w, int c, int pad0, int pad1, float gain, float* out, nfe_stream_t stream) {
+    NFE_REQUIRE(in && out && n > 0 && h > 0 && w > 0 && c > 0 && pad0 >= 0 && pad1 >= 0, "nfe_upfirdn2d_polyphase: bad arguments");
+    const int oh = h + pad0 + pad1 - 3, ow = w + pad0 + pad1 - 3;
+    NFE_REQUIRE(oh > 0 && ow > 0, "nfe_upfirdn2d_polyphase: empty output");
+    const long long total = (long long)n * ((oh + 1) & ~1) * ((ow + 1) & ~1) * c;
+    hipLaunchKernelGGL(upfirdn_kernel<true>, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream,
+                       in, n, h, w, c, 1, 1, pad0, gain, oh, ow, out);
+    NFE_CHECK_LAUNCH("upfirdn_kernel<polyphase>");
     return NFE_OK;
 }
 

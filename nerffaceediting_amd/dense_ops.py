@@ -308,6 +308,19 @@ def resize_bilinear_backward(g, h, w, antialias=True):
     return out
 
 
+def upfirdn2d_polyphase(x, padding=(2, 2), gain=1.0):
+    """upfirdn2d(x, up=1, down=1, padding, gain) [N,OH,OW,C] delivered as its four polyphase images stacked along the channels:
+    [N, ceil(OH/2), ceil(OW/2), 4C], zeros beyond OH / OW (include/nfe_dense.h: nfe_upfirdn2d_polyphase)."""
+    lib = _lib.load()
+    x = _dev(x, "x", (None, None, None, None))
+    N, H, W, C = x.shape
+    OH, OW = H + padding[0] + padding[1] - 3, W + padding[0] + padding[1] - 3
+    out = torch.empty(N, (OH + 1) // 2, (OW + 1) // 2, 4 * C, device=x.device)
+    _call(x.device, lambda: lib.nfe_upfirdn2d_polyphase(_ptr(x), N, H, W, C, int(padding[0]), int(padding[1]), float(gain), _ptr(out), _stream()),
+          "nfe_upfirdn2d_polyphase")
+    return out
+
+
 def bias_act_backward(out, grad=None, grad_rgb=None, rgb_w=None, rgb_s=None, scale=None, gain=1.0, clamp=None):
     """Backward of bias_act('lrelu', gain, clamp) (bias_act.py:93-125) at a layer's saved output `out` [N,H,W,C], in ONE pass, with the
     block's transposed ToRGB folded in (include/nfe_dense.h: nfe_bias_act_backward):

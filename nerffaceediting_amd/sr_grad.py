@@ -95,10 +95,8 @@ def _conv_bwd_up(layer, g_pre_d, s):
     N, H2, _, Co = g_pre_d.shape
     H = H2 // 2
     g_pre = g_pre_d
-    gT = dense_ops.upfirdn2d(g_pre_d.contiguous(), padding=(2, 2), gain=4.0)          # [N,2H+1,2H+1,Co]
-    pad = torch.zeros(N, 2 * H + 2, 2 * H + 2, Co, device=g_pre.device)
-    pad[:, :2 * H + 1, :2 * H + 1] = gT
-    stack = pad.view(N, H + 1, 2, H + 1, 2, Co).permute(0, 1, 3, 2, 4, 5).reshape(N, H + 1, H + 1, 4 * Co).contiguous()
+    # g_T = FIR^T (d . g_pre), [N,2H+1,2H+1,Co], delivered as its four polyphase images stacked along the channels [N,H+1,H+1,4Co]
+    stack = dense_ops.upfirdn2d_polyphase(g_pre_d.contiguous(), padding=(2, 2), gain=4.0)
     ones = torch.ones(N, 4 * Co, device=g_pre.device)
     zeros = torch.zeros(layer.in_channels, device=g_pre.device)
     gx = dense_ops.modulated_conv(stack, ones, _bwd_up(layer), layer.in_channels, _lib.NFE_CONV_3X3, zeros, dcoef=s, lrelu=False,

@@ -291,3 +291,20 @@ def test_bias_act_backward_is_the_lrelu_clamp_derivative_with_torgb_folded_in(wi
     if with_scale:
         want = want * sc[:, None, None, :]
     assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+
+
+@pytest.mark.parametrize("H,W,C", [(8, 8, 16), (7, 10, 8)])
+def test_upfirdn2d_polyphase_is_the_stacked_padded_fir(H, W, C, dev):
+    """nfe_upfirdn2d_polyphase (ABI v13) against what sr_grad did in torch before: the (2, 2)-padded FIR of nfe_upfirdn2d, zero-padded to an
+    even size and rearranged so that channel block (a, b) of pixel (y, x) is pixel (2y + a, 2x + b) - bit for bit."""
+    from nerffaceediting_amd import dense_ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(2, H, W, C, generator=g).to(dev)
+    got = dense_ops.upfirdn2d_polyphase(x, padding=(2, 2), gain=4.0)
+    gT = dense_ops.upfirdn2d(x, padding=(2, 2), gain=4.0)                       # [N, H+1, W+1, C]
+    N, OH, OW, _ = gT.shape
+    GH, GW = (OH + 1) // 2 * 2, (OW + 1) // 2 * 2
+    pad = torch.zeros(N, GH, GW, C, device=dev)
+    pad[:, :OH, :OW] = gT
+    want = pad.view(N, GH // 2, 2, GW // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, GH // 2, GW // 2, 4 * C)
+    assert got.shape == want.shape and torch.equal(got, want)
