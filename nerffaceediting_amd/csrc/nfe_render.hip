@@ -2353,6 +2353,14 @@ static int ws_mode() {
     static const int v = [] { const char* e = getenv("NFE_RENDER_WS"); return e ? atoi(e) : NFE_RENDER_WS_DEFAULT; }();
     return v;
 }
+// Fewest 32-ray blocks for which the wave-specialised launch is used (NFE_RENDER_WS_MIN_RB overrides for A/B).  4 096: a batch of four
+// 128^2 views (2 048 blocks, the FFHQ configuration) stays on the fused kernel - alone the wave-specialised launch is 3-5 % faster there,
+// but its 512-thread workgroups with ~150 KB of LDS own a CU, and inside the three-stream pipeline the dense kernels of the neighbouring
+// batches then cannot share it: FFHQ 821-836 -> 838-856 views/s with the fused kernel (fp16 convs 1 380-1 394 -> 1 400-1 405).
+static long long ws_min_ray_blocks() {
+    static const long long v = [] { const char* e = getenv("NFE_RENDER_WS_MIN_RB"); const long long x = e ? atoll(e) : 0; return x > 0 ? x : 4096ll; }();
+    return v;
+}
 template <int NP, int WPS, bool DUAL = false, bool SIGMA_ONLY = false>
 static void launch_render_ws(const RenderK& P, long long total_rb, hipStream_t st) {
     constexpr int bytes = ws_lds_bytes<NP>();
@@ -2425,7 +2433,7 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
         return NFE_OK;
     }
     if (ws_mode() && math == NFE_MATH_BF16X3 && P.density_noise == 0.0f && !P.tap_colors && (sigma_only || !P.out_weights) &&
-        total_rb >= 2048 && (long long)P.N * P.M * P.S < (1ll << 31)) {
+        total_rb >= ws_min_ray_blocks() && (long long)P.N * P.M * P.S < (1ll << 31)) {
         // pairs per workgroup x 10 + waves per SIMD.  Shipped: 42.  The 3- and 4-waves-per-SIMD geometries (63, 33, 84, 44) were built and
         // measured slower (profiles/experiments/r04_render_ws.md); they are compiled only with -DNFE_WS_GEOMETRIES (and need WS_BUFS = 1 to fit their tiles into 160 KB of LDS)
 #if WS_BUFS == 1 && defined(NFE_WS_GEOMETRIES)       // experiment builds only

@@ -498,7 +498,7 @@ def test_wave_specialised_launch_matches_the_fused_kernel(dev, tmp_path):
     for mode in ("0", "42"):
         out = str(tmp_path / f"ws{mode}.npz")
         r = subprocess.run([sys.executable, "-c", _WS_PROG, out, "60" if mode != "0" else "0"], cwd=root,
-                           env=dict(os.environ, NFE_RENDER_WS=mode, NFE_WS_CHILD="1", PYTHONPATH=root), capture_output=True, text=True, timeout=900)
+                           env=dict(os.environ, NFE_RENDER_WS=mode, NFE_RENDER_WS_MIN_RB="2048", NFE_WS_CHILD="1", PYTHONPATH=root), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, r.stderr[-3000:]
         z = np.load(out)
         res[mode] = [z[k] for k in z.files]
