@@ -30,15 +30,35 @@ def init_process_group(dist, backend, **kw):
     """dist.init_process_group for a rank started by spawn_ranks: free_port() has released the port before rank 0 binds it again, so
     another process can take it in between.  That shows as 'address already in use' in rank 0; the rank then exits with
     RENDEZVOUS_BUSY and the parent starts all ranks again on a fresh port (three attempts)."""
+    # RCCL prints a version banner ("RCCL version : ...", five lines) through C stdio when its first communicator is made (eagerly here:
+    # device_id=).  On a pipe that text sits in libc's buffer and reaches stdout at exit - behind the one JSON line a bench rank prints.
+    # File descriptor 1 points at stderr while the communicator is created and libc's buffers are flushed before it is restored.
+    import ctypes
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
     try:
         dist.init_process_group(backend, **kw)
+        if backend == "nccl" and "device_id" in kw:
+            import torch
+            dist.barrier(device_ids=[kw["device_id"].index])          # the communicator exists (and has said what it has to say) before fd 1 returns
+            torch.cuda.synchronize(kw["device_id"])
     except Exception as e:          # torch raises DistNetworkError / RuntimeError depending on the store
+        ctypes.CDLL(None).fflush(None)
+        os.dup2(saved, 1)
+        os.close(saved)
+        saved = None
         text = str(e).lower()
         if os.environ.get("NFE_LAUNCHER") == "self" and ("address already in use" in text or "eaddrinuse" in text):
             print(f"[launch] rank {os.environ.get('RANK')}: rendezvous port {os.environ.get('MASTER_PORT')} is taken", file=sys.stderr)
             sys.stderr.flush()
             os._exit(RENDEZVOUS_BUSY)
         raise
+    finally:
+        if saved is not None:
+            ctypes.CDLL(None).fflush(None)
+            os.dup2(saved, 1)
+            os.close(saved)
 
 
 def launched_by_a_launcher(env=None):

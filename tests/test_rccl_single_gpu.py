@@ -96,7 +96,9 @@ def test_bench_force_collective_reports_the_nccl_backend():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-collective", "--steps", "4", "--warmup", "1",
                         "--preroll-s", "0.2", "--no-cpu-baseline", "--orbit-frames", "16"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines[:6]          # ONE line on stdout: RCCL's version banner (NCCL_DEBUG=VERSION on the GPU boxes) goes to stderr
+    out = json.loads(lines[0])
     assert out["distributed"]["backend"] == "nccl" and out["distributed"]["world_size"] == 1, out["distributed"]
     assert out["n_gpus"] == 1 and out["value"] > 2.0e6
     assert out["strong_scaling"]["frames"] == 16 and out["strong_scaling"]["rank_blocks"][0]["frames"] == [0, 16]
