@@ -29,12 +29,13 @@
 extern "C" {
 #endif
 
-#define NFE_ABI_VERSION 13
+#define NFE_ABI_VERSION 14
 
 #define NFE_OK 0
 #define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */
 #define NFE_ELAUNCH (-2)     /* HIP launch / runtime error */
 #define NFE_EWORKSPACE (-3)  /* workspace too small */
+#define NFE_EHANDOFF (-4)    /* an EARLIER nfe_render call lost wave hand-offs (see "lost hand-offs" at nfe_render) */
 
 #define NFE_PLANE_CHANNELS 32   /* channels per plane (triplane.py:113-115) */
 #define NFE_NUM_PLANES 3
@@ -175,7 +176,21 @@ uint64_t nfe_render_sample_colors_floats(int n_views, int n_rays, int n_samples)
  * importance sampling the coarse depths / weights and the merged depths of every ray (density_noise: see above) */
 uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int depth_resolution,
                                     int depth_resolution_importance);
+/* Lost hand-offs (ABI v14).  Large launches run the wave-specialised kernel: gather waves hand feature tiles to decoder waves of
+ * the same workgroup through LDS counters.  A wave that waits longer than ~50 ms for its partner gives up instead of hanging the
+ * GPU (never observed; a bounded wait is the safety net).  Such a call is NOT silent garbage:
+ *   - the kernel that closes every nfe_render call overwrites ALL four outputs of that call with NaN, and
+ *   - it adds the number of abandoned waits to a pinned host word of the process, so that the NEXT nfe_render (any stream, any
+ *     thread) launches nothing, returns NFE_EHANDOFF with the count in nfe_last_error(), and clears the word: the caller repeats
+ *     its work.  No host synchronisation is involved anywhere; the reference's TORCH_CHECK convention (bias_act.cpp:39-55) has no
+ *     asynchronous failures, this is the closest a stream-ordered library gets.
+ * nfe_render_status() reads (clear != 0: and resets) the same word at any time, e.g. after the caller's own synchronisation
+ * point: *lost_handoffs = abandoned waits, *poisoned_calls = nfe_render calls whose outputs were set to NaN.  Either may be NULL. */
 int nfe_render(const nfe_render_args* args, nfe_stream_t stream);
+int nfe_render_status(uint32_t* lost_handoffs, uint32_t* poisoned_calls, int clear);
+/* Names of the render kernels the last nfe_render call of THIS thread launched, space separated, in launch order (e.g.
+ * "render_ws_kernel<4,2,SIGMA_ONLY> importance_kernel render_ws_kernel<4,2,DUAL>"); diagnostic, valid until the thread's next call. */
+const char* nfe_render_last_kernels(void);
 
 /* ---- a15: renderer.run_model on caller-supplied points (triplane.py:140-157, renderer.py:259-287)
  * coords [N,P,3] -> rgb [N,P,32], sigma [N,P], seg [N,P,15]. Plane/affine/decoder arguments as in

@@ -9,6 +9,9 @@
 // (:288-300).  See DESIGN.md §4 for the lane mapping and the MFMA operand layouts.
 #include "nfe_common.h"
 
+#include <atomic>
+#include <cstring>
+
 #ifndef NFE_RENDER_WS_DEFAULT
 #define NFE_RENDER_WS_DEFAULT 42    // 0: fused render_kernel; NP * 10 + WPS: render_ws_kernel, NP producer-consumer pairs per workgroup at WPS waves per SIMD
 #endif
@@ -53,6 +56,8 @@ struct RenderK {
     int seg_count;                 // SPLIT variants: depth segments per ray block (each marched by its own wave)
     float* partials;               // SPLIT variants: [N*M, seg_count, PARTIAL_FLOATS] segment composites, see render_combine_kernel
     unsigned long long* clock_probe;   // optional [4]: {s_memtime, s_memrealtime} of workgroup 0 / wave 0 at kernel start and end
+    unsigned* handoff_aborts;      // render_ws_kernel: count of wave pairs that abandoned a hand-off wait (word 2 of the workspace; every pass of a call adds here)
+    int ws_spin_limit;             // render_ws_kernel: polls after which a hand-off wait is abandoned (WS_SPIN_LIMIT; NFE_WS_SPIN_LIMIT shortens it for the abort test)
 };
 
 // LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then per wave AFF_FLOATS of
@@ -1472,15 +1477,17 @@ constexpr int WS_SPIN_LIMIT = 1 << 18;                      // x (s_sleep 1 + an
 
 // Wait until *flag has reached `need` (wrap-safe).  Returns false when the wait was abandoned: the flag's pair is then marked
 // aborted and every later wait of the pair returns at once - the launch finishes with garbage in that pair's rays and a count in
-// depth_minmax[2] instead of hanging the GPU.
-__device__ __forceinline__ bool ws_wait(unsigned* flags, int which, unsigned need) {
+// RenderK::handoff_aborts instead of hanging the GPU.  The count is not silent: depth_clamp_kernel, which closes every nfe_render
+// call, turns ALL outputs of a call with a non-zero count into NaN and adds the count to the library's pinned host status word, so
+// that the next nfe_render of the process fails with NFE_EHANDOFF (nfe_render.h, "lost hand-offs").
+__device__ __forceinline__ bool ws_wait(unsigned* flags, int which, unsigned need, int spin_limit) {
     int spins = 0;
     while (true) {
         const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
         if ((int)(v - need) >= 0) return true;
         const unsigned ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (ab != 0u) return false;
-        if (++spins > WS_SPIN_LIMIT) {
+        if (++spins > spin_limit) {
             __hip_atomic_store(flags + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return false;
         }
@@ -1774,14 +1781,14 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 // geometry tile + depths of sample `step` go to set step % WS_BUFS: the consumer must have read that set's previous
                 // content, the geometry tile of sample step - WS_BUFS
                 float* tile_g = tile_g0 + (int)(step % WS_BUFS) * WS_SET_FLOATS + opq;
-                if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 1u);
+                if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 1u, P.ws_spin_limit);
                 ws_write_tile(tile_g, lane, qn);
                 if (h == 0) tile_g[WS_T_OFF + j] = t;
                 if (SIGMA_ONLY) {                     // no appearance tile: both halves of the sample's count move at once
                     ws_signal(flags, 0, 2u * step + 2u, lane);
                 } else {
                     ws_signal(flags, 0, 2u * step + 1u, lane);
-                    if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 2u);
+                    if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 2u, P.ws_spin_limit);
                     ws_write_tile(tile_g + XCHG_FLOATS, lane, qd);
                     ws_signal(flags, 0, 2u * step + 2u, lane);
                 }
@@ -1797,8 +1804,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 atomicMin(P.depth_minmax + 0, f2ord(tmin));
                 atomicMax(P.depth_minmax + 1, f2ord(tmax));
             }
-            if (lane == 0 && !alive) atomicAdd(P.depth_minmax + 2, 1u);
         }
+        if (P.handoff_aborts && lane == 0 && !alive) atomicAdd(P.handoff_aborts, 1u);
 #ifdef WS_ONLY_PRODUCER
     } else if (false) {
 #else
@@ -1834,7 +1841,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 f32x16 og, oa;
                 float t;
                 {
-                    if (alive) alive = ws_wait(flags, 0, 2u * step + 1u);
+                    if (alive) alive = ws_wait(flags, 0, 2u * step + 1u, P.ws_spin_limit);
                     f32x2 fn[8];
                     ws_read_tile(tile_g, lane, fn);
                     t = tile_g[WS_T_OFF + j];
@@ -1848,7 +1855,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
 #endif
                 }
                 if (!SIGMA_ONLY) {
-                    if (alive) alive = ws_wait(flags, 0, 2u * step + 2u);
+                    if (alive) alive = ws_wait(flags, 0, 2u * step + 2u, P.ws_spin_limit);
                     f32x2 fd[8];
                     ws_read_tile(tile_g + XCHG_FLOATS, lane, fd);
                     ws_signal(flags, 1, 2u * step + 2u, lane);
@@ -1925,7 +1932,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 }
             }
         }
-        if (P.depth_minmax && lane == 0 && !alive) atomicAdd(P.depth_minmax + 2, 1u);
+        if (P.handoff_aborts && lane == 0 && !alive) atomicAdd(P.handoff_aborts, 1u);
     }
     if (probe && lane == 0) { P.clock_probe[2] = __builtin_amdgcn_s_memtime(); P.clock_probe[3] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -1967,10 +1974,26 @@ __global__ __launch_bounds__(256) void render_combine_kernel(RenderK P, int sigm
     }
 }
 
-// nan_to_num(depth, inf) then clamp to the whole-tensor [min,max] of sampled depths (ray_marcher.py:93-94)
-__global__ void depth_clamp_kernel(float* depth, long long n, const unsigned* minmax) {
+// nan_to_num(depth, inf) then clamp to the whole-tensor [min,max] of sampled depths (ray_marcher.py:93-94).
+// This kernel closes every nfe_render call, so it is also where a lost wave hand-off of render_ws_kernel becomes an error instead
+// of silent garbage: with minmax[2] != 0 every output of the call is overwritten with NaN and the count goes to the pinned host
+// status word (system-scope atomic), which the next nfe_render / nfe_render_status reads without any synchronisation.
+__global__ void depth_clamp_kernel(float* depth, float* rgb, float* seg, float* wsum, long long n, const unsigned* minmax, unsigned* host_status) {
     const float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned lost = minmax[2];
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
+    if (lost != 0u) {
+        const float bad = __uint_as_float(0x7fc00000u);
+        for (long long i = i0; i < n; i += stride) { depth[i] = bad; wsum[i] = bad; }
+        for (long long i = i0; i < n * NFE_RGB_CHANNELS; i += stride) rgb[i] = bad;
+        for (long long i = i0; i < n * NFE_SEG_CHANNELS; i += stride) seg[i] = bad;
+        if (i0 == 0 && host_status) {
+            __hip_atomic_fetch_add(host_status + 0, lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_fetch_add(host_status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        return;
+    }
+    for (long long i = i0; i < n; i += stride) {
         float d = depth[i];
         if (d != d) d = INFINITY;
         depth[i] = fminf(fmaxf(d, lo), hi);
@@ -1978,7 +2001,7 @@ __global__ void depth_clamp_kernel(float* depth, long long n, const unsigned* mi
 }
 
 __global__ void minmax_init_kernel(unsigned* minmax) {
-    minmax[0] = 0xFFFFFFFFu; minmax[1] = 0u; minmax[2] = 0u;      // [2]: hand-off waits abandoned by render_ws_kernel (must stay 0)
+    minmax[0] = 0xFFFFFFFFu; minmax[1] = 0u; minmax[2] = 0u;      // [2]: hand-off waits abandoned by render_ws_kernel in any pass of this call (RenderK::handoff_aborts)
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2315,21 +2338,38 @@ __global__ __launch_bounds__(256, 2) void decoder_kernel(DecoderK P) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
+constexpr int MAX_DEVICES = 64;
+static int current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess && dev >= 0 ? dev : 0; }
+// CU count of the CURRENT device (a process may render on several: one cached value per device id)
 static int num_cus() {
-    static int cus = 0;
+    static std::atomic<int> cached[MAX_DEVICES];
+    const int dev = current_device();
+    int cus = dev < MAX_DEVICES ? cached[dev].load(std::memory_order_relaxed) : 0;
     if (!cus) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-            cus = prop.multiProcessorCount;
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         if (cus <= 0) cus = 256;
+        if (dev < MAX_DEVICES) cached[dev].store(cus, std::memory_order_relaxed);
     }
     return cus;
 }
 
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute belongs to the (kernel, device) pair, so callers apply it per
+// device (LdsOptIn below) and a failure is an error of the launch, not something to find out from the launch's own failure.
 template <typename K>
-static void allow_lds(K kernel, int bytes) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+static hipError_t allow_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
+struct LdsOptIn {          // one per kernel instantiation (function-local static): which devices have the attribute
+    std::atomic<unsigned long long> done{0};
+    template <typename K> hipError_t apply(K kernel, int bytes) {
+        const int dev = current_device();
+        if (dev < MAX_DEVICES && (done.load(std::memory_order_acquire) >> dev & 1ull)) return hipSuccess;
+        const hipError_t e = allow_lds(kernel, bytes);
+        if (e == hipSuccess && dev < MAX_DEVICES) done.fetch_or(1ull << dev, std::memory_order_release);
+        return e;
+    }
+};
 
 template <bool DUAL, bool SIGMA_ONLY>
 static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_t st) {
@@ -2347,6 +2387,34 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
     }
 }
 
+// Which render kernels the last nfe_render call of this thread launched, in order (nfe_render_last_kernels: tests assert that a
+// fixture reaches the kernel variant it is meant to pin).
+static thread_local char g_kernels[256] = "";
+static void note_kernel(const char* name) {
+    const size_t have = strlen(g_kernels), add = strlen(name);
+    if (have + add + 2 >= sizeof(g_kernels)) return;
+    if (have) { g_kernels[have] = ' '; memcpy(g_kernels + have + 1, name, add + 1); } else memcpy(g_kernels, name, add + 1);
+}
+
+// Lost hand-offs (render_ws_kernel, see ws_wait): a pinned, device-visible host word per process.  depth_clamp_kernel adds a call's
+// abort count to word 0 (and 1 to word 1 = poisoned calls) with system-scope atomics; the host reads it WITHOUT synchronising at the
+// start of the next nfe_render (-> NFE_EHANDOFF, count reported and cleared) and in nfe_render_status.  Allocation failure leaves the
+// pointer null: outputs are still poisoned with NaN, only the return-code path is absent.
+static unsigned* handoff_status_word() {
+    static unsigned* word = [] {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return (unsigned*)nullptr; }
+        memset(p, 0, 64);
+        return (unsigned*)p;
+    }();
+    return word;
+}
+// polls of a hand-off wait before it is abandoned; NFE_WS_SPIN_LIMIT (read once) exists for tests/test_handoff_abort_gpu.py
+static int ws_spin_limit() {
+    static const int v = [] { const char* e = getenv("NFE_WS_SPIN_LIMIT"); const long long x = e ? atoll(e) : 0; return x > 0 && x < (1ll << 30) ? (int)x : WS_SPIN_LIMIT; }();
+    return v;
+}
+
 // Wave-specialised launch (render_ws_kernel): one plane set, full split-bf16 decoder, no noise / cross / kept colours, and enough
 // ray blocks to fill the chip without the depth split.  NFE_RENDER_WS=0 keeps the fused kernel (A/B, tests).
 static int ws_mode() {
@@ -2362,7 +2430,7 @@ static long long ws_min_ray_blocks() {
     return v;
 }
 template <int NP, int WPS, bool DUAL = false, bool SIGMA_ONLY = false>
-static void launch_render_ws(const RenderK& P, long long total_rb, hipStream_t st) {
+static hipError_t launch_render_ws(const RenderK& P, long long total_rb, hipStream_t st) {
     constexpr int bytes = ws_lds_bytes<NP>();
     constexpr int per_cu = (WPS * 4) / (2 * NP);          // workgroups per CU that make WPS waves per SIMD
     static_assert(per_cu >= 1 && per_cu * bytes <= 160 * 1024, "LDS of the resident workgroups");
@@ -2372,12 +2440,15 @@ static void launch_render_ws(const RenderK& P, long long total_rb, hipStream_t s
     const bool generic = P.depth_mode != DEPTH_STRATIFIED;
 #define NFE_WS_LAUNCH(SQ, GE)                                                                                                    \
     {                                                                                                                            \
-        static const bool once_ = (allow_lds(render_ws_kernel<NP, WPS, SQ, GE, DUAL, SIGMA_ONLY>, bytes), true); (void)once_;    \
+        static LdsOptIn opt_;                                                                                                    \
+        const hipError_t e_ = opt_.apply(render_ws_kernel<NP, WPS, SQ, GE, DUAL, SIGMA_ONLY>, bytes);                            \
+        if (e_ != hipSuccess) return e_;                                                                                         \
         hipLaunchKernelGGL((render_ws_kernel<NP, WPS, SQ, GE, DUAL, SIGMA_ONLY>), dim3((unsigned)blocks), dim3(NP * 128), bytes, st, P); \
     }
     if (P.H == P.W) { if (generic) NFE_WS_LAUNCH(true, true) else NFE_WS_LAUNCH(true, false) }
     else { if (generic) NFE_WS_LAUNCH(false, true) else NFE_WS_LAUNCH(false, false) }
 #undef NFE_WS_LAUNCH
+    return hipSuccess;
 }
 
 static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math, hipStream_t st) {
@@ -2394,8 +2465,11 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
     dim3 grid((unsigned)blocks);
     if (P.dec_cross) {       // validated by nfe_render: one plane set, split-bf16 decoder, no density_noise; the coarse pass of a
                              // two-pass render runs the full decoder too (sigma needs the appearance head's hidden layer)
-        allow_lds(render_kernel<false, false, NFE_MATH_BF16X3, false, true>, RENDER_LDS_BYTES_CROSS);
+        static LdsOptIn opt;
+        const hipError_t e = opt.apply(render_kernel<false, false, NFE_MATH_BF16X3, false, true>, RENDER_LDS_BYTES_CROSS);
+        if (e != hipSuccess) return fail(NFE_ELAUNCH, "render_kernel<CROSS>: LDS opt-in: %s", hipGetErrorString(e));
         hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, true>), grid, dim3(256), RENDER_LDS_BYTES_CROSS, st, P);
+        note_kernel("render_kernel<CROSS>");
         NFE_CHECK_LAUNCH("render_kernel");
         return NFE_OK;
     }
@@ -2426,6 +2500,7 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
             if (dual) { NFE_LAUNCH_SPLIT(true, false) } else { NFE_LAUNCH_SPLIT(false, false) }
         }
 #undef NFE_LAUNCH_SPLIT
+        note_kernel(sigma_only ? "render_kernel<SPLIT,SIGMA_ONLY>+render_combine_kernel" : dual ? "render_kernel<SPLIT,DUAL>+render_combine_kernel" : "render_kernel<SPLIT>+render_combine_kernel");
         NFE_CHECK_LAUNCH("render_kernel (split)");
         const long long rays = (long long)P.N * P.M;
         hipLaunchKernelGGL(render_combine_kernel, dim3((unsigned)((rays + 3) / 4)), dim3(256), 0, st, Q, sigma_only ? 1 : 0);
@@ -2434,21 +2509,13 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
     }
     if (ws_mode() && math == NFE_MATH_BF16X3 && P.density_noise == 0.0f && !P.tap_colors && (sigma_only || !P.out_weights) &&
         total_rb >= ws_min_ray_blocks() && (long long)P.N * P.M * P.S < (1ll << 31)) {
-        // pairs per workgroup x 10 + waves per SIMD.  Shipped: 42.  The 3- and 4-waves-per-SIMD geometries (63, 33, 84, 44) were built and
-        // measured slower (profiles/experiments/r04_render_ws.md); they are compiled only with -DNFE_WS_GEOMETRIES (and need WS_BUFS = 1 to fit their tiles into 160 KB of LDS)
-#if WS_BUFS == 1 && defined(NFE_WS_GEOMETRIES)       // experiment builds only
-        switch (ws_mode()) {
-            case 63: launch_render_ws<6, 3>(P, total_rb, st); break;
-            case 33: launch_render_ws<3, 3>(P, total_rb, st); break;
-            case 84: launch_render_ws<8, 4>(P, total_rb, st); break;
-            case 44: launch_render_ws<4, 4>(P, total_rb, st); break;
-            default: launch_render_ws<4, 2>(P, total_rb, st); break;
-        }
-#else
-        if (sigma_only) launch_render_ws<4, 2, false, true>(P, total_rb, st);
-        else if (dual) launch_render_ws<4, 2, true, false>(P, total_rb, st);
-        else launch_render_ws<4, 2>(P, total_rb, st);
-#endif
+        // four pairs per workgroup at two waves per SIMD; the 3- and 4-waves-per-SIMD geometries of round 4 measured slower
+        // (profiles/experiments/r04_render_ws.md) and are no longer in this file
+        hipError_t e;
+        if (sigma_only) { e = launch_render_ws<4, 2, false, true>(P, total_rb, st); note_kernel("render_ws_kernel<4,2,SIGMA_ONLY>"); }
+        else if (dual) { e = launch_render_ws<4, 2, true, false>(P, total_rb, st); note_kernel("render_ws_kernel<4,2,DUAL>"); }
+        else { e = launch_render_ws<4, 2>(P, total_rb, st); note_kernel("render_ws_kernel<4,2>"); }
+        if (e != hipSuccess) return fail(NFE_ELAUNCH, "render_ws_kernel: LDS opt-in (%d bytes): %s", ws_lds_bytes<4>(), hipGetErrorString(e));
         NFE_CHECK_LAUNCH("render_ws_kernel");
         return NFE_OK;
     }
@@ -2457,6 +2524,7 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
     } else {
         if (dual) launch_render_math<true, false>(P, math, grid, st); else launch_render_math<false, false>(P, math, grid, st);
     }
+    note_kernel(sigma_only ? "render_kernel<SIGMA_ONLY>" : dual ? "render_kernel<DUAL>" : "render_kernel");
     NFE_CHECK_LAUNCH("render_kernel");
     return NFE_OK;
 }
@@ -2581,6 +2649,20 @@ extern "C" uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int D, i
     return b;
 }
 
+extern "C" const char* nfe_render_last_kernels(void) { return g_kernels; }
+
+extern "C" int nfe_render_status(uint32_t* lost_handoffs, uint32_t* poisoned_calls, int clear) {
+    unsigned* status = handoff_status_word();
+    unsigned lost = 0, calls = 0;
+    if (status) {
+        if (clear) { lost = __atomic_exchange_n(status + 0, 0u, __ATOMIC_RELAXED); calls = __atomic_exchange_n(status + 1, 0u, __ATOMIC_RELAXED); }
+        else { lost = __atomic_load_n(status + 0, __ATOMIC_RELAXED); calls = __atomic_load_n(status + 1, __ATOMIC_RELAXED); }
+    }
+    if (lost_handoffs) *lost_handoffs = lost;
+    if (poisoned_calls) *poisoned_calls = calls;
+    return NFE_OK;
+}
+
 extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a != nullptr, "nfe_render: args is null");
     NFE_REQUIRE(a->struct_size == sizeof(nfe_render_args), "nfe_render: struct_size %u != %zu (ABI mismatch)",
@@ -2613,6 +2695,17 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     if (a->workspace_bytes < need) return fail(NFE_EWORKSPACE, "nfe_render: workspace %llu < %llu bytes",
                                                (unsigned long long)a->workspace_bytes, (unsigned long long)need);
     hipStream_t st = (hipStream_t)stream;
+    g_kernels[0] = 0;
+    unsigned* status = handoff_status_word();
+    if (status) {       // an EARLIER call's lost hand-offs (its outputs are NaN): reported once, by the next call, without a host sync
+        const unsigned lost = __atomic_exchange_n(status + 0, 0u, __ATOMIC_RELAXED);
+        if (lost) {
+            const unsigned calls = __atomic_exchange_n(status + 1, 0u, __ATOMIC_RELAXED);
+            return fail(NFE_EHANDOFF, "nfe_render: %u earlier render call(s) of this process lost %u wave hand-offs in render_ws_kernel "
+                                      "(a producer / consumer wave gave up waiting for its partner); their outputs were set to NaN. "
+                                      "Nothing was launched by this call; repeat it (NFE_RENDER_WS=0 selects the fused kernel)", calls, lost);
+        }
+    }
     const uint64_t nr = (uint64_t)a->n_views * a->n_rays;
     char* ws = (char*)a->workspace;
     unsigned* minmax = (unsigned*)ws; ws += 256;
@@ -2636,6 +2729,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.dec_cross = a->decoder_cross;
     P.clock_probe = reinterpret_cast<unsigned long long*>(a->clock_probe);
     P.partials = a->decoder_cross ? nullptr : partials;
+    P.handoff_aborts = minmax + 2; P.ws_spin_limit = ws_spin_limit();
     if (a->decoder_cross)
         NFE_REQUIRE(a->planes_geo == a->planes_app && a->decoder_math == NFE_MATH_BF16X3 && a->density_noise == 0.0f,
                     "nfe_render: decoder_cross (SegmentationOSGDecoder) needs one plane set, NFE_MATH_BF16X3 and density_noise == 0");
@@ -2684,6 +2778,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
             if (mx <= 64) NFE_IMP(1) else if (mx <= 128) NFE_IMP(2) else NFE_IMP(4)
 #undef NFE_IMP
         }
+        note_kernel("importance_kernel");
         NFE_CHECK_LAUNCH("importance_kernel");
         // pass 3: march the merged samples
         RenderK F = P;
@@ -2698,7 +2793,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     }
     long long cb = ((long long)nr + 255) / 256;
     if (cb > 4096) cb = 4096;
-    hipLaunchKernelGGL(depth_clamp_kernel, dim3((unsigned)cb), dim3(256), 0, st, a->depth, (long long)nr, minmax);
+    hipLaunchKernelGGL(depth_clamp_kernel, dim3((unsigned)cb), dim3(256), 0, st, a->depth, a->rgb, a->seg, a->wsum, (long long)nr, minmax, status);
     NFE_CHECK_LAUNCH("depth_clamp_kernel");
     return NFE_OK;
 }
@@ -2732,7 +2827,9 @@ extern "C" int nfe_point_query(const float* planes_geo, const float* planes_app,
     const bool dual = planes_geo != planes_app;
     dim3 grid((unsigned)blocks), block(256);
     if (decoder_cross) {
-        allow_lds(point_kernel<false, NFE_MATH_BF16X3, true>, RENDER_LDS_BYTES_CROSS);
+        static LdsOptIn opt;
+        const hipError_t e = opt.apply(point_kernel<false, NFE_MATH_BF16X3, true>, RENDER_LDS_BYTES_CROSS);
+        if (e != hipSuccess) return fail(NFE_ELAUNCH, "point_kernel<CROSS>: LDS opt-in: %s", hipGetErrorString(e));
         hipLaunchKernelGGL((point_kernel<false, NFE_MATH_BF16X3, true>), grid, block, RENDER_LDS_BYTES_CROSS, st, P);
     } else if (decoder_math == NFE_MATH_FP32) {
         if (dual) hipLaunchKernelGGL((point_kernel<true, NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);
@@ -2764,7 +2861,9 @@ extern "C" int nfe_decoder_forward(const float* features_geo, const float* featu
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((unsigned)blocks), block(256);
     if (decoder_cross) {
-        allow_lds(decoder_kernel<NFE_MATH_BF16X3, true>, RENDER_LDS_BYTES_CROSS);
+        static LdsOptIn opt;
+        const hipError_t e = opt.apply(decoder_kernel<NFE_MATH_BF16X3, true>, RENDER_LDS_BYTES_CROSS);
+        if (e != hipSuccess) return fail(NFE_ELAUNCH, "decoder_kernel<CROSS>: LDS opt-in: %s", hipGetErrorString(e));
         hipLaunchKernelGGL((decoder_kernel<NFE_MATH_BF16X3, true>), grid, block, RENDER_LDS_BYTES_CROSS, st, P);
     } else if (decoder_math == NFE_MATH_FP32) {
         hipLaunchKernelGGL((decoder_kernel<NFE_MATH_FP32>), grid, block, RENDER_LDS_BYTES, st, P);

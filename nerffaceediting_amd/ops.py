@@ -62,6 +62,22 @@ def render_handoff_aborts(device=None):
     return int(ws[:12].view(torch.int32)[2].item())
 
 
+def render_status(clear=False):
+    """nfe_render_status (no synchronisation): (lost_handoffs, poisoned_calls) of this process since the last clear.  A render call
+    whose wave-specialised kernel abandoned a hand-off wait has NaN in all its outputs and is counted here once its closing kernel has
+    run; the next render call raises RuntimeError (NFE_EHANDOFF) by itself - this is for callers that want to look first, e.g. right
+    after their own synchronisation point."""
+    lost, calls = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    _lib.check(_lib.load().nfe_render_status(ctypes.byref(lost), ctypes.byref(calls), 1 if clear else 0), "nfe_render_status")
+    return int(lost.value), int(calls.value)
+
+
+def render_last_kernels():
+    """Names of the render kernels the last ops.render call of this thread launched (nfe_render_last_kernels), as a list."""
+    s = _lib.load().nfe_render_last_kernels()
+    return s.decode().split() if s else []
+
+
 def ray_sampler(cam2world, intrinsics, resolution):
     """RaySampler.forward (ray_sampler.py:24-62): [N,4,4],[N,3,3] -> origins, dirs [N,R*R,3]."""
     lib = _lib.load()

@@ -168,7 +168,9 @@ def gen_render_full_size(name="fullsize_render", seed=401, N=1, R=512, H=256, D=
       fullsize_render: BASELINE config-2 size, 512^2 rays x 64 samples, 256^2 planes, one view;
       cfg5_render:     BASELINE config 5 (projector.py:33-34: 96 + 96 samples), 128^2 rays, two views, swapped statistics;
       ffhq_render:     the FFHQ rendering_kwargs (train.py:306-307: 128^2 rays, 48 + 48 samples), two views with
-                       swapped appearance statistics (norm_planes != normalised denorm_planes: the editing path)."""
+                       swapped appearance statistics (norm_planes != normalised denorm_planes: the editing path);
+      cfg5_render_ws:  config 5 at its THROUGHPUT launch shape: two 512^2 views (16 384 ray blocks), 96 + 96 samples, swapped
+                       statistics - the size at which the library takes its wave-specialised two-pass kernels."""
     rng = np.random.RandomState(seed)
     planes = smooth_planes(rng, N, H)
     dec_np = orc.random_decoder(seed + 1, bias_scale=0.3)
@@ -437,6 +439,8 @@ def main():
                          angles=((0.35, -0.15), (-0.3, 0.1)))
     gen_render_full_size("cfg5_render", seed=421, N=2, R=128, H=256, D=96, Ni=96, swap=True, stride=7, chunk=8192,
                          angles=((0.3, -0.1), (-0.25, 0.15)))
+    gen_render_full_size("cfg5_render_ws", seed=431, N=2, R=512, H=256, D=96, Ni=96, swap=True, stride=127, chunk=8192,
+                         angles=((0.3, -0.1), (-0.25, 0.15)))
     gen_legacy_renderer()
     gen_segmentation_decoder()
     gen_decoder_forward()
@@ -471,6 +475,10 @@ if __name__ == "__main__":
         # BASELINE config 5: 96 + 96 samples (projector.py:33-34), two plane sets with swapped statistics (utils.py:176 path)
         os.makedirs(OUT, exist_ok=True)
         gen_render_full_size("cfg5_render", seed=421, N=2, R=128, H=256, D=96, Ni=96, swap=True, stride=7, chunk=8192,
+                             angles=((0.3, -0.1), (-0.25, 0.15)))
+    elif len(sys.argv) > 1 and sys.argv[1] == "cfg5_render_ws":
+        os.makedirs(OUT, exist_ok=True)
+        gen_render_full_size("cfg5_render_ws", seed=431, N=2, R=512, H=256, D=96, Ni=96, swap=True, stride=127, chunk=8192,
                              angles=((0.3, -0.1), (-0.25, 0.15)))
     elif len(sys.argv) > 1 and sys.argv[1] == "ffhq_render":
         os.makedirs(OUT, exist_ok=True)

@@ -1,0 +1,89 @@
+"""The error surface of a lost wave hand-off in render_ws_kernel (include/nfe_render.h, "lost hand-offs"; NFE_EHANDOFF).
+
+The wave-specialised render kernel bounds its producer / consumer waits so that a lost partner can never hang the GPU.  A wait
+that gives up must not become silent garbage: the reference's ops fail loudly (TORCH_CHECK, torch_utils/ops/bias_act.cpp:39-55).
+Here a child interpreter shortens the bound to ONE poll (NFE_WS_SPIN_LIMIT=1, read once per process: a consumer's first wait
+for a tile that needs a whole gather is then certain to be abandoned) and checks the three things the header promises:
+  1. every output of the affected call is NaN;
+  2. the NEXT render call raises RuntimeError (NFE_EHANDOFF) naming the count, and launches nothing;
+  3. the call after that works again (the status word was cleared) - with the bound back in force it would abort again, so the
+     child checks this through the fused kernel (too few ray blocks for the wave-specialised launch).
+Both passes of a two-pass render count (the coarse sigma-only pass has no depth min/max words but does have the abort counter)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PROG = r"""
+import numpy as np, torch
+from nerffaceediting_amd import ops
+from oracle import render_oracle as orc           # camera construction only
+dev = torch.device("cuda:0")
+g = torch.Generator(device="cpu").manual_seed(5)
+N, R, H = 1, 512, 64
+raw = torch.randn(N, 96, H, H, generator=g).to(dev)
+mean, std = ops.plane_stats(raw)
+packed, aff = ops.plane_pack(raw), ops.make_affine(mean, std)
+shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+dec = ops.decoder_pack(*[(torch.randn(*s, generator=g) * (1.0 if len(s) == 2 else 0.2)).to(dev) for s in shapes])
+c2w = torch.from_numpy(orc.lookat_pose(np.pi / 2 + 0.3, np.pi / 2 - 0.2, [0, 0, 0.2], 2.7).reshape(1, 4, 4).astype(np.float32)).to(dev)
+K = torch.from_numpy(orc.fov_to_intrinsics(18.837)[None].astype(np.float32)).to(dev)
+cam = dict(cam2world=c2w, intrinsics=K, affines=aff)
+for D, Di, want in ((16, 0, ["render_ws_kernel<4,2>"]),
+                    (12, 12, ["render_ws_kernel<4,2,SIGMA_ONLY>", "importance_kernel", "render_ws_kernel<4,2>"])):
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    assert ops.render_status(clear=True) is not None
+    out = ops.render(packed, packed, dec, opts, resolution=R, **cam)[:4]          # 8 192 ray blocks: wave-specialised launch
+    assert ops.render_last_kernels() == want, ops.render_last_kernels()
+    torch.cuda.synchronize()
+    assert all(bool(torch.isnan(o).all()) for o in out), "outputs of a call that lost hand-offs must be NaN, all of them"
+    lost, calls = ops.render_status()
+    assert lost > 0 and calls == 1, (lost, calls)
+    assert ops.render_handoff_aborts() == lost
+    try:
+        ops.render(packed, packed, dec, opts, resolution=R, **cam)
+        raise SystemExit("the call after a poisoned one must raise")
+    except RuntimeError as e:
+        assert "(-4)" in str(e) and "lost %d wave hand-offs" % lost in str(e), str(e)
+    assert ops.render_status() == (0, 0)                                            # reported once, then cleared
+    small = ops.render(packed, packed, dec, opts, resolution=64, **cam)[:4]         # 128 ray blocks: fused kernel, no hand-off
+    assert not any(k.startswith("render_ws_kernel") for k in ops.render_last_kernels())
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(o).all()) for o in small) and ops.render_status() == (0, 0)
+print("HANDOFF_ABORT_OK")
+"""
+
+
+def test_lost_handoff_poisons_outputs_and_fails_the_next_call():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NFE_WS_SPIN_LIMIT="1", PYTHONPATH=root)
+    env.pop("NFE_RENDER_WS", None)
+    r = subprocess.run([sys.executable, "-c", PROG], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "HANDOFF_ABORT_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+def test_default_bound_loses_nothing():
+    """The shipped bound (2^18 polls, ~50 ms): a full-size launch reports zero lost hand-offs and a clean status word."""
+    import torch
+    from nerffaceediting_amd import ops
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(6)
+    raw = torch.randn(2, 96, 128, 128, generator=g).to(dev)
+    mean, std = ops.plane_stats(raw)
+    shapes = [(64, 32), (64,), (16, 64), (16,), (64, 32), (64,), (32, 64), (32,)]
+    dec = ops.decoder_pack(*[(torch.randn(*s, generator=g) * (1.0 if len(s) == 2 else 0.2)).to(dev) for s in shapes])
+    import numpy as np
+    from oracle import render_oracle as orc           # camera construction only
+    c2w = torch.from_numpy(np.concatenate([orc.lookat_pose(np.pi / 2 + y, np.pi / 2 - 0.2, [0, 0, 0.2], 2.7).reshape(1, 4, 4)
+                                           for y in (0.3, -0.3)]).astype(np.float32)).to(dev)
+    K = torch.from_numpy(np.repeat(orc.fov_to_intrinsics(18.837)[None], 2, 0).astype(np.float32)).to(dev)
+    ops.render_status(clear=True)
+    opts = dict(depth_resolution=32, depth_resolution_importance=32, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    out = ops.render(ops.plane_pack(raw), ops.plane_pack(raw), dec, opts, cam2world=c2w, intrinsics=K, resolution=512,
+                     affines=ops.make_affine(mean, std))[:4]
+    assert ops.render_last_kernels()[0] == "render_ws_kernel<4,2,SIGMA_ONLY>"
+    assert ops.render_handoff_aborts() == 0 and ops.render_status() == (0, 0)
+    assert all(bool(torch.isfinite(o).all()) for o in out)

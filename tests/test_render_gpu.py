@@ -314,6 +314,59 @@ def test_render_two_pass_dual_vs_reference(name, math, dev):
         assert da.shape == (N, R * R, D + Ni) and bool((da[..., 1:] >= da[..., :-1]).all()), "merged depths must be sorted"
 
 
+@pytest.mark.parametrize("math", ["bf16x3"])
+def test_two_pass_wave_specialised_kernels_vs_reference(math, dev):
+    """BASELINE config 5 at its THROUGHPUT launch shape, against the reference renderer (renderer.py:301-363 through the editing
+    entry of utils.py:176; sample counts of projector.py:33-34): two 512^2 views = 16 384 ray blocks, 96 + 96 samples, swapped
+    appearance statistics.  At this size nfe_render takes the kernels `bench.py --workload twopass` times - render_ws_kernel<4,2,
+    SIGMA_ONLY> for the coarse pass and render_ws_kernel<4,2,DUAL> (two plane sets) or <4,2> (single gather + affines) for the
+    final pass - which the 128^2 fixture (`cfg5_render`, 1 024 ray blocks) never reaches.  The test asserts the kernel names the
+    library reports for the call, that no wave hand-off was lost, and the outputs of every 127th ray + the fp64 means."""
+    import ast
+    import torch
+    from nerffaceediting_amd import ops
+    z = load("cfg5_render_ws")
+    seed, N, R, H, D, Ni, stride = (int(z[k]) for k in ("seed", "N", "R", "H", "D", "Ni", "stride"))
+    rng = np.random.RandomState(seed)
+    base = rng.randn(N, 96, H, H).astype(np.float32)                 # gen_golden.smooth_planes
+    mu = rng.randn(1, 96, 1, 1).astype(np.float32) * 0.7
+    sd = np.exp(rng.randn(1, 96, 1, 1).astype(np.float32) * 0.5)
+    planes = (base * sd + mu).astype(np.float32)
+    dec = orc.random_decoder(seed + 1, bias_scale=0.3)
+    u_c = rng.rand(N, R * R, D).astype(np.float32)
+    u_f = rng.rand(N * R * R, Ni).astype(np.float32)
+    opts = ast.literal_eval(str(z["options"]))
+    assert (opts["depth_resolution"], opts["depth_resolution_importance"], R) == (96, 96, 512)
+    p = _t(planes, dev)
+    mean, std = ops.plane_stats(p)
+    normed = (p - mean) / (std + 1e-8)
+    denormed = normed * std.flip(0) + mean.flip(0)
+    names = ["geo_net.0.weight", "geo_net.0.bias", "geo_net.2.weight", "geo_net.2.bias",
+             "app_net.0.weight", "app_net.0.bias", "app_net.2.weight", "app_net.2.bias"]
+    decp = ops.decoder_pack(*[_t(dec[k], dev) for k in names])
+    cam = dict(cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev), resolution=R,
+               u_coarse=_t(u_c, dev), u_fine=_t(u_f, dev), decoder_math=math)
+    idx = torch.arange(0, R * R, stride, device=dev)
+    aff = ops.make_affine(mean, std, mean.flip(0).contiguous(), std.flip(0).contiguous())
+    packed = ops.plane_pack(p)
+    forms = {"dual": (ops.plane_pack(normed.contiguous()), ops.plane_pack(denormed.contiguous()), None, "render_ws_kernel<4,2,DUAL>"),
+             "single": (packed, packed, aff, "render_ws_kernel<4,2>")}
+    del normed, denormed
+    ops.render_status(clear=True)
+    for form, (pg, pa, af, final_kernel) in forms.items():
+        rgb, seg, depth, wsum = ops.render(pg, pa, decp, opts, affines=af, **cam)[:4]       # no taps: the throughput call
+        kernels = ops.render_last_kernels()
+        assert kernels == ["render_ws_kernel<4,2,SIGMA_ONLY>", "importance_kernel", final_kernel], kernels
+        assert ops.render_handoff_aborts() == 0 and ops.render_status() == (0, 0)
+        errs = {"rgb": max_abs(rgb[:, idx].cpu().numpy(), z["rgb"]), "seg": max_abs(seg[:, idx].cpu().numpy(), z["seg"]),
+                "depth": max_abs(depth[:, idx].cpu().numpy(), z["depth"]), "wsum": max_abs(wsum[:, idx].cpu().numpy(), z["wsum"])}
+        print("cfg5_render_ws", form, math, kernels, errs)
+        for k, e in errs.items():
+            assert e <= TIGHT[math] or (k == "depth" and e <= TOL), (form, k, e)
+        assert max_abs(rgb.double().mean(dim=(0, 1)).cpu().numpy(), z["rgb_mean"]) <= 2e-5
+        assert abs(float(wsum.double().mean()) - float(z["wsum_mean"])) <= 2e-5
+
+
 def test_depth_split_launches_match_unsplit(dev):
     """Few-ray launches cut every ray block's march into depth segments marched by different waves (render_combine_kernel
     composites them).  Same inputs, split on (this process) vs off (NFE_RENDER_SPLIT=0 is read once per process: child
