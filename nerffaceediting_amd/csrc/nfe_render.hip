@@ -46,7 +46,7 @@ struct RenderK {
     float* rgb; float* seg; float* depth; float* wsum; int channels_first;
     float* out_depths;             // optional [N*M, S]
     float* out_weights;            // optional [N*M, S-1]
-    unsigned* depth_minmax;        // ordered-uint {min, max}
+    unsigned* depth_minmax;        // ordered-uint {min, max}, and [2] = wave pairs of render_ws_kernel that abandoned a hand-off wait
     float density_noise;           // std of the Gaussian added to sigma (renderer.py:285-286), NOISE variants only
     const int* src_buf;            // DEPTH_BUFFER + NOISE: [N*M, S] which draw each merged sample is (k, or D + fine rank)
     const float* dec_cross;        // CROSS variants: packed cross fragments (nfe_decoder_pack_cross)
@@ -56,8 +56,6 @@ struct RenderK {
     int seg_count;                 // SPLIT variants: depth segments per ray block (each marched by its own wave)
     float* partials;               // SPLIT variants: [N*M, seg_count, PARTIAL_FLOATS] segment composites, see render_combine_kernel
     unsigned long long* clock_probe;   // optional [4]: {s_memtime, s_memrealtime} of workgroup 0 / wave 0 at kernel start and end
-    unsigned* handoff_aborts;      // render_ws_kernel: count of wave pairs that abandoned a hand-off wait (word 2 of the workspace; every pass of a call adds here)
-    int ws_spin_limit;             // render_ws_kernel: polls after which a hand-off wait is abandoned (WS_SPIN_LIMIT; NFE_WS_SPIN_LIMIT shortens it for the abort test)
 };
 
 // LDS map (floats): [0, DEC_FLOATS) decoder image shared by the block's 4 waves, then per wave AFF_FLOATS of
@@ -132,6 +130,9 @@ __device__ __forceinline__ float min126_bits(float y) { return __int_as_float(mi
 #ifndef NFE_SOFTPLUS_MINFORM
 #define NFE_SOFTPLUS_MINFORM 0
 #endif
+#ifndef NFE_SOFTPLUS_PHASED
+#define NFE_SOFTPLUS_PHASED 1
+#endif
 #ifndef NFE_SOFTPLUS_SCALAR
 #define NFE_SOFTPLUS_SCALAR 0      // 1: EXPERIMENT ONLY, KNOWN WRONG - plain v_add_f32 through inline asm instead of v_pk_add_f32.  The asm
 #endif                             // instruction reads a v_exp_f32 / v_log_f32 result one instruction after it was written, without the wait state
@@ -142,7 +143,30 @@ __device__ __forceinline__ float add_f32_plain(float a, float b) {      // an ad
     asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// vector ALU and transcendental instructions stay on their side of this fence; MFMA, LDS, scalar and memory instructions may cross
+#define NFE_VALU_FENCE() __builtin_amdgcn_sched_barrier(0x4 | 0x8 | 0x10 | 0x80)
 __device__ __forceinline__ void softplus_log2_x16(f32x16& a) {
+#if NFE_SOFTPLUS_PHASED
+    // Four phases of INDEPENDENT instructions (16 exps, 8 packed adds, 16 logs, 8 packed adds + 16 integer max): left to itself the
+    // scheduler sometimes emits the per-pair dependent chain exp, exp -> add -> log, log -> add with a hazard nop between every two
+    // instructions (+9 % kernel cycles, found in round 5 when an unrelated edit flipped it); the fences pin the batched order.
+    f32x2 e[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = f32x2{exp2_fast(-__builtin_fabsf(a[2 * r])), exp2_fast(-__builtin_fabsf(a[2 * r + 1]))};
+    NFE_VALU_FENCE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = e[r] + splat(1.0f);
+    NFE_VALU_FENCE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) e[r] = f32x2{log2_fast(e[r][0]), log2_fast(e[r][1])};
+    NFE_VALU_FENCE();
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const f32x2 l = e[r] + f32x2{relu_bits(a[2 * r]), relu_bits(a[2 * r + 1])};
+        a[2 * r] = l[0]; a[2 * r + 1] = l[1];
+    }
+    return;
+#endif
 #pragma unroll
     for (int r = 0; r < 16; r += 2) {
 #if NFE_SOFTPLUS_SCALAR
@@ -1477,17 +1501,18 @@ constexpr int WS_SPIN_LIMIT = 1 << 18;                      // x (s_sleep 1 + an
 
 // Wait until *flag has reached `need` (wrap-safe).  Returns false when the wait was abandoned: the flag's pair is then marked
 // aborted and every later wait of the pair returns at once - the launch finishes with garbage in that pair's rays and a count in
-// RenderK::handoff_aborts instead of hanging the GPU.  The count is not silent: depth_clamp_kernel, which closes every nfe_render
+// depth_minmax[2] instead of hanging the GPU.  The count is not silent: depth_clamp_kernel, which closes every nfe_render
 // call, turns ALL outputs of a call with a non-zero count into NaN and adds the count to the library's pinned host status word, so
 // that the next nfe_render of the process fails with NFE_EHANDOFF (nfe_render.h, "lost hand-offs").
-__device__ __forceinline__ bool ws_wait(unsigned* flags, int which, unsigned need, int spin_limit) {
+__device__ int g_ws_spin_limit = WS_SPIN_LIMIT;            // device global, read only on the slow path of a wait (NFE_WS_SPIN_LIMIT: the abort test shortens it)
+__device__ __forceinline__ bool ws_wait(unsigned* flags, int which, unsigned need) {
     int spins = 0;
     while (true) {
         const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
         if ((int)(v - need) >= 0) return true;
         const unsigned ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (ab != 0u) return false;
-        if (++spins > spin_limit) {
+        if (++spins > __builtin_nontemporal_load(&g_ws_spin_limit)) {
             __hip_atomic_store(flags + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return false;
         }
@@ -1781,14 +1806,14 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 // geometry tile + depths of sample `step` go to set step % WS_BUFS: the consumer must have read that set's previous
                 // content, the geometry tile of sample step - WS_BUFS
                 float* tile_g = tile_g0 + (int)(step % WS_BUFS) * WS_SET_FLOATS + opq;
-                if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 1u, P.ws_spin_limit);
+                if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 1u);
                 ws_write_tile(tile_g, lane, qn);
                 if (h == 0) tile_g[WS_T_OFF + j] = t;
                 if (SIGMA_ONLY) {                     // no appearance tile: both halves of the sample's count move at once
                     ws_signal(flags, 0, 2u * step + 2u, lane);
                 } else {
                     ws_signal(flags, 0, 2u * step + 1u, lane);
-                    if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 2u, P.ws_spin_limit);
+                    if (alive) alive = ws_wait(flags, 1, 2u * (step - (unsigned)WS_BUFS) + 2u);
                     ws_write_tile(tile_g + XCHG_FLOATS, lane, qd);
                     ws_signal(flags, 0, 2u * step + 2u, lane);
                 }
@@ -1804,8 +1829,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 atomicMin(P.depth_minmax + 0, f2ord(tmin));
                 atomicMax(P.depth_minmax + 1, f2ord(tmax));
             }
+            if (lane == 0 && !alive) atomicAdd(P.depth_minmax + 2, 1u);
         }
-        if (P.handoff_aborts && lane == 0 && !alive) atomicAdd(P.handoff_aborts, 1u);
 #ifdef WS_ONLY_PRODUCER
     } else if (false) {
 #else
@@ -1841,7 +1866,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 f32x16 og, oa;
                 float t;
                 {
-                    if (alive) alive = ws_wait(flags, 0, 2u * step + 1u, P.ws_spin_limit);
+                    if (alive) alive = ws_wait(flags, 0, 2u * step + 1u);
                     f32x2 fn[8];
                     ws_read_tile(tile_g, lane, fn);
                     t = tile_g[WS_T_OFF + j];
@@ -1855,7 +1880,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
 #endif
                 }
                 if (!SIGMA_ONLY) {
-                    if (alive) alive = ws_wait(flags, 0, 2u * step + 2u, P.ws_spin_limit);
+                    if (alive) alive = ws_wait(flags, 0, 2u * step + 2u);
                     f32x2 fd[8];
                     ws_read_tile(tile_g + XCHG_FLOATS, lane, fd);
                     ws_signal(flags, 1, 2u * step + 2u, lane);
@@ -1932,7 +1957,7 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                 }
             }
         }
-        if (P.handoff_aborts && lane == 0 && !alive) atomicAdd(P.handoff_aborts, 1u);
+        if (P.depth_minmax && lane == 0 && !alive) atomicAdd(P.depth_minmax + 2, 1u);
     }
     if (probe && lane == 0) { P.clock_probe[2] = __builtin_amdgcn_s_memtime(); P.clock_probe[3] = __builtin_amdgcn_s_memrealtime(); }
 }
@@ -1980,7 +2005,7 @@ __global__ __launch_bounds__(256) void render_combine_kernel(RenderK P, int sigm
 // status word (system-scope atomic), which the next nfe_render / nfe_render_status reads without any synchronisation.
 __global__ void depth_clamp_kernel(float* depth, float* rgb, float* seg, float* wsum, long long n, const unsigned* minmax, unsigned* host_status) {
     const float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
-    const unsigned lost = minmax[2];
+    const unsigned lost = minmax[2] + minmax[6];       // final pass + coarse pass (whose min / max words 4, 5 are scratch)
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
     if (lost != 0u) {
         const float bad = __uint_as_float(0x7fc00000u);
@@ -2001,7 +2026,8 @@ __global__ void depth_clamp_kernel(float* depth, float* rgb, float* seg, float* 
 }
 
 __global__ void minmax_init_kernel(unsigned* minmax) {
-    minmax[0] = 0xFFFFFFFFu; minmax[1] = 0u; minmax[2] = 0u;      // [2]: hand-off waits abandoned by render_ws_kernel in any pass of this call (RenderK::handoff_aborts)
+    minmax[0] = 0xFFFFFFFFu; minmax[1] = 0u; minmax[2] = 0u;      // [2]: hand-off waits abandoned by render_ws_kernel (must stay 0)
+    minmax[4] = 0xFFFFFFFFu; minmax[5] = 0u; minmax[6] = 0u;      // the same three words for the coarse pass of a two-pass call: its min / max are not used, its count is
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2409,10 +2435,18 @@ static unsigned* handoff_status_word() {
     }();
     return word;
 }
-// polls of a hand-off wait before it is abandoned; NFE_WS_SPIN_LIMIT (read once) exists for tests/test_handoff_abort_gpu.py
-static int ws_spin_limit() {
-    static const int v = [] { const char* e = getenv("NFE_WS_SPIN_LIMIT"); const long long x = e ? atoll(e) : 0; return x > 0 && x < (1ll << 30) ? (int)x : WS_SPIN_LIMIT; }();
-    return v;
+// Polls of a hand-off wait before it is abandoned: the device global g_ws_spin_limit.  NFE_WS_SPIN_LIMIT (read once) overrides it for
+// tests/test_handoff_abort_gpu.py; the symbol is written once per device, and only when the variable is set.
+static int apply_ws_spin_limit() {
+    static const int v = [] { const char* e = getenv("NFE_WS_SPIN_LIMIT"); const long long x = e ? atoll(e) : 0; return x > 0 && x < (1ll << 30) ? (int)x : 0; }();
+    if (!v) return NFE_OK;
+    static std::atomic<unsigned long long> done{0};
+    const int dev = current_device();
+    if (dev < MAX_DEVICES && (done.load(std::memory_order_acquire) >> dev & 1ull)) return NFE_OK;
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_ws_spin_limit), &v, sizeof(int));
+    if (e != hipSuccess) return fail(NFE_ELAUNCH, "NFE_WS_SPIN_LIMIT: hipMemcpyToSymbol: %s", hipGetErrorString(e));
+    if (dev < MAX_DEVICES) done.fetch_or(1ull << dev, std::memory_order_release);
+    return NFE_OK;
 }
 
 // Wave-specialised launch (render_ws_kernel): one plane set, full split-bf16 decoder, no noise / cross / kept colours, and enough
@@ -2729,7 +2763,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.dec_cross = a->decoder_cross;
     P.clock_probe = reinterpret_cast<unsigned long long*>(a->clock_probe);
     P.partials = a->decoder_cross ? nullptr : partials;
-    P.handoff_aborts = minmax + 2; P.ws_spin_limit = ws_spin_limit();
+    if (int rc = apply_ws_spin_limit()) return rc;
     if (a->decoder_cross)
         NFE_REQUIRE(a->planes_geo == a->planes_app && a->decoder_math == NFE_MATH_BF16X3 && a->density_noise == 0.0f,
                     "nfe_render: decoder_cross (SegmentationOSGDecoder) needs one plane set, NFE_MATH_BF16X3 and density_noise == 0");
@@ -2756,7 +2790,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         int* src_all = a->density_noise > 0.0f ? (int*)ws : nullptr;      // present only with density_noise (checked above)
         // pass 1: coarse densities -> weights (only sigma is needed: geometry net, geometry planes)
         RenderK C = P;
-        C.S = D; C.depth_mode = mode; C.u = a->u_coarse; C.depth_minmax = nullptr;
+        C.S = D; C.depth_mode = mode; C.u = a->u_coarse; C.depth_minmax = minmax + 4;      // scratch min / max, and the coarse pass's abort count
         C.out_depths = t_c; C.out_weights = w_c;
         int rc = launch_render(C, dual, true, math, st);
         if (rc) return rc;

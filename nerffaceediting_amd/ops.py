@@ -52,14 +52,15 @@ def _workspace(device, nbytes):
 
 def render_handoff_aborts(device=None):
     """Diagnostic (synchronises): how many producer / consumer waits render_ws_kernel abandoned in the LAST nfe_render call issued
-    from the current stream of `device` (word 2 of the render workspace, zeroed by every call).  Must be 0: a non-zero count means a
+    from the current stream of `device` (words 2 and 6 of the render workspace, zeroed by every call).  Must be 0: a non-zero count means a
     wave pair lost its partner, finished with garbage in its rays instead of hanging the GPU, and the outputs are invalid."""
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
     ws = _workspaces.get((device.index, torch.cuda.current_stream(device).cuda_stream))
     if ws is None:
         return 0
     torch.cuda.synchronize(device)
-    return int(ws[:12].view(torch.int32)[2].item())
+    words = ws[:32].view(torch.int32).cpu()
+    return int(words[2]) + int(words[6])         # final pass + coarse pass of a two-pass call
 
 
 def render_status(clear=False):

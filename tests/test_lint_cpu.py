@@ -74,6 +74,61 @@ def test_pk_opsel_fixer_commutes_exactly_the_hazardous_form():
         assert f.fix_line(ok) == (ok, 0) and f.hazardous(ok) is None
 
 
+def test_pk_opsel_fixer_fails_closed_on_anything_it_cannot_parse():
+    """Round 5: a `v_pk_{mul,add,fma}_f32` line the pass does not fully understand is a BUILD ERROR, never "not hazardous": unknown
+    modifier spellings, wrong bit counts, unknown operand kinds, a missing operand, an unknown packed-fp32 opcode.  Trailing flags
+    (`clamp`) and the three-source / `neg_*` spellings are parsed and survive the rewrite; comments of both tool chains are ignored."""
+    import pytest
+    f = _fixer()
+    for broken in ("\tv_pk_mul_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,1] opsel_hi:[1,0]",       # misspelt modifier
+                   "\tv_pk_mul_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,1,0]",                     # three bits for two sources
+                   "\tv_pk_fma_f32 v[8:9], v[6:7], v[10:11], v[12:13] op_sel:[0,1]",             # two bits for three sources
+                   "\tv_pk_mul_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,2]",                       # not a bit
+                   "\tv_pk_mul_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,1] mul:2",                 # an output modifier nobody has seen here
+                   "\tv_pk_mul_f32 v[8:9], v[6:7], @weird op_sel:[0,1]",                         # operand kind
+                   "\tv_pk_mul_f32 v[8:9], v[6:7] op_sel:[0,1]",                                 # too few operands
+                   "\tv_pk_fma_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,1]",
+                   "\tv_pk_mul_f32 v8, v[6:7], v[10:11]",                                        # destination is not a pair
+                   "\tv_pk_mul_f32_dpp v[8:9], v[6:7], v[10:11] op_sel:[0,1]",
+                   "\tv_pk_max_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,1]"):                      # an opcode the finding was never tested on
+        with pytest.raises(f.ParseError):
+            f.hazardous(broken)
+        with pytest.raises(f.ParseError):
+            f.fix_line(broken)
+    new, n = f.fix_line("\tv_pk_add_f32 v[2:3], v[4:5], v[0:1] op_sel:[0,1] clamp")
+    assert n == 1 and new == "\tv_pk_add_f32 v[2:3], v[0:1], v[4:5] op_sel:[1,0] clamp"
+    new, n = f.fix_line("\tv_pk_fma_f32 v[0:1], v[6:7], v[8:9], v[2:3] op_sel:[0,1,1] op_sel_hi:[1,0,1] neg_lo:[1,0,1] neg_hi:[0,1,0] clamp ; encoding: [0x00]")
+    assert n == 1 and new == "\tv_pk_fma_f32 v[0:1], v[8:9], v[6:7], v[2:3] op_sel:[1,0,1] op_sel_hi:[0,1,1] neg_lo:[0,1,1] neg_hi:[1,0,0] clamp"
+    # llvm-objdump spelling (encoding column behind //), constants and scalar pairs as sources
+    assert f.hazardous("\tv_pk_mul_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,1] op_sel_hi:[1,0]     // 000000001F20: D3B14008 1002150C") is not None
+    for ok in ("\tv_pk_mul_f32 v[8:9], v[6:7], 1.0 op_sel_hi:[1,0]", "\tv_pk_add_f32 v[8:9], s[6:7], v[10:11]   // 0000: 00",
+               "\tv_pk_fma_f32 v[8:9], v[6:7], -0.5, v[10:11] op_sel_hi:[1,0,1]", "\tv_pk_mov_b32 v[8:9], v[6:7], v[10:11] op_sel:[0,1]"):
+        assert f.hazardous(ok) is None
+    # the command line: a parse failure is exit code 2 and leaves no output file behind that a Makefile rule could pick up as current
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        src, dst = os.path.join(td, "in.s"), os.path.join(td, "out.s")
+        open(src, "w").write("\tv_pk_mul_f32 v[8:9], v[6:7], v[10:11] op_sel:[0,1] weird:1\n")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "nerffaceediting_amd", "csrc", "pk_opsel_fix.py"), src, dst], capture_output=True, text=True)
+        assert r.returncode == 2 and "PARSE FAILURE" in r.stdout and not os.path.exists(dst)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "nerffaceediting_amd", "csrc", "pk_opsel_fix.py"), "--check", src], capture_output=True, text=True)
+        assert r.returncode == 2
+
+
+def test_no_hazardous_packed_fp32_operand_form_in_the_built_library():
+    """ANY build path: the gfx950 code objects inside nerffaceediting_amd/libnfe_render.so itself are disassembled (llvm-objdump -d)
+    and every packed-fp32 instruction is parsed and checked - so a library produced by a script that bypassed the Makefile's pass
+    (tools/ablate.sh once did) cannot ship the form unnoticed."""
+    csrc = os.path.join(ROOT, "nerffaceediting_amd", "csrc")
+    subprocess.check_call(["make", "-s", "-C", csrc, "-j4"], stdout=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, os.path.join(csrc, "pk_opsel_fix.py"), "--check-lib", os.path.join(ROOT, "nerffaceediting_amd", "libnfe_render.so")],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:]
+    import re
+    m = re.search(r"(\d+) code objects, (\d+) packed-fp32 mul/add/fma instructions, 0 hazardous, 0 unparsed", r.stdout)
+    assert m and int(m.group(1)) == 4 and int(m.group(2)) > 20000, r.stdout
+
+
 def test_no_hazardous_packed_fp32_operand_form_in_the_built_kernels():
     """The assembly the shipped objects are made from (csrc/build/*.hip.s, written by the Makefile AFTER the pass) contains no
     instance of the form, and hipcc's own output of at least one file does contain it (i.e. the pass is still needed and still
