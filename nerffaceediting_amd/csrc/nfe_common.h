@@ -94,23 +94,8 @@ struct Taps { int xc0, xc1, yc0, yc1; float w[4]; float wdef; };   // wdef = (su
 // 2-3 blamed the combined form `(vx && vy) ? w : 0` for zeros in lanes 48-63 (r02_lane_mask.md); the cause was the packed multiply
 // the vectoriser made of the weight products in BOTH forms (v_pk_mul_f32 ... op_sel:[0,1]: profiles/experiments/r04_pk_opsel_hazard.md),
 // which the build's assembly pass (csrc/pk_opsel_fix.py) now commutes.  -DNFE_TAPS_COMBINED=1 keeps the old form as a reproducer.
-#ifndef NFE_WAR_PAD
-#define NFE_WAR_PAD ""
-#endif
-#ifndef NFE_TAPS_NOP_A
-#define NFE_TAPS_NOP_A 0
-#endif
-#ifndef NFE_TAPS_NOP_B
-#define NFE_TAPS_NOP_B 0
-#endif
-#ifndef NFE_TAPS_COMBINED
-#define NFE_TAPS_COMBINED 0     // 1: EXPERIMENT ONLY (tools/repro_lane_mask.py): round 2's `(vx && vy) ? wx * wy : 0` weights, whose
-#endif                          //    scalar-unit mask combination came back stale for lanes 48-63 in bwd_scatter_sorted_kernel
 struct Axis {
     int c0, c1; float a0, a1; float in;
-#if NFE_TAPS_COMBINED
-    bool v0, v1; float e, d; int x0, x1, size;
-#endif
 };
 // Hide a value from the optimiser (no instruction): used where it would otherwise re-combine two per-lane conditions into one
 // scalar-unit mask operation (see above).
@@ -126,71 +111,12 @@ __device__ __forceinline__ Axis axis_geometry(int size, float g) {
     a.a1 = (unsigned)x1 < (unsigned)size ? d : 0.0f;
     a.c0 = min(max(x0, 0), size - 1); a.c1 = min(max(x1, 0), size - 1);
     a.in = opaque_f((unsigned)x0 < (unsigned)(size - 1) ? 1.0f : 0.0f);   // 0 <= x0 and x0 + 1 < size; opaque: see taps_from_axes
-#if NFE_TAPS_COMBINED
-    a.v0 = (unsigned)x0 < (unsigned)size; a.v1 = (unsigned)x1 < (unsigned)size; a.e = e; a.d = d; a.x0 = x0; a.x1 = x1; a.size = size;
-#endif
     return a;
 }
 __device__ __forceinline__ Taps taps_from_axes(const Axis& u, const Axis& v) {      // u indexes W, v indexes H
     Taps t;
     t.xc0 = u.c0; t.xc1 = u.c1; t.yc0 = v.c0; t.yc1 = v.c1;
-#if NFE_TAPS_COMBINED == 1
-    t.w[0] = (u.v0 && v.v0) ? u.e * v.e : 0.0f; t.w[1] = (u.v1 && v.v0) ? u.d * v.e : 0.0f;
-    t.w[2] = (u.v0 && v.v1) ? u.e * v.d : 0.0f; t.w[3] = (u.v1 && v.v1) ? u.d * v.d : 0.0f;
-#elif NFE_TAPS_COMBINED == 2
-    // the sequence pinned in inline asm INSIDE the real kernels: two VALU compares into SGPR pairs, NFE_TAPS_NOP_A wait states,
-    // the scalar AND into vcc, NFE_TAPS_NOP_B wait states, the select.  Only w[1]; the other three weights are the separable form.
-#define NFE_STR2(x) #x
-#define NFE_STR(x) NFE_STR2(x)
-    t.w[0] = u.a0 * v.a0; t.w[2] = u.a0 * v.a1; t.w[3] = u.a1 * v.a1;
-    {
-        float w1 = u.d * v.e;
-        unsigned long long m0, m1;
-        asm volatile("v_cmp_gt_u32_e64 %0, %3, %4\n\tv_cmp_gt_u32_e64 %1, %5, %6\n\t"
-                     "s_nop " NFE_STR(NFE_TAPS_NOP_A) "\n\ts_and_b64 vcc, %0, %1\n\ts_nop " NFE_STR(NFE_TAPS_NOP_B) "\n\t"
-                     "v_cndmask_b32_e32 %2, 0, %2, vcc"
-                     : "=&s"(m0), "=&s"(m1), "+v"(w1) : "s"(u.size), "v"(u.x1), "s"(v.size), "v"(v.x0) : "vcc");
-        t.w[1] = w1;
-    }
-#elif NFE_TAPS_COMBINED == 5
-    // probe (results are garbage on purpose): w[1] keeps the combined form on the SAME two flags whose single-compare selects are
-    // written beside it as 1.0 / 0.0 in w[2] (vx1) and w[3] (vy0): a record with w[1] == 0 but w[2] == w[3] == 1 shows that the
-    // compares were right and the scalar combination / its select was not (tools/debug_bwd_df.py prints the records).
-    t.w[0] = (u.v0 && v.v0) ? u.e * v.e : 0.0f; t.w[1] = (u.v1 && v.v0) ? u.d * v.e : 0.0f;
-    t.w[2] = u.v1 ? 1.0f : 0.0f; t.w[3] = v.v0 ? 1.0f : 0.0f;
-#elif NFE_TAPS_COMBINED == 4
-    // RAW experiment: as 2, but the two mask registers are ZEROED by the scalar unit first, so that a scalar read that overtakes
-    // the VALU compare's write shows (in 2 the registers still hold the previous sample's - identical - masks: a stale read is
-    // invisible, which is also why tools/microbench/lane_mask.hip never failed).  NFE_WAR_PAD sits between the compares and the AND.
-    t.w[0] = u.a0 * v.a0; t.w[2] = u.a0 * v.a1; t.w[3] = u.a1 * v.a1;
-    {
-        float w1 = u.d * v.e;
-        unsigned long long m0, m1;
-        asm volatile("s_mov_b64 %0, 0\n\ts_mov_b64 %1, 0\n\t"
-                     "v_cmp_gt_u32_e64 %0, %3, %4\n\tv_cmp_gt_u32_e64 %1, %5, %6\n\t" NFE_WAR_PAD
-                     "s_and_b64 vcc, %0, %1\n\t"
-                     "v_cndmask_b32_e32 %2, 0, %2, vcc"
-                     : "=&s"(m0), "=&s"(m1), "+v"(w1) : "s"(u.size), "v"(u.x1), "s"(v.size), "v"(v.x0) : "vcc");
-        t.w[1] = w1;
-    }
-#elif NFE_TAPS_COMBINED == 3
-    // WAR experiment: the select reads its lane mask from an SGPR pair, and the scalar unit OVERWRITES that pair right behind it
-    // (NFE_WAR_PAD = instructions in between).  If a wave64 VALU instruction reads its mask operand pass by pass (lanes 48-63 last),
-    // a scalar write issued behind it can reach the register first when the VALU is delayed by the SIMD's other wave.
-    t.w[0] = u.a0 * v.a0; t.w[2] = u.a0 * v.a1; t.w[3] = u.a1 * v.a1;
-    {
-        float w1 = u.d * v.e;
-        unsigned long long m0, m1;
-        asm volatile("v_cmp_gt_u32_e64 %0, %3, %4\n\tv_cmp_gt_u32_e64 %1, %5, %6\n\t"
-                     "s_and_b64 %0, %0, %1\n\t"
-                     "v_cndmask_b32_e64 %2, 0, %2, %0\n\t" NFE_WAR_PAD
-                     "s_mov_b64 %0, 0"
-                     : "=&s"(m0), "=&s"(m1), "+v"(w1) : "s"(u.size), "v"(u.x1), "s"(v.size), "v"(v.x0));
-        t.w[1] = w1;
-    }
-#else
     t.w[0] = u.a0 * v.a0; t.w[1] = u.a1 * v.a0; t.w[2] = u.a0 * v.a1; t.w[3] = u.a1 * v.a1;
-#endif
     // (sum - 1) when a tap is outside, exactly 0 when all four are inside - as arithmetic on the two 1.0 / 0.0 flags.  The select
     // form `u.in * v.in != 0 ? 0 : sum - 1` was folded back by the compiler into v_cmp, v_cmp, s_and_b64, v_cndmask: the shape the
     // comment above keeps out of these kernels (tools/lint_lane_masks.py, S1).

@@ -12,14 +12,7 @@
 #include <atomic>
 #include <cstring>
 
-#ifndef NFE_RENDER_WS_DEFAULT
-#define NFE_RENDER_WS_DEFAULT 42    // 0: fused render_kernel; NP * 10 + WPS: render_ws_kernel, NP producer-consumer pairs per workgroup at WPS waves per SIMD
-#endif
-#ifdef NFE_SQUARE_RUNTIME
-#define NFE_SQUARE_RT 1
-#else
-#define NFE_SQUARE_RT 0
-#endif
+#define NFE_RENDER_WS_DEFAULT 1     // environment NFE_RENDER_WS: 0 = always the fused render_kernel, otherwise render_ws_kernel<4, 2> where it applies
 
 namespace nfe {
 
@@ -84,15 +77,8 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 union Frag { bf16x8 v; uint4 q; unsigned u[4]; };
 
-#ifndef NFE_PK_SCALAR
-#define NFE_PK_SCALAR 0      // experiment (with -fno-slp-vectorize): two v_fma_f32 instead of one v_pk_fma_f32 - packed fp32 shares the matrix
-#endif                       // pipe and cannot execute beside another wave's MFMA; plain VALU can (SQ_VALU_MFMA_COEXEC_CYCLES)
 __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
-#if NFE_PK_SCALAR
-    return f32x2{__builtin_fmaf(a[0], b[0], c[0]), __builtin_fmaf(a[1], b[1], c[1])};
-#else
     return __builtin_elementwise_fma(a, b, c);
-#endif
 }
 __device__ __forceinline__ f32x2 splat(float x) { return f32x2{x, x}; }
 
@@ -117,36 +103,13 @@ __device__ __forceinline__ float softplus_log2(float y) {
 // canonicalising v_max before the real one)
 __device__ __forceinline__ float relu_bits(float y) { return __int_as_float(max(__float_as_int(y), 0)); }
 
-// min(y, 126.0f) as one integer min on the bit pattern (negative floats are negative ints and stay; fminf costs a canonicalising
-// v_max before the v_min)
-__device__ __forceinline__ float min126_bits(float y) { return __int_as_float(min(__float_as_int(y), 0x42fc0000)); }
-
 // softplus_log2 over a whole accumulator.  Default: max(y,0) + log2(1 + 2^-|y|) - 4 instructions per value (v_exp with a free
 // -|y| source modifier, half a v_pk_add, v_log, v_max_i32, half a v_pk_add), no overflow, no threshold select, and exact for
 // every y: torch's Softplus returns x itself above its threshold and so does this form (the log term is 0 there).
-// NFE_SOFTPLUS_MINFORM=1 is the 3.5-instruction form log2(1 + 2^min(y, 126)) tried in round 2: it measured the same kernel
-// time (6.77 vs 6.79 ms) but saturates at y = 126, i.e. returns 87.3 for a hidden pre-activation x > 87.3 where the reference
-// returns x (edited / optimised planes can reach that), so it is not the default.
-#ifndef NFE_SOFTPLUS_MINFORM
-#define NFE_SOFTPLUS_MINFORM 0
-#endif
-#ifndef NFE_SOFTPLUS_PHASED
-#define NFE_SOFTPLUS_PHASED 1
-#endif
-#ifndef NFE_SOFTPLUS_SCALAR
-#define NFE_SOFTPLUS_SCALAR 0      // 1: EXPERIMENT ONLY, KNOWN WRONG - plain v_add_f32 through inline asm instead of v_pk_add_f32.  The asm
-#endif                             // instruction reads a v_exp_f32 / v_log_f32 result one instruction after it was written, without the wait state
-                                   // hipcc inserts only for its own instructions: run-dependent results on MI355X.  Kept as the reproducer of
-                                   // profiles/experiments/r04_asm_trans_hazard.md; tools/asm_audit.py (rule TRNS) flags all 36 sites.
-__device__ __forceinline__ float add_f32_plain(float a, float b) {      // an add the SLP vectoriser cannot pair into v_pk_add_f32
-    float r;
-    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
+// (The 3.5-instruction form log2(1 + 2^min(y, 126)) of round 2 saturates at x = 87.3 where the reference returns x; not kept.)
 // vector ALU and transcendental instructions stay on their side of this fence; MFMA, LDS, scalar and memory instructions may cross
 #define NFE_VALU_FENCE() __builtin_amdgcn_sched_barrier(0x4 | 0x8 | 0x10 | 0x80)
 __device__ __forceinline__ void softplus_log2_x16(f32x16& a) {
-#if NFE_SOFTPLUS_PHASED
     // Four phases of INDEPENDENT instructions (16 exps, 8 packed adds, 16 logs, 8 packed adds + 16 integer max): left to itself the
     // scheduler sometimes emits the per-pair dependent chain exp, exp -> add -> log, log -> add with a hazard nop between every two
     // instructions (+9 % kernel cycles, found in round 5 when an unrelated edit flipped it); the fences pin the batched order.
@@ -164,22 +127,6 @@ __device__ __forceinline__ void softplus_log2_x16(f32x16& a) {
     for (int r = 0; r < 8; ++r) {
         const f32x2 l = e[r] + f32x2{relu_bits(a[2 * r]), relu_bits(a[2 * r + 1])};
         a[2 * r] = l[0]; a[2 * r + 1] = l[1];
-    }
-    return;
-#endif
-#pragma unroll
-    for (int r = 0; r < 16; r += 2) {
-#if NFE_SOFTPLUS_SCALAR
-        const float e0 = add_f32_plain(exp2_fast(-__builtin_fabsf(a[r])), 1.0f), e1 = add_f32_plain(exp2_fast(-__builtin_fabsf(a[r + 1])), 1.0f);
-        a[r] = add_f32_plain(log2_fast(e0), relu_bits(a[r])); a[r + 1] = add_f32_plain(log2_fast(e1), relu_bits(a[r + 1]));
-#elif NFE_SOFTPLUS_MINFORM
-        const f32x2 e = f32x2{exp2_fast(min126_bits(a[r])), exp2_fast(min126_bits(a[r + 1]))} + splat(1.0f);
-        a[r] = log2_fast(e[0]); a[r + 1] = log2_fast(e[1]);
-#else
-        const f32x2 e = f32x2{exp2_fast(-__builtin_fabsf(a[r])), exp2_fast(-__builtin_fabsf(a[r + 1]))} + splat(1.0f);
-        const f32x2 l = f32x2{log2_fast(e[0]), log2_fast(e[1])} + f32x2{relu_bits(a[r]), relu_bits(a[r + 1])};
-        a[r] = l[0]; a[r + 1] = l[1];
-#endif
     }
 }
 
@@ -212,11 +159,7 @@ template <int I> __device__ __forceinline__ float quad_bcast(float v) { return _
 
 // One 16-byte piece of a texel: uniform base (SGPR pair) + 32-bit byte offset (the saddr form of global_load).
 __device__ __forceinline__ float4 texel_piece(const float* __restrict__ base, unsigned byte_off) {
-#ifdef NFE_ABLATE_GATHER   // timing experiment only (tools/ablate.sh): no plane loads
-    return make_float4((float)byte_off, 1.0f, 2.0f, 3.0f);
-#else
     return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
-#endif
 }
 
 // Bilinear weights travel through the LDS crossbar (ds_swizzle, quad-perm mode: no LDS memory, no VALU issue
@@ -227,12 +170,9 @@ template <int I> __device__ __forceinline__ float quad_swizzle(float v) {
 // ---- the gather, software-pipelined over the three planes (one plane set) ---------------------------------
 // Six batches of 8 loads (plane p, tap pair): two batches are in flight; the loads of batch b+2 are issued right
 // after batch b has been consumed, so only the first batch's latency is exposed per sample instead of one per plane.
-#ifndef NFE_PIPE_SWIZZLE
-#define NFE_PIPE_SWIZZLE 1
-#endif
 #define NFE_PIPE_ISSUE_I(S, K, I)                                                                          \
     vg[S][(K) * 4 + I] = texel_piece(base_, (unsigned)quad_bcast<I>((int)off_) + qoff_bytes);                \
-    if (NFE_PIPE_SWIZZLE) wq[S][(K) * 4 + I] = quad_swizzle<I>(wk_); else if (I == 0) wq[S][K] = wk_;
+    wq[S][(K) * 4 + I] = quad_swizzle<I>(wk_);
 #define NFE_PIPE_ISSUE(S, PL, K0)                                                                          \
     {                                                                                                      \
         const float* base_ = pg + (PL) * plane_elems;                                                      \
@@ -244,7 +184,7 @@ template <int I> __device__ __forceinline__ float quad_swizzle(float v) {
     }
 #define NFE_PIPE_FMA(S, K, I)                                                                              \
     {                                                                                                      \
-        const f32x2 w2 = splat(NFE_PIPE_SWIZZLE ? wq[S][(K) * 4 + I] : quad_bcast<I>(wq[S][K]));            \
+        const f32x2 w2 = splat(wq[S][(K) * 4 + I]);                                                        \
         sg[2 * I + 0] = pk_fma(w2, f32x2{vg[S][(K) * 4 + I].x, vg[S][(K) * 4 + I].y}, sg[2 * I + 0]);      \
         sg[2 * I + 1] = pk_fma(w2, f32x2{vg[S][(K) * 4 + I].z, vg[S][(K) * 4 + I].w}, sg[2 * I + 1]);      \
     }
@@ -336,9 +276,6 @@ __device__ __forceinline__ void plane_affine_acc(const float* __restrict__ aff, 
 // is bound by exactly that count.  The arithmetic that produces weights, offsets and sums is the general
 // path's, in the same order: results are bit-identical.  The decision is one ballot -> s_cmp -> s_cbranch_scc per sample (the
 // stable branch form of profiles/experiments/r02_square_branch.md), taken before any load of the sample is in flight.
-#ifndef NFE_INB_FAST
-#define NFE_INB_FAST 1
-#endif
 struct InbAxes { int x0, y0, z0; float fx, fy, fz; };
 // floor coordinate and fraction of the three axes exactly as axis_geometry computes them; true when every lane is inside
 __device__ __forceinline__ bool inb_axes(int size, float gx, float gy, float gz, InbAxes& a) {
@@ -348,21 +285,12 @@ __device__ __forceinline__ bool inb_axes(int size, float gx, float gy, float gz,
     a.fx = ix - fx0; a.fy = iy - fy0; a.fz = iz - fz0;
     a.x0 = (int)fx0; a.y0 = (int)fy0; a.z0 = (int)fz0;                   // saturating conversion: far-away samples fail the test below
     const unsigned worst = max(max((unsigned)a.x0, (unsigned)a.y0), (unsigned)a.z0);        // negative -> huge
-#if NFE_INB_FAST == 2          // instruction census only (tools/isa_census.py): the fast path unconditionally, no general path in the loop
-    (void)worst;
-    return true;
-#else
     return __builtin_amdgcn_ballot_w64(worst >= (unsigned)(size - 1)) == 0;
-#endif
 }
 // one 16-byte piece at (uniform base) + (32-bit byte offset) + (compile-time immediate)
 template <int IMM>
 __device__ __forceinline__ float4 texel_piece_imm(const char* __restrict__ base, unsigned byte_off) {
-#ifdef NFE_ABLATE_GATHER
-    return make_float4((float)byte_off, 1.0f, 2.0f, 3.0f);
-#else
     return *reinterpret_cast<const float4*>(base + byte_off + IMM);
-#endif
 }
 #define NFE_INB_PLANE(PL, A0, B0, FA, FB)          /* plane PL: axis a indexes W (taps a0, a0+1), axis b indexes H */         \
     off0[PL] = (unsigned)((B0) * W + (A0)) * 128u;                                                                             \
@@ -484,12 +412,10 @@ template <bool SQUARE>
 __device__ __forceinline__ void gather_pipelined_dual(const float* __restrict__ pg, const float* __restrict__ pa, int H, int W,
                                                       long long plane_elems, const float* __restrict__ aff, int lane,
                                                       float gx, float gy, float gz, f32x2 (&qn)[8], f32x2 (&qd)[8]) {
-#if NFE_INB_FAST && !defined(NFE_SQUARE_RUNTIME)
     if (SQUARE) {
         InbAxes ia;
         if (inb_axes(W, gx, gy, gz, ia)) { gather_pipelined_dual_inb(pg, pa, W, plane_elems, aff, lane, ia, qn, qd); return; }
     }
-#endif
     Taps tp[3];
     unsigned offs[3][4];
     Axis ax_xw, ax_zh;
@@ -546,12 +472,10 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
                                                  const float* __restrict__ aff, int lane, float gx, float gy, float gz,
                                                  f32x2 (&qn)[8], f32x2 (&qd)[8]) {
     // project_onto_planes (renderer.py:39-53): p0=(x,y), p1=(x,z), p2=(z,x); first coord indexes W.
-#if NFE_INB_FAST && !defined(NFE_SQUARE_RUNTIME)
     if (SQUARE) {
         InbAxes ia;
         if (inb_axes(W, gx, gy, gz, ia)) { gather_pipelined_inb<SIGMA_ONLY>(pg, W, plane_elems, aff, lane, ia, qn, qd); return; }
     }
-#endif
     Taps tp[3];
     unsigned offs[3][4];
     Axis ax_xw, ax_zh;
@@ -560,22 +484,8 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     //      that as the branch going the wrong way; it is the packed multiplies of the tap_geometry arm (56 x v_pk_mul_f32 ... op_sel:[0,1],
     //      profiles/experiments/r04_pk_opsel_hazard.md): through the build's assembly pass the same source is stable;
     //   6: the condition re-made by s_cmp at every site;   10: as 1, but both arms compute the square geometry (both stable either way).
-#ifdef NFE_SQUARE_RUNTIME
-    const bool SQ_RT = (H == W);
-#if NFE_SQUARE_RUNTIME == 6
-#define SQUARE_AT(i) (sq_flag_scc(H, W) != 0)
-#else
-#define SQUARE_AT(i) SQ_RT
-#endif
-#else
-#define SQUARE_AT(i) SQUARE
-#endif
-#if defined(NFE_SQUARE_RUNTIME) && NFE_SQUARE_RUNTIME == 10
-#define NFE_ELSE_GEOM(PL, U, V, AU, AV) asm volatile("; else arm " #PL); NFE_PIPE_GEOM_AX(PL, AU, AV)
-#else
 #define NFE_ELSE_GEOM(PL, U, V, AU, AV) NFE_PIPE_GEOM(PL, U, V)
-#endif
-    if (SQUARE_AT(0)) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) }
+    if (SQUARE) { ax_xw = axis_geometry(W, gx); NFE_PIPE_GEOM_AX(0, ax_xw, axis_geometry(H, gy)) }
     else { ax_xw = axis_geometry(W, gx); NFE_ELSE_GEOM(0, gx, gy, ax_xw, axis_geometry(H, gy)) }
     const int ll = launder(lane);
     const int qoff = (ll >> 5) * 16 + (ll & 3) * 4;
@@ -587,14 +497,14 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     for (int c = 0; c < 8; ++c) sg[c] = splat(0.0f);
     NFE_PIPE_ISSUE(0, 0, 0) NFE_PIPE_ISSUE(1, 0, 2)
     // the next plane's tap geometry runs under the loads in flight
-    if (SQUARE_AT(1)) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) }
+    if (SQUARE) { ax_zh = axis_geometry(H, gz); NFE_PIPE_GEOM_AX(1, ax_xw, ax_zh) }
     else { ax_zh = axis_geometry(H, gz); NFE_ELSE_GEOM(1, gx, gz, ax_xw, ax_zh) }
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(0) NFE_PIPE_ISSUE(0, 1, 0)
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(1) NFE_PIPE_ISSUE(1, 1, 2)
     plane_affine_acc<SIGMA_ONLY, 0>(aff, qoff, tp[0], sg, qn, qd);
-    if (SQUARE_AT(2)) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_ELSE_GEOM(2, gz, gx, ax_zh, ax_xw) }
+    if (SQUARE) { NFE_PIPE_GEOM_AX(2, ax_zh, ax_xw) } else { NFE_ELSE_GEOM(2, gz, gx, ax_zh, ax_xw) }
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(0) NFE_PIPE_ISSUE(0, 2, 0)
     __builtin_amdgcn_sched_barrier(0);
@@ -605,7 +515,6 @@ __device__ __forceinline__ void gather_pipelined(const float* __restrict__ pg, i
     __builtin_amdgcn_sched_barrier(0);
     NFE_PIPE_CONSUME(1)
     plane_affine_acc<SIGMA_ONLY, 2>(aff, qoff, tp[2], sg, qn, qd);
-#undef SQUARE_AT
 #undef NFE_ELSE_GEOM
 }
 
@@ -801,9 +710,6 @@ __device__ __forceinline__ void load_bias1(const float* __restrict__ lds, int ne
 // of half h holds the hidden units of K positions 16 s + 8 h + e (s = k-step 0..3, e = 0..7: mlp_bf16's operand order), whose row-0
 // weights are the hi + lo bf16 pairs in lane 32 h of the layer-1 fragments - constants of the launch, fetched once per wave
 // (sigma_row_weights) and kept in 32 registers.  fp32 products of unsplit activations: not less exact than the split-bf16 form.
-#ifndef NFE_SIGMA_ROW
-#define NFE_SIGMA_ROW 1
-#endif
 __device__ __forceinline__ void sigma_row_weights(const float* __restrict__ lds, int lane, float (&w)[32]) {
     const uint4* F = reinterpret_cast<const uint4*>(lds) + 32 * (lane >> 5);         // row 0 lives in lane 32 h of every fragment
 #pragma unroll
@@ -858,45 +764,6 @@ __device__ __forceinline__ void split_hidden(const f32x16& a0, const f32x16& a1,
     }
 }
 
-// Instruction-level interleave of a stage (sched_group_barrier: the scheduler must emit the groups in this order inside the
-// scheduling region that ends at the next sched_barrier(0)).  Without it hipcc clusters a stage's MFMAs at its top and runs the
-// other head's softplus behind them (ISA: "MMMMMM" then 32 x "TTvvPnTTnP"), so the matrix pipe idles under the transcendentals and
-// vice versa; an MFMA holds the SIMD's vector issue for 8 of its 32 cycles only (MI355X_MICROARCH.md, cycle constants), the other
-// 24 take two transcendentals or up to six plain VALU instructions for free.
-#ifndef NFE_MLP_IGLP
-#define NFE_MLP_IGLP 0
-#endif
-#if NFE_MLP_IGLP
-#define NFE_IGLP_MFMA_TRANS(N)                                                                             \
-    _Pragma("unroll") for (int g_ = 0; g_ < (N); ++g_) {                                                   \
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA */                             \
-        __builtin_amdgcn_sched_group_barrier(0x400, NFE_IGLP_T, 0);      /* transcendentals */             \
-        __builtin_amdgcn_sched_group_barrier(0x002, NFE_IGLP_V, 0);      /* other VALU */                  \
-    }
-// a layer-1 stage: every k-step first needs its 8 hidden values split into bf16 pairs (VALU), then issues 3 MFMAs
-#define NFE_IGLP_SPLIT_MFMA_TRANS(KS)                                                                      \
-    _Pragma("unroll") for (int k_ = 0; k_ < (KS); ++k_) {                                                  \
-        __builtin_amdgcn_sched_group_barrier(0x002, NFE_IGLP_SPLIT, 0);  /* split of this k-step */        \
-        _Pragma("unroll") for (int g_ = 0; g_ < 3; ++g_) {                                                 \
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                             \
-            __builtin_amdgcn_sched_group_barrier(0x400, NFE_IGLP_T, 0);                                    \
-            __builtin_amdgcn_sched_group_barrier(0x002, NFE_IGLP_V, 0);                                    \
-        }                                                                                                  \
-    }
-#else
-#define NFE_IGLP_MFMA_TRANS(N)
-#define NFE_IGLP_SPLIT_MFMA_TRANS(KS)
-#endif
-#ifndef NFE_IGLP_SPLIT
-#define NFE_IGLP_SPLIT 20
-#endif
-#ifndef NFE_IGLP_T
-#define NFE_IGLP_T 5
-#endif
-#ifndef NFE_IGLP_V
-#define NFE_IGLP_V 8
-#endif
-
 template <bool CROSS = false>
 __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
                                               int lane, f32x16& og, f32x16& oa) {
@@ -939,7 +806,6 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
     }
     softplus_log2_x16(g0); softplus_log2_x16(g1);
     load_bias1(lds, 0, h, og);
-    NFE_IGLP_MFMA_TRANS(12)
     __builtin_amdgcn_sched_barrier(0);
     // ---- S4
 #pragma unroll
@@ -953,7 +819,6 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
     }
     softplus_log2_x16(p0); softplus_log2_x16(p1);
     load_bias1(lds, 1, h, oa);
-    NFE_IGLP_SPLIT_MFMA_TRANS(4)
     __builtin_amdgcn_sched_barrier(0);
     // ---- S5
 #pragma unroll
@@ -976,136 +841,17 @@ __device__ __forceinline__ void mlp_pair_bf16(const float* __restrict__ lds, con
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// ---- the same pairing, interleaved by hand at instruction level (round 4) -------------------------------
-// hipcc schedules a stage of mlp_pair_bf16 as "all MFMAs, then all of the other head's softplus" (sched_group_barrier patterns
-// were honoured for one stage and silently dropped for the other), so the two pipes take turns instead of overlapping.  Here every
-// MFMA is followed by a fixed share of the partner head's vector work and a scheduling fence: the MFMA holds the SIMD's vector
-// issue for 8 of its 32 cycles, the transcendentals behind it run in the other 24.
-#ifndef NFE_MLP_INTERLEAVE
-#define NFE_MLP_INTERLEAVE 0
-#endif
-__device__ __forceinline__ void softplus_pair(f32x16& a0, f32x16& a1, int p) {       // values 2p, 2p + 1 of the 32 hidden units a lane holds
-    f32x16& a = p < 8 ? a0 : a1;
-    const int r = 2 * (p & 7);
-#if NFE_SOFTPLUS_SCALAR
-    const float e0 = add_f32_plain(exp2_fast(-__builtin_fabsf(a[r])), 1.0f), e1 = add_f32_plain(exp2_fast(-__builtin_fabsf(a[r + 1])), 1.0f);
-    a[r] = add_f32_plain(log2_fast(e0), relu_bits(a[r])); a[r + 1] = add_f32_plain(log2_fast(e1), relu_bits(a[r + 1]));
-#else
-    const f32x2 e = f32x2{exp2_fast(-__builtin_fabsf(a[r])), exp2_fast(-__builtin_fabsf(a[r + 1]))} + splat(1.0f);
-    const f32x2 l = f32x2{log2_fast(e[0]), log2_fast(e[1])} + f32x2{relu_bits(a[r]), relu_bits(a[r + 1])};
-    a[r] = l[0]; a[r + 1] = l[1];
-#endif
-}
-// softplus pairs issued behind MFMA i of a 12-MFMA stage (16 pairs in all)
-#define NFE_IL_SHARE(I) (((I) % 3) == 0 ? 2 : 1)
-#define NFE_IL_SOFTPLUS(A0, A1, I)                                                                         \
-    {                                                                                                      \
-        _Pragma("unroll") for (int c_ = 0; c_ < NFE_IL_SHARE(I); ++c_) softplus_pair(A0, A1, pi_++);        \
-        __builtin_amdgcn_sched_barrier(0);                                                                 \
-    }
-
-__device__ __forceinline__ void mlp_pair_bf16_il(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
-                                                 int lane, f32x16& og, f32x16& oa) {
-    lane = launder(lane);
-    const int h = lane >> 5;
-    const uint4* F = reinterpret_cast<const uint4*>(lds) + lane;
-    __builtin_amdgcn_sched_barrier(0);
-    Frag gh[2], gl[2], ah[2], al[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int w = 0; w < 4; ++w) split_pair(fn[4 * s + w][0], fn[4 * s + w][1], gh[s].u[w], gl[s].u[w]);
-    f32x16 g0, g1, p0, p1;
-    load_bias0(lds, 0, h, g0, g1);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- S2: geometry layer 0 | appearance features -> bf16 pairs (two words behind each of the first eight MFMAs... one per MFMA)
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        Frag h0, l0, h1, l1;
-        h0.q = NFE_L0_FRAG(0, 0, s, 0); l0.q = NFE_L0_FRAG(0, 0, s, 1);
-        h1.q = NFE_L0_FRAG(0, 1, s, 0); l1.q = NFE_L0_FRAG(0, 1, s, 1);
-        g0 = NFE_MFMA_BF16(h0, gh[s], g0); split_pair(fd[4 * s + 0][0], fd[4 * s + 0][1], ah[s].u[0], al[s].u[0]); __builtin_amdgcn_sched_barrier(0);
-        g1 = NFE_MFMA_BF16(h1, gh[s], g1); split_pair(fd[4 * s + 1][0], fd[4 * s + 1][1], ah[s].u[1], al[s].u[1]); __builtin_amdgcn_sched_barrier(0);
-        g0 = NFE_MFMA_BF16(h0, gl[s], g0); split_pair(fd[4 * s + 2][0], fd[4 * s + 2][1], ah[s].u[2], al[s].u[2]); __builtin_amdgcn_sched_barrier(0);
-        g1 = NFE_MFMA_BF16(h1, gl[s], g1); split_pair(fd[4 * s + 3][0], fd[4 * s + 3][1], ah[s].u[3], al[s].u[3]); __builtin_amdgcn_sched_barrier(0);
-        g0 = NFE_MFMA_BF16(l0, gh[s], g0); g1 = NFE_MFMA_BF16(l1, gh[s], g1);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-    load_bias0(lds, 1, h, p0, p1);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- S3: appearance layer 0 | softplus of the geometry hidden layer
-    {
-        int pi_ = 0;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            Frag h0, l0, h1, l1;
-            h0.q = NFE_L0_FRAG(1, 0, s, 0); l0.q = NFE_L0_FRAG(1, 0, s, 1);
-            h1.q = NFE_L0_FRAG(1, 1, s, 0); l1.q = NFE_L0_FRAG(1, 1, s, 1);
-            p0 = NFE_MFMA_BF16(h0, ah[s], p0); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 0)
-            p1 = NFE_MFMA_BF16(h1, ah[s], p1); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 1)
-            p0 = NFE_MFMA_BF16(h0, al[s], p0); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 2)
-            p1 = NFE_MFMA_BF16(h1, al[s], p1); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 3)
-            p0 = NFE_MFMA_BF16(l0, ah[s], p0); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 4)
-            p1 = NFE_MFMA_BF16(l1, ah[s], p1); NFE_IL_SOFTPLUS(g0, g1, 6 * s + 5)
-        }
-    }
-    load_bias1(lds, 0, h, og);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- S4: geometry layer 1 (k-step: split its 8 hidden values, 3 MFMAs) | softplus of the appearance hidden layer
-    {
-        int pi_ = 0;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            Frag hh, hl, wh, wl;
-            split_hidden(g0, g1, s, hh, hl);
-            wh.q = NFE_L1_FRAG(0, s, 0); wl.q = NFE_L1_FRAG(0, s, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            og = NFE_MFMA_BF16(wh, hh, og); NFE_IL_SOFTPLUS(p0, p1, 3 * s + 0)
-            og = NFE_MFMA_BF16(wh, hl, og); NFE_IL_SOFTPLUS(p0, p1, 3 * s + 1)
-            og = NFE_MFMA_BF16(wl, hh, og); NFE_IL_SOFTPLUS(p0, p1, 3 * s + 2)
-        }
-    }
-    load_bias1(lds, 1, h, oa);
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- S5: appearance layer 1 | appearance hidden -> bf16 pairs (the split of k-step s + 1 runs behind the MFMAs of k-step s)
-    {
-        Frag hh, hl, nh, nl;
-        split_hidden(p0, p1, 0, hh, hl);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            Frag wh, wl;
-            wh.q = NFE_L1_FRAG(1, s, 0); wl.q = NFE_L1_FRAG(1, s, 1);
-            oa = NFE_MFMA_BF16(wh, hh, oa);
-            if (s < 3) split_hidden(p0, p1, s + 1, nh, nl);
-            oa = NFE_MFMA_BF16(wh, hl, oa);
-            oa = NFE_MFMA_BF16(wl, hh, oa);
-            hh = nh; hl = nl;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-}
-
 // The decoder proper (DisentangledOSGDecoder.forward after the mean over planes, triplane.py:254-270) on features that
 // are already in "own" layout: fn / fd = channels 16h..16h+15 of this lane's point of the geometry / appearance set.
 // Outputs as eval_point documents them.
 template <bool SIGMA_ONLY, int MATH, bool CROSS>
 __device__ __forceinline__ void decode_features(const float* __restrict__ lds, const f32x2 (&fn)[8], const f32x2 (&fd)[8],
                                                 int lane, f32x16& og, f32x16& oa, const float (&wsig)[32]) {
-#ifdef NFE_ABLATE_MLP      // timing experiment only (tools/ablate.sh): no decoder
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { og[r] = fn[r >> 1][r & 1]; oa[r] = fd[r >> 1][r & 1]; }
-    return;
-#endif
-#ifndef NFE_MLP_PAIR
-#define NFE_MLP_PAIR 1
-#endif
-    constexpr bool PAIR = NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3;
-    static_assert(!CROSS || (NFE_MLP_PAIR && !SIGMA_ONLY && MATH == NFE_MATH_BF16X3), "the cross term lives in the paired split-bf16 decoder");
-    if (PAIR && NFE_MLP_INTERLEAVE && !CROSS) mlp_pair_bf16_il(lds, fn, fd, lane, og, oa);
-    else if (PAIR) mlp_pair_bf16<CROSS>(lds, fn, fd, lane, og, oa);
+    constexpr bool PAIR = !SIGMA_ONLY && MATH == NFE_MATH_BF16X3;
+    static_assert(!CROSS || PAIR, "the cross term lives in the paired split-bf16 decoder");
+    if (PAIR) mlp_pair_bf16<CROSS>(lds, fn, fd, lane, og, oa);
     else if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fn, 0, lane, og);
-    else if (SIGMA_ONLY && NFE_SIGMA_ROW) mlp_bf16_sigma(lds, fn, lane, wsig, og);      // wsig: sigma_row_weights(), once per wave
+    else if (SIGMA_ONLY) mlp_bf16_sigma(lds, fn, lane, wsig, og);      // wsig: sigma_row_weights(), once per wave
     else mlp_bf16(lds, fn, 0, lane, og);
     if (!SIGMA_ONLY) {
         if (MATH == NFE_MATH_FP32) mlp_fp32(lds, fd, 1, lane, oa);
@@ -1215,7 +961,7 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
     const bool probe = P.clock_probe != nullptr && blockIdx.x == 0 && wave == 0;
     if (probe && lane == 0) { P.clock_probe[0] = __builtin_amdgcn_s_memtime(); P.clock_probe[1] = __builtin_amdgcn_s_memrealtime(); }
     float wsig[32] = {};                     // sigma-only pass, split-bf16: row 0 of the geometry head's second layer (mlp_bf16_sigma)
-    if (SIGMA_ONLY && MATH == NFE_MATH_BF16X3 && NFE_SIGMA_ROW) sigma_row_weights(lds, lane, wsig);
+    if (SIGMA_ONLY && MATH == NFE_MATH_BF16X3) sigma_row_weights(lds, lane, wsig);
 
     const int S = P.S;
     const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
@@ -1485,18 +1231,14 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
 // Outputs are bit-identical to render_kernel's: same tap order in the bilinear sums, same MFMA order in each head (mlp_bf16), same
 // march arithmetic (tests/test_render_gpu.py::test_wave_specialised_kernel_is_bit_identical).
 // ------------------------------------------------------------------------------------------
-#ifndef WS_BUFS
 #define WS_BUFS 1                                           // tile sets per pair: 2 lets the producer run one sample further ahead (measured: no gain, 6.13 vs 6.12 ms)
-#endif
 constexpr int WS_SET_FLOATS = 2 * XCHG_FLOATS + 32;         // one set: geometry tile, appearance tile, 32 depths
 constexpr int WS_T_OFF = 2 * XCHG_FLOATS;
 constexpr int WS_FLAG_OFF = WS_BUFS * WS_SET_FLOATS;        // behind the sets: {full, taken, abort, -}
 constexpr int WS_PAIR_FLOATS = AFF_FLOATS + WS_FLAG_OFF + 4;
 static_assert(WS_PAIR_FLOATS % 4 == 0 && AFF_FLOATS % 4 == 0, "16-byte aligned tiles");
 template <int NP> constexpr int ws_lds_bytes() { return (DEC_FLOATS + NP * WS_PAIR_FLOATS) * 4; }
-#ifndef WS_SLEEP
 #define WS_SLEEP 2                                          // s_sleep argument of the hand-off poll (measured 0 / 2 / 8: 6.50 / 6.47 / 6.44 ms - polling is not the cost)
-#endif
 constexpr int WS_SPIN_LIMIT = 1 << 18;                      // x (s_sleep 1 + an LDS read) ~ 50 ms: a lost partner ends the wait, never the box
 
 // Wait until *flag has reached `need` (wrap-safe).  Returns false when the wait was abandoned: the flag's pair is then marked
@@ -1541,9 +1283,7 @@ __device__ __forceinline__ void ws_signal(unsigned* flags, int which, unsigned v
         sg[2 * i_ + 0] = pk_fma(w2, f32x2{vg[S][i_].x, vg[S][i_].y}, sg[2 * i_ + 0]);                      \
         sg[2 * i_ + 1] = pk_fma(w2, f32x2{vg[S][i_].z, vg[S][i_].w}, sg[2 * i_ + 1]);                      \
     }
-#ifndef NFE_WS_FLIGHT
 #define NFE_WS_FLIGHT 2            // tap batches (4 loads each) in flight in the producer's gather: 2 or 3
-#endif
 // the producer's gather on the in-bounds fast path (see gather_pipelined_inb): one byte offset per (plane, point)
 #define NFE_WSI_ISSUE(S, PL, K)                                                                            \
     {                                                                                                      \
@@ -1601,12 +1341,10 @@ template <bool SQUARE, bool SIGMA_ONLY>
 __device__ __forceinline__ void gather_pipelined_ws(const float* __restrict__ pg, int H, int W, long long plane_elems,
                                                     const float* __restrict__ aff, int lane, float gx, float gy, float gz,
                                                     f32x2 (&qn)[8], f32x2 (&qd)[8]) {
-#if NFE_INB_FAST
     if (SQUARE) {
         InbAxes ia;
         if (inb_axes(W, gx, gy, gz, ia)) { gather_pipelined_ws_inb<SIGMA_ONLY>(pg, W, plane_elems, aff, lane, ia, qn, qd); return; }
     }
-#endif
     Taps tp[3];
     unsigned offs[3][4];
     Axis ax_xw, ax_zh;
@@ -1692,13 +1430,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
     unsigned step = 0;                       // samples handed over so far by this pair (both roles count alike)
     bool alive = true;
 
-    // -DWS_ONLY_CONSUMER / -DWS_ONLY_PRODUCER: compile-only builds that drop the other role, for the per-role register census
-    // (hipcc -Rpass-analysis: consumer 152 VGPRs, producer 169-203); their launches would wait for a partner that never signals.
-#ifdef WS_ONLY_CONSUMER
-    if (false) {
-#else
+    // per-role register census (round 4, compile-only builds of one role each): consumer 152 VGPRs, producer 169-203
     if (producer) {
-#endif
         const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;
         int cur_view = -1;
         float tmin = INFINITY, tmax = -INFINITY;
@@ -1797,12 +1530,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                         qd[2 * i] = f32x2{bd.x, bd.y}; qd[2 * i + 1] = f32x2{bd.z, bd.w};
                     }
                 }
-#if !defined(WS_ABLATE) || WS_ABLATE != 1          // timing experiment: 1 = producer without its gather
                 if (DUAL) gather_pipelined_dual<SQUARE>(pg, pa, P.H, P.W, plane_elems, affk, lane, gx, gy, gz, qn, qd);
                 else gather_pipelined_ws<SQUARE, SIGMA_ONLY>(pg, P.H, P.W, plane_elems, affk, lane, gx, gy, gz, qn, qd);
-#else
-                qn[0][0] += gx; qd[0][0] += gy + gz;
-#endif
                 // geometry tile + depths of sample `step` go to set step % WS_BUFS: the consumer must have read that set's previous
                 // content, the geometry tile of sample step - WS_BUFS
                 float* tile_g = tile_g0 + (int)(step % WS_BUFS) * WS_SET_FLOATS + opq;
@@ -1831,13 +1560,9 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
             }
             if (lane == 0 && !alive) atomicAdd(P.depth_minmax + 2, 1u);
         }
-#ifdef WS_ONLY_PRODUCER
-    } else if (false) {
-#else
     } else {
-#endif
         float wsig[32];                          // sigma-only pass: row 0 of the geometry head's second layer (mlp_bf16_sigma)
-        if (SIGMA_ONLY && NFE_SIGMA_ROW) sigma_row_weights(lds, lane, wsig);
+        if (SIGMA_ONLY) sigma_row_weights(lds, lane, wsig);
 #pragma unroll 1
         for (long long rb = (long long)blockIdx.x * NP + pair; rb < total_rb; rb += n_pairs) {
             const int n = (int)(rb / blocks_per_view), b = (int)(rb % blocks_per_view);
@@ -1871,25 +1596,15 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
                     ws_read_tile(tile_g, lane, fn);
                     t = tile_g[WS_T_OFF + j];
                     ws_signal(flags, 1, 2u * step + (SIGMA_ONLY ? 2u : 1u), lane);
-#if !defined(WS_ABLATE) || WS_ABLATE != 2          // timing experiment: 2 = consumer without its decoder
-                    if (SIGMA_ONLY && NFE_SIGMA_ROW) mlp_bf16_sigma(ldsw, fn, lane, wsig, og);
+                    if (SIGMA_ONLY) mlp_bf16_sigma(ldsw, fn, lane, wsig, og);
                     else mlp_bf16(ldsw, fn, 0, lane, og);
-#else
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) og[r] = fn[r >> 1][r & 1];
-#endif
                 }
                 if (!SIGMA_ONLY) {
                     if (alive) alive = ws_wait(flags, 0, 2u * step + 2u);
                     f32x2 fd[8];
                     ws_read_tile(tile_g + XCHG_FLOATS, lane, fd);
                     ws_signal(flags, 1, 2u * step + 2u, lane);
-#if !defined(WS_ABLATE) || WS_ABLATE != 2
                     mlp_bf16(ldsw, fd, 1, lane, oa);
-#else
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) oa[r] = fd[r >> 1][r & 1];
-#endif
                 }
 #pragma unroll
                 for (int r = 0; r < (SIGMA_ONLY ? 0 : 16); r += 2) {    // sigmoid(x)*(1+2*0.001) - 0.001, triplane.py:269 (decode_features)
@@ -2407,7 +2122,7 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
         if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else if (P.tap_colors && !SIGMA_ONLY)
             hipLaunchKernelGGL((render_kernel<DUAL, false, NFE_MATH_BF16X3, false, false, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
-        else if (P.H == P.W && !NFE_SQUARE_RT)               // shared axis geometry + the in-bounds gather path (round 4: pays with two plane sets too)
+        else if (P.H == P.W)               // shared axis geometry + the in-bounds gather path (round 4: pays with two plane sets too)
             hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
     }
@@ -2523,7 +2238,7 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
         if (sblocks > cap) sblocks = cap;
         dim3 sgrid((unsigned)sblocks);
 #define NFE_LAUNCH_SPLIT(DU, SG)                                                                                                   \
-        if (P.H == P.W && !(DU) && !NFE_SQUARE_RT) hipLaunchKernelGGL((render_kernel<false, SG, NFE_MATH_BF16X3, false, false, true, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q); \
+        if (P.H == P.W && !(DU)) hipLaunchKernelGGL((render_kernel<false, SG, NFE_MATH_BF16X3, false, false, true, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q); \
         else hipLaunchKernelGGL((render_kernel<DU, SG, NFE_MATH_BF16X3, false, false, true>), sgrid, dim3(256), RENDER_LDS_BYTES, st, Q);
         if (sigma_only) {
             if (dual) { NFE_LAUNCH_SPLIT(true, true) } else { NFE_LAUNCH_SPLIT(false, true) }
@@ -2600,12 +2315,8 @@ int render_eval_pass(const nfe_render_backward_args* a, const float* decoder_pac
 // The same two quantities from the colours the forward kept (nfe_render_args.tap_sample_colors): one pass over 192 bytes per sample
 // instead of the gathers and both decoder heads.  Thread = (ray block, sample, lane of the block); the sums run in the evaluation
 // pass's order (16 colour features and 8 logits per channel half, halves added last).
-#ifndef NFE_DOT_K
 #define NFE_DOT_K 8
-#endif
-#ifndef NFE_DOT_UNROLL
 #define NFE_DOT_UNROLL 2
-#endif
 constexpr int DOT_K = NFE_DOT_K;      // samples per thread: the ray's 47 cotangents are loaded once per DOT_K samples
 __global__ __launch_bounds__(256) void color_dot_kernel(RenderK P, const float* __restrict__ colors) {
     const int S = P.S, blocks_per_view = (P.M + 31) >> 5, ksegs = (S + DOT_K - 1) / DOT_K;

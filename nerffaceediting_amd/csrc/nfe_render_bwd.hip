@@ -33,9 +33,7 @@ constexpr int BW_A1T = 5264;    // [64][32]
 constexpr int BB_A1 = 7312;     // [32]
 constexpr int BWD_DEC_FLOATS = 7344;
 constexpr int BWD_DEC_BYTES = 32768;
-#ifndef BWD_WAVES
 #define BWD_WAVES 2      // waves per SIMD the sample kernels are compiled for; 3 and 4 (168 / 128 VGPRs, spills) measured slower
-#endif
 
 struct BwdK {
     const float* planes_g; const float* planes_a; long long plane_view_stride; int H, W;
@@ -138,11 +136,7 @@ __device__ __forceinline__ void gather_set(const float* __restrict__ planes, con
         float wsum = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 5      // timing experiment: every tap reads the same texel row (no gather traffic)
-            const float4* tx = reinterpret_cast<const float4*>(planes + (g.off[4 * p + k] & 0));
-#else
             const float4* tx = reinterpret_cast<const float4*>(planes + g.off[4 * p + k]);
-#endif
             const f32x2 w = splat(g.w[4 * p + k]);
             wsum += g.w[4 * p + k];
 #pragma unroll
@@ -224,16 +218,10 @@ __device__ __forceinline__ void head_backward(const float* __restrict__ w0, cons
 // inside the MFMA chains made it 0.06 ms SLOWER, so it is their number, not their latency.)
 __device__ __forceinline__ float cot_rgb(const BwdK& P, int n, int m, int c) {      // includes the *2 of rgb*2-1
     if (!P.g_rgb) return 0.0f;
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 11     // timing experiment: no cotangent loads
-    return 0.01f * (float)(c + (m & 3));
-#endif
     return 2.0f * (P.channels_first ? P.g_rgb[((long long)n * 32 + c) * P.M + m] : P.g_rgb[((long long)n * P.M + m) * 32 + c]);
 }
 __device__ __forceinline__ float cot_seg(const BwdK& P, int n, int m, int c) {
     if (!P.g_seg) return 0.0f;
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 11
-    return 0.02f * (float)(c + (m & 3));
-#endif
     return P.channels_first ? P.g_seg[((long long)n * 15 + c) * P.M + m] : P.g_seg[((long long)n * P.M + m) * 15 + c];
 }
 
@@ -403,13 +391,7 @@ __device__ __forceinline__ void scatter_set(float* __restrict__ tile, const f32x
         for (int k = 0; k < 12; ++k) {
             const int off = __shfl(geo.off[k], src);
             const float w = __shfl(geo.w[k], src);
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 1      // timing experiments only: plain stores / no memory operation
-            if ((alive ? w : 0.0f) != 0.0f) grad[off + ch] = v * w * sc[k >> 2];
-#elif defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 2
-            if ((alive ? w : 0.0f) != 0.0f) asm volatile("" :: "v"(v * w * sc[k >> 2]), "v"(off));
-#else
             if ((alive ? w : 0.0f) != 0.0f) unsafeAtomicAdd(grad + off + ch, v * w * sc[k >> 2]);
-#endif
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -530,11 +512,7 @@ __device__ __forceinline__ void bsplit(float a, float b, unsigned& hi, unsigned&
     bwd_bf16x2 p = {(__bf16)(a - __uint_as_float(ua & 0xffff0000u)), (__bf16)(b - __uint_as_float(ub & 0xffff0000u))};
     lo = *reinterpret_cast<unsigned*>(&p);
 }
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 9      // timing experiment 9: fragments made up in registers (no fragment traffic)
-#define NFE_BFRAG(F, i) make_uint4((unsigned)(i) * 0x01010101u + (unsigned)lane, 0x3c003c00u, (unsigned)lane << 7, 0x3c003c00u)
-#else
 #define NFE_BFRAG(F, i) (F)[(i) * 64]
-#endif
 __device__ __forceinline__ f32x16 mfma3(const BFrag& ah, const BFrag& al, const BFrag& bh, const BFrag& bl, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, c, 0, 0, 0);
@@ -676,21 +654,9 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 constexpr int SORT_TILE_STRIDE = 68;      // floats per sample row: rows stay 16-byte aligned (the gather exchange uses ds_*_b128)
 constexpr unsigned KEY_INVALID = 0xFFFFFFFFu;
 constexpr int BIN_SHIFT = 3, BIN_MASK = 7, BIN_TEXELS = 9;       // plane tiles of the binned form: 8 x 8 texels + the far taps' row/column
-#ifndef NFE_BIN_SEGMENT
 #define NFE_BIN_SEGMENT 4096
-#endif
-#ifndef NFE_BWD_COT_STAGED
 #define NFE_BWD_COT_STAGED 1       // decoder-backward kernel: output cotangents fetched coalesced and handed over through the tile (0: per-lane loads)
-#endif
-#ifndef NFE_BWD_BATCH_ATOMICS
-#define NFE_BWD_BATCH_ATOMICS 1    // the three planes' rank atomics of a wave in flight together (0: one round trip after the other)
-#endif
-#ifndef NFE_BWD_DF_DEPTH_MAJOR
-#define NFE_BWD_DF_DEPTH_MAJOR 0
-#endif
-#ifndef NFE_BWD_DEPTH_FAST
 #define NFE_BWD_DEPTH_FAST 0       // A/B: block order of the decoder-backward launch (1 = the depths of one ray tile are neighbours)
-#endif
 constexpr int BIN_SEGMENT = NFE_BIN_SEGMENT;                                // records per workgroup before a bin is split (at most BIN_SPLIT ways)
 constexpr int BIN_SPLIT = 4;
 constexpr int BIN_BATCH = 16;                                    // records (256-byte row loads) a wave keeps in flight
@@ -750,13 +716,7 @@ __device__ __forceinline__ void gather_pair_coop(const BwdK& P, int n, const Sam
             float wsum = 0.0f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 5      // timing experiment: every tap reads texel row 0 (no gather traffic)
-                const int off = __shfl(geo.off[4 * p + k], src) & 0;
-#elif defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 10   // timing experiment: eight different, always cache-resident rows per load (same request count, no misses)
-                const int off = (__shfl(geo.off[4 * p + k], src) & 0) + s8 * 32 + (4 * p + k) * 256;
-#else
                 const int off = __shfl(geo.off[4 * p + k], src);
-#endif
                 const float w = __shfl(geo.w[4 * p + k], src);
                 wsum += w;
                 if (DO_G) sg = fma4(w, *reinterpret_cast<const float4*>(pg + off), sg);
@@ -932,19 +892,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
         for (int c = 0; c < 32; ++c) tile[lane * SORT_TILE_STRIDE + 32 + c] = df[c >> 1][c & 1] * (1.0f / 3.0f);
     }
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 3      // timing experiment: decoder phase only
-    if (tile[lane] != 12345.678f) return;
-#endif
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 6      // timing experiment: gather + decoder only
-    if (BINNED) { if (tile[lane] != 12345.678f) return; }
-#endif
     if (BINNED) {       // feature gradients to the chunk buffer, one bin record per (sample, plane); bwd_accumulate_kernel adds them up
         __builtin_amdgcn_wave_barrier();
-#if NFE_BWD_DF_DEPTH_MAJOR        // A/B: order of the chunk's df rows and records (which waves' rows are neighbours in memory)
-        const unsigned wave = ((unsigned)blockIdx.z * (unsigned)P.S + (unsigned)kdepth) * (unsigned)P.t_count + (unsigned)bx;
-#else
         const unsigned wave = ((unsigned)blockIdx.z * (unsigned)P.t_count + (unsigned)bx) * (unsigned)P.S + (unsigned)kdepth;
-#endif
         float* dst = P.df + (size_t)wave * 4096 + lane;
 #pragma unroll 8
         for (int sidx = 0; sidx < 64; ++sidx) dst[sidx * 64] = tile[sidx * SORT_TILE_STRIDE + lane];
@@ -993,23 +943,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             float w0 = tp.w[0], w1 = tp.w[1], w2 = tp.w[2], w3v = tp.w[3];
             if (sx == 0) { w0 += w1; w2 += w3v; w1 = 0.0f; w3v = 0.0f; }
             if (sy == 0) { w0 += w2; w1 += w3v; w2 = 0.0f; w3v = 0.0f; }
-#if !NFE_BWD_BATCH_ATOMICS
-            {
-                unsigned base = 0;
-                if (first_lane == lane) base = __hip_atomic_fetch_add(P.counts + bin, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                rank += (unsigned)__shfl((int)base, first_lane & 63);
-            }
-#endif
             bin3[p] = bin; rank3[p] = rank; group3[p] = group; first3[p] = first_lane; any3[p] = any;
             loc3[p] = (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK));
             w3[p] = make_float4(w0, w1, w2, w3v);
         }
         unsigned base3[3] = {0u, 0u, 0u};
-#if NFE_BWD_BATCH_ATOMICS && (!defined(NFE_BWD_ABLATE) || NFE_BWD_ABLATE != 8)     // timing experiment 8: no rank atomics
 #pragma unroll
         for (int p = 0; p < 3; ++p)
             if (first3[p] == lane) base3[p] = __hip_atomic_fetch_add(P.counts + bin3[p], group3[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             const unsigned rank = rank3[p] + (unsigned)__shfl((int)base3[p], first3[p] & 63);
@@ -1096,11 +1037,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const float w = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(wreg[u & 3]), i + (u >> 2)));
                 acc = fmaf(v[u], w, acc);
                 if (kk[u] & 1u) {
-#if defined(NFE_BWD_ABLATE) && NFE_BWD_ABLATE == 4      // timing experiment: no atomics
-                    if (base) asm volatile("" :: "v"(acc * sc), "v"(kk[u]));
-#else
                     if (base) unsafeAtomicAdd(base + (long long)(kk[u] >> 8) * 32, acc * sc);
-#endif
                     acc = 0.0f;
                 }
             }
@@ -1280,21 +1217,14 @@ __device__ __forceinline__ void acc_tile_add4(const unsigned (&t)[4], const floa
                  "v_fma_f32 " ACC_V("1") ", " B ", " R ", " ACC_V("1") "\n" \
                  "v_fma_f32 " ACC_V("9") ", " C ", " R ", " ACC_V("9") "\n" \
                  "v_fma_f32 " ACC_V("10") ", " D ", " R ", " ACC_V("10") "\n"
-#ifndef ACC_WC
 #define ACC_WC "s"                 // experiment: "v" keeps SGPR operands out of the index-mode VOP3
-#endif
-#ifndef ACC_NOP_A                // REQUIRED wait states between an index-mode change (s_set_gpr_idx_on / _idx: an SALU write of M0 and
 #define ACC_NOP_A "s_nop 3\n"    // MODE) and the first indexed VALU.  Without them that VALU occasionally ran with the stale index or
-#endif                           // mode: `bench.py --workload editstep` died with "Memory access fault" in 2 of 14 runs (a write through
+                             // mode: `bench.py --workload editstep` died with "Memory access fault" in 2 of 14 runs (a write through
                                  // a stale M0 lands outside the wave's registers); 44 of 44 clean with them, 4 of 48 failing with the
                                  // wait states placed before the change or after s_set_gpr_idx_off instead (tools/r03_edit_rep.sh).
                                  // The compiler inserts such wait states around its own M0 users, not inside inline asm.
-#ifndef ACC_NOP_B
 #define ACC_NOP_B ""            // experiment: wait states between the last indexed VALU and the next index-mode change
-#endif
-#ifndef ACC_NOP_C
 #define ACC_NOP_C ""            // experiment: wait states after s_set_gpr_idx_off
-#endif
     asm volatile("s_set_gpr_idx_on %0, 0xc\n" ACC_NOP_A
                  ACC_FMA4("%0", "%4", "%5", "%6", "%7", "%20")
                  ACC_NOP_B "s_set_gpr_idx_idx %1\n" ACC_NOP_A
@@ -1311,9 +1241,6 @@ __device__ __forceinline__ void acc_tile_add4(const unsigned (&t)[4], const floa
 #undef ACC_FMA4
 }
 #pragma clang diagnostic pop
-#ifndef ACC_GROUP
-#define ACC_GROUP 4
-#endif
 template <int K> __device__ __forceinline__ float acc_tile_get() {
     float v;
     asm volatile("v_mov_b32 %0, v[" ACC_STR(ACC_TB) "+%1]" : "=v"(v) : "n"(K));
@@ -1353,19 +1280,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(ACC_TB))) void b
         auto fetch = [&](float (&v)[BIN_BATCH], int i0) {
 #pragma unroll
             for (int u = 0; u < BIN_BATCH; ++u) {
-#if defined(ACC_ABLATE) && ACC_ABLATE == 1      // timing experiment: no row loads
-                v[u] = __int_as_float(__builtin_amdgcn_readlane((int)key.x, i0 + u) + lane);
-#else
                 v[u] = df[(size_t)(unsigned)__builtin_amdgcn_readlane((int)key.x, i0 + u) * 64];
-#endif
             }
         };
         auto rl = [&](float x, int i) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), i)); };
         auto add = [&](const float (&v)[BIN_BATCH], int i0) {
-#if defined(ACC_ABLATE) && ACC_ABLATE == 2          // timing experiment: rows loaded, nothing added
-#pragma unroll
-            for (int u = 0; u < BIN_BATCH; ++u) asm volatile("" :: "v"(v[u]));
-#elif ACC_GROUP == 4
 #pragma unroll
             for (int u = 0; u < BIN_BATCH; u += 4) {
                 unsigned t[4]; float w[4][4], r[4];
@@ -1378,13 +1297,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(ACC_TB))) void b
                 }
                 acc_tile_add4(t, w, r);
             }
-#else
-#pragma unroll
-            for (int u = 0; u < BIN_BATCH; ++u) {
-                const int i = i0 + u;
-                acc_tile_add((unsigned)__builtin_amdgcn_readlane((int)key.y, i), rl(wq.x, i), rl(wq.y, i), rl(wq.z, i), rl(wq.w, i), v[u]);
-            }
-#endif
         };
         const int cnt = (int)min(64u, last - r0);
         fetch(va, 0);
@@ -1413,10 +1325,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(ACC_TB))) void b
     const float sc = scale ? scale[p * 32 + ch] : 1.0f;
     if (!g) return;
     g += (long long)n * P.grad_view_stride + (long long)p * P.H * P.W * 32 + ch;
-#if defined(ACC_ABLATE) && ACC_ABLATE == 3          // timing experiment: the tile is not added to the planes
-    asm volatile("" :: "v"(acc_tile_get<0>()), "v"(acc_tile_get<80>()));
-    return;
-#endif
     acc_tile_flush<0>(g, sc, ty << BIN_SHIFT, tx << BIN_SHIFT, P.H, P.W);
 }
 

@@ -31,16 +31,17 @@ def test_inline_asm_audit_and_accumulate_reg_kernel_register_contract():
 
 
 def test_asm_audit_detects_the_reproduced_hazard():
-    """The detector must see what the hardware punished: the experiment build -DNFE_SOFTPLUS_SCALAR=1 (an inline-asm v_add_f32 that
+    """The detector must see what the hardware punished: csrc/experiments/softplus_scalar_hazard.hip (an inline-asm v_add_f32 that
     reads a v_exp_f32 / v_log_f32 result without the wait state: run-dependent results on MI355X,
-    profiles/experiments/r04_asm_trans_hazard.md) has to fail rule TRNS, in every render kernel that contains the statement."""
-    env = dict(os.environ, ASM_AUDIT_FLAGS="-DNFE_SOFTPLUS_SCALAR=1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_audit.py"), "--files", "nfe_render.hip"], capture_output=True, text=True, timeout=900, env=env)
+    profiles/experiments/r04_asm_trans_hazard.md; rounds 3-4 carried it as a -D switch inside the product file, round 5 moved it
+    out) has to fail rule TRNS at every one of its statements."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "asm_audit.py"), "--files", "experiments/softplus_scalar_hazard.hip"],
+                       capture_output=True, text=True, timeout=900)
     assert r.returncode == 1, r.stdout[-2000:]
     hits = [l for l in r.stdout.splitlines() if l.startswith("VIOLATION") and "TRNS" in l]
-    assert len(hits) >= 100 and all("v_add_f32 reads the result of v_" in l for l in hits), hits[:3]
-    kernels = {l.split(":")[0] for l in hits}
-    assert any("render_ws_kernel" in k for k in kernels) and any("render_kernel" in k for k in kernels)
+    assert len(hits) >= 4 and all("v_add_f32 reads the result of v_" in l for l in hits), hits[:3]     # 7 of the 32 statements sit right behind their transcendental
+    assert "x32    in   1 kernels  [TRNS]" in r.stdout                                                  # and all 32 were seen and checked
+    assert all("softplus_scalar_hazard_kernel" in l.split(":")[0] for l in hits)
 
 
 def _fixer():

@@ -107,7 +107,7 @@ def test_backward_sweep(seed, dev):
     g2, a2 = ops.render_backward(pg, pa, decp_heads, 1.0, c["opts"], out2[4]["depths_all"], cots, sample_colors=out2[4]["sample_colors"],
                                  sample_colors_resolution=out2[4]["sample_colors_resolution"], **kw)
     r2, ra2 = ops.render_backward(pg, pa, decp_heads, 1.0, c["opts"], out2[4]["depths_all"], cots, **kw)
-    # (5e-6: the two forms feed the same float atomics, whose order differs from launch to launch - tools/r04_flake_probe.py measured up
+    # (5e-6: the two forms feed the same float atomics, whose order differs from launch to launch - tools/archive/r04_flake_probe.py measured up
     # to 1.02e-6 between two launches of the SAME form on case 6, whose 6 x 6 planes collect ~280 contributions per texel)
     for got, ref in ((g2, r2), (a2, ra2)):
         assert float((got - ref).abs().max()) <= 5e-6 * float(ref.abs().max()) + 1e-9, seed
