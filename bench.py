@@ -38,18 +38,20 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import bench_roofline as rl
+
 VIEWS_PER_GPU, R, D, PLANE = 4, 512, 64, 256
 BYTES_PER_RAY_S1 = D * 1 * 1536 + 196        # S=1 (single-gather identity) -> 98 500 B/ray
-HBM_PEAK_GBS = 8000.0                        # MI355X_MICROARCH.md: 8 TB/s spec
-PEAK_CLOCK_GHZ = 2.4                         # MI355X shader clock (hipDeviceProp clockRate); the chip holds 1.9-2.2 GHz under this load
-N_CU, N_SIMD = 256, 1024
-# Per-launch hardware counters of the dominant kernel, from rocprofv3 --pmc passes of THIS command on the shipped build
-# (tools/r04_profile2.sh: tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed).  PMC cannot be collected
-# inside the timed process.
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_issue_floor.json")
-# Static instruction mix of the kernels' per-sample loops (tools/isa_census.py) and the SIMD cycles one wave-instruction of each
-# class costs (tools/microbench/valu_rate.hip at two waves per SIMD): the `simd_pipes` ceiling below.
-CENSUS_FILE = os.path.join(ROOT, "profiles", "r04_isa_census.json")
+HBM_PEAK_GBS = rl.HBM_PEAK_GBS               # MI355X_MICROARCH.md: 8 TB/s spec
+# Per-launch hardware counters of every kernel a roofline block names: rocprofv3 --pmc passes of THESE commands on the shipped build
+# (tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed under profiles/; PMC cannot be collected inside the timed
+# process).  All roofline arithmetic lives in bench_roofline.py: one formula per number, the same for every workload.
+PMC = {"render": "r04_issue_floor.json", "render_fp32": "r04_issue_floor_fp32.json",
+       "twopass_final": "r04_issue_floor_twopass_final.json", "twopass_sigma": "r04_issue_floor_twopass_sigma.json",
+       "twopass_importance": "r04_issue_floor_twopass_importance.json"}
+# split-bf16 decoder: 3 MFMAs per product, and the geometry head's second layer runs a 32-row M block for 16 rows (8 192 padded of the
+# 7 168 algorithmic MACs per sample): matrix work issued per algorithmic flop
+DECODER_MFMA_WORK = 3.0 * 8192.0 / 7168.0
 
 
 def backward_roofline(bwd_ms, samples, logical_gbs):
@@ -65,7 +67,7 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
         rec = json.load(open(path))
     ach = rec["hbm_bytes_per_launch"] / rec["avg_ns_profiled"] if rec else None            # GB/s
     alg = samples * (3 * 256 + 3 * 28)                                                      # rows + records + index, per launch
-    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0 if rec else None,
+    return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if rec else None,
             "traffic": rec["hbm_bytes_per_launch"] if rec else None, "algorithmic_bytes_per_launch": alg,
             "kernel": "nfe::bwd_accumulate_reg_kernel (of: color_dot_kernel, bwd_ray_kernel, bwd_scatter_sorted_kernel<MFMA,BINNED>, "
                       "bwd_bin_fill_kernel, bwd_accumulate_reg_kernel)",
@@ -81,119 +83,6 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
                     "index per record, the accumulate pass (one wave owns an 8x8 texel tile in registers) reads index, record and row once per "
                     "plane; the forward keeps the decoders' per-sample outputs (192 B per sample) so that no sample is re-evaluated.  logical "
                     "gather + scatter bytes / time is quoted for reference only (planes and gradients are cache resident)"}
-
-
-def pmc_fractions(name, share_of_ms=None, total_ms=None, steps_per_launch=None):
-    """Ceilings of a kernel from its committed counter file profiles/<name> (one rocprofv3 --pmc record per launch, tools/pmc.sh):
-    busy cycles of each unit / kernel cycles.  The kernel cycles are the PROFILED launch's (GRBM_GUI_ACTIVE / 8 XCDs) unless the
-    caller gives this run's time of the whole multi-kernel step (`total_ms`) and the kernel's share of it under the profiler
-    (`share_of_ms`): then the profiled clock x (share x total_ms).  simd_pipes: the no-overlap SIMD execution time of the retired
-    instructions (issue_model's docstring); without a census of this variant the non-transcendental VALU instructions are priced at
-    the fused kernel's average (3.55 cycles) and the transcendentals at 163 per 32-sample step (`steps_per_launch`), 0 if unknown."""
-    path = os.path.join(ROOT, "profiles", name)
-    try:
-        c = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    clk = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["avg_ns_profiled"] * 1e-9)
-    ms = share_of_ms * total_ms if (share_of_ms and total_ms) else c["avg_ns_profiled"] * 1e-6
-    cycles = ms * 1e-3 * clk
-    hbm = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0
-    mfma_cost = c["SQ_VALU_MFMA_BUSY_CYCLES"] / max(c["SQ_INSTS_MFMA"], 1.0)                 # 32 (bf16 32x32x16) or 64 (f32 32x32x2)
-    trans = 163.0 * steps_per_launch if steps_per_launch else 0.0
-    other = max(c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"] - trans, 0.0)
-    fr = {"ta_busy": c["TA_TA_BUSY"] / N_CU / cycles, "l1_request": c["TCP_TOTAL_CACHE_ACCESSES"] / N_CU / cycles,
-          "matrix_pipe": c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / cycles,
-          "simd_pipes": (other * 3.55 + trans * 8.29 + c["SQ_INSTS_MFMA"] * mfma_cost) / N_SIMD / cycles,
-          "hbm": hbm / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)}
-    bound = max(fr, key=fr.get)
-    return {"kernel": c["kernel"], "kernel_ms": ms, "kernel_ms_profiled": c["avg_ns_profiled"] * 1e-6, "clock_ghz_profiled": clk / 1e9,
-            "bound": bound, "frac": fr[bound], "fractions": fr, "hbm_bytes": hbm, "counters_file": "profiles/" + name,
-            "wave_life_split": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
-                                "waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]}}
-
-
-def issue_model(kern_ms, logical_bytes, resident_waves=2 * N_SIMD, clock_ghz=None):
-    """The ceilings that can bind render_kernel, each as (cycles this resource is busy per launch) / (kernel cycles), with the
-    kernel cycles = the kernel time measured HERE x the effective shader clock of the profiled run (GRBM_GUI_ACTIVE / 8 XCDs /
-    profiled kernel time; SQ_* counters are quad-cycles, MI355X_MICROARCH.md):
-      wave_issue   share of a wave's life spent issuing instructions: SQ_ACTIVE_INST_ANY x 4 / resident waves (the grid is
-                   persistent: 2 workgroups x 4 waves per CU live for the whole launch).  The rest is issue stalls on
-                   dependencies / busy pipes (SQ_WAIT_INST_ANY) and s_waitcnt (SQ_WAIT_ANY), which two waves per SIMD - all
-                   that 256 VGPRs allow - cannot hide.  tools/microbench/valu_rate.hip (profiles/r02_valu_rate.txt): a wave
-                   issues at most one VALU instruction per 4.9 cycles, alone or beside a second wave;
-      matrix_pipe  SQ_VALU_MFMA_BUSY_CYCLES per SIMD (32 cycles per v_mfma_f32_32x32x16_bf16);
-      l1_request   TCP_TOTAL_CACHE_ACCESSES / 256 CUs at one 64-byte request per clock per CU;
-      ta_busy      TA_TA_BUSY per CU (texture-addresser busy cycles);
-      hbm          (2 x FETCH_SIZE + WRITE_SIZE) bytes against 8 TB/s  (gfx950 FETCH_SIZE correction, MI355X_MICROARCH.md);
-      logical_gather  SURVEY 8(d)'s algorithmic gather bytes against 8 TB/s - NOT a physical bound (the 25 MB plane set of a
-                   view is L2 / Infinity-Cache resident): kept because north_star quotes it; it exceeds 1.
-      simd_pipes   (round 4) the SIMD's execution time for the instructions the launch retires: measured instruction counts
-                   (SQ_INSTS_VALU, SQ_INSTS_MFMA, per launch) x the SIMD cycles one wave-instruction of its class occupies when two
-                   or more waves share the SIMD (plain VALU 2.47, packed fp32 4.53, transcendental 8.29, DPP / v_perm / v_cvt_pk
-                   4.45, v_mfma_f32_32x32x16_bf16 32: tools/microbench/valu_rate.hip, profiles/r02_valu_rate.txt), the VALU classes in
-                   the proportion of the kernel's static instruction census (profiles/r04_isa_census.json), summed as if nothing
-                   overlapped, per SIMD.  That no-overlap sum is 0.79-0.84 of the measured kernel time for the builds of this
-                   kernel (fused / wave-specialised, with / without the in-bounds gather path), and three or four waves per SIMD,
-                   or a hand-interleaved MFMA / transcendental order, shorten nothing (profiles/experiments/r04_render_ws.md): the
-                   SIMD executes this instruction mix essentially back to back; the remainder is LDS / L1 latency that the two
-                   waves of a SIMD do not cover.  It is the binding ceiling; rounds 1-3 read the same state as "no unit above
-                   0.5: latency-bound at two waves per SIMD".
-    Returns (bound name, dict of fractions, detail)."""
-    try:
-        with open(PMC_FILE) as f:
-            c = json.load(f)
-    except (OSError, ValueError):
-        return None, {}, {"note": f"{os.path.relpath(PMC_FILE, ROOT)} missing: run tools/r03_profile.sh"}
-    t = kern_ms * 1e-3
-    clk_prof = c["GRBM_GUI_ACTIVE"] / 8.0 / (c["avg_ns_profiled"] * 1e-9)     # effective shader clock of the profiled launches, Hz
-    # kernel cycles of THIS run: its own in-kernel clock (s_memtime against the 100 MHz s_memrealtime, stamped at both ends of every
-    # timed launch: nfe_render_args.clock_probe) when available, else the profiled run's clock
-    clk = clock_ghz * 1e9 if clock_ghz else clk_prof
-    cycles = t * clk
-    hbm_bytes = 2.0 * c["FETCH_SIZE"] * 1024.0 + c["WRITE_SIZE"] * 1024.0
-    frac = {"wave_issue": c["SQ_ACTIVE_INST_ANY"] * 4.0 / resident_waves / cycles,
-            "matrix_pipe": c["SQ_VALU_MFMA_BUSY_CYCLES"] / N_SIMD / cycles,
-            "l1_request": c["TCP_TOTAL_CACHE_ACCESSES"] / N_CU / cycles,
-            "ta_busy": c["TA_TA_BUSY"] / N_CU / cycles,
-            "hbm": hbm_bytes / t / (HBM_PEAK_GBS * 1e9), "logical_gather": logical_bytes / t / (HBM_PEAK_GBS * 1e9)}
-    census = None
-    try:
-        with open(CENSUS_FILE) as f:
-            census = json.load(f)
-        cost = census["simd_cycles_per_instruction"]
-        ws = "render_ws_kernel" in c.get("kernel", "")
-        fin = census.get("inbounds_fraction_config2", 0.9)
-        k = census["kernels"]
-
-        def mix(parts):                       # class counts per sample step of the dominant kernel, in-bounds / general steps weighted
-            out = {}
-            for name, wgt in parts:
-                for cls, n in k[name]["by_class"].items():
-                    out[cls] = out.get(cls, 0.0) + wgt * n
-            return out
-        m = mix([("render_ws_kernel.consumer", 1.0), ("render_ws_kernel.producer.inbounds", fin), ("render_ws_kernel.producer.general", 1.0 - fin)] if ws
-                else [("render_kernel.inbounds", fin), ("render_kernel.general", 1.0 - fin)])
-        valu_cls = ["valu", "valu_pk", "valu_trans", "valu_dpp/perm"]
-        static_valu = sum(m.get(x, 0.0) for x in valu_cls)
-        dyn_valu = c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]            # SQ_INSTS_VALU counts the MFMAs too (census: 1 085 + 48 against 1 117 measured)
-        simd_cycles = sum(m.get(x, 0.0) / static_valu * dyn_valu * cost[x] for x in valu_cls) + c["SQ_INSTS_MFMA"] * cost["mfma"]
-        frac["simd_pipes"] = simd_cycles / N_SIMD / cycles
-    except (OSError, ValueError, KeyError, ZeroDivisionError):
-        census = None
-    physical = {k: v for k, v in frac.items() if k != "logical_gather"}
-    bound = max(physical, key=physical.get)
-    detail = {"counters_file": os.path.relpath(PMC_FILE, ROOT), "kernel_profiled": c.get("kernel"), "kernel_ms_profiled": c["avg_ns_profiled"] / 1e6,
-              "effective_clock_ghz": clk / 1e9, "effective_clock_source": "in-run s_memtime / s_memrealtime" if clock_ghz else "profiled run",
-              "profiled_clock_ghz": clk_prof / 1e9, "valu_instructions": c["SQ_INSTS_VALU"], "mfma_instructions": c["SQ_INSTS_MFMA"],
-              "l1_requests": c["TCP_TOTAL_CACHE_ACCESSES"], "hbm_bytes": hbm_bytes,
-              "wave_life_split": {"issuing": c["SQ_ACTIVE_INST_ANY"] / c["SQ_WAVE_CYCLES"], "issue_stall": c["SQ_WAIT_INST_ANY"] / c["SQ_WAVE_CYCLES"],
-                                  "waitcnt": c["SQ_WAIT_ANY"] / c["SQ_WAVE_CYCLES"]},
-              "l2_hit_rate": c["TCC_HIT"] / max(c["TCC_HIT"] + c["TCC_MISS"], 1.0)}
-    if census is not None:
-        detail["census_file"] = os.path.relpath(CENSUS_FILE, ROOT)
-        detail["simd_cycles_per_instruction"] = census["simd_cycles_per_instruction"]
-    return bound, frac, detail
 
 
 def synth_inputs(torch, dev, seed):
@@ -323,34 +212,34 @@ def extra_workload(args, torch, dist, dev, rank, world):
         n_total, M = world * VIEWS_PER_GPU, R * R
         bytes_ray = (Dc + Dc) * 2 * 1536 + Dc * 1536 + 196      # final pass: 192 samples x 2 plane sets; coarse pass: 96 x geometry set
         ach = VIEWS_PER_GPU * M * bytes_ray / (ms * 1e-3) / 1e9
-        # counter-derived ceilings of the three kernels of the step (profiles/r04_issue_floor_twopass_*.json, tools/r04_profile1.sh);
-        # each kernel's time in THIS run = its share of the step under the profiler x this run's step time
-        rb = VIEWS_PER_GPU * (M // 32)
-        recs = {"final": ("r04_issue_floor_twopass_final.json", rb * 2 * Dc), "sigma": ("r04_issue_floor_twopass_sigma.json", rb * Dc * 64.0 / 163.0),
-                "importance": ("r04_issue_floor_twopass_importance.json", None)}
-        prof = {k: pmc_fractions(v[0]) for k, v in recs.items()}
+        # counter-derived roofline of the three kernels of the step (bench_roofline.kernel_block); each kernel's time in THIS run = its
+        # share of the step under the profiler x this run's step time
+        samples = {"final": VIEWS_PER_GPU * M * 2 * Dc, "sigma": VIEWS_PER_GPU * M * Dc}
+        recs = {"final": PMC["twopass_final"], "sigma": PMC["twopass_sigma"], "importance": PMC["twopass_importance"]}
+        prof = {k: rl.load(v) for k, v in recs.items()}
         kern = None
         if all(prof.values()):
-            tot = sum(p["kernel_ms_profiled"] for p in prof.values())
-            kern = {k: pmc_fractions(recs[k][0], share_of_ms=prof[k]["kernel_ms_profiled"] / tot, total_ms=ms, steps_per_launch=recs[k][1]) for k in recs}
+            tot = sum(p["avg_ns_profiled"] for p in prof.values())
+            kern = {"final": rl.kernel_block(recs["final"], kernel_ms=ms * prof["final"]["avg_ns_profiled"] / tot, flops=samples["final"] * rl.FLOPS_PER_SAMPLE,
+                                             mfma_type="bf16", mfma_work_multiplier=DECODER_MFMA_WORK,
+                                             gather_bytes=samples["final"] * 2 * rl.GATHER_BYTES_PER_SAMPLE_SET),
+                    "sigma": rl.kernel_block(recs["sigma"], kernel_ms=ms * prof["sigma"]["avg_ns_profiled"] / tot,
+                                             gather_bytes=samples["sigma"] * rl.GATHER_BYTES_PER_SAMPLE_SET),
+                    "importance": rl.kernel_block(recs["importance"], kernel_ms=ms * prof["importance"]["avg_ns_profiled"] / tot)}
         dom = kern["final"] if kern else None
         return dict(base, metric="rays/s, 512^2 x (96+96)-sample two-pass dual-plane render", value=n_total * M * args.steps / dt,
                     unit="rays/s", ms_per_step=dt / args.steps * 1e3, scaling="weak", dtype="f32",
                     config={"workload": "BASELINE config 5: render core through the (norm, denorm) entry, appearance statistics swapped "
                                         "between views, 4 views/GPU/step, 512^2 rays, 96 coarse + 96 importance samples",
                             "views_per_step": n_total, "parallelism": f"views-dp{world}"},
-                    roofline={"bound": dom["bound"] if dom else None, "frac": dom["frac"] if dom else None,
-                              "achieved": dom["frac"] * dom["clock_ghz_profiled"] if dom else None, "peak": dom["clock_ghz_profiled"] if dom else None,
-                              "unit": "G busy-cycles/s per unit" if dom else None, "traffic": dom["hbm_bytes"] if dom else None,
-                              "kernel": dom["kernel"] if dom else "nfe::render_kernel<DUAL> (final pass)", "kernel_ms": dom["kernel_ms"] if dom else None,
-                              "step_ms": ms, "kernels": kern, "logical_gather_gbs": ach,
-                              "note": "dominant kernel = the final pass over the 192 merged samples with both plane sets (70 % of the step): "
-                                      "texture addresser 0.78 and L1 request rate 0.75 busy beside a SIMD that is 0.7 busy by the no-overlap "
-                                      "instruction model - co-limited, no single unit saturated; `kernels` lists the same ceilings for the "
-                                      "sigma-only coarse pass and importance_kernel (instruction-bound: one wave per ray); every fraction = "
-                                      "busy cycles from the committed rocprofv3 --pmc record of that kernel / (its share of this run's step "
-                                      "time x the profiled clock); logical_gather_gbs = SURVEY 8(d) gather bytes of all three passes / "
-                                      "their time, not a physical rate (planes are cache resident)"})
+                    roofline=dict(rl.headline_fields(dom), kernel=dom["kernel"] if dom else "nfe::render_ws_kernel<4,2,DUAL> (final pass)",
+                                  kernel_ms=dom["kernel_ms"] if dom else None, step_ms=ms, kernels=kern, logical_gather_gbs=ach,
+                                  note="dominant kernel = the final pass over the 192 merged samples with both plane sets; bound / frac = the "
+                                       "largest COUNTER-MEASURED busy fraction of that kernel (bench_roofline.py: `fractions`; `models` are "
+                                       "instruction-count diagnostics and never the bound); `kernels` lists the same record for the sigma-only "
+                                       "coarse pass and importance_kernel; every fraction = busy cycles from the committed rocprofv3 --pmc record "
+                                       "of that kernel / (its share of this run's step time x the profiled clock); logical_gather_gbs = SURVEY "
+                                       "8(d) gather bytes of all three passes / their time, not a physical rate (planes are cache resident)"))
 
     if args.workload == "editstep":          # forward + backward of the renderer w.r.t. both plane sets, FFHQ rendering config
         Re, Dc = 128, 48
@@ -455,8 +344,8 @@ def extra_workload(args, torch, dist, dev, rank, world):
                     roofline={"bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": None, "kernel": "nfe::conv3_kernel<*> + upfir/torgb (backbone + SR stages)",
                               "kernel_ms": dense_ms,
-                              "kernels": DENSE_KERNEL_PMC["bf16x3" if conv_math == "bf16x3" else "bf16"], "conv_math": conv_math,
-                              "render_stage": pmc_fractions("r04_issue_floor.json") if not ffhq else None,
+                              "kernels": dense_kernel_pmc(conv_math), "conv_math": conv_math,
+                              "render_stage": render_kernel_block() if not ffhq else None,
                               "note": "289.1 GFLOP per view (SURVEY 8d) / single-stream time of the backbone + SR stages (stage_ms); "
                                       "split-bf16 issues 3 MFMAs per product, so the matrix pipe does 3x these flops in that mode.  `kernels`: "
                                       "matrix-pipe busy fraction of each conv kernel variant = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel "
@@ -471,34 +360,48 @@ def extra_workload(args, torch, dist, dev, rank, world):
                 roofline=orbit_roofline(out))
 
 
-# matrix-pipe busy fraction of the conv kernel variants (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), over all launches
-# of a `tools/time_full.py` run under rocprofv3 --pmc: profiles/r03_pmc_dense_*.txt; the dense kernels have not changed since)
-DENSE_KERNEL_PMC = {
-    "bf16": {"source": "profiles/r03_pmc_dense_bf16.txt",
-             "conv3_kernel<1,2,false,2,8,2> (plain 3x3, 8 waves)": {"matrix_pipe": 0.57, "tflops_whole_kernel": 1240},
-             "conv3_kernel<1,1,true,2,4,2> (up-sampling, fused FIR epilogue)": {"matrix_pipe": 0.25, "share_of_conv_time": 0.48, "share_of_conv_macs": 0.23}},
-    "bf16x3": {"source": "profiles/r03_pmc_dense_x3.txt",
-               "conv3_kernel<3,2,false,1,4,4> (plain 3x3, split-bf16)": {"matrix_pipe": 0.85, "note": "K loop; three MFMAs per product"}},
-}
+# matrix-pipe busy fraction of the conv kernel variants = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) over all launches of a
+# `tools/time_full.py` run under rocprofv3 --pmc, written by tools/dense_pmc_table.py into the committed JSON next to the raw summary
+DENSE_PMC_FILE = "r04_dense_kernels.json"
+
+
+def dense_kernel_pmc(conv_math):
+    t = rl.load(DENSE_PMC_FILE)
+    if t is None:
+        return None
+    key = {"bf16x3": "bf16x3", "bf16": "bf16", "fp16": "fp16"}.get(conv_math, conv_math)
+    return dict(t.get(key, {}), table="profiles/" + DENSE_PMC_FILE)
 
 
 MATH_NAME = {"bf16x3": "split-bf16 (fp32-grade, 3 MFMAs per product)", "bf16": "bf16", "fp16": "fp16-operand (the reference's GPU arithmetic, 1 MFMA per product)"}
 
 
+def render_kernel_block(kernel_ms=None, clock_ghz=None):
+    """bench_roofline record of the headline render kernel (4 views x 512^2 x 64): the ONE place that says which counter file, census
+    entries and algorithmic work belong to it, so that every workload prints the same numbers for it."""
+    c = rl.load(PMC["render"])
+    if c is None:
+        return None
+    samples = VIEWS_PER_GPU * R * R * D
+    return rl.kernel_block(PMC["render"], kernel_ms=kernel_ms, clock_ghz=clock_ghz, census_parts=rl.render_census_parts(c["kernel"]),
+                           flops=samples * rl.FLOPS_PER_SAMPLE, mfma_type="bf16", mfma_work_multiplier=DECODER_MFMA_WORK,
+                           gather_bytes=VIEWS_PER_GPU * R * R * BYTES_PER_RAY_S1)
+
+
 def orbit_roofline(out):
     """The orbit job is 77 % render kernel (8-view launches of the headline kernel, 1.56 ms per 512^2 x 64 view): its roofline block is
     that kernel's, from the same committed counter record as the headline line; the dense stages' aggregate stays beside it."""
-    r = pmc_fractions("r04_issue_floor.json")
+    r = render_kernel_block()
     if r is None:
         return {"bound": None, "frac": None, "achieved": None, "peak": None, "unit": None, "traffic": None, "kernel": None, "kernel_ms": None}
     per_view_ms = r["kernel_ms_profiled"] / VIEWS_PER_GPU
-    return {"bound": r["bound"], "frac": r["frac"], "achieved": r["frac"] * r["clock_ghz_profiled"], "peak": r["clock_ghz_profiled"],
-            "unit": "G busy-cycles/s per unit", "traffic": r["hbm_bytes"], "kernel": r["kernel"], "kernel_ms": r["kernel_ms_profiled"],
-            "fractions": r["fractions"], "render_share_of_pass": per_view_ms * 1e-3 * out["frames_per_rank"] / out["seconds_per_pass"],
+    return dict(rl.headline_fields(r), **{"kernel": r["kernel"], "kernel_ms": r["kernel_ms_profiled"],
+            "fractions": r["fractions"], "models": r["models"], "algorithmic": r.get("algorithmic"), "render_share_of_pass": per_view_ms * 1e-3 * out["frames_per_rank"] / out["seconds_per_pass"],
             "dense_tflops": out["dense_tflops"], "dense_frac_of_bf16_peak": out["dense_tflops"] / MFMA_BF16_PEAK_TFLOPS,
             "note": "dominant kernel = the render kernel (render_share_of_pass of this rank's wall time, from its profiled 4-view launch "
                     "time); fractions = busy cycles / kernel cycles of the committed rocprofv3 --pmc record of the headline command "
-                    "(profiles/r04_issue_floor.json), not re-measured by this run; dense_tflops = this rank's conv flops / wall time"}
+                    "(%s: the same record and the same formulas as the default bench line, at the profiled launch's own time and clock), "
+                    "not re-measured by this run; dense_tflops = this rank's conv flops / wall time" % r["counters_file"]})
 
 
 def orbit_job(args, torch, dist, dev, rank, world, frames=512, G=None, steps=1, warmup=0, chunk=8, return_frames=False):
@@ -770,13 +673,10 @@ def main():
         pr = probes.cpu().numpy().astype(np.float64)
         ok = (pr[:, 3] > pr[:, 1]) & (pr[:, 2] > pr[:, 0])
         clock_ghz = float(np.median((pr[ok, 2] - pr[ok, 0]) / (pr[ok, 3] - pr[ok, 1]) * 0.1)) if ok.any() else None   # 100 MHz reference
-        bound, frac, detail = issue_model(kern_ms, launch_bytes, clock_ghz=clock_ghz)
-        if bound == "hbm":              # achieved / peak in the binding resource's own unit
-            ach, peak, unit = frac[bound] * HBM_PEAK_GBS, HBM_PEAK_GBS, "GB/s"
-        elif bound is not None:         # busy cycles per second of the binding unit (wave issue port, matrix pipe, L1, TA)
-            ach, peak, unit = frac[bound] * detail["effective_clock_ghz"], detail["effective_clock_ghz"], "G busy-cycles/s per unit"
-        else:
-            ach, peak, unit = None, None, None
+        blk = render_kernel_block(kernel_ms=kern_ms, clock_ghz=clock_ghz)
+        samples = VIEWS_PER_GPU * M * D
+        fp32_blk = rl.kernel_block(PMC["render_fp32"], kernel_ms=fp32_ms, flops=samples * rl.FLOPS_PER_SAMPLE, mfma_type="f32",
+                                   mfma_work_multiplier=8192.0 / 7168.0, gather_bytes=launch_bytes)
         out = {
             "metric": "rays/s, 512^2 x 64-sample tri-plane render", "value": value, "unit": "rays/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -789,20 +689,22 @@ def main():
                        "rays_per_view": M, "depth_samples": D, "parallelism": f"views-dp{world}",
                        "preroll_steps": n_pre, "preroll_s": args.preroll_s},
             "distributed": dist_info,
-            "roofline": {"bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                         "frac": frac.get(bound) if bound else None, "traffic": detail.get("hbm_bytes"),
-                         "kernel": detail.get("kernel_profiled") or "nfe::render_ws_kernel<4,2,SQUARE=1,GENERIC=0>", "kernel_ms": kern_ms,
-                         "kernel_mcycles": kern_ms * 1e-3 * detail["effective_clock_ghz"] * 1e3 if detail.get("effective_clock_ghz") else None,   # shader cycles per launch (x 1e6): the box-independent figure (clocks differ by +-4 % between boxes)
-                         "kernel_ms_fp32_exact": fp32_ms, "fp32_exact": pmc_fractions("r04_issue_floor_fp32.json", share_of_ms=1.0, total_ms=fp32_ms, steps_per_launch=VIEWS_PER_GPU * (M // 32) * D),
-                         "fractions": frac,
-                         "algorithmic_bytes_per_launch": launch_bytes, "detail": detail,
-                         "note": "frac = busy cycles of the binding resource per launch (hardware counters of this build, profiles/) / "
-                                 "kernel cycles (kernel time measured here with HIP events x effective clock); `fractions` lists every "
-                                 "ceiling: per-wave instruction issue, matrix pipe, L1 request rate, TA, true HBM traffic, and SURVEY "
-                                 "8(d)'s logical gather bytes (not physical: planes are cache resident, so it exceeds 1), and simd_pipes = the "
-                                 "SIMD's own execution time for the retired instruction mix (the binding one: more waves per SIMD or a "
-                                 "different instruction order do not shorten the kernel, fewer / cheaper instructions do, DESIGN.md 6.1); "
-                                 "traffic = HBM bytes per launch"},
+            "roofline": dict(rl.headline_fields(blk), **{
+                "kernel": blk["kernel"] if blk else "nfe::render_ws_kernel<4,2,SQUARE=1,GENERIC=0>", "kernel_ms": kern_ms,
+                "kernel_mcycles": blk["kernel_mcycles"] if blk else None,   # shader cycles per launch (x 1e6): the box-independent figure (clocks differ by +-4 % between boxes)
+                "fractions": blk["fractions"] if blk else None, "models": blk["models"] if blk else None,
+                "algorithmic": blk.get("algorithmic") if blk else None,
+                "kernel_ms_fp32_exact": fp32_ms, "fp32_exact": fp32_blk,
+                "algorithmic_bytes_per_launch": launch_bytes, "detail": blk,
+                "note": "bound / frac = the LARGEST COUNTER-MEASURED busy fraction of a hardware unit (`fractions`: texture addresser, L1 "
+                        "request rate, matrix pipe, LDS issue, true HBM traffic - busy cycles of the committed rocprofv3 --pmc record of "
+                        "this command / (unit count x kernel cycles), kernel cycles = this run's HIP-event time x the clock the kernel "
+                        "itself read).  `models` are diagnostics from instruction counts x micro-benchmarked SIMD cycles per class and are "
+                        "never the bound: valu_pipe, simd_no_overlap (round 4's simd_pipes: vector and matrix time summed), "
+                        "simd_overlap_aware = max(valu + 8 n_mfma, 32 n_mfma) and the counter mfma_coexec_share beside them.  "
+                        "`algorithmic`: SURVEY 8(d)'s 0.94 GFLOP/kray against the bf16 MFMA peak at the split mode's 3.43x issued work, "
+                        "and its 98 500 B/ray against the aggregate L1 bandwidth (256 CUs x 64 B/clk) and, as north_star quotes it, "
+                        "against 8 TB/s (not physical: the planes are cache resident, HBM carries `traffic`).  Formulas: bench_roofline.py"}),
         }
         if strong is not None:
             out["strong_scaling"] = strong

@@ -1,5 +1,7 @@
-"""CPU: the roofline arithmetic of bench.py on the committed counter / census files (no GPU): the bench line must not depend on
-anything that is missing on the driver's box, and the ceilings must stay physical."""
+"""CPU: the roofline arithmetic of bench.py / bench_roofline.py on the committed counter and census files (no GPU).  The bench line
+must not depend on anything that is missing on the driver's box; `bound` / `frac` must be a counter-measured busy fraction of a
+hardware unit (never an instruction-count model); one kernel must print the same numbers in every workload; and every number must
+be recomputable from the committed files with the one formula bench_roofline.py documents for it."""
 import json
 import os
 import sys
@@ -8,37 +10,103 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def test_headline_roofline_block_from_committed_counters():
+def _counters(name):
+    return json.load(open(os.path.join(ROOT, "profiles", name)))
+
+
+def test_headline_bound_is_the_largest_counter_measured_unit():
     import bench
-    assert os.path.exists(bench.PMC_FILE) and os.path.exists(bench.CENSUS_FILE)
-    bound, frac, detail = bench.issue_model(6.25, bench.VIEWS_PER_GPU * bench.R * bench.R * bench.BYTES_PER_RAY_S1, clock_ghz=2.3)
-    assert bound == "simd_pipes", (bound, frac)
-    for k in ("wave_issue", "matrix_pipe", "l1_request", "ta_busy", "hbm", "simd_pipes"):
-        assert 0.0 < frac[k] < 1.0, (k, frac[k])              # physical ceilings stay below 1
-    assert frac["logical_gather"] > 1.0                        # SURVEY 8(d)'s logical bytes are not a physical rate
-    assert 0.7 < frac["simd_pipes"] < 0.95 and detail["census_file"].endswith("r04_isa_census.json")
-    assert "render_ws_kernel" in detail["kernel_profiled"]
+    import bench_roofline as rl
+    blk = bench.render_kernel_block(kernel_ms=6.25, clock_ghz=2.3)
+    assert blk is not None and "render_ws_kernel" in blk["kernel"]
+    c = _counters(bench.PMC["render"])
+    cycles = 6.25e-3 * 2.3e9
+    want = {"ta_busy": c["TA_TA_BUSY"] / 256 / cycles, "l1_request": c["TCP_TOTAL_CACHE_ACCESSES"] / 256 / cycles,
+            "matrix_pipe": c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / cycles, "lds_issue": c["SQ_ACTIVE_INST_LDS"] * 4 / 1024 / cycles,
+            "hbm": (2 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024 / 6.25e-3 / 8e12}
+    assert set(blk["fractions"]) == set(want)
+    for k, v in want.items():
+        assert abs(blk["fractions"][k] - v) <= 1e-12 and 0.0 < v < 1.0, (k, v, blk["fractions"][k])
+    assert blk["bound"] == max(want, key=want.get) == "ta_busy" and blk["frac"] == blk["fractions"]["ta_busy"]
+    assert 0.45 < blk["frac"] < 0.60                                # the texture addresser, about half busy
+    assert not set(blk["models"]) & set(blk["fractions"])            # a model can never be picked as the bound
+    h = rl.headline_fields(blk)
+    assert h["bound"] == "ta_busy" and abs(h["achieved"] / h["peak"] - h["frac"]) < 1e-12 and h["traffic"] == blk["hbm_bytes"]
+
+
+def test_simd_models_follow_their_formulas():
+    """valu_pipe = sum(class count x class cost), simd_no_overlap = valu + 32 n_mfma, simd_overlap_aware = max(valu + 8 n_mfma, 32
+    n_mfma), all / (1024 SIMDs x cycles); class counts = census proportions x dynamic SQ_INSTS_VALU (MFMAs excluded)."""
+    import bench
+    import bench_roofline as rl
+    blk = bench.render_kernel_block(kernel_ms=6.25, clock_ghz=2.3)
+    c, census = _counters(bench.PMC["render"]), _counters(rl.DEFAULT_CENSUS)
+    mix = rl.census_mix(census, rl.render_census_parts(c["kernel"]))
+    cost = census["simd_cycles_per_instruction"]
+    static = sum(mix[x] for x in rl.VALU_CLASSES)
+    dyn = c["SQ_INSTS_VALU"] - c["SQ_INSTS_MFMA"]
+    valu = sum(mix[x] / static * dyn * cost[x] for x in rl.VALU_CLASSES)
+    n = c["SQ_INSTS_MFMA"]
+    per = 1024 * 6.25e-3 * 2.3e9
+    m = blk["models"]
+    assert abs(m["valu_pipe"] - valu / per) < 1e-12
+    assert abs(m["simd_no_overlap"] - (valu + 32 * n) / per) < 1e-9
+    assert abs(m["simd_overlap_aware"] - max(valu + 8 * n, 32 * n) / per) < 1e-9
+    assert m["valu_pipe"] < m["simd_overlap_aware"] < m["simd_no_overlap"] < 1.0
+    assert 0.5 < m["valu_pipe"] < 0.7 and 0.7 < m["simd_no_overlap"] < 0.95
+    # an unknown kernel variant gets no modelled numbers at all (round 4 priced it at an average cost)
+    assert rl.render_census_parts("void nfe::render_ws_kernel<4, 2, true, true, true, false>(nfe::RenderK)") is None
+    two = rl.kernel_block(bench.PMC["twopass_final"])
+    assert two["models"]["valu_pipe"] is None and two["models"]["simd_no_overlap"] is None and two["census_file"] is None
+
+
+def test_same_kernel_same_numbers_in_every_workload():
+    """The default line (own time and clock), --workload full (`render_stage`) and --workload orbit use ONE function for the headline
+    kernel: at equal time and clock they print identical fractions, models and algorithmic figures."""
+    import bench
+    a = bench.render_kernel_block()
+    b = bench.render_kernel_block(kernel_ms=a["kernel_ms"], clock_ghz=a["clock_ghz"])
+    for k in ("fractions", "models", "algorithmic", "bound", "frac"):
+        assert a[k] == b[k], k
+    orbit = bench.orbit_roofline({"frames_per_rank": 512, "seconds_per_pass": 1.0, "dense_tflops": 100.0})
+    assert orbit["fractions"] == a["fractions"] and orbit["models"] == a["models"] and orbit["bound"] == a["bound"] and orbit["frac"] == a["frac"]
+
+
+def test_algorithmic_block():
+    """0.94 GFLOP per kray and 98 500 B per ray (S = 1).  Flops against the bf16 MFMA peak at the split mode's issued work
+    (3 MFMAs per product x 8 192 / 7 168 padding) - which must reproduce the measured matrix-pipe fraction - and gather bytes against the
+    aggregate L1 bandwidth, which must reproduce the measured L1 request fraction (every request is one 64-byte line)."""
+    import bench
+    blk = bench.render_kernel_block()
+    a = blk["algorithmic"]
+    rays = bench.VIEWS_PER_GPU * bench.R * bench.R
+    assert abs(a["flops_per_launch"] / rays * 1000 / 1e9 - 0.9175) < 1e-3            # 64 x 14 336 flop per ray = 0.9175 GFLOP per kray (+ bilinear)
+    assert a["gather_bytes_per_launch"] == rays * 98500
+    assert abs(a["frac_of_mfma_peak"] / blk["fractions"]["matrix_pipe"] - 1.0) < 0.12   # peak 2.5 PF is quoted at 2.4 GHz; the run held less
+    assert abs(a["frac_of_l1_aggregate"] / blk["fractions"]["l1_request"] - 1.0) < 0.02
+    assert a["frac_of_hbm_logical"] > 1.0 and blk["fractions"]["hbm"] < 0.02            # logical bytes are not a physical rate
+    assert 0.8 < a["frac_of_fp32_matrix_peak"] < 1.2
 
 
 def test_counter_files_of_every_reported_kernel_parse():
     import bench
-    steps = bench.VIEWS_PER_GPU * (bench.R * bench.R // 32)
-    for name, spl in (("r04_issue_floor_twopass_final.json", steps * 192), ("r04_issue_floor_twopass_sigma.json", steps * 96 * 64.0 / 163.0),
-                      ("r04_issue_floor_twopass_importance.json", None), ("r04_issue_floor_fp32.json", steps * 64)):
-        r = bench.pmc_fractions(name, steps_per_launch=spl)
-        assert r is not None, name
-        assert r["bound"] in r["fractions"] and 0.3 < r["frac"] < 1.0, (name, r["fractions"])
-        assert all(0.0 <= v < 1.0 for v in r["fractions"].values()), (name, r["fractions"])
-    fp32 = bench.pmc_fractions("r04_issue_floor_fp32.json", steps_per_launch=steps * 64)
-    assert 0.55 < fp32["fractions"]["matrix_pipe"] < 0.7            # 128 x 64-cycle fp32 MFMAs per 32 samples: 0.6, not 1.0
-    assert bench.pmc_fractions("does_not_exist.json") is None
+    import bench_roofline as rl
+    for key in ("twopass_final", "twopass_sigma", "twopass_importance", "render_fp32"):
+        r = rl.kernel_block(bench.PMC[key])
+        assert r is not None, key
+        assert r["bound"] in r["fractions"] and all(0.0 <= v < 1.0 for v in r["fractions"].values()), (key, r["fractions"])
+    assert rl.kernel_block(bench.PMC["twopass_final"])["bound"] == "ta_busy" and rl.kernel_block(bench.PMC["twopass_final"])["frac"] > 0.75
+    fp32 = rl.kernel_block(bench.PMC["render_fp32"])
+    assert fp32["bound"] == "matrix_pipe" and 0.55 < fp32["frac"] < 0.7     # 128 x 64-cycle fp32 MFMAs per 32 samples
+    assert rl.kernel_block("does_not_exist.json") is None and rl.headline_fields(None)["frac"] is None
 
 
 def test_census_file_is_consistent():
-    c = json.load(open(os.path.join(ROOT, "profiles", "r04_isa_census.json")))
+    import bench_roofline as rl
+    c = _counters(rl.DEFAULT_CENSUS)
     cost = c["simd_cycles_per_instruction"]
     for name, k in c["kernels"].items():
         cls = k["by_class"]
-        assert k["valu_total"] == sum(cls.get(x, 0) for x in ("valu", "valu_pk", "valu_trans", "valu_dpp/perm")), name
+        assert k["valu_total"] == sum(cls.get(x, 0) for x in rl.VALU_CLASSES), name
         assert abs(k["simd_cycles"] - sum(cls.get(x, 0) * v for x, v in cost.items())) <= 1, name
     assert c["kernels"]["render_kernel.inbounds"]["valu_total"] < c["kernels"]["render_kernel.general"]["valu_total"]
