@@ -646,8 +646,12 @@ template <int MBW> constexpr int conv3_ec_bytes() { return 3 * 32 * MBW * 4 > 10
 // WV..WV+LW-1 only stage operands: they keep STAGES-1 K-groups of LDS-DMA in flight, wait for the oldest one and meet the compute
 // waves at the one barrier per K-group.  The load stream no longer stops while a wave is in its MFMA phase (and vice versa): in
 // the symmetric form the two halves of the work overlapped by a quarter only (profiles/experiments/r03_conv3_negative.md).
-template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
-__global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 8 || (UP2 && TERMS == 3 && WV == 8)) ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
+// FU (round 5) > 0: the FUSED up-sampling form as a compile-time variant at FU waves per SIMD (no edge-column accumulators, branches
+// and bookkeeping of the unfused form in its K loop); FU = 0: fused or not at run time (P.up_fused).  Three workgroups per CU (FU = 3,
+// 168 registers) were measured and do not pay: profiles/experiments/r05_up_conv.md.
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0, int FU = 0>
+__global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NBW * MBW > 8 || (UP2 && TERMS == 3 && WV == 8)) ? 1 : ((STAGES * conv3_stage_bytes<TERMS, MBW, NBW * WV>() > 80 * 1024) ? 1 : 2) * WV / 4)) void conv3_kernel(Conv3K P) {
+    static_assert(FU == 0 || UP2, "FU: fused up-sampling variants only");
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
     constexpr int NACC = UP2 ? 4 : 1;
     constexpr int A_CHUNKS = MBW * 9 * PARTS;
@@ -668,8 +672,8 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
     // the tile width): the extra column x = W is not tiled (a 32-wide tile for one column); the right-most tile of every tile
     // row computes it as ONE extra N-block on wave 0 (lane = tile row): that column only sees input column W-1 through the
     // three kw = 2 taps, i.e. phases (a, b = 0), and its B fragments are column 32 of the patch the tile has staged anyway.
-    const bool fusedup = UP2 && P.up_fused;                // wave-uniform
-    const bool edge_mode = UP2 && !fusedup && (P.W % C3_TW) == 0;
+    const bool fusedup = UP2 && (FU > 0 || P.up_fused);    // wave-uniform
+    const bool edge_mode = UP2 && FU == 0 && !fusedup && (P.W % C3_TW) == 0;
     const int gw = UP2 ? (edge_mode ? P.W : P.W + 1) : P.W;
     const int tiles_x = fusedup ? (P.W + 29) / 30 : (gw + C3_TW - 1) / C3_TW;
     // XCD-aware order (split-bf16 variants): workgroups reach the 8 XCDs round-robin in dispatch order and every XCD has its own
@@ -744,6 +748,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
         unsigned char* base = lds + stage * STAGE_BYTES;
         // weights: chunk (m, t, part) <- packed[((mb0+m)*G + g)*18 + t*2 + part]
         for (int c = iw; c < A_CHUNKS; c += IW) {
+            if ((C3_ABM) & 1024) break;          // timing experiment: no weight staging
             const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
             const uint4* src = P.packed + (((long long)(mb0 + m) * G_all + g_base + g) * 18 + t * 2 + part) * 64 + lane;
             lds_dma16(src, base + c * 1024);
@@ -751,7 +756,7 @@ __global__ __launch_bounds__(64 * (WV + LW), LW ? (WV + LW) / 4 : ((NBW * MBW > 
 #pragma unroll
         for (int k = 0; k < B_PER_WAVE; ++k) {
             const int c = iw + IW * k;
-            if (c < C3_B_CHUNKS) {
+            if (c < C3_B_CHUNKS && !((C3_ABM) & 2048)) {      // 2048: timing experiment, no patch staging
 #pragma unroll
                 for (int part = 0; part < PARTS; ++part) {
                     const unsigned short* xs = part ? P.xl : P.xh;
@@ -1883,6 +1888,9 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
 #define C3_STAGES_X3 1
 #define C3_STAGES_X3_UP 1
 #endif
+#ifndef C3_UP_FUSED_WAVES
+#define C3_UP_FUSED_WAVES 0          // 0 = the run-time form (shipped).  > 0: waves per SIMD (= workgroups per CU) of a compile-time fused variant of the up-sampling kernel in bf16 / fp16: 2 measured the same as 0 (same box, three repetitions); 3 (168 registers: no patch-fragment cache, or 19 spilled dwords) measured 0 to -4 % on the 256-channel layers and +10 % on the 32-channel one, with the cache and its spills +40 %
+#endif
 #ifndef C3_MID
 #define C3_MID 0
 #endif
@@ -1930,27 +1938,27 @@ static bool up_fused(int math, int ksplit, int cin) {
 }
 
 static_assert(conv3_ec_bytes<2>() == 1024 && conv3_ec_bytes<4>() == 1536, "epilogue constants: three float rows of 32 * MBW channels");
-template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0, int FU = 0>
 static void launch_conv3_t(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override);
 // the bf16 variant table serves fp16 too: same tiles, stages and thresholds, the kernel instantiated with TERMS = 2
-template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0>
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW = 2, int LW = 0, int FU = 0>
 static void launch_conv3(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override = 0) {
-    if constexpr (TERMS == 1) { if (K.f16) { launch_conv3_t<2, MBW, UP2, STAGES, WV, NBW, LW>(K, mode_h, mode_w, st, tiles_override); return; } }
-    launch_conv3_t<TERMS, MBW, UP2, STAGES, WV, NBW, LW>(K, mode_h, mode_w, st, tiles_override);
+    if constexpr (TERMS == 1) { if (K.f16) { launch_conv3_t<2, MBW, UP2, STAGES, WV, NBW, LW, FU>(K, mode_h, mode_w, st, tiles_override); return; } }
+    launch_conv3_t<TERMS, MBW, UP2, STAGES, WV, NBW, LW, FU>(K, mode_h, mode_w, st, tiles_override);
 }
-template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW, int LW>
+template <int TERMS, int MBW, bool UP2, int STAGES, int WV, int NBW, int LW, int FU>
 static void launch_conv3_t(const Conv3K& K, int mode_h, int mode_w, hipStream_t st, unsigned tiles_override) {
     constexpr int ROWS = NBW * WV;
     constexpr int ring = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>(), fused_t = UP2 ? conv3_fused_t_bytes(ROWS) : 0;
     constexpr int bytes = (ring > fused_t ? ring : fused_t) + conv3_ec_bytes<MBW>();  // ring (or the fused FIR's tile) + the epilogue constants
     static bool once = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW, FU>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
     }();
     (void)once;
     const unsigned tiles = tiles_override ? tiles_override : ((mode_h + ROWS - 1) / ROWS) * ((mode_w + C3_TW - 1) / C3_TW);
     Conv3K K2 = K; K2.c3_tiles = (int)tiles;
     dim3 grid(c3_xcd_order(TERMS) ? (tiles + 7) / 8 * 8 : tiles, K.Cout / (32 * MBW), K.N * (K.ksplit > 1 ? K.ksplit : 1));
-    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW>), grid, dim3(64 * (WV + LW)), bytes, st, K2);
+    hipLaunchKernelGGL((conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW, FU>), grid, dim3(64 * (WV + LW)), bytes, st, K2);
 }
 
 // Which layers take the LDS-DMA path.  The tiles are 32 pixels wide; split-bf16 wants images at least that wide (narrower ones waste
@@ -2186,7 +2194,7 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             if (up_fused(math, c3ks, a->cin)) {                 // FIR and layer epilogue inside the conv kernel, overlapping tiles
                 K.up_fused = 1; K.next_styles = P.next_styles; K.split_hi = P.split_hi; K.split_lo = P.split_lo;
                 const unsigned tiles = (unsigned)((a->h + 5) / 6) * (unsigned)((a->w + 29) / 30);      // ROWS = 8: 6 x 30 new extended-input pixels per tile
-                if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4>(K, 0, 0, st, tiles);
+                if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4, 2, 0, C3_UP_FUSED_WAVES>(K, 0, 0, st, tiles);
                 else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, 0, 0, st, tiles);
                 break;
             }
