@@ -1413,6 +1413,197 @@ __global__ __launch_bounds__(256, 2) void torgb_kernel(ConvK P) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// ToRGB, coalesced form (round 5; rows that are a multiple of 32 pixels wide, Cout a multiple of 32 - the 96-channel tri-plane image
+// path of the backbone).  torgb_kernel above gives every lane its own operand bytes straight from memory: a lane's 32 bytes of a
+// K-group, its four skip taps and its output piece are 16-byte accesses 128 to 512 bytes apart, and the texture addresser handles
+// such an instruction at one lane per clock (63 cycles against 17 for four adjacent lanes x 16 contiguous bytes:
+// profiles/r01_gather_rate_microbench.txt) - counters of the shipped kernel: TA 0.70 busy, 80 % of a wave's life in s_waitcnt, HBM at
+// 2.0-2.3 TB/s (profiles/r04_pmc_dense_bf16.txt).  Here every global access is four adjacent lanes on 64 contiguous bytes and the
+// re-ordering happens in LDS:
+//   * inputs: one K-group of the wave's 32 pixels = 2 KiB = two instructions (lane = pixel l >> 2, piece l & 3), written to a
+//     swizzled LDS tile and read back in MFMA-operand order (lane (j, h): bytes 32 h .. + 31 of pixel j), four K-groups in flight;
+//   * skip image (upsample2d of the previous resolution, networks_stylegan2.py:453-456): the 2 rows x 18 half-resolution pixels a
+//     32-pixel row segment touches are staged per M-block (eight lanes per 128-byte slice) and the four taps come from LDS;
+//   * outputs: through a 32 pixel x 32 channel tile, so a store instruction writes eight whole 128-byte texels / pixel slices.
+// Arithmetic and its order are torgb_kernel's (MFMA order over K-groups and parts, epilogue_act(acc + bias) + the taps in skip_up2's
+// order): bit-identical outputs.  One 512-thread workgroup per CU (the weight fragments are shared by its eight waves).
+// ------------------------------------------------------------------------------------------------
+constexpr int TC_WAVES = 8, TC_PF = 4;
+constexpr int TC_TILE_FLOATS = 32 * 36;                               // 32 pixels x 32 channels, row stride 36: the x tile (512 floats) lives here too
+constexpr int TC_SKIP_FLOATS = 2 * 18 * 32;
+__host__ __device__ constexpr int tc_wave_floats(int cin) { return TC_TILE_FLOATS + TC_SKIP_FLOATS + cin; }
+static int num_cus_dense() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+    }
+    return cus;
+}
+
+template <int TERMS, int MB>
+__global__ __launch_bounds__(64 * TC_WAVES, 2) void torgb_coalesced_kernel(ConvK P) {
+    constexpr int PARTS = TERMS == 3 ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    uint4* ldsA = reinterpret_cast<uint4*>(lds);                     // [mb][g][part][lane]
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int G = P.Cin >> 4;
+    for (int i = tid; i < MB * G * PARTS * 64; i += 64 * TC_WAVES) {
+        const int ln = i & 63, part = (i >> 6) % PARTS, r = (i >> 6) / PARTS, g = r % G, mb = r / G;
+        ldsA[i] = P.packed[(((long long)mb * G + g) * 2 + part) * 64 + ln];
+    }
+    float* wl = reinterpret_cast<float*>(lds + (size_t)MB * G * PARTS * 1024) + (size_t)wave * tc_wave_floats(P.Cin);
+    float* tile = wl;                                    // x tile during the K loop, output tile in the epilogue
+    float* skp = wl + TC_TILE_FLOATS;                    // the current M-block's skip slice (the next one waits in registers)
+    float* sty = skp + TC_SKIP_FLOATS;                   // this view's styles
+    __syncthreads();
+    const int HW = P.H * P.W, nblk = HW >> 5, hs = P.H >> 1, ws = P.W >> 1;
+    const long long total = (long long)P.N * nblk;
+    const int pq = lane >> 2, pc = lane & 3;             // coalesced input loads: pixel pq (+16), 16-byte piece pc of the K-group
+    int sty_n = -1;
+    for (long long blk = (long long)blockIdx.x * TC_WAVES + wave; blk < total; blk += (long long)gridDim.x * TC_WAVES) {
+        const int n = (int)(blk / nblk), p0 = (int)(blk % nblk) * 32;
+        const int y = p0 / P.W, x0 = p0 % P.W;
+        if (n != sty_n) {                                // wave-uniform; same-wave LDS operations execute in order
+            for (int i = lane * 4; i < P.Cin; i += 256) *reinterpret_cast<float4*>(sty + i) = *reinterpret_cast<const float4*>(P.styles + (long long)n * P.Cin + i);
+            sty_n = n;
+        }
+        // ---- skip slices: half-resolution rows ya, ya + 1 and pixels hx0 .. hx0 + 17 (clamped: skip_up2 gives such taps weight 0)
+        const int ya = (y & 1) ? (y >> 1) : (y >> 1) - 1, hx0 = (x0 >> 1) - 1;
+        auto skip_load = [&](int mb, f32x4 (&v)[5]) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int chunk = min(it * 8 + (lane >> 3), 35), a = chunk / 18, px = chunk % 18;   // 36 slices of 128 bytes, eight lanes each (the last instruction's upper lanes repeat slice 35)
+                const int yc = min(max(ya + a, 0), hs - 1), xc = min(max(hx0 + px, 0), ws - 1);
+                v[it] = *reinterpret_cast<const f32x4*>(P.skip + (((long long)n * hs + yc) * ws + xc) * P.Cout + 32 * mb + 4 * (lane & 7));
+            }
+        };
+        auto skip_store = [&](const f32x4 (&v)[5]) {
+#pragma unroll
+            for (int it = 0; it < 5; ++it) {
+                const int chunk = min(it * 8 + (lane >> 3), 35), px = chunk % 18;                   // duplicates write the same value to the same place
+                *reinterpret_cast<f32x4*>(skp + chunk * 32 + 4 * ((lane & 7) ^ (px & 7))) = v[it];
+            }
+        };
+        f32x4 skv[5];
+#pragma unroll
+        for (int it = 0; it < 5; ++it) skv[it] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (P.skip) skip_load(0, skv);
+        // ---- K loop: TC_PF K-groups of coalesced loads in flight
+        const float* xrow = P.x + ((long long)n * HW + p0) * P.Cin;
+        f32x16 acc[MB];
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mb][r] = 0.0f;
+        f32x4 ring[TC_PF][2];
+#pragma unroll
+        for (int g = 0; g < TC_PF; ++g) {                 // (a layer with fewer K-groups than TC_PF re-reads its last one: harmless)
+            const int gc = min(g, G - 1);
+            ring[g][0] = *reinterpret_cast<const f32x4*>(xrow + (long long)pq * P.Cin + 16 * gc + 4 * pc);
+            ring[g][1] = *reinterpret_cast<const f32x4*>(xrow + (long long)(pq + 16) * P.Cin + 16 * gc + 4 * pc);
+        }
+        // x tile: 16-byte unit (pixel q, piece c) at q * 4 + (c ^ ((q >> 2) & 3)): the operand reads (16 lanes = 16 pixels, one piece) hit 16 bank groups
+        const int wr0 = (pq * 4 + (pc ^ ((pq >> 2) & 3))) * 4, wr1 = ((pq + 16) * 4 + (pc ^ (((pq + 16) >> 2) & 3))) * 4;
+        const int rdq = (j >> 2) & 3;
+        const int rd0 = (j * 4 + ((2 * h) ^ rdq)) * 4, rd1 = (j * 4 + ((2 * h + 1) ^ rdq)) * 4;
+#pragma unroll 1
+        for (int g0 = 0; g0 < G; g0 += TC_PF) {
+#pragma unroll
+            for (int u = 0; u < TC_PF; ++u) {
+                const int g = g0 + u;
+                if (g < G) {                              // wave-uniform
+                *reinterpret_cast<f32x4*>(tile + wr0) = ring[u][0];
+                *reinterpret_cast<f32x4*>(tile + wr1) = ring[u][1];
+                {
+                    const int gn = min(g + TC_PF, G - 1);         // past the end: the last K-group once more, never used
+                    ring[u][0] = *reinterpret_cast<const f32x4*>(xrow + (long long)pq * P.Cin + 16 * gn + 4 * pc);
+                    ring[u][1] = *reinterpret_cast<const f32x4*>(xrow + (long long)(pq + 16) * P.Cin + 16 * gn + 4 * pc);
+                }
+                const float4 x0v = *reinterpret_cast<const float4*>(tile + rd0), x1v = *reinterpret_cast<const float4*>(tile + rd1);
+                const float4 s0 = *reinterpret_cast<const float4*>(sty + 16 * g + 8 * h), s1 = *reinterpret_cast<const float4*>(sty + 16 * g + 8 * h + 4);
+                Frag8 bh, bl;
+                split2<TERMS>(x0v.x * s0.x, x0v.y * s0.y, bh.u[0], bl.u[0]);
+                split2<TERMS>(x0v.z * s0.z, x0v.w * s0.w, bh.u[1], bl.u[1]);
+                split2<TERMS>(x1v.x * s1.x, x1v.y * s1.y, bh.u[2], bl.u[2]);
+                split2<TERMS>(x1v.z * s1.z, x1v.w * s1.w, bh.u[3], bl.u[3]);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    Frag8 ah, al;
+                    ah.q = ldsA[((mb * G + g) * PARTS + 0) * 64 + lane];
+                    acc[mb] = mfma16<TERMS>(ah.v, bh.v, acc[mb], 0, 0, 0);
+                    if (TERMS == 3) {
+                        al.q = ldsA[((mb * G + g) * PARTS + 1) * 64 + lane];
+                        acc[mb] = mfma16<TERMS>(ah.v, bl.v, acc[mb], 0, 0, 0);
+                        acc[mb] = mfma16<TERMS>(al.v, bh.v, acc[mb], 0, 0, 0);
+                    }
+                }
+                }
+            }
+        }
+        // ---- epilogue per M-block: act(acc + bias) + skip taps -> output tile -> whole-line stores
+        const int x = x0 + j;
+        const int xa = (x & 1) ? (x >> 1) : (x >> 1) - 1;
+        const float wya = (y & 1) ? 0.75f : 0.25f, wyb = 1.0f - wya, wxa = (x & 1) ? 0.75f : 0.25f, wxb = 1.0f - wxa;
+        const int ysv[2] = {ya, ya + 1}, xsv[2] = {xa, xa + 1};
+        const float wyv[2] = {wya, wyb}, wxv[2] = {wxa, wxb};
+        float wgt[2][2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const float wye = (unsigned)ysv[a] < (unsigned)hs ? wyv[a] : 0.0f, wxe = (unsigned)xsv[b] < (unsigned)ws ? wxv[b] : 0.0f;
+                wgt[a][b] = wye * wxe;
+            }
+        if (P.skip) skip_store(skv);
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb) {
+            if (P.skip && mb + 1 < MB) skip_load(mb + 1, skv);          // in flight under this M-block's epilogue
+            const float* sk = skp;
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) {
+                const int o0 = 32 * mb + 8 * qq + 4 * h;
+                float v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) v[i] = epilogue_act(acc[mb][4 * qq + i] + P.bias[o0 + i], 0, P.act_gain, P.clamp);
+                if (P.skip) {
+                    float4 r = make_float4(0, 0, 0, 0);
+                    float4 t[2][2];
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            const int px = xsv[b] - hx0;                 // 0 .. 17
+                            t[a][b] = *reinterpret_cast<const float4*>(sk + (a * 18 + px) * 32 + 4 * ((2 * qq + h) ^ (px & 7)));
+                        }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int b = 0; b < 2; ++b) {
+                            r.x = fmaf(wgt[a][b], t[a][b].x, r.x); r.y = fmaf(wgt[a][b], t[a][b].y, r.y);
+                            r.z = fmaf(wgt[a][b], t[a][b].z, r.z); r.w = fmaf(wgt[a][b], t[a][b].w, r.w);
+                        }
+                    v[0] += r.x; v[1] += r.y; v[2] += r.z; v[3] += r.w;
+                }
+                *reinterpret_cast<float4*>(tile + j * 36 + 8 * qq + 4 * h) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            if (P.skip && mb + 1 < MB) skip_store(skv);            // after this M-block's taps were read (same-wave LDS operations execute in order)
+            float* orow = P.out_planes ? P.out + ((((long long)n * 3 + mb) * P.H + y) * P.W + x0) * 32
+                                       : P.out + ((long long)n * HW + p0) * P.Cout + 32 * mb;
+            const long long ostride = P.out_planes ? 32 : P.Cout;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {             // eight lanes per pixel: 128 contiguous bytes each
+                const int pp = 8 * it + (lane >> 3), c = lane & 7;
+                const float4 v4 = *reinterpret_cast<const float4*>(tile + pp * 36 + 4 * c);
+                *reinterpret_cast<float4*>(orow + (long long)pp * ostride + 4 * c) = v4;
+            }
+        }
+    }
+}
+
 template <int TERMS, int MB>
 static void launch_torgb_t(const ConvK& P, hipStream_t st);
 template <int TERMS, int MB>
@@ -1427,6 +1618,20 @@ static void launch_torgb_t(const ConvK& P, hipStream_t st) {
     if (bytes > allowed) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(torgb_kernel<TERMS, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         allowed = bytes;
+    }
+    // coalesced form (see torgb_coalesced_kernel): whole 32-pixel row segments, whole 32-channel output slices, LDS for eight waves
+    static const bool coalesced_on = [] { const char* e = getenv("NFE_TORGB_COALESCED"); return !e || e[0] != '0'; }();
+    const int cbytes = bytes + TC_WAVES * tc_wave_floats(P.Cin) * 4;
+    if (coalesced_on && P.W % 32 == 0 && P.Cout == 32 * MB && P.Cin % 16 == 0 && (P.Cin & 3) == 0 && cbytes <= 160 * 1024 && !(P.skip && ((P.H | P.W) & 1))) {
+        static int callowed = 0;
+        if (cbytes > callowed) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(torgb_coalesced_kernel<TERMS, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, cbytes);
+            callowed = cbytes;
+        }
+        const long long cblocks = ((long long)P.N * (P.H * P.W / 32) + TC_WAVES - 1) / TC_WAVES;
+        const long long cap = (long long)num_cus_dense() * (cbytes <= 80 * 1024 ? 2 : 1);
+        hipLaunchKernelGGL((torgb_coalesced_kernel<TERMS, MB>), dim3((unsigned)(cblocks < cap ? cblocks : cap)), dim3(64 * TC_WAVES), cbytes, st, P);
+        return;
     }
     const long long blocks = ((long long)P.N * ((P.H * P.W + 31) / 32) + 3) / 4;
     hipLaunchKernelGGL((torgb_kernel<TERMS, MB>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), bytes, st, P);
@@ -1897,15 +2102,6 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
 #ifndef C3_BIG
 #define C3_BIG 0          // measured slower (1 wave per SIMD, compiler-scheduled): bf16 SR 3.8 -> 4.0 ms, split-bf16 3.26 -> 3.45 ms
 #endif
-static int num_cus_dense() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
 #ifndef C3_TALL_MIN_TILES
 #define C3_TALL_MIN_TILES 4          // use the 8-wave 32x16 tile from 64 rows up
 #endif

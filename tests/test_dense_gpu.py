@@ -320,6 +320,60 @@ def test_torgb_fast_paths_match_generic(shape, math, dev):
     assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
 
 
+_TORGB_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from nerffaceediting_amd import _lib, dense_ops as D
+dev = torch.device("cuda:0")
+out = {}
+for math in ("bf16x3", "bf16", "fp16"):
+    for k, (N, H, W, cin, cout, planes, with_skip) in enumerate(((2, 64, 64, 128, 96, False, True), (3, 32, 96, 256, 96, False, True), (2, 128, 128, 128, 96, True, True),
+                                                                 (1, 64, 32, 64, 96, False, False), (2, 32, 32, 32, 32, False, True))):
+        g = torch.Generator(device="cpu").manual_seed(40 + k)
+        x = torch.randn(N, H, W, cin, generator=g).to(dev)
+        styles = (torch.randn(N, cin, generator=g) * 0.05).to(dev)
+        weight = torch.randn(cout, cin, 1, 1, generator=g).to(dev)
+        bias = torch.randn(cout, generator=g).to(dev)
+        skip = torch.randn(N, H // 2, W // 2, cout, generator=g).to(dev) if with_skip else None
+        packed, _ = D.conv_pack(weight, math=math) if math == "fp16" else D.conv_pack(weight)
+        y = D.modulated_conv(x, styles, packed, cout, _lib.NFE_CONV_1X1, bias=bias, lrelu=False, act_gain=1.0, clamp=256.0, skip=skip, math=math,
+                             **({"out_planes": True} if planes else {}))
+        out[f"{math}_{k}"] = y.cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_coalesced_torgb_is_bit_identical_to_the_per_lane_form(dev, tmp_path):
+    """Round 5: torgb_coalesced_kernel (every global access = four adjacent lanes on 64 contiguous bytes, re-ordering in LDS; rows of
+    32 k pixels, 32 k output channels) against torgb_kernel (every lane fetches its own operand bytes): the SAME BITS - MFMA order,
+    epilogue and skip-tap order are unchanged.  NFE_TORGB_COALESCED is read once per process: one child process per form.  Cases:
+    96-channel image path with and without skip, the tri-plane output layout, non-square rows, one M-block, all three operand formats."""
+    import os
+    import subprocess
+    import sys
+    import inspect
+    from nerffaceediting_amd import dense_ops as D
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "torgb.py"
+    text = _TORGB_SCRIPT
+    if "out_planes" not in inspect.signature(D.modulated_conv).parameters:
+        text = text.replace('**({"out_planes": True} if planes else {})', "")
+    if "math" not in inspect.signature(D.conv_pack).parameters:
+        text = text.replace('D.conv_pack(weight, math=math) if math == "fp16" else D.conv_pack(weight)', 'D.conv_pack(weight)')
+    script.write_text(text)
+    res = {}
+    for tag, env in (("per_lane", {"NFE_TORGB_COALESCED": "0"}), ("coalesced", {"NFE_TORGB_COALESCED": "1"})):
+        f = tmp_path / f"{tag}.npz"
+        r = subprocess.run([sys.executable, str(script), root, str(f)], env=dict(os.environ, **env), timeout=600, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[tag] = np.load(f)
+    keys = sorted(res["per_lane"].files)
+    assert keys == sorted(res["coalesced"].files) and len(keys) >= 10
+    for k in keys:
+        a, b = res["per_lane"][k], res["coalesced"][k]
+        assert a.shape == b.shape and np.isfinite(a).all() and np.array_equal(a, b), (k, float(np.abs(a - b).max()))
+
+
 @pytest.mark.parametrize("math", ["bf16x3", "bf16"])
 @pytest.mark.parametrize("shape,C,want_x", [((2, 64, 64, 64, 128), 3, True), ((1, 96, 128, 32, 256), 3, False), ((3, 32, 32, 128, 64), 4, True),
                                             ((2, 40, 72, 48, 128), 1, False), ((2, 8, 8, 64, 128), 3, True), ((3, 16, 16, 32, 64), 3, False)])
