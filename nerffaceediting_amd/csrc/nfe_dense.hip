@@ -557,6 +557,9 @@ __device__ uint4 nfe_zero16[4];                                  // source of th
 #endif
 // LDS of the fused up-sampling epilogue: C3_UP_DBUF + 1 slice buffers of [2 halves][2 ROWS][64] float4
 constexpr int conv3_fused_t_bytes(int rows) { return (C3_UP_DBUF ? 2 : 1) * 2 * (2 * rows) * 64 * 16; }
+#ifndef C3_PATCH_SWZ
+#define C3_PATCH_SWZ 1                                           // 0: A/B - no XOR swizzle of the patch halves (ascending DMA addresses, 2-way conflicts on the fragment reads)
+#endif
 #ifndef C3_UP_BCACHE
 #define C3_UP_BCACHE 1                                           // up-sampling K loop: the six distinct patch fragments of a K-group in registers
 #endif
@@ -707,7 +710,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
         // LDS item 2p + (hh ^ bit3(p)) holds channel half hh of patch pixel p: the two halves of a pixel (32 contiguous
         // bytes in NHWC) are fetched by adjacent lanes = one L1 request, and the XOR keeps the 32-byte-stride fragment
         // reads conflict-free (pixels p and p+8 share a bank pair, their halves are swapped).
-        const int pp = item >> 1, hh = (item & 1) ^ ((pp >> 3) & 1), py = pp / C3_PW, px = pp % C3_PW;
+        const int pp = item >> 1, hh = (item & 1) ^ (C3_PATCH_SWZ ? (pp >> 3) & 1 : 0), py = pp / C3_PW, px = pp % C3_PW;
 #if (C3_ABM) & 16      // timing experiment: every workgroup stages tile 0 of view 0 (operands L2-resident); 6: and no MFMA
         const int y = 7 + py, x = 7 + px;
         const bool ok = pp < C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
@@ -726,7 +729,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
             const int pp = (NBW * wave + rr) * C3_PW + j + cc;
-            brd[rr][cc] = (2 * pp + (h ^ ((pp >> 3) & 1))) * 16;
+            brd[rr][cc] = (2 * pp + (h ^ (C3_PATCH_SWZ ? (pp >> 3) & 1 : 0))) * 16;
         }
 
     const bool edge_tile = edge_mode && tx0 + C3_TW == P.W;
@@ -734,7 +737,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #pragma unroll
     for (int dy = 0; dy < 2; ++dy) {
         const int pp = (min(j, C3_TH - 1) + dy) * C3_PW + C3_TW;
-        brde[dy] = (2 * pp + (h ^ ((pp >> 3) & 1))) * 16;
+        brde[dy] = (2 * pp + (h ^ (C3_PATCH_SWZ ? (pp >> 3) & 1 : 0))) * 16;
     }
     f32x16 acce[UP2 ? 2 : 1][MBW];                             // edge column, phases a = 0, 1 (b = 0)
 #pragma unroll
