@@ -46,9 +46,9 @@ HBM_PEAK_GBS = rl.HBM_PEAK_GBS               # MI355X_MICROARCH.md: 8 TB/s spec
 # Per-launch hardware counters of every kernel a roofline block names: rocprofv3 --pmc passes of THESE commands on the shipped build
 # (tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed under profiles/; PMC cannot be collected inside the timed
 # process).  All roofline arithmetic lives in bench_roofline.py: one formula per number, the same for every workload.
-PMC = {"render": "r04_issue_floor.json", "render_fp32": "r04_issue_floor_fp32.json",
-       "twopass_final": "r04_issue_floor_twopass_final.json", "twopass_sigma": "r04_issue_floor_twopass_sigma.json",
-       "twopass_importance": "r04_issue_floor_twopass_importance.json"}
+PMC = {"render": "r05_issue_floor.json", "render_fp32": "r05_issue_floor_fp32.json",
+       "twopass_final": "r05_issue_floor_twopass_final.json", "twopass_sigma": "r05_issue_floor_twopass_sigma.json",
+       "twopass_importance": "r05_issue_floor_twopass_importance.json"}                 # tools/r05_profile.sh
 # split-bf16 decoder: 3 MFMAs per product, and the geometry head's second layer runs a 32-row M block for 16 rows (8 192 padded of the
 # 7 168 algorithmic MACs per sample): matrix work issued per algorithmic flop
 DECODER_MFMA_WORK = 3.0 * 8192.0 / 7168.0
@@ -62,7 +62,7 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
     import json
     import os
     rec = None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_backward_counters.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_backward_counters.json")      # the backward kernels are unchanged since round 4
     if os.path.exists(path):
         rec = json.load(open(path))
     ach = rec["hbm_bytes_per_launch"] / rec["avg_ns_profiled"] if rec else None            # GB/s
@@ -362,7 +362,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
 
 # matrix-pipe busy fraction of the conv kernel variants = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) over all launches of a
 # `tools/time_full.py` run under rocprofv3 --pmc, written by tools/dense_pmc_table.py into the committed JSON next to the raw summary
-DENSE_PMC_FILE = "r04_dense_kernels.json"
+DENSE_PMC_FILE = "r05_dense_kernels.json"
 
 
 def dense_kernel_pmc(conv_math):
@@ -520,8 +520,8 @@ def exchange_check(args, torch, dist, rank, world):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)      # 0.6 s of timed launches at the headline shape (round 4's default 20 = 0.13 s)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", choices=["render", "full", "ffhq", "orbit", "twopass", "editstep", "exchange"], default="render")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",

@@ -19,16 +19,22 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // Operand formats of the implicit GEMMs, the TERMS template argument of every kernel below:
 //   3  split-bf16 (hi + lo, three MFMAs per product, fp32-grade)      NFE_CONV_BF16X3
 //   1  bf16 (one MFMA per product)                                    NFE_CONV_BF16
-//   2  fp16 (one MFMA per product, v_mfma_f32_32x32x16_f16)           NFE_CONV_F16: the arithmetic the reference's GPU path uses
-//      for its fp16 layers (networks_stylegan2.py:421-423: fp16 operands, clamp +-256) - 11 significand bits against bf16's 8 at the
-//      same MFMA rate; accumulation stays fp32 and the activations between layers stay fp32 (only the MFMA operands are rounded).
+//   2  fp16 (one MFMA per product, v_mfma_f32_32x32x16_f16)           NFE_CONV_F16: the operand FORMAT of the reference's fp16 layers
+//      (networks_stylegan2.py:421-423: fp16 operands, clamp +-256) - 11 significand bits against bf16's 8 at the same MFMA rate;
+//      accumulation stays fp32 and the activations between layers stay fp32 (only the MFMA operands are rounded).  NOT the reference's
+//      fp16 arithmetic in one respect: its fused modulated conv pre-normalises weights (/ max|w| / sqrt(I k k)) and styles (/ max|s|)
+//      so that no product leaves the fp16 range (networks_stylegan2.py:54-56); here the raw weights and activation x style are rounded
+//      to fp16 directly and SATURATE at +-65504 (f16_pair): an operand beyond the range (a huge style on the unclamped 4^2..16^2
+//      layers, which the reference keeps in fp32) is clipped, it never becomes inf -> NaN
+//      (tests/test_dense_gpu.py::test_fp16_operands_saturate_instead_of_overflowing).
 // Everything that is "one part or two" asks TERMS == 3; TERMS 1 and 2 differ only in the conversion and the MFMA opcode.
 template <int TERMS>
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
     if constexpr (TERMS == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
-__device__ __forceinline__ unsigned f16_pair(float a, float b) {           // round to nearest even; beyond +-65504 -> +-inf (clamped layers never get there)
+__device__ __forceinline__ unsigned f16_pair(float a, float b) {           // round to nearest even, saturating at +-65504 (was +-inf)
+    a = __builtin_amdgcn_fmed3f(a, -65504.0f, 65504.0f); b = __builtin_amdgcn_fmed3f(b, -65504.0f, 65504.0f);
     f16x2 p = {(_Float16)a, (_Float16)b};
     return __builtin_bit_cast(unsigned, p);
 }

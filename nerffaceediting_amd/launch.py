@@ -48,8 +48,7 @@ def init_process_group(dist, backend, **kw):
         os.dup2(saved, 1)
         os.close(saved)
         saved = None
-        text = str(e).lower()
-        if os.environ.get("NFE_LAUNCHER") == "self" and ("address already in use" in text or "eaddrinuse" in text):
+        if os.environ.get("NFE_LAUNCHER") == "self" and _address_in_use(e):
             print(f"[launch] rank {os.environ.get('RANK')}: rendezvous port {os.environ.get('MASTER_PORT')} is taken", file=sys.stderr)
             sys.stderr.flush()
             os._exit(RENDEZVOUS_BUSY)
@@ -59,6 +58,23 @@ def init_process_group(dist, backend, **kw):
             ctypes.CDLL(None).fflush(None)
             os.dup2(saved, 1)
             os.close(saved)
+
+
+def _address_in_use(exc):
+    """EADDRINUSE from the rendezvous store, recognised by errno where the exception (or one it wraps) carries one, by type name
+    (torch.distributed.DistNetworkError) together with the message otherwise - the message alone differs between torch versions."""
+    import errno
+    seen = set()
+    e = exc
+    while e is not None and id(e) not in seen:
+        seen.add(id(e))
+        if getattr(e, "errno", None) == errno.EADDRINUSE:
+            return True
+        text = str(e).lower()
+        if "address already in use" in text or "eaddrinuse" in text or "errno: 98" in text or "error code: 98" in text:
+            return True
+        e = e.__cause__ or e.__context__
+    return False
 
 
 def launched_by_a_launcher(env=None):
@@ -97,9 +113,10 @@ def spawn_ranks(script, argv, nprocs, env=None, timeout=None, stdout=None):
             raise KeyboardInterrupt(f"signal {signum}")
         for sig in (signal.SIGTERM, signal.SIGINT):
             restore[sig] = signal.signal(sig, on_signal)
+    deadline = None if timeout is None else time.time() + timeout          # ONE deadline for all attempts (it restarted per attempt)
     try:
         for attempt in range(3):
-            rc, text = _run_ranks(script, argv, nprocs, base, procs, stop_all, timeout, stdout)
+            rc, text = _run_ranks(script, argv, nprocs, base, procs, stop_all, deadline, timeout, stdout)
             if rc != RENDEZVOUS_BUSY or attempt == 2:
                 return rc, text
             stop_all()
@@ -112,7 +129,10 @@ def spawn_ranks(script, argv, nprocs, env=None, timeout=None, stdout=None):
             signal.signal(sig, old)
 
 
-def _run_ranks(script, argv, nprocs, base, procs, stop_all, timeout, stdout):
+def _run_ranks(script, argv, nprocs, base, procs, stop_all, deadline, timeout, stdout):
+    """One attempt, against the caller's single deadline.  Rank 0's stdout is buffered until the attempt has ended and is echoed only
+    if it did not end in RENDEZVOUS_BUSY, so that nothing of an attempt that is going to be replayed reaches the caller's stdout (the
+    contract is exactly one result line; a rank's own output is one line at its very end, so nothing is lost by not streaming it)."""
     for r in range(nprocs):
         e = dict(base, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(script)] + list(argv), env=e,
@@ -122,11 +142,8 @@ def _run_ranks(script, argv, nprocs, base, procs, stop_all, timeout, stdout):
     def pump():
         for line in procs[0].stdout:
             captured.append(line)
-            stdout.write(line)
-            stdout.flush()
     t = threading.Thread(target=pump, daemon=True)
     t.start()
-    deadline = None if timeout is None else time.time() + timeout
     rc = 0
     live = set(range(nprocs))
     while live:
@@ -146,4 +163,8 @@ def _run_ranks(script, argv, nprocs, base, procs, stop_all, timeout, stdout):
         else:
             time.sleep(0.05)
     t.join(5)
+    if rc != RENDEZVOUS_BUSY:                  # a busy rendezvous is replayed on another port: its output is dropped, not echoed
+        for line in captured:
+            stdout.write(line)
+        stdout.flush()
     return rc, "".join(captured)

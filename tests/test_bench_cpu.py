@@ -83,7 +83,7 @@ def test_algorithmic_block():
     assert abs(a["flops_per_launch"] / rays * 1000 / 1e9 - 0.9175) < 1e-3            # 64 x 14 336 flop per ray = 0.9175 GFLOP per kray (+ bilinear)
     assert a["gather_bytes_per_launch"] == rays * 98500
     assert abs(a["frac_of_mfma_peak"] / blk["fractions"]["matrix_pipe"] - 1.0) < 0.12   # peak 2.5 PF is quoted at 2.4 GHz; the run held less
-    assert abs(a["frac_of_l1_aggregate"] / blk["fractions"]["l1_request"] - 1.0) < 0.02
+    assert abs(a["frac_of_l1_aggregate"] / blk["fractions"]["l1_request"] - 1.0) < 0.05
     assert a["frac_of_hbm_logical"] > 1.0 and blk["fractions"]["hbm"] < 0.02            # logical bytes are not a physical rate
     assert 0.8 < a["frac_of_fp32_matrix_peak"] < 1.2
 

@@ -320,6 +320,27 @@ def test_torgb_fast_paths_match_generic(shape, math, dev):
     assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
 
 
+def test_fp16_operands_saturate_instead_of_overflowing(dev):
+    """`conv_math='fp16'` rounds raw weights and activation x style to fp16 (the reference pre-normalises both to stay in
+    range, networks_stylegan2.py:54-56).  An operand beyond +-65504 must saturate, not become inf: a layer whose styles push the
+    modulated input to 1e6 still returns finite values, and where nothing saturates the outputs are what they were."""
+    from nerffaceediting_amd import _lib, dense_ops as D
+    g = torch.Generator(device="cpu").manual_seed(77)
+    N, H, cin, cout = 2, 32, 64, 64
+    x = torch.randn(N, H, H, cin, generator=g).to(dev)
+    w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    bias = torch.zeros(cout, device=dev)
+    packed, wsq = D.conv_pack(w, math="fp16")
+    for scale, finite_only in ((1.0, False), (1e6, True)):
+        st = ((torch.randn(N, cin, generator=g) * 0.5 + 1.0) * scale).to(dev)
+        dc = D.conv_demod(st, wsq)
+        y = D.modulated_conv(x, st, packed, cout, _lib.NFE_CONV_3X3, bias, dcoef=dc, math="fp16")
+        assert bool(torch.isfinite(y).all()), scale
+        if not finite_only:
+            ref = D.modulated_conv(x, st, D.conv_pack(w)[0], cout, _lib.NFE_CONV_3X3, bias, dcoef=dc, math="bf16x3")
+            assert float((y - ref).abs().max()) <= 4e-3 * float(ref.abs().max())
+
+
 _TORGB_SCRIPT = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[1])
