@@ -753,29 +753,79 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #pragma unroll
             for (int r = 0; r < 16; ++r) acce[a][m][r] = 0.0f;
 
-    auto issue = [&](int g, int stage) {
+    // Source pointers of this wave's LDS-DMA chunks, kept RUNNING (round 5): issue() is called for K-groups 0, 1, 2, ... in order, so a
+    // pointer advances by one K-group per call (two vector adds) instead of being rebuilt from (M-block, K-group, tap, part) with
+    // 64-bit scalar multiplies every time - the K loop of the up-sampling kernel spent 120 of its 198 instructions per K-group on that
+    // (static census of the ISA), and a wave of this kernel issues instructions for 45 % of its life (SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES).
+    // Not for the register-tight variants (plain bf16 / fp16 at four waves per SIMD: 128 registers, the six pointer pairs spill and the
+    // 8-view SR head got 4 % SLOWER): those rebuild their addresses as before (RUNPTR = false).
+    constexpr bool RUNPTR = UP2 || TERMS == 3;
+    constexpr int A_PER_WAVE = (A_CHUNKS + IW - 1) / IW;
+    const uint4* aptr[A_PER_WAVE];
+#pragma unroll
+    for (int kk = 0; kk < A_PER_WAVE; ++kk) {
+        const int c = min((issues ? iw : 0) + IW * kk, A_CHUNKS - 1);          // chunk (m, t, part) <- packed[((mb0+m)*G + g)*18 + t*2 + part]
+        const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
+        aptr[kk] = P.packed + (((long long)(mb0 + m) * G_all + g_base) * 18 + t * 2 + part) * 64 + lane;
+    }
+    const unsigned short* bptr[B_PER_WAVE][PARTS];
+    long long bstep[B_PER_WAVE];                                // elements per K-group: 0 for a padding lane (it stays on the zero page)
+#pragma unroll
+    for (int k = 0; k < B_PER_WAVE; ++k) {
+        bstep[k] = boff[k] >= 0 ? plane16 : 0;
+#pragma unroll
+        for (int part = 0; part < PARTS; ++part) {
+            const unsigned short* xs = part ? P.xl : P.xh;
+#if (C3_ABM) & 32
+            bptr[k][part] = xs + (long long)g_base * plane16 + (((issues ? iw : 0) + IW * k) * 64 + lane) * 8; bstep[k] = plane16;
+#else
+            bptr[k][part] = boff[k] >= 0 ? xs + boff[k] + (long long)g_base * plane16 : reinterpret_cast<const unsigned short*>(nfe_zero16);
+#endif
+        }
+    }
+    int g_next = 0;                                            // the K-group the next issue() call stages
+    auto issue = [&](int stage) {
         unsigned char* base = lds + stage * STAGE_BYTES;
-        // weights: chunk (m, t, part) <- packed[((mb0+m)*G + g)*18 + t*2 + part]
-        for (int c = iw; c < A_CHUNKS; c += IW) {
-            if ((C3_ABM) & 1024) break;          // timing experiment: no weight staging
-            const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
-            const uint4* src = P.packed + (((long long)(mb0 + m) * G_all + g_base + g) * 18 + t * 2 + part) * 64 + lane;
-            lds_dma16(src, base + c * 1024);
+        if constexpr (!RUNPTR) {
+            const int g = g_next++;
+            for (int c = iw; c < A_CHUNKS; c += IW) {
+                if ((C3_ABM) & 1024) break;
+                const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
+                const uint4* src = P.packed + (((long long)(mb0 + m) * G_all + g_base + g) * 18 + t * 2 + part) * 64 + lane;
+                lds_dma16(src, base + c * 1024);
+            }
+#pragma unroll
+            for (int k = 0; k < B_PER_WAVE; ++k) {
+                const int c = iw + IW * k;
+                if (c < C3_B_CHUNKS && !((C3_ABM) & 2048)) {
+#pragma unroll
+                    for (int part = 0; part < PARTS; ++part) {
+                        const unsigned short* xs = part ? P.xl : P.xh;
+#if (C3_ABM) & 32
+                        const void* src = (const void*)(xs + (long long)(g_base + g) * plane16 + (c * 64 + lane) * 8);
+#else
+                        const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + (long long)(g_base + g) * plane16) : (const void*)nfe_zero16;
+#endif
+                        lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
+                    }
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int kk = 0; kk < A_PER_WAVE; ++kk) {
+            const int c = iw + IW * kk;
+            if (c < A_CHUNKS && !((C3_ABM) & 1024)) lds_dma16(aptr[kk], base + c * 1024);      // 1024: timing experiment, no weight staging
+            aptr[kk] += 18 * 64;
         }
 #pragma unroll
         for (int k = 0; k < B_PER_WAVE; ++k) {
             const int c = iw + IW * k;
-            if (c < C3_B_CHUNKS && !((C3_ABM) & 2048)) {      // 2048: timing experiment, no patch staging
 #pragma unroll
-                for (int part = 0; part < PARTS; ++part) {
-                    const unsigned short* xs = part ? P.xl : P.xh;
-#if (C3_ABM) & 32
-                    const void* src = (const void*)(xs + (long long)(g_base + g) * plane16 + (c * 64 + lane) * 8);
-#else
-                    const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + (long long)(g_base + g) * plane16) : (const void*)nfe_zero16;
-#endif
-                    lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
-                }
+            for (int part = 0; part < PARTS; ++part) {
+                if (c < C3_B_CHUNKS && !((C3_ABM) & 2048))                                    // 2048: timing experiment, no patch staging
+                    lds_dma16(bptr[k][part], base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
+                bptr[k][part] += bstep[k];
             }
         }
     };
@@ -819,7 +869,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
     static_assert(LW == 0 || (STAGES >= 2 && !UP2), "loader waves need a ring of at least two stages; plain 3x3 only");
     if (issues)
         for (int pre = 0; pre < STAGES - 1; ++pre)
-            if (pre < G) issue(pre, pre);
+            if (pre < G) issue(pre);
     int stage = 0;
     if (loader) {                       // ---- loader waves: the whole K loop, then done (no epilogue, no further barriers) ----
         for (int g = 0; g < G; ++g) {
@@ -827,14 +877,14 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
             if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
             __syncthreads();            // stage g is complete for everybody; the compute waves are done with stage g-1
-            if (g + STAGES - 1 < G) issue(g + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);
+            if (g + STAGES - 1 < G) issue(stage == 0 ? STAGES - 1 : stage - 1);
             stage = stage + 1 == STAGES ? 0 : stage + 1;
         }
         return;
     }
     for (int g = 0; g < G; ++g) {
         C3_STAMPK(ts0);
-        if (STAGES == 1) { __syncthreads(); issue(g, 0); }
+        if (STAGES == 1) { __syncthreads(); issue(0); }
         // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
         if (LW > 0) {}                  // compute waves issue no loads: the loader waves wait for them
         else if ((C3_ABM) & 64) {}
@@ -845,7 +895,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
         C3_STAMPK(ts0b);
         const bool more = g + STAGES - 1 < G;
         const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
-        if (LW == 0 && STAGES >= 2 && more) issue(g + STAGES - 1, nstage);
+        if (LW == 0 && STAGES >= 2 && more) issue(nstage);
         C3_STAMPK(ts1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
