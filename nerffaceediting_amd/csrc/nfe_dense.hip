@@ -1157,6 +1157,12 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
                     dst[(h * TYL + 2 * (NBW * wave + nb) + (a >> 1)) * XS + 2 * j + (a & 1)] =
                         make_float4(acc[a][0][nb][4 * qq], acc[a][0][nb][4 * qq + 1], acc[a][0][nb][4 * qq + 2], acc[a][0][nb][4 * qq + 3]);
         };
+        // Store addresses (round 5): element offsets of this thread's first output row at slice 0, advanced by one row per step and by
+        // constants per slice - the per-row 64-bit index arithmetic (n, Y, X, channel quad -> offset, twice) was 100 of a slice's 690
+        // instructions, in a kernel whose waves issue instructions for 45 % of their lives.
+        const int Yf = 2 * ty0 + y0;
+        const long long o_first = (((long long)n * OH + Yf) * OW + X) * P.Cout + 4 * (8 * mb0 + hs), o_row = (long long)OW * P.Cout;
+        const long long s_first = split_index(n, P.Cout >> 4, OH, OW, Yf, X, 8 * mb0 + hs), s_row = (long long)OW * 4, s_plane = (long long)OH * OW * 4;
         if (C3_UP_DBUF) { put_slice(0); __syncthreads(); }
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
@@ -1167,6 +1173,9 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
                 const float4 b = *reinterpret_cast<const float4*>(ec + EC + 8 * qq + 4 * hs);
                 const float4 s2 = *reinterpret_cast<const float4*>(ec + 2 * EC + 8 * qq + 4 * hs);
                 const float4* col = Tl + (C3_UP_DBUF ? (qq & 1) * SLICE : 0) + (hs * TYL) * XS + Xl - 1;
+                // (The FIR as packed fp32 FMAs - half the instructions, bit-identical - was measured in round 5: -6 % on the 32-channel layer,
+                // whose launch is all epilogue, +2.5 / +6 % on the 256-channel layers: packed fp32 runs on the matrix pipe and contends with the
+                // co-resident workgroup's MFMAs.  Scalar FMAs stay.)
                 auto hrow = [&](int yl) {
                     const float4* rp = col + yl * XS;
                     const float4 t0 = rp[0], t1 = rp[1], t2 = rp[2], t3 = rp[3];
@@ -1178,8 +1187,10 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
                     return a4;
                 };
                 float4 w0 = hrow(y0 - 1), w1 = hrow(y0), w2 = hrow(y0 + 1);
+                long long oi = o_first + 8 * qq - o_row, si = s_first + (qq >> 1) * s_plane + 2 * (qq & 1) - s_row;   // channel quad 8 mb0 + 2 qq + hs
 #pragma unroll
                 for (int r = 0; r < SEG_ROWS; ++r) {
+                    oi += o_row; si += s_row;
                     const float4 w3 = hrow(y0 + r + 2);
                     float4 sm = make_float4(0, 0, 0, 0);
                     sm.x = fmaf(F[0], w0.x, sm.x); sm.y = fmaf(F[0], w0.y, sm.y); sm.z = fmaf(F[0], w0.z, sm.z); sm.w = fmaf(F[0], w0.w, sm.w);
@@ -1195,11 +1206,9 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
                     o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
                     o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
                     o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-                    const int c4 = 8 * mb0 + 2 * qq + hs;          // channel / 4
-                    if (P.out) *reinterpret_cast<float4*>(P.out + (((long long)n * OH + Y) * OW + X) * P.Cout + 4 * c4) = o;
+                    if (P.out) *reinterpret_cast<float4*>(P.out + oi) = o;
                     if (P.split_hi) {
                         unsigned h0, l0, h1, l1;
-                        const long long si = split_index(n, P.Cout >> 4, OH, OW, Y, X, c4);
                         if (TERMS == 3) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
                         else { split2<TERMS>(o.x * s2.x, o.y * s2.y, h0, l0); split2<TERMS>(o.z * s2.z, o.w * s2.w, h1, l1); }
                         P.split_hi[si] = make_uint2(h0, h1);
