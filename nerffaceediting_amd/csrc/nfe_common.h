@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 
@@ -25,6 +26,40 @@ const char* last_error();
         hipError_t e_ = hipGetLastError();                                                       \
         if (e_ != hipSuccess) return ::nfe::fail(NFE_ELAUNCH, "%s: %s", what, hipGetErrorString(e_)); \
     } while (0)
+
+// ---- host: device properties and the LDS opt-in, per device (a process may use several)
+constexpr int MAX_DEVICES = 64;
+static inline int current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess && dev >= 0 ? dev : 0; }
+// CU count of the CURRENT device (a process may render on several: one cached value per device id)
+static inline int num_cus() {
+    static std::atomic<int> cached[MAX_DEVICES];
+    const int dev = current_device();
+    int cus = dev < MAX_DEVICES ? cached[dev].load(std::memory_order_relaxed) : 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        if (cus <= 0) cus = 256;
+        if (dev < MAX_DEVICES) cached[dev].store(cus, std::memory_order_relaxed);
+    }
+    return cus;
+}
+
+// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute belongs to the (kernel, device) pair, so callers apply it per
+// device (LdsOptIn below) and a failure is an error of the launch, not something to find out from the launch's own failure.
+template <typename K>
+static inline hipError_t allow_lds(K kernel, int bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+struct LdsOptIn {          // one per kernel instantiation (function-local static): which devices have the attribute
+    std::atomic<unsigned long long> done{0};
+    template <typename K> hipError_t apply(K kernel, int bytes) {
+        const int dev = current_device();
+        if (dev < MAX_DEVICES && (done.load(std::memory_order_acquire) >> dev & 1ull)) return hipSuccess;
+        const hipError_t e = allow_lds(kernel, bytes);
+        if (e == hipSuccess && dev < MAX_DEVICES) done.fetch_or(1ull << dev, std::memory_order_release);
+        return e;
+    }
+};
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));

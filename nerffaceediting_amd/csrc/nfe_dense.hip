@@ -1501,16 +1501,6 @@ constexpr int TC_WAVES = 8, TC_PF = 4;
 constexpr int TC_TILE_FLOATS = 32 * 36;                               // 32 pixels x 32 channels, row stride 36: the x tile (512 floats) lives here too
 constexpr int TC_SKIP_FLOATS = 2 * 18 * 32;
 __host__ __device__ constexpr int tc_wave_floats(int cin) { return TC_TILE_FLOATS + TC_SKIP_FLOATS + cin; }
-static int num_cus_dense() {
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0; hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-    }
-    return cus;
-}
-
 template <int TERMS, int MB>
 __global__ __launch_bounds__(64 * TC_WAVES, 2) void torgb_coalesced_kernel(ConvK P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
@@ -1697,7 +1687,7 @@ static void launch_torgb_t(const ConvK& P, hipStream_t st) {
             callowed = cbytes;
         }
         const long long cblocks = ((long long)P.N * (P.H * P.W / 32) + TC_WAVES - 1) / TC_WAVES;
-        const long long cap = (long long)num_cus_dense() * (cbytes <= 80 * 1024 ? 2 : 1);
+        const long long cap = (long long)num_cus() * (cbytes <= 80 * 1024 ? 2 : 1);
         hipLaunchKernelGGL((torgb_coalesced_kernel<TERMS, MB>), dim3((unsigned)(cblocks < cap ? cblocks : cap)), dim3(64 * TC_WAVES), cbytes, st, P);
         return;
     }
@@ -2251,13 +2241,13 @@ static int conv3_ksplit(int mode, int n, int h, int w, int cin, int cout, int ma
         if (!on) return 0;
         const long long wgs = (long long)((h + 1 + 7) / 8) * ((w % 32 == 0 ? w : w + 1 + 31) / 32) * (cout / 32) * n;
         int ks = 1;
-        while (ks < 4 && wgs * ks < 4LL * num_cus_dense() && G / (ks * 2) >= 4) ks *= 2;
+        while (ks < 4 && wgs * ks < 4LL * num_cus() && G / (ks * 2) >= 4) ks *= 2;
         return ks > 1 ? ks : 0;
     }
-    const int rows = (h >= 16 * C3_TALL_MIN_TILES && (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense()) ? 16 : 8;
+    const int rows = (h >= 16 * C3_TALL_MIN_TILES && (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus()) ? 16 : 8;
     const long long wgs = (long long)((h + rows - 1) / rows) * ((w + 31) / 32) * (cout / 64) * n;
     int ks = 1;
-    while (ks < 4 && wgs * ks < 2LL * num_cus_dense() && G / (ks * 2) >= 8) ks *= 2;
+    while (ks < 4 && wgs * ks < 2LL * num_cus() && G / (ks * 2) >= 8) ks *= 2;
     return ks > 1 ? ks : 0;
 }
 
@@ -2268,17 +2258,17 @@ static int conv3_variant(int mode, int math, int n, int h, int w, int cout) {
     const bool bf16 = math == NFE_CONV_BF16;
     if (mode == NFE_CONV_3X3_UP2) return C3V_UP;
     const bool tall = h >= 16 * C3_TALL_MIN_TILES;
-    const bool fills = (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense();
-    if (C3_BIG && cout % 128 == 0 && h >= 16 && (long long)((h + 15) / 16) * ((w + 31) / 32) * (cout / 128) * n >= 2LL * num_cus_dense()) return C3V_BIG;
+    const bool fills = (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus();
+    if (C3_BIG && cout % 128 == 0 && h >= 16 && (long long)((h + 15) / 16) * ((w + 31) / 32) * (cout / 128) * n >= 2LL * num_cus()) return C3V_BIG;
     // round 3: 32x16 tile, four compute waves (4 rows x 2 M-blocks each) + four loader waves, one workgroup per CU, ring of 4 (bf16)
     // or 2 (split-bf16) stages
     static const int lc = [] { const char* e = getenv("NFE_C3_LC"); return e ? atoi(e) : C3_LC_DEFAULT; }();
-    if (lc && tall && (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus_dense()) return C3V_LC;
+    if (lc && tall && (long long)((h + 15) / 16) * ((w + 31) / 32) * ((cout + 63) / 64) * n >= num_cus()) return C3V_LC;
     if (C3_MID && tall && bf16) return C3V_MID;
     // round 3: 128 channels x 32x16 pixels on EIGHT waves (4 M-blocks x 2 rows per wave, 128 accumulator registers, one workgroup per
     // CU): 1.37x fewer staged bytes per MFMA than the 64-channel tile and 72 MFMAs per wave between barriers instead of 36
     static const int wide8 = [] { const char* e = getenv("NFE_C3_WIDE8"); return e ? atoi(e) : C3_WIDE8_DEFAULT; }();
-    if (wide8 && bf16 && tall && cout % 128 == 0 && (long long)((h + 15) / 16) * ((w + 31) / 32) * (cout / 128) * n >= num_cus_dense()) return C3V_WIDE8;
+    if (wide8 && bf16 && tall && cout % 128 == 0 && (long long)((h + 15) / 16) * ((w + 31) / 32) * (cout / 128) * n >= num_cus()) return C3V_WIDE8;
     if (!bf16 && tall && fills) return C3V_X3_TALL4;
     if (tall && fills) return C3V_TALL8;
     return C3V_BASE;

@@ -2079,39 +2079,6 @@ __global__ __launch_bounds__(256, 2) void decoder_kernel(DecoderK P) {
 // ------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------
-constexpr int MAX_DEVICES = 64;
-static int current_device() { int dev = 0; return hipGetDevice(&dev) == hipSuccess && dev >= 0 ? dev : 0; }
-// CU count of the CURRENT device (a process may render on several: one cached value per device id)
-static int num_cus() {
-    static std::atomic<int> cached[MAX_DEVICES];
-    const int dev = current_device();
-    int cus = dev < MAX_DEVICES ? cached[dev].load(std::memory_order_relaxed) : 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        if (cus <= 0) cus = 256;
-        if (dev < MAX_DEVICES) cached[dev].store(cus, std::memory_order_relaxed);
-    }
-    return cus;
-}
-
-// Opt a kernel into more than 64 KB of dynamic LDS.  The attribute belongs to the (kernel, device) pair, so callers apply it per
-// device (LdsOptIn below) and a failure is an error of the launch, not something to find out from the launch's own failure.
-template <typename K>
-static hipError_t allow_lds(K kernel, int bytes) {
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-}
-struct LdsOptIn {          // one per kernel instantiation (function-local static): which devices have the attribute
-    std::atomic<unsigned long long> done{0};
-    template <typename K> hipError_t apply(K kernel, int bytes) {
-        const int dev = current_device();
-        if (dev < MAX_DEVICES && (done.load(std::memory_order_acquire) >> dev & 1ull)) return hipSuccess;
-        const hipError_t e = allow_lds(kernel, bytes);
-        if (e == hipSuccess && dev < MAX_DEVICES) done.fetch_or(1ull << dev, std::memory_order_release);
-        return e;
-    }
-};
-
 template <bool DUAL, bool SIGMA_ONLY>
 static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_t st) {
     const bool noise = P.density_noise > 0.0f;

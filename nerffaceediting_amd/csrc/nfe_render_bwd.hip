@@ -512,7 +512,6 @@ __device__ __forceinline__ void bsplit(float a, float b, unsigned& hi, unsigned&
     bwd_bf16x2 p = {(__bf16)(a - __uint_as_float(ua & 0xffff0000u)), (__bf16)(b - __uint_as_float(ub & 0xffff0000u))};
     lo = *reinterpret_cast<unsigned*>(&p);
 }
-#define NFE_BFRAG(F, i) (F)[(i) * 64]
 __device__ __forceinline__ f32x16 mfma3(const BFrag& ah, const BFrag& al, const BFrag& bh, const BFrag& bl, f32x16 c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bh.v, c, 0, 0, 0);
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah.v, bl.v, c, 0, 0, 0);
@@ -527,12 +526,44 @@ __device__ __forceinline__ void acc_operand(const f32x16& a, int s1, BFrag& bh, 
 
 // One head for both N-blocks.  f: this lane's sample, 32 channels (lane = sample).  dout_of(b, r, acc y or nullptr) supplies the
 // cotangent of the head's outputs in B-operand order.  Result: tile[(32b + j) * stride + col0 + 16h + r] = df / 3.
-template <bool APP, typename DoutGeo, typename DoutApp>
-__device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const float* __restrict__ dec, const f32x2 (&f)[16], int lane,
+// Where the fragments and the biases come from: global memory (one wave per workgroup: every wave fetches all it uses, 178 KB per
+// 64 samples) or the workgroup's LDS image (bwd_decoder_kernel).  frag(i): this lane's 16 bytes of fragment i; bias0(head, k) /
+// bias1(k): four consecutive biases of layer 0 / of the appearance head's layer 1.
+struct FragGlobal {
+    const uint4* F; const float* dec;                 // F = fragments + lane
+    __device__ __forceinline__ uint4 frag(int i) const { return F[i * 64]; }
+    __device__ __forceinline__ float4 bias0(int head, int k) const { return *reinterpret_cast<const float4*>(dec + (head ? BB_A0 : BB_G0) + k); }
+    __device__ __forceinline__ float4 bias1(int k) const { return *reinterpret_cast<const float4*>(dec + BB_A1 + k); }
+    __device__ __forceinline__ void launder() {
+        unsigned long long fp = reinterpret_cast<unsigned long long>(F);
+        asm volatile("; nfe_launder %0" : "+v"(fp));
+        F = reinterpret_cast<const uint4*>(fp);
+    }
+};
+constexpr int BWD_LDS_BIAS = BWD_FRAG_BYTES;          // 160 floats: geometry layer 0 [64], appearance layer 0 [64], appearance layer 1 [32]
+constexpr int BWD_LDS_TILES = BWD_LDS_BIAS + 1024;
+struct FragLds {
+    unsigned off;                                     // byte offset of this lane's 16 bytes inside a fragment
+    __device__ __forceinline__ uint4 frag(int i) const {
+        extern __shared__ __attribute__((aligned(16))) unsigned char nfe_bwd_lds[];
+        return *reinterpret_cast<const uint4*>(nfe_bwd_lds + off + i * 1024);
+    }
+    __device__ __forceinline__ float4 bias0(int head, int k) const {
+        extern __shared__ __attribute__((aligned(16))) unsigned char nfe_bwd_lds[];
+        return *reinterpret_cast<const float4*>(nfe_bwd_lds + BWD_LDS_BIAS + (head * 64 + k) * 4);
+    }
+    __device__ __forceinline__ float4 bias1(int k) const {
+        extern __shared__ __attribute__((aligned(16))) unsigned char nfe_bwd_lds[];
+        return *reinterpret_cast<const float4*>(nfe_bwd_lds + BWD_LDS_BIAS + (128 + k) * 4);
+    }
+    __device__ __forceinline__ void launder() { asm volatile("; nfe_launder %0" : "+v"(off)); }
+};
+
+template <bool APP, typename Frag, typename DoutGeo, typename DoutApp>
+__device__ __forceinline__ void head_mfma(Frag F, const f32x2 (&f)[16], int lane,
                                           float* __restrict__ tile, int stride, int col0, DoutGeo dout_geo, DoutApp dout_app) {
     const int j = lane & 31, h = lane >> 5;
     const int head = APP ? 1 : 0;
-    const float* b0 = dec + (APP ? BB_A0 : BB_G0);
     // ---- B operands of F0 for both N-blocks: word w of k-step s holds channels 16s + 2w, +1 (Y) / 16s + 8 + 2w, +1 (X)
     BFrag bh[2][2], bl[2][2];                       // [block][k-step]
 #pragma unroll
@@ -549,18 +580,14 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
         }
 #pragma unroll 1
     for (int b = 0; b < 2; ++b) {
-        {   // the fragment loads are loop invariant: hoisted, all 52 of them would sit in registers (208 VGPRs) for the whole kernel
-            unsigned long long fp = reinterpret_cast<unsigned long long>(F);
-            asm volatile("; nfe_launder %0" : "+v"(fp));
-            F = reinterpret_cast<const uint4*>(fp);
-        }
+        F.launder();          // the fragment loads are loop invariant: hoisted, all 52 of them would sit in registers (208 VGPRs) for the whole kernel
         // ---- F0: pre-activations of the 64 hidden units (2 M-blocks), bias first
         f32x16 pre[2];
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bb = *reinterpret_cast<const float4*>(b0 + 32 * mb + 8 * q + 4 * h);
+                const float4 bb = F.bias0(head, 32 * mb + 8 * q + 4 * h);
                 pre[mb][4 * q] = bb.x; pre[mb][4 * q + 1] = bb.y; pre[mb][4 * q + 2] = bb.z; pre[mb][4 * q + 3] = bb.w;
             }
 #pragma unroll
@@ -568,7 +595,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 BFrag ah, al;
-                ah.q = NFE_BFRAG(F, BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 0); al.q = NFE_BFRAG(F, BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 1);
+                ah.q = F.frag(BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 0); al.q = F.frag(BF_F0 + ((head * 2 + mb) * 2 + s) * 2 + 1);
                 pre[mb] = mfma3(ah, al, b == 0 ? bh[0][s] : bh[1][s], b == 0 ? bl[0][s] : bl[1][s], pre[mb]);
             }
         f32x16 dh[2];
@@ -581,7 +608,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
             f32x16 y;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bb = *reinterpret_cast<const float4*>(dec + BB_A1 + 16 * h + 4 * q);
+                const float4 bb = F.bias1(16 * h + 4 * q);
                 y[4 * q] = bb.x; y[4 * q + 1] = bb.y; y[4 * q + 2] = bb.z; y[4 * q + 3] = bb.w;
             }
 #pragma unroll
@@ -591,7 +618,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
                 for (int r = 0; r < 8; ++r) hv[8 * (s & 1) + r] = softplus_t(pre[s >> 1][8 * (s & 1) + r]);
                 BFrag hh, hl, ah, al;
                 acc_operand(hv, s & 1, hh, hl);
-                ah.q = NFE_BFRAG(F, BF_F1A + s * 2 + 0); al.q = NFE_BFRAG(F, BF_F1A + s * 2 + 1);
+                ah.q = F.frag(BF_F1A + s * 2 + 0); al.q = F.frag(BF_F1A + s * 2 + 1);
                 y = mfma3(ah, al, hh, hl, y);
             }
             dout_app(b, y);                                       // y[r] <- cotangent of app output channel 16h + r
@@ -603,7 +630,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 #pragma unroll
                 for (int mb = 0; mb < 2; ++mb) {
                     BFrag ah, al;
-                    ah.q = NFE_BFRAG(F, BF_DHA + (mb * 2 + s) * 2 + 0); al.q = NFE_BFRAG(F, BF_DHA + (mb * 2 + s) * 2 + 1);
+                    ah.q = F.frag(BF_DHA + (mb * 2 + s) * 2 + 0); al.q = F.frag(BF_DHA + (mb * 2 + s) * 2 + 1);
                     dh[mb] = mfma3(ah, al, dhh, dhl, dh[mb]);
                 }
             }
@@ -617,7 +644,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
                 BFrag ah, al;
-                ah.q = NFE_BFRAG(F, BF_DHG + mb * 2 + 0); al.q = NFE_BFRAG(F, BF_DHG + mb * 2 + 1);
+                ah.q = F.frag(BF_DHG + mb * 2 + 0); al.q = F.frag(BF_DHG + mb * 2 + 1);
                 dh[mb] = mfma3(ah, al, dhh, dhl, dh[mb]);
             }
         }
@@ -635,7 +662,7 @@ __device__ __forceinline__ void head_mfma(const uint4* __restrict__ F, const flo
             }
             BFrag ph, pl, ah, al;
             acc_operand(dp, s & 1, ph, pl);
-            ah.q = NFE_BFRAG(F, BF_DF + (head * 4 + s) * 2 + 0); al.q = NFE_BFRAG(F, BF_DF + (head * 4 + s) * 2 + 1);
+            ah.q = F.frag(BF_DF + (head * 4 + s) * 2 + 0); al.q = F.frag(BF_DF + (head * 4 + s) * 2 + 1);
             df = mfma3(ah, al, ph, pl, df);
         }
         float* row = tile + (32 * b + j) * stride + col0 + 16 * h;
@@ -732,10 +759,11 @@ __device__ __forceinline__ void gather_pair_coop(const BwdK& P, int n, const Sam
     __builtin_amdgcn_wave_barrier();
 }
 // this lane's sample (lane = sample) back from the tile
+template <int STRIDE>
 __device__ __forceinline__ void tile_row(const float* tile, int lane, int col0, f32x2 (&f)[16]) {
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(tile + lane * SORT_TILE_STRIDE + col0 + 4 * q);
+        const float4 v = *reinterpret_cast<const float4*>(tile + lane * STRIDE + col0 + 4 * q);
         f[2 * q] = f32x2{v.x, v.y}; f[2 * q + 1] = f32x2{v.z, v.w};
     }
 }
@@ -767,7 +795,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     const float* dec = P.dec;
     const bool do_g = P.grad_g != nullptr, do_a = P.grad_a != nullptr && P.g_rgb != nullptr;
     if (MFMA) {       // decoder forward + backward on the matrix cores (head_mfma): 64 samples = two N-blocks of 32
-        const uint4* F = P.bfrag + lane;
+        const FragGlobal F{P.bfrag + lane, dec};
         const int jj = lane & 31, hh = lane >> 5;
         f32x2 f[16];
         const int sets = sgpr_nonnull(P.grad_g) | (sgpr_nonnull(P.grad_a) & sgpr_nonnull(P.g_rgb)) << 1;
@@ -782,7 +810,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // it has read them), and the lanes pick their values up with two / four ds_read_b128.
         const bool staged = NFE_BWD_COT_STAGED && !P.channels_first;
         if (do_g) {
-            tile_row(tile, lane, 0, f);
+            tile_row<SORT_TILE_STRIDE>(tile, lane, 0, f);
             if (staged) {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
@@ -794,7 +822,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            head_mfma<false>(F, dec, f, lane, tile, SORT_TILE_STRIDE, 0,
+            head_mfma<false>(F, f, lane, tile, SORT_TILE_STRIDE, 0,
                              [&](int b, float (&d)[8]) {          // outputs 8h..8h+7 of sample 32b + j: sigma = 0, seg = 1..15 (triplane.py:260-261)
                                  const int src = 32 * b + jj;
                                  const float gs = __shfl(gsig, src), om = __shfl(omega, src);
@@ -819,7 +847,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int c = 0; c < 32; ++c) tile[lane * SORT_TILE_STRIDE + c] = 0.0f;
         }
         if (do_a) {
-            tile_row(tile, lane, 32, f);
+            tile_row<SORT_TILE_STRIDE>(tile, lane, 32, f);
             if (staged) {
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll 4
@@ -831,7 +859,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            head_mfma<true>(F, dec, f, lane, tile, SORT_TILE_STRIDE, 32, [](int, float (&)[8]) {},
+            head_mfma<true>(F, f, lane, tile, SORT_TILE_STRIDE, 32, [](int, float (&)[8]) {},
                             [&](int b, f32x16& y) {               // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269), channel 16h + r
                                 const int src = 32 * b + jj;
                                 const float om = __shfl(omega, src);
@@ -1040,6 +1068,261 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     if (base) unsafeAtomicAdd(base + (long long)(kk[u] >> 8) * 32, acc * sc);
                     acc = 0.0f;
                 }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Decoder-backward pass of the binned form, workgroup version (round 5).  The single-wave kernel above is bound by its texture
+// requests (TA 0.67 busy, matrix pipe 0.089, profiles/r04_backward_counters.json) and nearly half of them fetch WEIGHTS: every wave
+// reads the 52 fragments + biases it uses from global memory, 178 KB per 64 samples - as many 64-byte lines as its gathers.  Here a
+// persistent workgroup of eight waves (still 256 registers each, two per SIMD, one workgroup per CU) stages the fragment image once into
+// LDS (52 KB) and every wave then walks items (64 samples = one ray tile at one depth) on its own: no workgroup barrier after the
+// staging.  To fit eight tiles beside the image the two plane sets of an item are processed one after the other through a 64 x 32
+// tile (stride 36 floats, 9 KB per wave): gather set -> tile -> the lane's sample -> head forward / backward -> feature gradients ->
+// tile -> one half (128 B) of the item's 64 rows of df.  Arithmetic per channel is that of the single-wave kernel, operation for
+// operation (its outputs are bit-identical; tests/test_backward_gpu.py compares the two), records and ranks likewise.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int DEC_WAVES = 8;
+constexpr int DEC_TILE_STRIDE = 36;                              // floats per sample row (32 channels of ONE plane set + pad; rows 16-byte aligned)
+constexpr int DEC_TILE_BYTES = 64 * DEC_TILE_STRIDE * 4;
+constexpr int DEC_LDS_BYTES = BWD_LDS_TILES + DEC_WAVES * DEC_TILE_BYTES;
+static_assert(DEC_LDS_BYTES <= 160 * 1024, "fragment image + eight tiles must fit a CU's LDS");
+
+// One plane set of the wave's 64 samples with eight lanes per texel row (gather_pair_coop for a single set): tile[sample][0..31], already / 3
+template <int SET>
+__device__ __forceinline__ void gather_set_coop(const BwdK& P, int n, const SampleGeo& geo, int lane, float* tile) {
+    const int s8 = lane >> 3, c4 = (lane & 7) * 4;
+    const float* pl = (SET ? P.planes_a : P.planes_g) + (long long)n * P.plane_view_stride + c4;
+    float4 sc[3], sh[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        sc[p] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        sh[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+    if (sgpr_nonnull(P.aff[2 * SET]) != 0) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            sc[p] = *reinterpret_cast<const float4*>(P.aff[2 * SET] + n * 96 + p * 32 + c4);
+            sh[p] = *reinterpret_cast<const float4*>(P.aff[2 * SET + 1] + n * 96 + p * 32 + c4);
+        }
+    }
+    auto fma4 = [](float w, const float4& v, const float4& a) { return make_float4(fmaf(w, v.x, a.x), fmaf(w, v.y, a.y), fmaf(w, v.z, a.z), fmaf(w, v.w, a.w)); };
+    auto affine = [](const float4& s, const float4& c, float wsum, const float4& h, const float4& f) {
+        return make_float4(f.x + fmaf(s.x, c.x, wsum * h.x), f.y + fmaf(s.y, c.y, wsum * h.y), f.z + fmaf(s.z, c.z, wsum * h.z), f.w + fmaf(s.w, c.w, wsum * h.w));
+    };
+#pragma unroll 4
+    for (int i = 0; i < 8; ++i) {
+        const int src = 8 * i + s8;
+        float4 fs = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            float4 sm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float wsum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int off = __shfl(geo.off[4 * p + k], src);
+                const float w = __shfl(geo.w[4 * p + k], src);
+                wsum += w;
+                sm = fma4(w, *reinterpret_cast<const float4*>(pl + off), sm);
+            }
+            fs = affine(sm, sc[p], wsum, sh[p], fs);
+        }
+        const float third = 1.0f / 3.0f;        // mean over planes, triplane.py:251
+        *reinterpret_cast<float4*>(tile + src * DEC_TILE_STRIDE + c4) = make_float4(fs.x * third, fs.y * third, fs.z * third, fs.w * third);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// the tile's 64 rows -> columns col .. col + 31 of the item's 64 df rows (eight rows of 128 B per store instruction)
+template <bool ZERO>
+__device__ __forceinline__ void store_half_rows(const float* tile, float* __restrict__ dst, int lane, int col) {
+    __builtin_amdgcn_wave_barrier();
+    const int s8 = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int row = 8 * i + s8;
+        const float4 v = ZERO ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : *reinterpret_cast<const float4*>(tile + row * DEC_TILE_STRIDE + c4);
+        *reinterpret_cast<float4*>(dst + row * 64 + col + c4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_decoder_kernel(BwdK P, unsigned n_items, unsigned n_views) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nfe_bwd_lds[];
+    {   // the fragment image and the biases, once per workgroup
+        uint4* sf = reinterpret_cast<uint4*>(nfe_bwd_lds);
+        for (int i = threadIdx.x; i < BF_COUNT * 64; i += 64 * DEC_WAVES) sf[i] = P.bfrag[i];
+        float* sb = reinterpret_cast<float*>(nfe_bwd_lds + BWD_LDS_BIAS);
+        const int i = threadIdx.x;
+        if (i < 160) sb[i] = P.dec[i < 64 ? BB_G0 + i : (i < 128 ? BB_A0 + i - 64 : BB_A1 + i - 128)];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float* tile = reinterpret_cast<float*>(nfe_bwd_lds + BWD_LDS_TILES + wave_in_wg * DEC_TILE_BYTES);
+    const FragLds F{(unsigned)lane * 16u};
+    const int jj = lane & 31, hh = lane >> 5;
+    const bool do_g = P.grad_g != nullptr, do_a = P.grad_a != nullptr && P.g_rgb != nullptr;
+    const bool staged = NFE_BWD_COT_STAGED && !P.channels_first;
+    const unsigned per_depth = (unsigned)P.t_count, per_view = per_depth * (unsigned)P.S;
+#pragma unroll 1
+    for (unsigned item = blockIdx.x * DEC_WAVES + (unsigned)wave_in_wg; item < n_items; item += gridDim.x * DEC_WAVES) {
+        // item order = the single-wave kernel's block order: ray tiles fastest, then depths, then views (neighbours in the plane run together)
+        const unsigned bz = item / per_view, rest = item - bz * per_view;
+        const int kdepth = (int)(rest / per_depth), bx = (int)(rest - (unsigned)kdepth * per_depth);
+        const int n = (int)bz + P.n0, t = bx + P.t0;
+        int m; bool live = true;
+        if (P.R > 0 && (P.R & 7) == 0 && (long long)P.R * P.R == P.M) {       // 8x8 pixel tile
+            const int tiles_x = P.R >> 3;
+            m = ((t / tiles_x) * 8 + (lane >> 3)) * P.R + (t % tiles_x) * 8 + (lane & 7);
+        } else {
+            m = t * 64 + lane; live = m < P.M; m = min(m, P.M - 1);
+        }
+        const size_t rec = (((size_t)n * P.T + t) * P.S + kdepth) * 64 + (live ? lane : (m & 63));
+        const float t_sample = P.rec_t[rec];
+        const float gsig = P.rec_sig[rec], omega = P.rec_a[rec];
+        const unsigned wave = (bz * (unsigned)P.t_count + (unsigned)bx) * (unsigned)P.S + (unsigned)kdepth;      // the item's slot in the chunk
+        float* dst = P.df + (size_t)wave * 4096;
+        f32x2 f[16];
+        if (do_g) {
+            SampleGeo geo;
+            sample_geometry(P, n, m, t_sample, geo);
+            gather_set_coop<0>(P, n, geo, lane, tile);
+            tile_row<DEC_TILE_STRIDE>(tile, lane, 0, f);
+            if (staged) {                 // seg cotangents, 16 lanes per ray row, into columns 1..15 (column 0: sigma's slot, not read)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+                for (int i = 0; i < 16; ++i) {
+                    const int ss = 4 * i + (lane >> 4), c = lane & 15;
+                    const int ms = __shfl(m, ss);
+                    const float v = (P.g_seg && c < 15) ? P.g_seg[((long long)n * P.M + ms) * 15 + c] : 0.0f;
+                    if (c < 15) tile[ss * DEC_TILE_STRIDE + 1 + c] = v;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            head_mfma<false>(F, f, lane, tile, DEC_TILE_STRIDE, 0,
+                             [&](int b, float (&d)[8]) {          // outputs 8h..8h+7 of sample 32b + j: sigma = 0, seg = 1..15 (triplane.py:260-261)
+                                 const int src = 32 * b + jj;
+                                 const float gs = __shfl(gsig, src), om = __shfl(omega, src);
+                                 if (staged) {
+                                     const float4 c0 = *reinterpret_cast<const float4*>(tile + src * DEC_TILE_STRIDE + 8 * hh);
+                                     const float4 c1 = *reinterpret_cast<const float4*>(tile + src * DEC_TILE_STRIDE + 8 * hh + 4);
+                                     const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+#pragma unroll
+                                     for (int e = 0; e < 8; ++e) d[e] = (8 * hh + e) == 0 ? gs : om * cv[e];
+                                     return;
+                                 }
+                                 const int mm = __shfl(m, src);
+#pragma unroll
+                                 for (int e = 0; e < 8; ++e) {
+                                     const int o = 8 * hh + e;
+                                     d[e] = o == 0 ? gs : om * cot_seg(P, n, mm, o - 1);
+                                 }
+                             },
+                             [](int, f32x16&) {});
+            store_half_rows<false>(tile, dst, lane, 0);
+        } else {
+            store_half_rows<true>(tile, dst, lane, 0);
+        }
+        if (do_a) {
+            SampleGeo geo;
+            sample_geometry(P, n, m, opaque_f(t_sample), geo);        // again: 24 registers are not kept across the geometry head
+            gather_set_coop<1>(P, n, geo, lane, tile);
+            tile_row<DEC_TILE_STRIDE>(tile, lane, 0, f);
+            if (staged) {                 // rgb cotangents, eight lanes per ray row of 128 bytes; the * 2 of rgb * 2 - 1 here (cot_rgb)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+                for (int i = 0; i < 8; ++i) {
+                    const int ss = 8 * i + (lane >> 3), c4 = (lane & 7) * 4;
+                    const int ms = __shfl(m, ss);
+                    const float4 v = *reinterpret_cast<const float4*>(P.g_rgb + ((long long)n * P.M + ms) * 32 + c4);      // do_a: g_rgb is not null
+                    *reinterpret_cast<float4*>(tile + ss * DEC_TILE_STRIDE + c4) = make_float4(2.0f * v.x, 2.0f * v.y, 2.0f * v.z, 2.0f * v.w);
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            head_mfma<true>(F, f, lane, tile, DEC_TILE_STRIDE, 0, [](int, float (&)[8]) {},
+                            [&](int b, f32x16& y) {               // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269), channel 16h + r
+                                const int src = 32 * b + jj;
+                                const float om = __shfl(omega, src);
+                                if (staged) {
+                                    const float* cr = tile + src * DEC_TILE_STRIDE + 16 * hh;
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const float4 cv = *reinterpret_cast<const float4*>(cr + 4 * q);
+                                        const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                                        for (int u = 0; u < 4; ++u) {
+                                            const float sg = sigmoid_t(y[4 * q + u]);
+                                            y[4 * q + u] = om * c4[u] * 1.002f * sg * (1.0f - sg);
+                                        }
+                                    }
+                                    return;
+                                }
+                                const int mm = __shfl(m, src);
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const float sg = sigmoid_t(y[r]);
+                                    y[r] = om * cot_rgb(P, n, mm, 16 * hh + r) * 1.002f * sg * (1.0f - sg);
+                                }
+                            });
+            store_half_rows<false>(tile, dst, lane, 32);
+        } else {
+            store_half_rows<true>(tile, dst, lane, 32);
+        }
+        // ---- one bin record per (sample, plane), as in the single-wave kernel
+        const unsigned idx = wave * 64 + (unsigned)lane;
+        const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
+        float ro[3], rd[3];
+        ray_of(P, n, m, ro, rd);
+        const float tt = t_sample;
+        const float cx = P.coord_scale * fmaf(tt, rd[0], ro[0]), cy = P.coord_scale * fmaf(tt, rd[1], ro[1]), cz = P.coord_scale * fmaf(tt, rd[2], ro[2]);
+        unsigned bin3[3], rank3[3], group3[3], loc3[3];
+        int first3[3];
+        float4 w3[3];
+        bool any3[3];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const Taps tp = tap_geometry(P.H, P.W, p == 2 ? cz : cx, p == 0 ? cy : (p == 1 ? cz : cx));      // as sample_geometry
+            const int x0 = tp.xc0, x1 = tp.xc1, y0 = tp.yc0, y1 = tp.yc1;
+            const bool any = (live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
+            const unsigned bin = any ? (bz * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
+                                     : KEY_INVALID;
+            unsigned rank = 0, group = 0;
+            int first_lane = -1;                      // stays -1 on lanes without a record
+            const unsigned long long have = __ballot(any);
+            unsigned todo_lo = (unsigned)have, todo_hi = (unsigned)(have >> 32);
+            for (;;) {
+                todo_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_lo); todo_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_hi);
+                asm volatile("; nfe_launder %0 %1" : "+s"(todo_lo), "+s"(todo_hi));
+                if ((todo_lo | todo_hi) == 0u) break;
+                const int leader = todo_lo ? __builtin_ctz(todo_lo) : 32 + __builtin_ctz(todo_hi);
+                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                const unsigned long long same = __ballot(bin == b);          // b is a live record's bin, dead lanes hold KEY_INVALID
+                if (bin == b) { rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull)); group = (unsigned)__popcll(same); first_lane = leader; }
+                todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
+            }
+            const int sx = x1 - x0, sy = y1 - y0;        // clamped taps folded (see the single-wave kernel)
+            float w0 = tp.w[0], w1 = tp.w[1], w2 = tp.w[2], w3v = tp.w[3];
+            if (sx == 0) { w0 += w1; w2 += w3v; w1 = 0.0f; w3v = 0.0f; }
+            if (sy == 0) { w0 += w2; w1 += w3v; w2 = 0.0f; w3v = 0.0f; }
+            bin3[p] = bin; rank3[p] = rank; group3[p] = group; first3[p] = first_lane; any3[p] = any;
+            loc3[p] = (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK));
+            w3[p] = make_float4(w0, w1, w2, w3v);
+        }
+        unsigned base3[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+            if (first3[p] == lane) base3[p] = __hip_atomic_fetch_add(P.counts + bin3[p], group3[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const unsigned rank = rank3[p] + (unsigned)__shfl((int)base3[p], first3[p] & 63);
+            const size_t slot = (size_t)p * ((size_t)n_views * P.t_count * P.S * 64) + idx;
+            P.binrank[slot] = make_uint2(bin3[p], rank);
+            if (any3[p]) {
+                P.rec_key[slot] = make_uint2(idx, loc3[p]);
+                P.rec_w[slot] = w3[p];
             }
         }
     }
@@ -1439,6 +1722,7 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     hipLaunchKernelGGL(bwd_ray_kernel, dim3((unsigned)(((long long)a->n_views * P.T + 3) / 4)), dim3(256), 0, st, P);
     NFE_CHECK_LAUNCH("bwd_ray_kernel");
     static const bool valu_dec = [] { const char* e = getenv("NFE_BWD_DECODER"); return e && e[0] == 'v'; }();      // A/B knob: "valu"
+    static const bool single_wave = [] { const char* e = getenv("NFE_BWD_DECODER"); return e && e[0] == 's'; }();   // A/B knob: "single" = round 4's one-wave workgroups
     static const bool acc_lds = [] { const char* e = getenv("NFE_BWD_ACC"); return e && e[0] == 'l'; }();            // A/B knob: "lds" = tile in LDS
     unsigned* frags = (unsigned*)((char*)P.rec_t + rec_bytes + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4));
     if (direct) {
@@ -1485,8 +1769,16 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
             if (hipMemsetAsync(P.counts, 0, (size_t)nbins * 4, st) != hipSuccess) return fail(NFE_ELAUNCH, "nfe_render_backward: hipMemsetAsync failed");
             const dim3 tgrid = NFE_BWD_DEPTH_FAST ? dim3((unsigned)a->n_samples, nt, nv) : dim3(nt, (unsigned)a->n_samples, nv);
             if (valu_dec) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<false, true>), tgrid, dim3(64), 0, st, P);
-            else hipLaunchKernelGGL((bwd_scatter_sorted_kernel<true, true>), tgrid, dim3(64), 0, st, P);
-            NFE_CHECK_LAUNCH("bwd_scatter_sorted_kernel<binned>");
+            else if (single_wave) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<true, true>), tgrid, dim3(64), 0, st, P);
+            else {      // persistent workgroups of eight waves, the fragment image in LDS; items in the block order of tgrid
+                static LdsOptIn opt;
+                const hipError_t e = opt.apply(bwd_decoder_kernel, DEC_LDS_BYTES);
+                if (e != hipSuccess) return fail(NFE_ELAUNCH, "bwd_decoder_kernel: LDS opt-in: %s", hipGetErrorString(e));
+                const unsigned long long n_items = (unsigned long long)nv * nt * (unsigned)a->n_samples;       // <= slots_max / 64 < 2^32
+                const unsigned wgs = (unsigned)min((unsigned long long)num_cus(), (n_items + DEC_WAVES - 1) / DEC_WAVES);
+                hipLaunchKernelGGL(bwd_decoder_kernel, dim3(wgs), dim3(64 * DEC_WAVES), DEC_LDS_BYTES, st, P, (unsigned)n_items, nv);
+            }
+            NFE_CHECK_LAUNCH("decoder-backward kernel (binned form)");
             hipLaunchKernelGGL(bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, P.counts, P.offsets, (int)nbins);
             hipLaunchKernelGGL(bwd_bin_fill_kernel, dim3((unsigned)((slots * 3 + 255) / 256)), dim3(256), 0, st, P, slots * 3);
             if (acc_lds) hipLaunchKernelGGL(bwd_accumulate_kernel, dim3(nbins, BIN_SPLIT), dim3(64), 0, st, P);

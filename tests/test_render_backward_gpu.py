@@ -197,12 +197,14 @@ def test_backward_full_size_vs_reference_autograd(dev):
 
 
 @pytest.mark.parametrize("env", [{"NFE_BWD_SCATTER": "direct"}, {"NFE_BWD_SCATTER": "sorted"}, {"NFE_BWD_CHUNK": "30000"},
-                                 {"NFE_BWD_CHUNK": "400000", "NFE_BWD_DECODER": "valu"}],
-                         ids=["direct", "sorted", "binned_ray_chunks", "binned_view_chunks_valu"])
+                                 {"NFE_BWD_CHUNK": "400000", "NFE_BWD_DECODER": "valu"}, {"NFE_BWD_DECODER": "single"},
+                                 {"NFE_BWD_CHUNK": "400000", "NFE_BWD_DECODER": "single"}],
+                         ids=["direct", "sorted", "binned_ray_chunks", "binned_view_chunks_valu", "single_wave_decoder", "single_wave_decoder_chunks"])
 def test_other_scatter_forms(env):
     """The default scatter is the binned form in one chunk.  Same goldens for: the one-atomic-row-per-tap form (planes beyond 2^24
     texels), the sorted-run form (planes whose 8 x 8 tiling exceeds the bin table), the binned form cut into chunks of ray tiles
-    and of whole views, and the fp32 VALU decoder.  The switches are read once per process, so the cases run in a child interpreter."""
+    and of whole views, the fp32 VALU decoder, and round 4's decoder-backward kernel (one wave per workgroup, fragments from global
+    memory; the default since round 5 is bwd_decoder_kernel: persistent eight-wave workgroups, fragments in LDS).  The switches are read once per process, so the cases run in a child interpreter."""
     import os
     import subprocess
     import sys
