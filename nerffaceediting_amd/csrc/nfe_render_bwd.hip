@@ -51,6 +51,7 @@ struct BwdK {
     // binned scatter (one chunk of views x 64-ray tiles): feature gradients, bin records and their sorted list
     float* df; uint2* rec_key; float4* rec_w; uint2* binrank; unsigned* counts; unsigned* offsets; unsigned* perm;
     int n0, t0, t_count, bins_x, bins_y;      // chunk origin (view, ray tile), ray tiles per view in the chunk, plane tiles
+    unsigned* abort_word;                     // bwd_decoder_kernel: pairs that abandoned a hand-off wait; the accumulate pass writes NaN when it is not 0
 };
 
 struct PrepK { const float* w[8]; float lr_mul; float* out; };
@@ -1074,255 +1075,398 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Decoder-backward pass of the binned form, workgroup version (round 5).  The single-wave kernel above is bound by its texture
-// requests (TA 0.67 busy, matrix pipe 0.089, profiles/r04_backward_counters.json) and nearly half of them fetch WEIGHTS: every wave
-// reads the 52 fragments + biases it uses from global memory, 178 KB per 64 samples - as many 64-byte lines as its gathers.  Here a
-// persistent workgroup of eight waves (still 256 registers each, two per SIMD, one workgroup per CU) stages the fragment image once into
-// LDS (52 KB) and every wave then walks items (64 samples = one ray tile at one depth) on its own: no workgroup barrier after the
-// staging.  To fit eight tiles beside the image the two plane sets of an item are processed one after the other through a 64 x 32
-// tile (stride 36 floats, 9 KB per wave): gather set -> tile -> the lane's sample -> head forward / backward -> feature gradients ->
-// tile -> one half (128 B) of the item's 64 rows of df.  Arithmetic per channel is that of the single-wave kernel, operation for
-// operation (its outputs are bit-identical; tests/test_backward_gpu.py compares the two), records and ranks likewise.
+// Decoder-backward pass of the binned form, wave-specialised (round 5).  The single-wave kernel above leaves every phase exposed:
+// per 64 samples a wave walks ~8 dependent memory round trips (records, two gather batches per plane set, cotangents, rank atomics)
+// and ~5 700 vector instructions, two waves per SIMD at 256 registers - the SIMD issues vector work 47 % of the time, the texture
+// addresser is 0.49-0.67 busy, the matrix pipe 0.09 (profiles/r04_backward_counters.json, r05_pmc_backward.txt).
+// Here a persistent workgroup of eight waves (one per CU) is four PAIRS, producer wave w and consumer wave w + 4 on the same SIMD:
+//   producer  item -> sample geometry -> gather of one plane set (eight lanes per texel row, sums in registers) + that set's output
+//             cotangents (already multiplied by omega; dL/dsigma in column 0 of the geometry set's) -> waits until the consumer has
+//             released the pair's tile -> writes both tiles, publishes; after both sets: the item's bin records and rank atomics.
+//   consumer  waits for a published set -> its sample's 32 features from the tile -> head forward / backward on the matrix cores
+//             (fragments and biases from the workgroup's LDS image, staged once: the single-wave kernel fetched 178 KB of them per
+//             item) -> feature gradients through the tile into registers -> releases the tile -> 64 half rows (128 B) of df.
+// The producer's loads for the next set are in flight (its sums sit in registers) while the consumer still owns the tile, so one tile
+// pair per wave pair is enough: 52 KB image + 4 x 18 KB.  Hand-off: two LDS counters per pair (ws_wait / ws_signal of
+// render_ws_kernel); an abandoned wait marks the pair, the launch ends, and P.abort_word makes the accumulate pass write NaN.
+// Arithmetic per channel is that of the single-wave kernel, operation for operation (tests compare the two forms).
 // ------------------------------------------------------------------------------------------------------------
-constexpr int DEC_WAVES = 8;
+#ifndef DEC_ABLATE
+#define DEC_ABLATE 0
+#endif
+#ifndef DEC_RING
+#define DEC_RING 3
+#endif
+constexpr int DEC_PAIRS = 4;
 constexpr int DEC_TILE_STRIDE = 36;                              // floats per sample row (32 channels of ONE plane set + pad; rows 16-byte aligned)
 constexpr int DEC_TILE_BYTES = 64 * DEC_TILE_STRIDE * 4;
-constexpr int DEC_LDS_BYTES = BWD_LDS_TILES + DEC_WAVES * DEC_TILE_BYTES;
-static_assert(DEC_LDS_BYTES <= 160 * 1024, "fragment image + eight tiles must fit a CU's LDS");
+constexpr int DEC_GEO_BYTES = 64 * 24 * 4;                       // the item's tap geometry, [sample][12 offsets, 12 weights]: read back with lane = (sample of a group, ...)
+constexpr int DEC_AFF_BYTES = 2 * 3 * 64 * 4;                    // the view's appearance statistics, [set][plane][32 scales, 32 shifts] (1 / 0 without)
+constexpr int DEC_PAIR_BYTES = 2 * DEC_TILE_BYTES + 16 + DEC_GEO_BYTES + DEC_AFF_BYTES;      // feature tile, cotangent tile, {published, released, abort, -}, geometry, statistics
+constexpr int DEC_LDS_BYTES = BWD_LDS_TILES + DEC_PAIRS * DEC_PAIR_BYTES;
+static_assert(DEC_LDS_BYTES <= 160 * 1024 && DEC_PAIR_BYTES % 16 == 0, "fragment image + four tile pairs must fit a CU's LDS");
+constexpr int DEC_SPIN_LIMIT = 1 << 19;                          // polls (s_sleep 2 + an LDS read each, ~100 ms) before a hand-off wait is abandoned
 
-// One plane set of the wave's 64 samples with eight lanes per texel row (gather_pair_coop for a single set): tile[sample][0..31], already / 3
-template <int SET>
-__device__ __forceinline__ void gather_set_coop(const BwdK& P, int n, const SampleGeo& geo, int lane, float* tile) {
-    const int s8 = lane >> 3, c4 = (lane & 7) * 4;
-    const float* pl = (SET ? P.planes_a : P.planes_g) + (long long)n * P.plane_view_stride + c4;
-    float4 sc[3], sh[3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        sc[p] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        sh[p] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+__device__ __forceinline__ bool dec_wait(unsigned* flags, int which, unsigned need) {
+    int spins = 0;
+    while (true) {
+        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + which, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(v - need) >= 0) return true;
+        const unsigned ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (ab != 0u) return false;
+        if (++spins > DEC_SPIN_LIMIT) {
+            __hip_atomic_store(flags + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
     }
-    if (sgpr_nonnull(P.aff[2 * SET]) != 0) {
+}
+__device__ __forceinline__ void dec_signal(unsigned* flags, int which, unsigned value, int lane) {      // release: this wave's LDS accesses are complete
+    if (lane == 0) __hip_atomic_store(flags + which, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// The producer's work on one item as a software pipeline of STAGES: per plane set eight gather stages (one group of eight samples:
+// lane = (sample of the group, four channels), twelve 16-byte loads = the twelve taps of the group's rows) and one cotangent stage
+// (the set's output cotangents, coalesced).  A stage is ISSUED two stages before it is CONSUMED, into a ring of three 48-register
+// buffers, so 24-36 loads are in flight while the tap sums of an older group are formed - and across the hand-off: the first groups
+// of the appearance set are in flight while the producer waits for the consumer to release the tile.  (Two batches of 48 loads per
+// set, each waited for in full before anything else happened, made the producer the slower role: 2.8 ms per launch against the
+// consumer's 1.4; profiles/experiments/r05_backward_ws.md.)  Same arithmetic per channel as gather_pair_coop, operation for operation.
+struct ProdCtx {
+    const BwdK& P;
+    int n, m, lane; float gsig, omega;
+    float* feat; float* cot; unsigned* flags; const float* geo; const float* aff;      // geo / aff: the pair's LDS copies (DEC_GEO_BYTES, DEC_AFF_BYTES)
+};
+__device__ __forceinline__ float& comp(float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }      // k is a constant after unrolling
+__device__ __forceinline__ float comp(const float4& v, int k) { return k == 0 ? v.x : (k == 1 ? v.y : (k == 2 ? v.z : v.w)); }
+__device__ __forceinline__ int pinned(int v) { asm volatile("; nfe_pin %0" : "+v"(v)); return v; }       // not before the statement in front of it
+#define NFE_STAGE_FENCE() { asm volatile("" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+
+template <int SET, int G>
+__device__ __forceinline__ void prod_issue(const ProdCtx& c, float4 (&b)[12]) {
+    const BwdK& P = c.P;
+    const int lane = c.lane, s8 = lane >> 3, c4 = (lane & 7) * 4;
+    if constexpr (G < 8) {
+        const int src = pinned(8 * G + s8);
+        const float* pl = (SET ? P.planes_a : P.planes_g) + (long long)c.n * P.plane_view_stride + c4;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            sc[p] = *reinterpret_cast<const float4*>(P.aff[2 * SET] + n * 96 + p * 32 + c4);
-            sh[p] = *reinterpret_cast<const float4*>(P.aff[2 * SET + 1] + n * 96 + p * 32 + c4);
+            const int4 off = *reinterpret_cast<const int4*>(c.geo + src * 24 + 4 * p);
+            b[4 * p + 0] = *reinterpret_cast<const float4*>(pl + off.x);
+            b[4 * p + 1] = *reinterpret_cast<const float4*>(pl + off.y);
+            b[4 * p + 2] = *reinterpret_cast<const float4*>(pl + off.z);
+            b[4 * p + 3] = *reinterpret_cast<const float4*>(pl + off.w);
+        }
+    } else if constexpr (SET == 0) {         // seg cotangent c - 1 of sample 4 i + (lane >> 4) in column c = lane & 15 (column 0: dL/dsigma, from a register)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int ms = __shfl(c.m, pinned(4 * i + (lane >> 4)));
+            comp(b[i >> 2], i & 3) = cot_seg(P, c.n, ms, max((lane & 15) - 1, 0));
+        }
+    } else {                                  // rgb cotangents, eight lanes per ray row of 128 bytes; the * 2 of rgb * 2 - 1 here (cot_rgb)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int ms = __shfl(c.m, pinned(8 * i + s8));
+            if (!P.channels_first) {
+                const float4 g4 = *reinterpret_cast<const float4*>(P.g_rgb + ((long long)c.n * P.M + ms) * 32 + c4);      // this set is differentiated: g_rgb is not null
+                b[i] = make_float4(2.0f * g4.x, 2.0f * g4.y, 2.0f * g4.z, 2.0f * g4.w);
+            } else {
+                b[i] = make_float4(cot_rgb(P, c.n, ms, c4), cot_rgb(P, c.n, ms, c4 + 1), cot_rgb(P, c.n, ms, c4 + 2), cot_rgb(P, c.n, ms, c4 + 3));
+            }
         }
     }
-    auto fma4 = [](float w, const float4& v, const float4& a) { return make_float4(fmaf(w, v.x, a.x), fmaf(w, v.y, a.y), fmaf(w, v.z, a.z), fmaf(w, v.w, a.w)); };
-    auto affine = [](const float4& s, const float4& c, float wsum, const float4& h, const float4& f) {
-        return make_float4(f.x + fmaf(s.x, c.x, wsum * h.x), f.y + fmaf(s.y, c.y, wsum * h.y), f.z + fmaf(s.z, c.z, wsum * h.z), f.w + fmaf(s.w, c.w, wsum * h.w));
-    };
-#pragma unroll 4
-    for (int i = 0; i < 8; ++i) {
-        const int src = 8 * i + s8;
+}
+
+// returns false when the hand-off wait was abandoned
+template <int SET, int G>
+__device__ __forceinline__ bool prod_consume(const ProdCtx& c, const float4 (&b)[12], float4 (&acc)[8], unsigned& q, bool alive) {
+    const int lane = c.lane, s8 = lane >> 3, c4 = (lane & 7) * 4;
+    if constexpr (G < 8) {
+        auto fma4 = [](float w, const float4& v, const float4& a) { return make_float4(fmaf(w, v.x, a.x), fmaf(w, v.y, a.y), fmaf(w, v.z, a.z), fmaf(w, v.w, a.w)); };
+        auto affine = [](const float4& s, const float4& cc, float wsum, const float4& h, const float4& f) {
+            return make_float4(f.x + fmaf(s.x, cc.x, wsum * h.x), f.y + fmaf(s.y, cc.y, wsum * h.y), f.z + fmaf(s.z, cc.z, wsum * h.z), f.w + fmaf(s.w, cc.w, wsum * h.w));
+        };
+        const int src = pinned(8 * G + s8);
         float4 fs = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
             float4 sm = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             float wsum = 0.0f;
+            const float4 w4 = *reinterpret_cast<const float4*>(c.geo + src * 24 + 12 + 4 * p);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                const int off = __shfl(geo.off[4 * p + k], src);
-                const float w = __shfl(geo.w[4 * p + k], src);
+                const float w = comp(w4, k);
                 wsum += w;
-                sm = fma4(w, *reinterpret_cast<const float4*>(pl + off), sm);
+                sm = fma4(w, b[4 * p + k], sm);
             }
-            fs = affine(sm, sc[p], wsum, sh[p], fs);
+            const float4 scp = *reinterpret_cast<const float4*>(c.aff + (SET * 3 + p) * 64 + c4), shp = *reinterpret_cast<const float4*>(c.aff + (SET * 3 + p) * 64 + 32 + c4);
+            fs = affine(sm, scp, wsum, shp, fs);
         }
-        const float third = 1.0f / 3.0f;        // mean over planes, triplane.py:251
-        *reinterpret_cast<float4*>(tile + src * DEC_TILE_STRIDE + c4) = make_float4(fs.x * third, fs.y * third, fs.z * third, fs.w * third);
-    }
-    __builtin_amdgcn_wave_barrier();
-}
-
-// the tile's 64 rows -> columns col .. col + 31 of the item's 64 df rows (eight rows of 128 B per store instruction)
-template <bool ZERO>
-__device__ __forceinline__ void store_half_rows(const float* tile, float* __restrict__ dst, int lane, int col) {
-    __builtin_amdgcn_wave_barrier();
-    const int s8 = lane >> 3, c4 = (lane & 7) * 4;
+        // (formed HERE: without this the optimiser sinks the whole sum behind the hand-off wait, where acc is first read, and every tap
+        // load of the set stays live until then - 2.5 KB of spills per lane)
+        asm volatile("; nfe_pin %0 %1 %2 %3" : "+v"(fs.x), "+v"(fs.y), "+v"(fs.z), "+v"(fs.w));
+        acc[G] = fs;
+        return alive;
+    } else {
+        // the set's tiles: features / 3 (mean over planes, triplane.py:251) and the cotangents already multiplied by omega
+        float4 cv[8];
+        if constexpr (SET == 0) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = 8 * i + s8;
-        const float4 v = ZERO ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : *reinterpret_cast<const float4*>(tile + row * DEC_TILE_STRIDE + c4);
-        *reinterpret_cast<float4*>(dst + row * 64 + col + c4) = v;
+            for (int i = 0; i < 16; ++i) {
+                const int ss = pinned(4 * i + (lane >> 4));
+                const float gs = __shfl(c.gsig, ss), om = __shfl(c.omega, ss);
+                comp(cv[i >> 2], i & 3) = (lane & 15) == 0 ? gs : om * comp(b[i >> 2], i & 3);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float om = __shfl(c.omega, pinned(8 * i + s8));
+                cv[i] = make_float4(om * b[i].x, om * b[i].y, om * b[i].z, om * b[i].w);
+            }
+        }
+        if (alive) alive = dec_wait(c.flags, 1, q);
+        const float third = 1.0f / 3.0f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            *reinterpret_cast<float4*>(c.feat + (8 * i + s8) * DEC_TILE_STRIDE + c4) = make_float4(acc[i].x * third, acc[i].y * third, acc[i].z * third, acc[i].w * third);
+        if constexpr (SET == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) c.cot[(4 * i + (lane >> 4)) * DEC_TILE_STRIDE + (lane & 15)] = comp(cv[i >> 2], i & 3);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(c.cot + (8 * i + s8) * DEC_TILE_STRIDE + c4) = cv[i];
+        }
+        dec_signal(c.flags, 0, ++q, lane);
+        return alive;
     }
-    __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(64 * DEC_WAVES) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_decoder_kernel(BwdK P, unsigned n_items, unsigned n_views) {
+// stage t of an item's sequence: nine per differentiated plane set
+template <bool DO_G, bool DO_A, int T> struct ProdStage {
+    static constexpr int SET = (DO_G && DO_A) ? (T >= 9 ? 1 : 0) : (DO_A ? 1 : 0);
+    static constexpr int G = T - ((DO_G && DO_A && T >= 9) ? 9 : 0);
+};
+template <bool DO_G, bool DO_A, int T>
+__device__ __forceinline__ bool prod_run(const ProdCtx& c, float4 (&buf)[DEC_RING][12], float4 (&acc)[8], unsigned& q, bool alive) {
+    constexpr int NST = 9 * ((DO_G ? 1 : 0) + (DO_A ? 1 : 0));
+    if constexpr (T < NST) {
+        if constexpr (T + DEC_RING - 1 < NST) prod_issue<ProdStage<DO_G, DO_A, T + DEC_RING - 1>::SET, ProdStage<DO_G, DO_A, T + DEC_RING - 1>::G>(c, buf[(T + DEC_RING - 1) % DEC_RING]);
+        NFE_STAGE_FENCE();
+        alive = prod_consume<ProdStage<DO_G, DO_A, T>::SET, ProdStage<DO_G, DO_A, T>::G>(c, buf[T % DEC_RING], acc, q, alive);
+        NFE_STAGE_FENCE();
+        return prod_run<DO_G, DO_A, T + 1>(c, buf, acc, q, alive);
+    } else {
+        return alive;
+    }
+}
+template <bool DO_G, bool DO_A>
+__device__ __forceinline__ bool prod_item(const ProdCtx& c, unsigned& q, bool alive) {
+    float4 buf[DEC_RING][12], acc[8];
+    prod_issue<ProdStage<DO_G, DO_A, 0>::SET, 0>(c, buf[0]);
+    if constexpr (DEC_RING > 2) prod_issue<ProdStage<DO_G, DO_A, 1>::SET, 1>(c, buf[1]);
+    return prod_run<DO_G, DO_A, 0>(c, buf, acc, q, alive);
+}
+
+// an item's place: ray tiles fastest, then depths, then views - the single-wave kernel's block order (neighbours in the plane run together)
+struct DecItem { int n, t, kdepth, bx; unsigned bz; int m; bool live; size_t rec; unsigned slot; };
+__device__ __forceinline__ DecItem dec_item(const BwdK& P, unsigned item, int lane) {
+    DecItem it;
+    const unsigned per_depth = (unsigned)P.t_count, per_view = per_depth * (unsigned)P.S;
+    it.bz = item / per_view;
+    const unsigned rest = item - it.bz * per_view;
+    it.kdepth = (int)(rest / per_depth); it.bx = (int)(rest - (unsigned)it.kdepth * per_depth);
+    it.n = (int)it.bz + P.n0; it.t = it.bx + P.t0;
+    it.live = true;
+    if (P.R > 0 && (P.R & 7) == 0 && (long long)P.R * P.R == P.M) {       // 8x8 pixel tile
+        const int tiles_x = P.R >> 3;
+        it.m = ((it.t / tiles_x) * 8 + (lane >> 3)) * P.R + (it.t % tiles_x) * 8 + (lane & 7);
+    } else {
+        it.m = it.t * 64 + lane; it.live = it.m < P.M; it.m = min(it.m, P.M - 1);
+    }
+    // (dead lanes of a view's last tile repeat its last ray, whose slot is m & 63 of the same tile: nobody wrote theirs)
+    it.rec = (((size_t)it.n * P.T + it.t) * P.S + it.kdepth) * 64 + (it.live ? lane : (it.m & 63));
+    it.slot = (it.bz * (unsigned)P.t_count + (unsigned)it.bx) * (unsigned)P.S + (unsigned)it.kdepth;      // the item's 64 sample slots in the chunk
+    return it;
+}
+
+__global__ __launch_bounds__(128 * DEC_PAIRS) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_decoder_kernel(BwdK P, unsigned n_items, unsigned n_views) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nfe_bwd_lds[];
-    {   // the fragment image and the biases, once per workgroup
+    {   // the fragment image and the biases, once per workgroup; hand-off counters to zero
         uint4* sf = reinterpret_cast<uint4*>(nfe_bwd_lds);
-        for (int i = threadIdx.x; i < BF_COUNT * 64; i += 64 * DEC_WAVES) sf[i] = P.bfrag[i];
+        for (int i = threadIdx.x; i < BF_COUNT * 64; i += 128 * DEC_PAIRS) sf[i] = P.bfrag[i];
         float* sb = reinterpret_cast<float*>(nfe_bwd_lds + BWD_LDS_BIAS);
         const int i = threadIdx.x;
         if (i < 160) sb[i] = P.dec[i < 64 ? BB_G0 + i : (i < 128 ? BB_A0 + i - 64 : BB_A1 + i - 128)];
+        if (i < 4 * DEC_PAIRS) *reinterpret_cast<unsigned*>(nfe_bwd_lds + BWD_LDS_TILES + (i >> 2) * DEC_PAIR_BYTES + 2 * DEC_TILE_BYTES + (i & 3) * 4) = 0u;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave_in_wg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    float* tile = reinterpret_cast<float*>(nfe_bwd_lds + BWD_LDS_TILES + wave_in_wg * DEC_TILE_BYTES);
-    const FragLds F{(unsigned)lane * 16u};
-    const int jj = lane & 31, hh = lane >> 5;
+    const int pair = wave_in_wg & (DEC_PAIRS - 1);
+    const bool producer = wave_in_wg < DEC_PAIRS;                 // waves w and w + 4 share a SIMD (MI355X_MICROARCH.md)
+    float* feat = reinterpret_cast<float*>(nfe_bwd_lds + BWD_LDS_TILES + pair * DEC_PAIR_BYTES);
+    float* cot = feat + 64 * DEC_TILE_STRIDE;
+    unsigned* flags = reinterpret_cast<unsigned*>(cot + 64 * DEC_TILE_STRIDE);       // {published, released, abort, -}
+    float* geo_lds = reinterpret_cast<float*>(flags + 4);
+    float* aff_lds = geo_lds + DEC_GEO_BYTES / 4;
     const bool do_g = P.grad_g != nullptr, do_a = P.grad_a != nullptr && P.g_rgb != nullptr;
-    const bool staged = NFE_BWD_COT_STAGED && !P.channels_first;
-    const unsigned per_depth = (unsigned)P.t_count, per_view = per_depth * (unsigned)P.S;
+    const unsigned first = blockIdx.x * DEC_PAIRS + (unsigned)pair, step = gridDim.x * DEC_PAIRS;
+    unsigned q = 0;                      // plane sets handed over so far
+    bool alive = true;
+    if (producer) {
+        const int s8 = lane >> 3, c4 = (lane & 7) * 4;
+        int aff_view = -1;
+        float nx_t = 0.0f, nx_sig = 0.0f, nx_om = 0.0f;          // the next item's records: their round trip under this item's gathers
+        if (first < n_items) {
+            const DecItem it = dec_item(P, first, lane);
+            nx_t = P.rec_t[it.rec]; nx_sig = P.rec_sig[it.rec]; nx_om = P.rec_a[it.rec];
+        }
 #pragma unroll 1
-    for (unsigned item = blockIdx.x * DEC_WAVES + (unsigned)wave_in_wg; item < n_items; item += gridDim.x * DEC_WAVES) {
-        // item order = the single-wave kernel's block order: ray tiles fastest, then depths, then views (neighbours in the plane run together)
-        const unsigned bz = item / per_view, rest = item - bz * per_view;
-        const int kdepth = (int)(rest / per_depth), bx = (int)(rest - (unsigned)kdepth * per_depth);
-        const int n = (int)bz + P.n0, t = bx + P.t0;
-        int m; bool live = true;
-        if (P.R > 0 && (P.R & 7) == 0 && (long long)P.R * P.R == P.M) {       // 8x8 pixel tile
-            const int tiles_x = P.R >> 3;
-            m = ((t / tiles_x) * 8 + (lane >> 3)) * P.R + (t % tiles_x) * 8 + (lane & 7);
-        } else {
-            m = t * 64 + lane; live = m < P.M; m = min(m, P.M - 1);
-        }
-        const size_t rec = (((size_t)n * P.T + t) * P.S + kdepth) * 64 + (live ? lane : (m & 63));
-        const float t_sample = P.rec_t[rec];
-        const float gsig = P.rec_sig[rec], omega = P.rec_a[rec];
-        const unsigned wave = (bz * (unsigned)P.t_count + (unsigned)bx) * (unsigned)P.S + (unsigned)kdepth;      // the item's slot in the chunk
-        float* dst = P.df + (size_t)wave * 4096;
-        f32x2 f[16];
-        if (do_g) {
-            SampleGeo geo;
-            sample_geometry(P, n, m, t_sample, geo);
-            gather_set_coop<0>(P, n, geo, lane, tile);
-            tile_row<DEC_TILE_STRIDE>(tile, lane, 0, f);
-            if (staged) {                 // seg cotangents, 16 lanes per ray row, into columns 1..15 (column 0: sigma's slot, not read)
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-                for (int i = 0; i < 16; ++i) {
-                    const int ss = 4 * i + (lane >> 4), c = lane & 15;
-                    const int ms = __shfl(m, ss);
-                    const float v = (P.g_seg && c < 15) ? P.g_seg[((long long)n * P.M + ms) * 15 + c] : 0.0f;
-                    if (c < 15) tile[ss * DEC_TILE_STRIDE + 1 + c] = v;
-                }
-                __builtin_amdgcn_wave_barrier();
+        for (unsigned item = first; item < n_items; item += step) {
+            const DecItem it = dec_item(P, item, lane);
+            const int n = it.n, m = it.m;
+            const float t_sample = nx_t, gsig = nx_sig, omega = nx_om;
+            if (item + step < n_items) {
+                const DecItem n1 = dec_item(P, item + step, lane);
+                nx_t = P.rec_t[n1.rec]; nx_sig = P.rec_sig[n1.rec]; nx_om = P.rec_a[n1.rec];
             }
-            head_mfma<false>(F, f, lane, tile, DEC_TILE_STRIDE, 0,
-                             [&](int b, float (&d)[8]) {          // outputs 8h..8h+7 of sample 32b + j: sigma = 0, seg = 1..15 (triplane.py:260-261)
-                                 const int src = 32 * b + jj;
-                                 const float gs = __shfl(gsig, src), om = __shfl(omega, src);
-                                 if (staged) {
-                                     const float4 c0 = *reinterpret_cast<const float4*>(tile + src * DEC_TILE_STRIDE + 8 * hh);
-                                     const float4 c1 = *reinterpret_cast<const float4*>(tile + src * DEC_TILE_STRIDE + 8 * hh + 4);
-                                     const float cv[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+            if (n != aff_view) {                 // a new view: its appearance statistics (or 1 / 0) into the pair's LDS copy
+                aff_view = n;
 #pragma unroll
-                                     for (int e = 0; e < 8; ++e) d[e] = (8 * hh + e) == 0 ? gs : om * cv[e];
-                                     return;
-                                 }
-                                 const int mm = __shfl(m, src);
-#pragma unroll
-                                 for (int e = 0; e < 8; ++e) {
-                                     const int o = 8 * hh + e;
-                                     d[e] = o == 0 ? gs : om * cot_seg(P, n, mm, o - 1);
-                                 }
-                             },
-                             [](int, f32x16&) {});
-            store_half_rows<false>(tile, dst, lane, 0);
-        } else {
-            store_half_rows<true>(tile, dst, lane, 0);
-        }
-        if (do_a) {
-            SampleGeo geo;
-            sample_geometry(P, n, m, opaque_f(t_sample), geo);        // again: 24 registers are not kept across the geometry head
-            gather_set_coop<1>(P, n, geo, lane, tile);
-            tile_row<DEC_TILE_STRIDE>(tile, lane, 0, f);
-            if (staged) {                 // rgb cotangents, eight lanes per ray row of 128 bytes; the * 2 of rgb * 2 - 1 here (cot_rgb)
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-                for (int i = 0; i < 8; ++i) {
-                    const int ss = 8 * i + (lane >> 3), c4 = (lane & 7) * 4;
-                    const int ms = __shfl(m, ss);
-                    const float4 v = *reinterpret_cast<const float4*>(P.g_rgb + ((long long)n * P.M + ms) * 32 + c4);      // do_a: g_rgb is not null
-                    *reinterpret_cast<float4*>(tile + ss * DEC_TILE_STRIDE + c4) = make_float4(2.0f * v.x, 2.0f * v.y, 2.0f * v.z, 2.0f * v.w);
+                for (int r = 0; r < 6; ++r) {      // [set = r / 3][plane = r % 3][lane: 32 scales, 32 shifts]
+                    const float* src = P.aff[2 * (r / 3) + (lane >> 5)];
+                    aff_lds[r * 64 + lane] = src ? src[n * 96 + (r % 3) * 32 + (lane & 31)] : (lane < 32 ? 1.0f : 0.0f);
                 }
-                __builtin_amdgcn_wave_barrier();
             }
-            head_mfma<true>(F, f, lane, tile, DEC_TILE_STRIDE, 0, [](int, float (&)[8]) {},
-                            [&](int b, f32x16& y) {               // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269), channel 16h + r
-                                const int src = 32 * b + jj;
-                                const float om = __shfl(omega, src);
-                                if (staged) {
-                                    const float* cr = tile + src * DEC_TILE_STRIDE + 16 * hh;
+            {
+                SampleGeo geo;
+                sample_geometry(P, n, m, t_sample, geo);
 #pragma unroll
-                                    for (int q = 0; q < 4; ++q) {
-                                        const float4 cv = *reinterpret_cast<const float4*>(cr + 4 * q);
-                                        const float c4[4] = {cv.x, cv.y, cv.z, cv.w};
+                for (int k = 0; k < 3; ++k) {
+                    *reinterpret_cast<int4*>(geo_lds + lane * 24 + 4 * k) = make_int4(geo.off[4 * k], geo.off[4 * k + 1], geo.off[4 * k + 2], geo.off[4 * k + 3]);
+                    *reinterpret_cast<float4*>(geo_lds + lane * 24 + 12 + 4 * k) = make_float4(geo.w[4 * k], geo.w[4 * k + 1], geo.w[4 * k + 2], geo.w[4 * k + 3]);
+                }
+            }
+            NFE_STAGE_FENCE();
+            // (the lane index laundered per item: the unrolled stages below derive some two hundred per-lane LDS and tile addresses from it,
+            // which loop-invariant code motion would otherwise compute once in front of the item loop - and spill, 2 KB per lane)
+            const ProdCtx ctx{P, n, m, pinned(lane), gsig, omega, feat, cot, flags, geo_lds, aff_lds};
+            if (do_g && do_a) alive = prod_item<true, true>(ctx, q, alive);
+            else if (do_g) alive = prod_item<true, false>(ctx, q, alive);
+            else alive = prod_item<false, true>(ctx, q, alive);
+            if (DEC_ABLATE & 4) continue;
+            // ---- one bin record per (sample, plane), as in the single-wave kernel
+            const unsigned idx = it.slot * 64 + (unsigned)lane;
+            const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
+            float ro[3], rd[3];
+            ray_of(P, n, m, ro, rd);
+            const float tt = t_sample;
+            const float cx = P.coord_scale * fmaf(tt, rd[0], ro[0]), cy = P.coord_scale * fmaf(tt, rd[1], ro[1]), cz = P.coord_scale * fmaf(tt, rd[2], ro[2]);
+            unsigned bin3[3], rank3[3], group3[3], loc3[3];
+            int first3[3];
+            float4 w3[3];
+            bool any3[3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const Taps tp = tap_geometry(P.H, P.W, p == 2 ? cz : cx, p == 0 ? cy : (p == 1 ? cz : cx));      // as sample_geometry
+                const int x0 = tp.xc0, x1 = tp.xc1, y0 = tp.yc0, y1 = tp.yc1;
+                const bool any = (it.live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
+                const unsigned bin = any ? (it.bz * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
+                                         : KEY_INVALID;
+                unsigned rank = 0, group = 0;
+                int first_lane = -1;                      // stays -1 on lanes without a record
+                const unsigned long long have = __ballot(any);
+                unsigned todo_lo = (unsigned)have, todo_hi = (unsigned)(have >> 32);
+                for (;;) {
+                    todo_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_lo); todo_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_hi);
+                    asm volatile("; nfe_launder %0 %1" : "+s"(todo_lo), "+s"(todo_hi));
+                    if ((todo_lo | todo_hi) == 0u) break;
+                    const int leader = todo_lo ? __builtin_ctz(todo_lo) : 32 + __builtin_ctz(todo_hi);
+                    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+                    const unsigned long long same = __ballot(bin == b);          // b is a live record's bin, dead lanes hold KEY_INVALID
+                    if (bin == b) { rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull)); group = (unsigned)__popcll(same); first_lane = leader; }
+                    todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
+                }
+                const int sx = x1 - x0, sy = y1 - y0;        // clamped taps folded (see the single-wave kernel)
+                float w0 = tp.w[0], w1 = tp.w[1], w2 = tp.w[2], w3v = tp.w[3];
+                if (sx == 0) { w0 += w1; w2 += w3v; w1 = 0.0f; w3v = 0.0f; }
+                if (sy == 0) { w0 += w2; w1 += w3v; w2 = 0.0f; w3v = 0.0f; }
+                bin3[p] = bin; rank3[p] = rank; group3[p] = group; first3[p] = first_lane; any3[p] = any;
+                loc3[p] = (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK));
+                w3[p] = make_float4(w0, w1, w2, w3v);
+            }
+            unsigned base3[3] = {0u, 0u, 0u};
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                if (first3[p] == lane) base3[p] = __hip_atomic_fetch_add(P.counts + bin3[p], group3[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const unsigned rank = rank3[p] + (unsigned)__shfl((int)base3[p], first3[p] & 63);
+                const size_t slot = (size_t)p * ((size_t)n_views * P.t_count * P.S * 64) + idx;
+                P.binrank[slot] = make_uint2(bin3[p], rank);
+                if (any3[p]) {
+                    P.rec_key[slot] = make_uint2(idx, loc3[p]);
+                    P.rec_w[slot] = w3[p];
+                }
+            }
+        }
+        if (!alive && lane == 0) atomicAdd(P.abort_word, 1u);
+    } else {
+        const FragLds F{(unsigned)lane * 16u};
+        const int jj = lane & 31, hh = lane >> 5;
+        const int s8 = lane >> 3, c4 = (lane & 7) * 4;
+        // a plane set's half of the item's 64 df rows (eight rows of 128 B per store instruction); the tile is released before the stores
+        auto half_rows = [&](float* __restrict__ dst, int col, bool have) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = have ? *reinterpret_cast<const float4*>(feat + (8 * i + s8) * DEC_TILE_STRIDE + c4) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (have) dec_signal(flags, 1, ++q, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(dst + (8 * i + s8) * 64 + col + c4) = v[i];
+        };
+#pragma unroll 1
+        for (unsigned item = first; item < n_items; item += step) {
+            const DecItem it = dec_item(P, item, lane);
+            float* dst = P.df + (size_t)it.slot * 4096;
+            f32x2 f[16];
+            if (do_g) {
+                if (alive) alive = dec_wait(flags, 0, q + 1);
+                tile_row<DEC_TILE_STRIDE>(feat, lane, 0, f);
+                if (!(DEC_ABLATE & 2))
+                head_mfma<false>(F, f, lane, feat, DEC_TILE_STRIDE, 0,
+                                 [&](int b, float (&d)[8]) {          // outputs 8h..8h+7 of sample 32b + j, as the producer laid them out
+                                     const float4 c0 = *reinterpret_cast<const float4*>(cot + (32 * b + jj) * DEC_TILE_STRIDE + 8 * hh);
+                                     const float4 c1 = *reinterpret_cast<const float4*>(cot + (32 * b + jj) * DEC_TILE_STRIDE + 8 * hh + 4);
+                                     d[0] = c0.x; d[1] = c0.y; d[2] = c0.z; d[3] = c0.w; d[4] = c1.x; d[5] = c1.y; d[6] = c1.z; d[7] = c1.w;
+                                 },
+                                 [](int, f32x16&) {});
+                __builtin_amdgcn_wave_barrier();
+                half_rows(dst, 0, true);
+            } else {
+                half_rows(dst, 0, false);
+            }
+            if (do_a) {
+                if (alive) alive = dec_wait(flags, 0, q + 1);
+                tile_row<DEC_TILE_STRIDE>(feat, lane, 0, f);
+                if (!(DEC_ABLATE & 2))
+                head_mfma<true>(F, f, lane, feat, DEC_TILE_STRIDE, 0, [](int, float (&)[8]) {},
+                                [&](int b, f32x16& y) {               // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269), channel 16h + r
+                                    const float* cr = cot + (32 * b + jj) * DEC_TILE_STRIDE + 16 * hh;
+#pragma unroll
+                                    for (int qq = 0; qq < 4; ++qq) {
+                                        const float4 cvv = *reinterpret_cast<const float4*>(cr + 4 * qq);
+                                        const float c4v[4] = {cvv.x, cvv.y, cvv.z, cvv.w};
 #pragma unroll
                                         for (int u = 0; u < 4; ++u) {
-                                            const float sg = sigmoid_t(y[4 * q + u]);
-                                            y[4 * q + u] = om * c4[u] * 1.002f * sg * (1.0f - sg);
+                                            const float sg = sigmoid_t(y[4 * qq + u]);
+                                            y[4 * qq + u] = c4v[u] * 1.002f * sg * (1.0f - sg);
                                         }
                                     }
-                                    return;
-                                }
-                                const int mm = __shfl(m, src);
-#pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    const float sg = sigmoid_t(y[r]);
-                                    y[r] = om * cot_rgb(P, n, mm, 16 * hh + r) * 1.002f * sg * (1.0f - sg);
-                                }
-                            });
-            store_half_rows<false>(tile, dst, lane, 32);
-        } else {
-            store_half_rows<true>(tile, dst, lane, 32);
-        }
-        // ---- one bin record per (sample, plane), as in the single-wave kernel
-        const unsigned idx = wave * 64 + (unsigned)lane;
-        const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
-        float ro[3], rd[3];
-        ray_of(P, n, m, ro, rd);
-        const float tt = t_sample;
-        const float cx = P.coord_scale * fmaf(tt, rd[0], ro[0]), cy = P.coord_scale * fmaf(tt, rd[1], ro[1]), cz = P.coord_scale * fmaf(tt, rd[2], ro[2]);
-        unsigned bin3[3], rank3[3], group3[3], loc3[3];
-        int first3[3];
-        float4 w3[3];
-        bool any3[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const Taps tp = tap_geometry(P.H, P.W, p == 2 ? cz : cx, p == 0 ? cy : (p == 1 ? cz : cx));      // as sample_geometry
-            const int x0 = tp.xc0, x1 = tp.xc1, y0 = tp.yc0, y1 = tp.yc1;
-            const bool any = (live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
-            const unsigned bin = any ? (bz * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
-                                     : KEY_INVALID;
-            unsigned rank = 0, group = 0;
-            int first_lane = -1;                      // stays -1 on lanes without a record
-            const unsigned long long have = __ballot(any);
-            unsigned todo_lo = (unsigned)have, todo_hi = (unsigned)(have >> 32);
-            for (;;) {
-                todo_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_lo); todo_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_hi);
-                asm volatile("; nfe_launder %0 %1" : "+s"(todo_lo), "+s"(todo_hi));
-                if ((todo_lo | todo_hi) == 0u) break;
-                const int leader = todo_lo ? __builtin_ctz(todo_lo) : 32 + __builtin_ctz(todo_hi);
-                const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-                const unsigned long long same = __ballot(bin == b);          // b is a live record's bin, dead lanes hold KEY_INVALID
-                if (bin == b) { rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull)); group = (unsigned)__popcll(same); first_lane = leader; }
-                todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
-            }
-            const int sx = x1 - x0, sy = y1 - y0;        // clamped taps folded (see the single-wave kernel)
-            float w0 = tp.w[0], w1 = tp.w[1], w2 = tp.w[2], w3v = tp.w[3];
-            if (sx == 0) { w0 += w1; w2 += w3v; w1 = 0.0f; w3v = 0.0f; }
-            if (sy == 0) { w0 += w2; w1 += w3v; w2 = 0.0f; w3v = 0.0f; }
-            bin3[p] = bin; rank3[p] = rank; group3[p] = group; first3[p] = first_lane; any3[p] = any;
-            loc3[p] = (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK));
-            w3[p] = make_float4(w0, w1, w2, w3v);
-        }
-        unsigned base3[3] = {0u, 0u, 0u};
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-            if (first3[p] == lane) base3[p] = __hip_atomic_fetch_add(P.counts + bin3[p], group3[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            const unsigned rank = rank3[p] + (unsigned)__shfl((int)base3[p], first3[p] & 63);
-            const size_t slot = (size_t)p * ((size_t)n_views * P.t_count * P.S * 64) + idx;
-            P.binrank[slot] = make_uint2(bin3[p], rank);
-            if (any3[p]) {
-                P.rec_key[slot] = make_uint2(idx, loc3[p]);
-                P.rec_w[slot] = w3[p];
+                                });
+                __builtin_amdgcn_wave_barrier();
+                half_rows(dst, 32, true);
+            } else {
+                half_rows(dst, 32, false);
             }
         }
     }
@@ -1444,7 +1588,7 @@ __global__ __launch_bounds__(64) void bwd_accumulate_kernel(BwdK P) {
     const int ch = lane & 31, set = lane >> 5;
     float* g = set ? ((P.grad_a && P.g_rgb) ? P.grad_a : nullptr) : P.grad_g;
     const float* scale = P.aff[2 * set] ? P.aff[2 * set] + n * 96 : nullptr;
-    const float sc = scale ? scale[p * 32 + ch] : 1.0f;
+    const float sc = *P.abort_word != 0u ? __builtin_nanf("") : (scale ? scale[p * 32 + ch] : 1.0f);       // see bwd_accumulate_reg_kernel
     if (g) g += (long long)n * P.grad_view_stride + (long long)p * P.H * P.W * 32 + ch;
 #pragma unroll 1
     for (int ly = 0; ly < BIN_TEXELS; ++ly) {
@@ -1605,7 +1749,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_num_vgpr(ACC_TB))) void b
     const int ch = lane & 31, set = lane >> 5;
     float* g = set ? ((P.grad_a && P.g_rgb) ? P.grad_a : nullptr) : P.grad_g;
     const float* scale = P.aff[2 * set] ? P.aff[2 * set] + n * 96 : nullptr;
-    const float sc = scale ? scale[p * 32 + ch] : 1.0f;
+    // a decoder-backward launch that lost a hand-off (bwd_decoder_kernel) must not pass for a result: every gradient it touches becomes NaN
+    const float sc = *P.abort_word != 0u ? __builtin_nanf("") : (scale ? scale[p * 32 + ch] : 1.0f);
     if (!g) return;
     g += (long long)n * P.grad_view_stride + (long long)p * P.H * P.W * 32 + ch;
     acc_tile_flush<0>(g, sc, ty << BIN_SHIFT, tx << BIN_SHIFT, P.H, P.W);
@@ -1634,7 +1779,7 @@ static uint64_t tiled_floats(int n_views, int n_rays, int n_samples) {
 // df rows + (key, weights) records + (bin, rank) + sorted record indices + counts and offsets
 static uint64_t binned_bytes(uint64_t slots) {
     return align256(slots * 256) + align256(slots * 3 * 8) + align256(slots * 3 * 16) + align256(slots * 3 * 8) + align256(slots * 3 * 4) +
-           2 * align256(BWD_MAX_BINS * 4);
+           2 * align256(BWD_MAX_BINS * 4) + 256;          // + the hand-off abort word
 }
 
 }  // namespace nfe
@@ -1753,7 +1898,9 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     P.binrank = (uint2*)bw; bw += align256(slots_max * 3 * 8);
     P.perm = (unsigned*)bw; bw += align256(slots_max * 3 * 4);
     P.counts = (unsigned*)bw; bw += align256(BWD_MAX_BINS * 4);
-    P.offsets = (unsigned*)bw;
+    P.offsets = (unsigned*)bw; bw += align256(BWD_MAX_BINS * 4);
+    P.abort_word = (unsigned*)bw;
+    if (hipMemsetAsync(P.abort_word, 0, 4, st) != hipSuccess) return fail(NFE_ELAUNCH, "nfe_render_backward: hipMemsetAsync failed");
     const uint64_t per_tile = 64ull * (uint64_t)a->n_samples, view_slots = (uint64_t)ray_tiles * per_tile;
     unsigned views_per_chunk = 1, tiles_per_chunk = ray_tiles;
     if (view_slots >= slots_max) tiles_per_chunk = (unsigned)(slots_max / per_tile);
@@ -1770,13 +1917,13 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
             const dim3 tgrid = NFE_BWD_DEPTH_FAST ? dim3((unsigned)a->n_samples, nt, nv) : dim3(nt, (unsigned)a->n_samples, nv);
             if (valu_dec) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<false, true>), tgrid, dim3(64), 0, st, P);
             else if (single_wave) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<true, true>), tgrid, dim3(64), 0, st, P);
-            else {      // persistent workgroups of eight waves, the fragment image in LDS; items in the block order of tgrid
+            else {      // persistent workgroups of four producer / consumer wave pairs, the fragment image in LDS; items in the block order of tgrid
                 static LdsOptIn opt;
                 const hipError_t e = opt.apply(bwd_decoder_kernel, DEC_LDS_BYTES);
                 if (e != hipSuccess) return fail(NFE_ELAUNCH, "bwd_decoder_kernel: LDS opt-in: %s", hipGetErrorString(e));
                 const unsigned long long n_items = (unsigned long long)nv * nt * (unsigned)a->n_samples;       // <= slots_max / 64 < 2^32
-                const unsigned wgs = (unsigned)min((unsigned long long)num_cus(), (n_items + DEC_WAVES - 1) / DEC_WAVES);
-                hipLaunchKernelGGL(bwd_decoder_kernel, dim3(wgs), dim3(64 * DEC_WAVES), DEC_LDS_BYTES, st, P, (unsigned)n_items, nv);
+                const unsigned wgs = (unsigned)min((unsigned long long)num_cus(), (n_items + DEC_PAIRS - 1) / DEC_PAIRS);
+                hipLaunchKernelGGL(bwd_decoder_kernel, dim3(wgs), dim3(128 * DEC_PAIRS), DEC_LDS_BYTES, st, P, (unsigned)n_items, nv);
             }
             NFE_CHECK_LAUNCH("decoder-backward kernel (binned form)");
             hipLaunchKernelGGL(bwd_bin_scan_kernel, dim3(1), dim3(1024), 0, st, P.counts, P.offsets, (int)nbins);
