@@ -1100,7 +1100,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 constexpr int DEC_PAIRS = 4;
 constexpr int DEC_TILE_STRIDE = 36;                              // floats per sample row (32 channels of ONE plane set + pad; rows 16-byte aligned)
 constexpr int DEC_TILE_BYTES = 64 * DEC_TILE_STRIDE * 4;
-constexpr int DEC_GEO_BYTES = 64 * 24 * 4;                       // the item's tap geometry, [sample][12 offsets, 12 weights]: read back with lane = (sample of a group, ...)
+constexpr int DEC_GEO_BYTES = 64 * 24 * 4;                       // the item's tap geometry, [sample][12 byte offsets, 12 weights]: read back with lane = (sample of a group, ...)
 constexpr int DEC_AFF_BYTES = 2 * 3 * 64 * 4;                    // the view's appearance statistics, [set][plane][32 scales, 32 shifts] (1 / 0 without)
 constexpr int DEC_PAIR_BYTES = 2 * DEC_TILE_BYTES + 16 + DEC_GEO_BYTES + DEC_AFF_BYTES;      // feature tile, cotangent tile, {published, released, abort, -}, geometry, statistics
 constexpr int DEC_LDS_BYTES = BWD_LDS_TILES + DEC_PAIRS * DEC_PAIR_BYTES;
@@ -1148,14 +1148,16 @@ __device__ __forceinline__ void prod_issue(const ProdCtx& c, float4 (&b)[12]) {
     const int lane = c.lane, s8 = lane >> 3, c4 = (lane & 7) * 4;
     if constexpr (G < 8) {
         const int src = pinned(8 * G + s8);
-        const float* pl = (SET ? P.planes_a : P.planes_g) + (long long)c.n * P.plane_view_stride + c4;
+        // wave-uniform base + a 32-bit byte offset per lane (a plane set the binned form accepts is below 4 GiB): one add per load
+        const char* base = reinterpret_cast<const char*>((SET ? P.planes_a : P.planes_g) + (long long)c.n * P.plane_view_stride);
+        const unsigned lane_off = (unsigned)c4 * 4u;
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
-            const int4 off = *reinterpret_cast<const int4*>(c.geo + src * 24 + 4 * p);
-            b[4 * p + 0] = *reinterpret_cast<const float4*>(pl + off.x);
-            b[4 * p + 1] = *reinterpret_cast<const float4*>(pl + off.y);
-            b[4 * p + 2] = *reinterpret_cast<const float4*>(pl + off.z);
-            b[4 * p + 3] = *reinterpret_cast<const float4*>(pl + off.w);
+            const uint4 off = *reinterpret_cast<const uint4*>(c.geo + src * 24 + 4 * p);        // byte offsets of the row's four taps
+            b[4 * p + 0] = *reinterpret_cast<const float4*>(base + (off.x + lane_off));
+            b[4 * p + 1] = *reinterpret_cast<const float4*>(base + (off.y + lane_off));
+            b[4 * p + 2] = *reinterpret_cast<const float4*>(base + (off.z + lane_off));
+            b[4 * p + 3] = *reinterpret_cast<const float4*>(base + (off.w + lane_off));
         }
     } else if constexpr (SET == 0) {         // seg cotangent c - 1 of sample 4 i + (lane >> 4) in column c = lane & 15 (column 0: dL/dsigma, from a register)
 #pragma unroll
@@ -1259,14 +1261,6 @@ __device__ __forceinline__ bool prod_run(const ProdCtx& c, float4 (&buf)[DEC_RIN
         return alive;
     }
 }
-template <bool DO_G, bool DO_A>
-__device__ __forceinline__ bool prod_item(const ProdCtx& c, unsigned& q, bool alive) {
-    float4 buf[DEC_RING][12], acc[8];
-    prod_issue<ProdStage<DO_G, DO_A, 0>::SET, 0>(c, buf[0]);
-    if constexpr (DEC_RING > 2) prod_issue<ProdStage<DO_G, DO_A, 1>::SET, 1>(c, buf[1]);
-    return prod_run<DO_G, DO_A, 0>(c, buf, acc, q, alive);
-}
-
 // an item's place: ray tiles fastest, then depths, then views - the single-wave kernel's block order (neighbours in the plane run together)
 struct DecItem { int n, t, kdepth, bx; unsigned bz; int m; bool live; size_t rec; unsigned slot; };
 __device__ __forceinline__ DecItem dec_item(const BwdK& P, unsigned item, int lane) {
@@ -1287,6 +1281,131 @@ __device__ __forceinline__ DecItem dec_item(const BwdK& P, unsigned item, int la
     it.rec = (((size_t)it.n * P.T + it.t) * P.S + it.kdepth) * 64 + (it.live ? lane : (it.m & 63));
     it.slot = (it.bz * (unsigned)P.t_count + (unsigned)it.bx) * (unsigned)P.S + (unsigned)it.kdepth;      // the item's 64 sample slots in the chunk
     return it;
+}
+
+// An item's tap geometry into the pair's LDS copy ([sample][12 byte offsets, 12 weights]; for a new view also its appearance
+// statistics, or 1 / 0) and the first half of its bin records (one per sample and plane, as in the single-wave kernel): bins, the lanes'
+// ranks among the wave's records of a bin, and ONE returning atomic per plane for the bases.  The bases are picked up by
+// dec_records_end a whole item's gathers later, so their round trip costs nothing.
+struct DecRecords { unsigned bin[3], rank[3], loc[3], base[3]; int first[3]; unsigned idx; };
+__device__ __forceinline__ void dec_geometry(const BwdK& P, const DecItem& it, float t_sample, int lane, float* geo_lds, float* aff_lds, int& aff_view, DecRecords& R) {
+    if (it.n != aff_view) {
+        aff_view = it.n;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) {      // [set = r / 3][plane = r % 3][lane: 32 scales, 32 shifts]
+            const float* src = P.aff[2 * (r / 3) + (lane >> 5)];
+            aff_lds[r * 64 + lane] = src ? src[it.n * 96 + (r % 3) * 32 + (lane & 31)] : (lane < 32 ? 1.0f : 0.0f);
+        }
+    }
+    float ro[3], rd[3];
+    ray_of(P, it.n, it.m, ro, rd);
+    const float cx = P.coord_scale * fmaf(t_sample, rd[0], ro[0]), cy = P.coord_scale * fmaf(t_sample, rd[1], ro[1]), cz = P.coord_scale * fmaf(t_sample, rd[2], ro[2]);
+    const unsigned plane_elems = (unsigned)(P.H * P.W * 32);
+    const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
+    R.idx = it.slot * 64 + (unsigned)lane;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {     // plane axes of generate_planes (renderer.py:23-37): (x,y), (x,z), (z,x) - sample_geometry's arithmetic
+        const Taps tp = tap_geometry(P.H, P.W, p == 2 ? cz : cx, p == 0 ? cy : (p == 1 ? cz : cx));
+        const int x0 = tp.xc0, x1 = tp.xc1, y0 = tp.yc0, y1 = tp.yc1;
+        const unsigned pb = (unsigned)p * plane_elems;
+        *reinterpret_cast<uint4*>(geo_lds + lane * 24 + 4 * p) = make_uint4((pb + (unsigned)(y0 * P.W + x0) * 32u) * 4u, (pb + (unsigned)(y0 * P.W + x1) * 32u) * 4u,
+                                                                             (pb + (unsigned)(y1 * P.W + x0) * 32u) * 4u, (pb + (unsigned)(y1 * P.W + x1) * 32u) * 4u);
+        *reinterpret_cast<float4*>(geo_lds + lane * 24 + 12 + 4 * p) = make_float4(tp.w[0], tp.w[1], tp.w[2], tp.w[3]);
+        const bool any = (it.live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
+        const unsigned bin = any ? (it.bz * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
+                                 : KEY_INVALID;
+        unsigned rank = 0, group = 0;
+        int first_lane = -1;                      // stays -1 on lanes without a record
+        const unsigned long long have = __ballot(any);
+        unsigned todo_lo = (unsigned)have, todo_hi = (unsigned)(have >> 32);
+        for (;;) {
+            todo_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_lo); todo_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_hi);
+            asm volatile("; nfe_launder %0 %1" : "+s"(todo_lo), "+s"(todo_hi));
+            if ((todo_lo | todo_hi) == 0u) break;
+            const int leader = todo_lo ? __builtin_ctz(todo_lo) : 32 + __builtin_ctz(todo_hi);
+            const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
+            const unsigned long long same = __ballot(bin == b);          // b is a live record's bin, dead lanes hold KEY_INVALID
+            if (bin == b) { rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull)); group = (unsigned)__popcll(same); first_lane = leader; }
+            todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
+        }
+        R.bin[p] = bin; R.rank[p] = rank; R.first[p] = first_lane;
+        R.loc[p] = (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK));
+        R.base[p] = 0u;
+        if (!(DEC_ABLATE & 4) && first_lane == lane) R.base[p] = __hip_atomic_fetch_add(P.counts + bin, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+// second half: the records' ranks and weights to memory.  The weights come back from the LDS geometry (still this item's); where
+// clamping makes two taps the same texel (equal offsets) their weights are folded into the first, as in the single-wave kernel.
+__device__ __forceinline__ void dec_records_end(const BwdK& P, const DecRecords& R, int lane, const float* geo_lds, unsigned n_views) {
+    if (DEC_ABLATE & 4) return;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const unsigned rank = R.rank[p] + (unsigned)__shfl((int)R.base[p], R.first[p] & 63);
+        const size_t slot = (size_t)p * ((size_t)n_views * P.t_count * P.S * 64) + R.idx;
+        P.binrank[slot] = make_uint2(R.bin[p], rank);
+        if (R.bin[p] != KEY_INVALID) {
+            const uint4 off = *reinterpret_cast<const uint4*>(geo_lds + lane * 24 + 4 * p);
+            const float4 w = *reinterpret_cast<const float4*>(geo_lds + lane * 24 + 12 + 4 * p);
+            float w0 = w.x, w1 = w.y, w2 = w.z, w3v = w.w;
+            if (off.y == off.x) { w0 += w1; w2 += w3v; w1 = 0.0f; w3v = 0.0f; }
+            if (off.z == off.x) { w0 += w2; w1 += w3v; w2 = 0.0f; w3v = 0.0f; }
+            P.rec_key[slot] = make_uint2(R.idx, R.loc[p]);
+            P.rec_w[slot] = make_float4(w0, w1, w2, w3v);
+        }
+    }
+}
+
+// The producer wave of a pair.  The stage pipeline does not drain between items: once the last stage of an item is consumed and its
+// records are written (its geometry in LDS is dead then) the next item's geometry is staged, its rank atomics and its first two
+// stages are issued.  Returns false when a
+// hand-off wait was abandoned.
+template <bool DO_G, bool DO_A>
+__device__ __forceinline__ bool dec_producer(const BwdK& P, unsigned first, unsigned step, unsigned n_items, unsigned n_views, int lane,
+                                             float* feat, float* cot, unsigned* flags, float* geo_lds, float* aff_lds) {
+    if (first >= n_items) return true;
+    unsigned q = 0;                      // plane sets handed over so far
+    bool alive = true;
+    int aff_view = -1;
+    float4 buf[DEC_RING][12], acc[8];
+    DecItem it = dec_item(P, first, lane);
+    float t_sample = P.rec_t[it.rec], gsig = P.rec_sig[it.rec], omega = P.rec_a[it.rec];
+    float nx_t = 0.0f, nx_sig = 0.0f, nx_om = 0.0f;          // the next item's records, one item ahead
+    if (first + step < n_items) {
+        const DecItem n1 = dec_item(P, first + step, lane);
+        nx_t = P.rec_t[n1.rec]; nx_sig = P.rec_sig[n1.rec]; nx_om = P.rec_a[n1.rec];
+    }
+    DecRecords R;
+    dec_geometry(P, it, t_sample, lane, geo_lds, aff_lds, aff_view, R);
+    NFE_STAGE_FENCE();
+    {
+        const ProdCtx c0{P, it.n, it.m, pinned(lane), gsig, omega, feat, cot, flags, geo_lds, aff_lds};
+        prod_issue<ProdStage<DO_G, DO_A, 0>::SET, 0>(c0, buf[0]);
+        if constexpr (DEC_RING > 2) prod_issue<ProdStage<DO_G, DO_A, 1>::SET, 1>(c0, buf[1]);
+    }
+#pragma unroll 1
+    for (unsigned item = first; item < n_items; item += step) {
+        // (the lane index laundered per item: the unrolled stages derive some two hundred per-lane LDS and tile addresses from it, which
+        // loop-invariant code motion would otherwise compute once in front of the item loop - and spill, 2 KB per lane)
+        const ProdCtx ctx{P, it.n, it.m, pinned(lane), gsig, omega, feat, cot, flags, geo_lds, aff_lds};
+        alive = prod_run<DO_G, DO_A, 0>(ctx, buf, acc, q, alive);
+        dec_records_end(P, R, lane, geo_lds, n_views);
+        NFE_STAGE_FENCE();
+        if (item + step < n_items) {
+            it = dec_item(P, item + step, lane);
+            t_sample = nx_t; gsig = nx_sig; omega = nx_om;
+            if (item + 2 * step < n_items) {
+                const DecItem n2 = dec_item(P, item + 2 * step, lane);
+                nx_t = P.rec_t[n2.rec]; nx_sig = P.rec_sig[n2.rec]; nx_om = P.rec_a[n2.rec];
+            }
+            dec_geometry(P, it, t_sample, lane, geo_lds, aff_lds, aff_view, R);
+            NFE_STAGE_FENCE();
+            const ProdCtx cn{P, it.n, it.m, pinned(lane), gsig, omega, feat, cot, flags, geo_lds, aff_lds};
+            prod_issue<ProdStage<DO_G, DO_A, 0>::SET, 0>(cn, buf[0]);
+            if constexpr (DEC_RING > 2) prod_issue<ProdStage<DO_G, DO_A, 1>::SET, 1>(cn, buf[1]);
+            NFE_STAGE_FENCE();
+        }
+    }
+    return alive;
 }
 
 __global__ __launch_bounds__(128 * DEC_PAIRS) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd_decoder_kernel(BwdK P, unsigned n_items, unsigned n_views) {
@@ -1314,102 +1433,9 @@ __global__ __launch_bounds__(128 * DEC_PAIRS) __attribute__((amdgpu_waves_per_eu
     unsigned q = 0;                      // plane sets handed over so far
     bool alive = true;
     if (producer) {
-        const int s8 = lane >> 3, c4 = (lane & 7) * 4;
-        int aff_view = -1;
-        float nx_t = 0.0f, nx_sig = 0.0f, nx_om = 0.0f;          // the next item's records: their round trip under this item's gathers
-        if (first < n_items) {
-            const DecItem it = dec_item(P, first, lane);
-            nx_t = P.rec_t[it.rec]; nx_sig = P.rec_sig[it.rec]; nx_om = P.rec_a[it.rec];
-        }
-#pragma unroll 1
-        for (unsigned item = first; item < n_items; item += step) {
-            const DecItem it = dec_item(P, item, lane);
-            const int n = it.n, m = it.m;
-            const float t_sample = nx_t, gsig = nx_sig, omega = nx_om;
-            if (item + step < n_items) {
-                const DecItem n1 = dec_item(P, item + step, lane);
-                nx_t = P.rec_t[n1.rec]; nx_sig = P.rec_sig[n1.rec]; nx_om = P.rec_a[n1.rec];
-            }
-            if (n != aff_view) {                 // a new view: its appearance statistics (or 1 / 0) into the pair's LDS copy
-                aff_view = n;
-#pragma unroll
-                for (int r = 0; r < 6; ++r) {      // [set = r / 3][plane = r % 3][lane: 32 scales, 32 shifts]
-                    const float* src = P.aff[2 * (r / 3) + (lane >> 5)];
-                    aff_lds[r * 64 + lane] = src ? src[n * 96 + (r % 3) * 32 + (lane & 31)] : (lane < 32 ? 1.0f : 0.0f);
-                }
-            }
-            {
-                SampleGeo geo;
-                sample_geometry(P, n, m, t_sample, geo);
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    *reinterpret_cast<int4*>(geo_lds + lane * 24 + 4 * k) = make_int4(geo.off[4 * k], geo.off[4 * k + 1], geo.off[4 * k + 2], geo.off[4 * k + 3]);
-                    *reinterpret_cast<float4*>(geo_lds + lane * 24 + 12 + 4 * k) = make_float4(geo.w[4 * k], geo.w[4 * k + 1], geo.w[4 * k + 2], geo.w[4 * k + 3]);
-                }
-            }
-            NFE_STAGE_FENCE();
-            // (the lane index laundered per item: the unrolled stages below derive some two hundred per-lane LDS and tile addresses from it,
-            // which loop-invariant code motion would otherwise compute once in front of the item loop - and spill, 2 KB per lane)
-            const ProdCtx ctx{P, n, m, pinned(lane), gsig, omega, feat, cot, flags, geo_lds, aff_lds};
-            if (do_g && do_a) alive = prod_item<true, true>(ctx, q, alive);
-            else if (do_g) alive = prod_item<true, false>(ctx, q, alive);
-            else alive = prod_item<false, true>(ctx, q, alive);
-            if (DEC_ABLATE & 4) continue;
-            // ---- one bin record per (sample, plane), as in the single-wave kernel
-            const unsigned idx = it.slot * 64 + (unsigned)lane;
-            const unsigned bins_per_plane = (unsigned)(P.bins_x * P.bins_y);
-            float ro[3], rd[3];
-            ray_of(P, n, m, ro, rd);
-            const float tt = t_sample;
-            const float cx = P.coord_scale * fmaf(tt, rd[0], ro[0]), cy = P.coord_scale * fmaf(tt, rd[1], ro[1]), cz = P.coord_scale * fmaf(tt, rd[2], ro[2]);
-            unsigned bin3[3], rank3[3], group3[3], loc3[3];
-            int first3[3];
-            float4 w3[3];
-            bool any3[3];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const Taps tp = tap_geometry(P.H, P.W, p == 2 ? cz : cx, p == 0 ? cy : (p == 1 ? cz : cx));      // as sample_geometry
-                const int x0 = tp.xc0, x1 = tp.xc1, y0 = tp.yc0, y1 = tp.yc1;
-                const bool any = (it.live ? (tp.w[0] + tp.w[1]) + (tp.w[2] + tp.w[3]) : 0.0f) != 0.0f;        // the weights are >= 0
-                const unsigned bin = any ? (it.bz * 3u + (unsigned)p) * bins_per_plane + (unsigned)((y0 >> BIN_SHIFT) * P.bins_x + (x0 >> BIN_SHIFT))
-                                         : KEY_INVALID;
-                unsigned rank = 0, group = 0;
-                int first_lane = -1;                      // stays -1 on lanes without a record
-                const unsigned long long have = __ballot(any);
-                unsigned todo_lo = (unsigned)have, todo_hi = (unsigned)(have >> 32);
-                for (;;) {
-                    todo_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_lo); todo_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)todo_hi);
-                    asm volatile("; nfe_launder %0 %1" : "+s"(todo_lo), "+s"(todo_hi));
-                    if ((todo_lo | todo_hi) == 0u) break;
-                    const int leader = todo_lo ? __builtin_ctz(todo_lo) : 32 + __builtin_ctz(todo_hi);
-                    const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)bin, leader);
-                    const unsigned long long same = __ballot(bin == b);          // b is a live record's bin, dead lanes hold KEY_INVALID
-                    if (bin == b) { rank = (unsigned)__popcll(same & ((1ull << lane) - 1ull)); group = (unsigned)__popcll(same); first_lane = leader; }
-                    todo_lo &= ~(unsigned)same; todo_hi &= ~(unsigned)(same >> 32);
-                }
-                const int sx = x1 - x0, sy = y1 - y0;        // clamped taps folded (see the single-wave kernel)
-                float w0 = tp.w[0], w1 = tp.w[1], w2 = tp.w[2], w3v = tp.w[3];
-                if (sx == 0) { w0 += w1; w2 += w3v; w1 = 0.0f; w3v = 0.0f; }
-                if (sy == 0) { w0 += w2; w1 += w3v; w2 = 0.0f; w3v = 0.0f; }
-                bin3[p] = bin; rank3[p] = rank; group3[p] = group; first3[p] = first_lane; any3[p] = any;
-                loc3[p] = (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK));
-                w3[p] = make_float4(w0, w1, w2, w3v);
-            }
-            unsigned base3[3] = {0u, 0u, 0u};
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-                if (first3[p] == lane) base3[p] = __hip_atomic_fetch_add(P.counts + bin3[p], group3[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const unsigned rank = rank3[p] + (unsigned)__shfl((int)base3[p], first3[p] & 63);
-                const size_t slot = (size_t)p * ((size_t)n_views * P.t_count * P.S * 64) + idx;
-                P.binrank[slot] = make_uint2(bin3[p], rank);
-                if (any3[p]) {
-                    P.rec_key[slot] = make_uint2(idx, loc3[p]);
-                    P.rec_w[slot] = w3[p];
-                }
-            }
-        }
+        if (do_g && do_a) alive = dec_producer<true, true>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
+        else if (do_g) alive = dec_producer<true, false>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
+        else alive = dec_producer<false, true>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
         if (!alive && lane == 0) atomicAdd(P.abort_word, 1u);
     } else {
         const FragLds F{(unsigned)lane * 16u};
