@@ -20,6 +20,13 @@
 
 #include <cstdlib>
 
+// No implicit multiply-add fusion in this file: every fma here is written as one.  The split-bf16 MFMA stages re-quantise their inputs
+// to 16 + 8 mantissa bits, which turns a one-ulp difference in an input (a product fused with the subtraction that forms its low
+// half in one kernel and not in another) into 1e-5 of the output: with fusion left to the compiler the two decoder-backward kernels
+// below - the same operations in the same order - differed by 4e-5 of the largest gradient, without it by the order of the
+// accumulate pass's adds (6e-7; tests/test_render_backward_gpu.py).  Measured cost: none (1.77 ms either way).
+#pragma clang fp contract(off)
+
 namespace nfe {
 
 // scaled decoder image in the workspace (floats)
@@ -1091,13 +1098,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 // render_ws_kernel); an abandoned wait marks the pair, the launch ends, and P.abort_word makes the accumulate pass write NaN.
 // Arithmetic per channel is that of the single-wave kernel, operation for operation (tests compare the two forms).
 // ------------------------------------------------------------------------------------------------------------
-#ifndef DEC_ABLATE
-#define DEC_ABLATE 0
-#endif
-#ifndef DEC_RING
-#define DEC_RING 3
-#endif
 constexpr int DEC_PAIRS = 4;
+constexpr int DEC_RING = 3;                                      // stage buffers of a producer: two stages in flight while one is consumed (a ring of two measured the same, 1.91 vs 1.88 ms)
 constexpr int DEC_TILE_STRIDE = 36;                              // floats per sample row (32 channels of ONE plane set + pad; rows 16-byte aligned)
 constexpr int DEC_TILE_BYTES = 64 * DEC_TILE_STRIDE * 4;
 constexpr int DEC_GEO_BYTES = 64 * 24 * 4;                       // the item's tap geometry, [sample][12 byte offsets, 12 weights]: read back with lane = (sample of a group, ...)
@@ -1331,13 +1333,12 @@ __device__ __forceinline__ void dec_geometry(const BwdK& P, const DecItem& it, f
         R.bin[p] = bin; R.rank[p] = rank; R.first[p] = first_lane;
         R.loc[p] = (unsigned)((y0 & BIN_MASK) * BIN_TEXELS + (x0 & BIN_MASK));
         R.base[p] = 0u;
-        if (!(DEC_ABLATE & 4) && first_lane == lane) R.base[p] = __hip_atomic_fetch_add(P.counts + bin, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (first_lane == lane) R.base[p] = __hip_atomic_fetch_add(P.counts + bin, group, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 // second half: the records' ranks and weights to memory.  The weights come back from the LDS geometry (still this item's); where
 // clamping makes two taps the same texel (equal offsets) their weights are folded into the first, as in the single-wave kernel.
 __device__ __forceinline__ void dec_records_end(const BwdK& P, const DecRecords& R, int lane, const float* geo_lds, unsigned n_views) {
-    if (DEC_ABLATE & 4) return;
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const unsigned rank = R.rank[p] + (unsigned)__shfl((int)R.base[p], R.first[p] & 63);
@@ -1458,7 +1459,6 @@ __global__ __launch_bounds__(128 * DEC_PAIRS) __attribute__((amdgpu_waves_per_eu
             if (do_g) {
                 if (alive) alive = dec_wait(flags, 0, q + 1);
                 tile_row<DEC_TILE_STRIDE>(feat, lane, 0, f);
-                if (!(DEC_ABLATE & 2))
                 head_mfma<false>(F, f, lane, feat, DEC_TILE_STRIDE, 0,
                                  [&](int b, float (&d)[8]) {          // outputs 8h..8h+7 of sample 32b + j, as the producer laid them out
                                      const float4 c0 = *reinterpret_cast<const float4*>(cot + (32 * b + jj) * DEC_TILE_STRIDE + 8 * hh);
@@ -1474,7 +1474,6 @@ __global__ __launch_bounds__(128 * DEC_PAIRS) __attribute__((amdgpu_waves_per_eu
             if (do_a) {
                 if (alive) alive = dec_wait(flags, 0, q + 1);
                 tile_row<DEC_TILE_STRIDE>(feat, lane, 0, f);
-                if (!(DEC_ABLATE & 2))
                 head_mfma<true>(F, f, lane, feat, DEC_TILE_STRIDE, 0, [](int, float (&)[8]) {},
                                 [&](int b, f32x16& y) {               // rgb = sigmoid(y) * 1.002 - 0.001 (triplane.py:269), channel 16h + r
                                     const float* cr = cot + (32 * b + jj) * DEC_TILE_STRIDE + 16 * hh;

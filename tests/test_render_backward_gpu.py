@@ -217,10 +217,8 @@ def test_other_scatter_forms(env):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_backward_is_repeatable(dev):
-    """Six launches of the editing-size backward give the same gradients up to the order of the float adds (1e-6 of the largest
-    entry).  Guards the binned scatter's record stream: a lane-mask hazard once zeroed single tap weights of lanes 48-63 in
-    a handful of waves per launch (profiles/experiments/r02_lane_mask.md), which moved gradients by percents from run to run."""
+def _editing_size_case(dev):
+    """Two 128^2 x (48 + 48) views on 256^2 planes, random cotangents: inputs of ops.render_backward as (args, kwargs)."""
     from nerffaceediting_amd import ops
     N, R, D, Di, H = 2, 128, 48, 48, 256
     g = torch.Generator(device="cpu").manual_seed(3)
@@ -235,9 +233,62 @@ def test_backward_is_repeatable(dev):
     opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
     cots = tuple(torch.randn(N, R * R, c, generator=g).to(dev) for c in (32, 15, 1, 1))
     out = ops.render(pn, pd, ops.decoder_pack(*heads), opts, seed=1, taps=True, **kw)
+    return (pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots), kw
+
+
+def _dump_editing_size_gradients(path):
+    """child-process entry of test_wave_specialised_decoder_kernel_matches_the_single_wave_kernel"""
+    from nerffaceediting_amd import ops
+    dev = torch.device("cuda:0")
+    out = {}
+    for need in ((True, True), (True, False), (False, True)):
+        args, kw = _editing_size_case(dev)
+        gg, ga = ops.render_backward(*args, need=need, **kw)
+        if need[0]:
+            out["g%d%d" % need] = gg.cpu().numpy()
+        if need[1]:
+            out["a%d%d" % need] = ga.cpu().numpy()
+    np.savez(path, **out)
+
+
+def test_wave_specialised_decoder_kernel_matches_the_single_wave_kernel(tmp_path):
+    """bwd_decoder_kernel (round 5: producer / consumer wave pairs, fragments in LDS, the default) against round 4's
+    bwd_scatter_sorted_kernel<true, true> (NFE_BWD_DECODER=single) on the editing-size case, both plane sets, the geometry set alone
+    and the appearance set alone (the three instantiations of the producer): per channel the two kernels do the same operations in
+    the same order, so the gradients may differ only by the order of the accumulate pass's float adds (the bound of
+    test_backward_is_repeatable, 1e-6 of the largest entry).  The switch is read once per process: two child interpreters."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for mode in ("default", "single"):
+        path = str(tmp_path / (mode + ".npz"))
+        env = dict(os.environ)
+        env.pop("NFE_BWD_DECODER", None)
+        if mode == "single":
+            env["NFE_BWD_DECODER"] = "single"
+        r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from tests.test_render_backward_gpu import _dump_editing_size_gradients as f; f(%r)" % (root, path)],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        got[mode] = dict(np.load(path))
+    assert sorted(got["default"]) == sorted(got["single"]) == ["a01", "a11", "g10", "g11"]
+    for k in got["default"]:
+        a, b = got["default"][k], got["single"][k]
+        scale = float(np.abs(b).max())
+        assert scale > 0 and np.isfinite(a).all()
+        assert float(np.abs(a - b).max()) <= 1e-6 * scale, (k, float(np.abs(a - b).max()), scale)
+
+
+def test_backward_is_repeatable(dev):
+    """Six launches of the editing-size backward give the same gradients up to the order of the float adds (1e-6 of the largest
+    entry).  Guards the binned scatter's record stream: a lane-mask hazard once zeroed single tap weights of lanes 48-63 in
+    a handful of waves per launch (profiles/experiments/r02_lane_mask.md), which moved gradients by percents from run to run."""
+    from nerffaceediting_amd import ops
+    args, kw = _editing_size_case(dev)
     runs = []
     for _ in range(6):
-        gg, ga = ops.render_backward(pn, pd, heads, 1.0, opts, out[4]["depths_all"], cots, **kw)
+        gg, ga = ops.render_backward(*args, **kw)
         runs.append((gg.clone(), ga.clone()))
     for k in (0, 1):
         scale = float(runs[0][k].abs().max())
