@@ -220,9 +220,12 @@ int nfe_decoder_forward(const float* features_geo, const float* features_app, in
  * decoder parameters are constants here.  The sample depths are constants too: stratified depths do not depend on
  * the planes and importance depths are detached in the reference (renderer.py:198,211), so the caller passes the
  * sorted depths the forward marched (nfe_render_args.tap_depths_all) and the gradient flows through that one march.
- * Three launches: per-sample re-evaluation (sigma and the cotangent-weighted colour), a per-ray reverse recurrence
- * (no divisions by 1 - alpha), per-sample decoder backward + scatter (fp32 atomics, one 128-byte texel row per
- * half-wave instruction).  density_noise is not supported (absent from every shipped config). */
+ * Passes: per-sample sigma and cotangent-weighted colour (from the forward's kept per-sample outputs, or a re-evaluation), a
+ * per-ray reverse recurrence (no divisions by 1 - alpha), the per-sample decoder backward (wave-specialised: gather waves hand
+ * feature tiles to decoder waves through LDS counters), and a binned accumulate pass.  density_noise is not supported (absent
+ * from every shipped config).
+ * Lost hand-offs: the decoder-backward kernel bounds its waits like the render kernel (~100 ms; never observed).  A launch that
+ * abandoned one does not pass for a result: the accumulate pass turns every gradient entry the call adds to into NaN. */
 typedef struct nfe_render_backward_args {
     uint32_t struct_size;              /* = sizeof(nfe_render_backward_args) */
     const float* planes_geo;           /* as in nfe_render_args (gather layout [Np,3,H,W,32]) */

@@ -1108,6 +1108,7 @@ constexpr int DEC_PAIR_BYTES = 2 * DEC_TILE_BYTES + 16 + DEC_GEO_BYTES + DEC_AFF
 constexpr int DEC_LDS_BYTES = BWD_LDS_TILES + DEC_PAIRS * DEC_PAIR_BYTES;
 static_assert(DEC_LDS_BYTES <= 160 * 1024 && DEC_PAIR_BYTES % 16 == 0, "fragment image + four tile pairs must fit a CU's LDS");
 constexpr int DEC_SPIN_LIMIT = 1 << 19;                          // polls (s_sleep 2 + an LDS read each, ~100 ms) before a hand-off wait is abandoned
+__device__ int g_dec_spin_limit = DEC_SPIN_LIMIT;                // read only on the slow path of a wait; NFE_WS_SPIN_LIMIT (tests/test_handoff_abort_gpu.py) shortens it
 
 __device__ __forceinline__ bool dec_wait(unsigned* flags, int which, unsigned need) {
     int spins = 0;
@@ -1116,7 +1117,7 @@ __device__ __forceinline__ bool dec_wait(unsigned* flags, int which, unsigned ne
         if ((int)(v - need) >= 0) return true;
         const unsigned ab = __builtin_amdgcn_readfirstlane(__hip_atomic_load(flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
         if (ab != 0u) return false;
-        if (++spins > DEC_SPIN_LIMIT) {
+        if (++spins > __builtin_nontemporal_load(&g_dec_spin_limit)) {
             __hip_atomic_store(flags + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             return false;
         }
@@ -1437,7 +1438,6 @@ __global__ __launch_bounds__(128 * DEC_PAIRS) __attribute__((amdgpu_waves_per_eu
         if (do_g && do_a) alive = dec_producer<true, true>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
         else if (do_g) alive = dec_producer<true, false>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
         else alive = dec_producer<false, true>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
-        if (!alive && lane == 0) atomicAdd(P.abort_word, 1u);
     } else {
         const FragLds F{(unsigned)lane * 16u};
         const int jj = lane & 31, hh = lane >> 5;
@@ -1495,6 +1495,7 @@ __global__ __launch_bounds__(128 * DEC_PAIRS) __attribute__((amdgpu_waves_per_eu
             }
         }
     }
+    if (!alive && lane == 0) atomicAdd(P.abort_word, 1u);       // either role: a wave that abandoned a wait (or found its pair marked) reports it
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1811,6 +1812,19 @@ static uint64_t binned_bytes(uint64_t slots) {
 
 using namespace nfe;
 
+// NFE_WS_SPIN_LIMIT (read once; the same variable as the render kernel's) into g_dec_spin_limit, once per device and only when set
+static int apply_dec_spin_limit() {
+    static const int v = [] { const char* e = getenv("NFE_WS_SPIN_LIMIT"); const long long x = e ? atoll(e) : 0; return x > 0 && x < (1ll << 30) ? (int)x : 0; }();
+    if (!v) return NFE_OK;
+    static std::atomic<unsigned long long> done{0};
+    const int dev = current_device();
+    if (dev < MAX_DEVICES && (done.load(std::memory_order_acquire) >> dev & 1ull)) return NFE_OK;
+    const hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_dec_spin_limit), &v, sizeof(int));
+    if (e != hipSuccess) return fail(NFE_ELAUNCH, "NFE_WS_SPIN_LIMIT: hipMemcpyToSymbol: %s", hipGetErrorString(e));
+    if (dev < MAX_DEVICES) done.fetch_or(1ull << dev, std::memory_order_release);
+    return NFE_OK;
+}
+
 extern "C" uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples) {
     return BWD_DEC_BYTES + 4 * align256(tiled_floats(n_views, n_rays, n_samples) * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES) +
            binned_bytes(chunk_slots(n_views, n_rays, n_samples));
@@ -1943,6 +1957,7 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
             if (valu_dec) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<false, true>), tgrid, dim3(64), 0, st, P);
             else if (single_wave) hipLaunchKernelGGL((bwd_scatter_sorted_kernel<true, true>), tgrid, dim3(64), 0, st, P);
             else {      // persistent workgroups of four producer / consumer wave pairs, the fragment image in LDS; items in the block order of tgrid
+                if (int rc = apply_dec_spin_limit()) return rc;
                 static LdsOptIn opt;
                 const hipError_t e = opt.apply(bwd_decoder_kernel, DEC_LDS_BYTES);
                 if (e != hipSuccess) return fail(NFE_ELAUNCH, "bwd_decoder_kernel: LDS opt-in: %s", hipGetErrorString(e));

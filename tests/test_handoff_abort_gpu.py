@@ -65,6 +65,37 @@ def test_lost_handoff_poisons_outputs_and_fails_the_next_call():
     assert r.returncode == 0 and "HANDOFF_ABORT_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
 
 
+BWD_PROG = r"""
+import numpy as np, torch
+from nerffaceediting_amd import ops
+from tests.test_render_backward_gpu import _editing_size_case
+dev = torch.device("cuda:0")
+args, kw = _editing_size_case(dev)                 # its forward: 2 x 128^2 rays = 1 024 ray blocks, the fused render kernel (no hand-off)
+assert not any(k.startswith("render_ws_kernel") for k in ops.render_last_kernels())
+for need in ((True, True), (True, False), (False, True)):
+    gg, ga = ops.render_backward(*args, need=need, **kw)
+    torch.cuda.synchronize()
+    for g, n in ((gg, need[0]), (ga, need[1])):
+        if not n:
+            continue
+        bad = torch.isnan(g)
+        assert bool(bad.any()), "gradients of a backward that lost hand-offs must be NaN"
+        assert bool(((g == 0) | bad).all()), "every entry the call touched must be NaN, none a plausible number"
+        assert int(bad.sum()) > 1000000
+print("BWD_HANDOFF_ABORT_OK")
+"""
+
+
+def test_lost_handoff_in_the_backward_poisons_the_gradients():
+    """bwd_decoder_kernel (producer / consumer wave pairs) under NFE_WS_SPIN_LIMIT=1: the consumer's first wait is abandoned, the
+    launch ends, and the accumulate pass writes NaN into every gradient entry it adds to (include/nfe_render.h, nfe_render_backward)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NFE_WS_SPIN_LIMIT="1", PYTHONPATH=root)
+    env.pop("NFE_BWD_DECODER", None)
+    r = subprocess.run([sys.executable, "-c", BWD_PROG], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BWD_HANDOFF_ABORT_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_default_bound_loses_nothing():
     """The shipped bound (2^18 polls, ~50 ms): a full-size launch reports zero lost hand-offs and a clean status word."""
     import torch
