@@ -2006,6 +2006,61 @@ __global__ __launch_bounds__(256) void upfirdn_kernel(const float* __restrict__ 
     }
 }
 
+// nfe_upfirdn2d_polyphase for C % 4 == 0 (round 5; the generic kernel above spends most of its 2 ms per 4 x 512^2 x 64 call on 64-bit
+// index divisions and sixteen scalar loads per output): one thread = one polyphase quad (outputs (2 y, 2 x) .. (2 y + 1, 2 x + 1)) of four
+// channels.  It loads the 5 x 5 input window once (25 x 16 bytes for 16 outputs), forms the ten horizontal sums its outputs share and then
+// the four vertical ones - per output the same fmas in the same order as the generic kernel (taps outside the image contribute
+// fma(F, 0, acc) = acc there, a skipped step here).  Grid: (quads of a row x channel groups, quad rows, views).
+__global__ __launch_bounds__(256) void upfir_poly4_kernel(const float* __restrict__ in, int H, int W, int C, int pad0, float gain, int OH, int OW,
+                                                          float* __restrict__ out) {
+    const float F[4] = {0.125f, 0.375f, 0.375f, 0.125f};
+    const int GH2 = (OH + 1) >> 1, GW2 = (OW + 1) >> 1, C4 = C >> 2;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int qx = t / C4, c = (t - qx * C4) * 4;
+    if (qx >= GW2) return;
+    const int qy = blockIdx.y, n = blockIdx.z;
+    const int u0 = 2 * qy - pad0, v0 = 2 * qx - pad0;          // window origin in the input
+    const float* src = in + (long long)n * H * W * C + c;
+    float4 rowv[5][2];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int u = u0 + r;
+        const bool rin = (unsigned)u < (unsigned)H;
+        float4 win[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int v = v0 + q;
+            const bool ok = rin && (unsigned)v < (unsigned)W;
+            const float4 x = *reinterpret_cast<const float4*>(src + ((long long)min(max(u, 0), H - 1) * W + min(max(v, 0), W - 1)) * C);
+            win[q] = ok ? x : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                a.x = fmaf(F[b], win[dx + b].x, a.x); a.y = fmaf(F[b], win[dx + b].y, a.y);
+                a.z = fmaf(F[b], win[dx + b].z, a.z); a.w = fmaf(F[b], win[dx + b].w, a.w);
+            }
+            rowv[r][dx] = a;
+        }
+    }
+    float* dst = out + (((long long)n * GH2 + qy) * GW2 + qx) * (4 * C) + c;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            float4 a = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                a.x = fmaf(F[k], rowv[dy + k][dx].x, a.x); a.y = fmaf(F[k], rowv[dy + k][dx].y, a.y);
+                a.z = fmaf(F[k], rowv[dy + k][dx].z, a.z); a.w = fmaf(F[k], rowv[dy + k][dx].w, a.w);
+            }
+            const bool live = 2 * qy + dy < OH && 2 * qx + dx < OW;          // beyond the odd-sized result: zeros
+            *reinterpret_cast<float4*>(dst + (dy * 2 + dx) * C) = live ? make_float4(a.x * gain, a.y * gain, a.z * gain, a.w * gain) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+}
+
 static unsigned grid1d(long long total, int per_block, long long cap = 1 << 16) {
     long long b = (total + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -2552,6 +2607,13 @@ extern "C" int nfe_upfirdn2d_polyphase(const float* in, int n, int h, int w, int
     NFE_REQUIRE(in && out && n > 0 && h > 0 && w > 0 && c > 0 && pad0 >= 0 && pad1 >= 0, "nfe_upfirdn2d_polyphase: bad arguments");
     const int oh = h + pad0 + pad1 - 3, ow = w + pad0 + pad1 - 3;
     NFE_REQUIRE(oh > 0 && ow > 0, "nfe_upfirdn2d_polyphase: empty output");
+    if (c % 4 == 0 && n <= 65535 && (oh + 1) / 2 <= 65535) {
+        const int gw2 = (ow + 1) / 2, gh2 = (oh + 1) / 2;
+        hipLaunchKernelGGL(upfir_poly4_kernel, dim3((unsigned)(((long long)gw2 * (c / 4) + 255) / 256), (unsigned)gh2, (unsigned)n), dim3(256), 0, (hipStream_t)stream,
+                           in, h, w, c, pad0, gain, oh, ow, out);
+        NFE_CHECK_LAUNCH("upfir_poly4_kernel");
+        return NFE_OK;
+    }
     const long long total = (long long)n * ((oh + 1) & ~1) * ((ow + 1) & ~1) * c;
     hipLaunchKernelGGL(upfirdn_kernel<true>, dim3(grid1d(total, 256, 1 << 15)), dim3(256), 0, (hipStream_t)stream,
                        in, n, h, w, c, 1, 1, pad0, gain, oh, ow, out);

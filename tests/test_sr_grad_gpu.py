@@ -293,7 +293,7 @@ def test_bias_act_backward_is_the_lrelu_clamp_derivative_with_torgb_folded_in(wi
     assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
 
 
-@pytest.mark.parametrize("H,W,C", [(8, 8, 16), (7, 10, 8)])
+@pytest.mark.parametrize("H,W,C", [(8, 8, 16), (7, 10, 8), (33, 40, 64), (128, 128, 128), (9, 8, 6)])          # C % 4 == 0: the quad kernel; else the generic one
 def test_upfirdn2d_polyphase_is_the_stacked_padded_fir(H, W, C, dev):
     """nfe_upfirdn2d_polyphase (ABI v13) against what sr_grad did in torch before: the (2, 2)-padded FIR of nfe_upfirdn2d, zero-padded to an
     even size and rearranged so that channel block (a, b) of pixel (y, x) is pixel (2y + a, 2x + b) - bit for bit."""
