@@ -62,24 +62,27 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
     import json
     import os
     rec = None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_backward_counters.json")      # the backward kernels are unchanged since round 4
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_backward_counters.json")
     if os.path.exists(path):
         rec = json.load(open(path))
     ach = rec["hbm_bytes_per_launch"] / rec["avg_ns_profiled"] if rec else None            # GB/s
     alg = samples * (3 * 256 + 3 * 28)                                                      # rows + records + index, per launch
     return {"bound": "hbm", "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS if rec else None,
             "traffic": rec["hbm_bytes_per_launch"] if rec else None, "algorithmic_bytes_per_launch": alg,
-            "kernel": "nfe::bwd_accumulate_reg_kernel (of: color_dot_kernel, bwd_ray_kernel, bwd_scatter_sorted_kernel<MFMA,BINNED>, "
-                      "bwd_bin_fill_kernel, bwd_accumulate_reg_kernel)",
+            "kernel": "nfe::bwd_accumulate_reg_kernel (of: color_dot_kernel, bwd_ray_kernel, bwd_decoder_kernel, bwd_bin_fill_kernel, "
+                      "bwd_accumulate_reg_kernel)",
+            # the longest kernel of the backward is not HBM-bound: its counter-measured unit fractions (same file, same box, same command)
+            "decoder_kernel": ({k: rec["decoder_kernel"][k] for k in ("kernel", "avg_ns_trace", "single_wave_kernel_avg_ns_trace", "valu_active", "ta_busy",
+                                                                      "mfma_busy", "lds_issue", "hbm_bytes_per_launch")} if rec else None),
             "kernel_ms": rec["avg_ns_profiled"] * 1e-6 if rec else None, "backward_ms": bwd_ms,
             "hbm_bytes_per_sample_model": 1240, "hbm_model_gbs": samples * 1240 / (bwd_ms * 1e-3) / 1e9,
             "logical_gather_scatter_gbs": logical_gbs,
-            "note": "achieved / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r04_backward_counters.json "
+            "note": "achieved / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r05_backward_counters.json "
                     "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE; duration = rocprofv3 kernel trace of the both-sets mode, which "
-                    "agrees with the duration under the counters to 0.6 %), not re-measured by this run; peak = the 8 TB/s HBM figure (a "
+                    "agrees with the duration under the counters to a few per cent), not re-measured by this run; peak = the 8 TB/s HBM figure (a "
                     "read-only stream reaches 6.3 TB/s on this machine, tools/microbench/read_bw.hip, so the kernel is at 0.87 of what reads "
                     "can get); backward_ms is this run's HIP-event time of the whole backward.  Per sample "
-                    "the decoder-backward kernel writes a 256-byte feature-gradient row and three 32-byte records, the fill pass sorts a 4-byte "
+                    "the decoder-backward kernel (wave-specialised since round 5: decoder_kernel holds its busy fractions - vector ALU, texture addresser, matrix pipe - none of them a bound) writes a 256-byte feature-gradient row and three 32-byte records, the fill pass sorts a 4-byte "
                     "index per record, the accumulate pass (one wave owns an 8x8 texel tile in registers) reads index, record and row once per "
                     "plane; the forward keeps the decoders' per-sample outputs (192 B per sample) so that no sample is re-evaluated.  logical "
                     "gather + scatter bytes / time is quoted for reference only (planes and gradients are cache resident)"}

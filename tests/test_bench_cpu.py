@@ -110,3 +110,18 @@ def test_census_file_is_consistent():
         assert k["valu_total"] == sum(cls.get(x, 0) for x in rl.VALU_CLASSES), name
         assert abs(k["simd_cycles"] - sum(cls.get(x, 0) * v for x, v in cost.items())) <= 1, name
     assert c["kernels"]["render_kernel.inbounds"]["valu_total"] < c["kernels"]["render_kernel.general"]["valu_total"]
+
+
+def test_backward_block_reads_the_committed_counters():
+    """--workload editstep: the HBM roofline of the accumulate pass and, beside it, the counter-measured busy fractions of the longest
+    kernel (the wave-specialised decoder-backward kernel), all from profiles/r05_backward_counters.json (tools/r05_backward_profile.sh)."""
+    import bench
+    c = _counters("r05_backward_counters.json")
+    r = bench.backward_roofline(3.5, c["samples_per_launch"], 1000.0)
+    assert r["bound"] == "hbm" and abs(r["achieved"] - c["hbm_bytes_per_launch"] / c["avg_ns_profiled"]) < 1e-9 and 0.5 < r["frac"] < 0.9
+    assert r["traffic"] == c["hbm_bytes_per_launch"] and 1.0 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.4
+    d, raw = r["decoder_kernel"], c["decoder_kernel"]["counters"]
+    assert "bwd_decoder_kernel" in d["kernel"] and d["avg_ns_trace"] < 0.85 * d["single_wave_kernel_avg_ns_trace"]
+    cycles = raw["GRBM_GUI_ACTIVE"] / 8
+    assert abs(d["valu_active"] - raw["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cycles) < 1e-12 and abs(d["ta_busy"] - raw["TA_TA_BUSY"] / 256 / cycles) < 1e-12
+    assert all(0.0 < d[k] < 1.0 for k in ("valu_active", "ta_busy", "mfma_busy", "lds_issue"))
