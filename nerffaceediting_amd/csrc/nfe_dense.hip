@@ -546,48 +546,12 @@ __global__ __launch_bounds__(256) void modsplit_kernel(const float4* __restrict_
 }
 
 __device__ uint4 nfe_zero16[4];                                  // source of the zero padding for LDS-DMA
-#ifndef C3_LC_GENERIC_LOOP
 #define C3_LC_GENERIC_LOOP 0     // 1: the compute waves of the loader / compute split run the generic fragment pipeline (A/B)
-#endif
-#ifndef C3_ABLATE
-#define C3_ABLATE 0       // timing experiments only (wrong results): 1 no LDS-DMA, 2 no MFMA, 3 no barriers in the K loop, 4 no fragment reads, 5 all workgroups stage the same tile, 6 = 5 + 2
-#endif
-#ifndef C3_ABM            // the same as a bit mask, so that experiments combine: 1 no LDS-DMA, 2 no MFMA, 4 no barrier, 8 no fragment reads, 16 same tile,
-#define C3_ABM (C3_ABLATE == 1 ? 1 : C3_ABLATE == 2 ? 2 : C3_ABLATE == 3 ? 4 : C3_ABLATE == 4 ? 8 : C3_ABLATE == 5 ? 16 : C3_ABLATE == 6 ? 18 : 0)
-#endif                    // 32 every patch lane reads its aligned slot of one contiguous KiB, 64 no vmcnt wait, 128 no epilogue
-#ifndef C3_DMA_BUILTIN
-#define C3_DMA_BUILTIN 0                                         // 1: the round-2 form (compiler-tracked LDS-DMA), kept for A/B
-#endif
-#ifndef C3_UP_DBUF
 #define C3_UP_DBUF 0                                             // 1: fused up-sampling epilogue with two FIR slice buffers (5 barriers per tile instead of 8): measured no gain (3.27 vs 3.27 ms FFHQ fp16 step), twice the LDS
-#endif
 // LDS of the fused up-sampling epilogue: C3_UP_DBUF + 1 slice buffers of [2 halves][2 ROWS][64] float4
 constexpr int conv3_fused_t_bytes(int rows) { return (C3_UP_DBUF ? 2 : 1) * 2 * (2 * rows) * 64 * 16; }
-#ifndef C3_PATCH_SWZ
 #define C3_PATCH_SWZ 1                                           // 0: A/B - no XOR swizzle of the patch halves (ascending DMA addresses, 2-way conflicts on the fragment reads)
-#endif
-#ifndef C3_UP_BCACHE
 #define C3_UP_BCACHE 1                                           // up-sampling K loop: the six distinct patch fragments of a K-group in registers
-#endif
-#ifndef C3_FRAG_PIPE
-#define C3_FRAG_PIPE 1                                           // A/B switch of the fragment-read pipeline in conv3_kernel
-#endif
-#ifdef C3_PROFILE      // diagnostic build only (tools/c3_profile.py): shader cycles summed over all waves of all conv3 launches
-__device__ unsigned long long c3_prof[8];
-#if C3_PROFILE + 0 == 2
-constexpr unsigned C3_PROF_SLOTS = 1u << 19;                     // light form: one record per wave, no atomics (they serialise the waves' ends)
-__device__ unsigned long long c3_prof_w[C3_PROF_SLOTS][2];       // {K loop incl. prologue, epilogue} cycles; slot = wave index mod table size
-#endif                        // {load phase, compute phase, epilogue, waves, vmcnt wait, barrier wait, prologue, -}
-#define C3_STAMP(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#if C3_PROFILE + 0 == 2   // light form: only wave start, epilogue start and end are stamped (the K loop runs undisturbed)
-#define C3_STAMPK(var) const unsigned long long var = 0
-#else
-#define C3_STAMPK(var) C3_STAMP(var)
-#endif
-#else
-#define C3_STAMP(var)
-#define C3_STAMPK(var)
-#endif
 
 struct Conv3K {
     const unsigned short* xh; const unsigned short* xl; const uint4* packed; const float* dcoef; const float* noise;
@@ -603,9 +567,7 @@ struct Conv3K {
     int f16;            // host-side only: launch the TERMS = 2 (fp16 operand) instantiation of the bf16 variant
 };                                                                  // (what modsplit_kernel would make of `out`), written by the epilogue
 
-#ifndef C3_XCD_ALL
 #define C3_XCD_ALL 0
-#endif
 __host__ __device__ constexpr bool c3_xcd_order(int terms) { return terms == 3 || C3_XCD_ALL; }
 
 // WV waves per workgroup, each owning NBW image rows of 32 pixels: tile = 32 x (NBW * WV) pixels (ROWS rows).
@@ -625,16 +587,8 @@ template <int ROWS> struct C3Tile {
 // showed it as ~4 300 cycles of "issue" per K-group; round 3).  The waits this kernel needs are its own explicit
 // `s_waitcnt vmcnt(N)` + s_barrier at the top of each K-group.
 __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
-#if (C3_ABM) & 1
-    return;
-#endif
-#if C3_DMA_BUILTIN
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)lds_dst, 16, 0, 0);
-#else
     const unsigned l = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds_dst;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory", "m0");
-#endif
 }
 
 // UP2: the stride-2 transposed convolution of the up-sampling layers as four output phases over the (H+1)x(W+1)
@@ -717,15 +671,9 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
         // bytes in NHWC) are fetched by adjacent lanes = one L1 request, and the XOR keeps the 32-byte-stride fragment
         // reads conflict-free (pixels p and p+8 share a bank pair, their halves are swapped).
         const int pp = item >> 1, hh = (item & 1) ^ (C3_PATCH_SWZ ? (pp >> 3) & 1 : 0), py = pp / C3_PW, px = pp % C3_PW;
-#if (C3_ABM) & 16      // timing experiment: every workgroup stages tile 0 of view 0 (operands L2-resident); 6: and no MFMA
-        const int y = 7 + py, x = 7 + px;
-        const bool ok = pp < C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
-        boff[k] = ok ? (((long long)0 * G_all * P.H + y) * P.W + x) * 16 + 8 * hh : -1;
-#else
         const int y = ty0 - 1 + py, x = tx0 - 1 + px;
         const bool ok = pp < C3_HALF_ITEMS && y >= 0 && y < P.H && x >= 0 && x < P.W;
         boff[k] = ok ? (((long long)n * G_all * P.H + y) * P.W + x) * 16 + 8 * hh : -1;     // group-major image: + g * H*W*16 per K-group
-#endif
     }
 
     // byte offsets of this lane's B fragments inside the patch: rows NBW*wave + (0..NBW+1), columns j + (0..2)
@@ -776,11 +724,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #pragma unroll
         for (int part = 0; part < PARTS; ++part) {
             const unsigned short* xs = part ? P.xl : P.xh;
-#if (C3_ABM) & 32
-            bptr[k][part] = xs + (long long)g_base * plane16 + (((issues ? iw : 0) + IW * k) * 64 + lane) * 8; bstep[k] = plane16;
-#else
             bptr[k][part] = boff[k] >= 0 ? xs + boff[k] + (long long)g_base * plane16 : reinterpret_cast<const unsigned short*>(nfe_zero16);
-#endif
         }
     }
     int g_next = 0;                                            // the K-group the next issue() call stages
@@ -789,7 +733,6 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
         if constexpr (!RUNPTR) {
             const int g = g_next++;
             for (int c = iw; c < A_CHUNKS; c += IW) {
-                if ((C3_ABM) & 1024) break;
                 const int part = c % PARTS, t = (c / PARTS) % 9, m = c / (PARTS * 9);
                 const uint4* src = P.packed + (((long long)(mb0 + m) * G_all + g_base + g) * 18 + t * 2 + part) * 64 + lane;
                 lds_dma16(src, base + c * 1024);
@@ -797,15 +740,11 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #pragma unroll
             for (int k = 0; k < B_PER_WAVE; ++k) {
                 const int c = iw + IW * k;
-                if (c < C3_B_CHUNKS && !((C3_ABM) & 2048)) {
+                if (c < C3_B_CHUNKS) {
 #pragma unroll
                     for (int part = 0; part < PARTS; ++part) {
                         const unsigned short* xs = part ? P.xl : P.xh;
-#if (C3_ABM) & 32
-                        const void* src = (const void*)(xs + (long long)(g_base + g) * plane16 + (c * 64 + lane) * 8);
-#else
                         const void* src = boff[k] >= 0 ? (const void*)(xs + boff[k] + (long long)(g_base + g) * plane16) : (const void*)nfe_zero16;
-#endif
                         lds_dma16(src, base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
                     }
                 }
@@ -815,7 +754,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #pragma unroll
         for (int kk = 0; kk < A_PER_WAVE; ++kk) {
             const int c = iw + IW * kk;
-            if (c < A_CHUNKS && !((C3_ABM) & 1024)) lds_dma16(aptr[kk], base + c * 1024);      // 1024: timing experiment, no weight staging
+            if (c < A_CHUNKS) lds_dma16(aptr[kk], base + c * 1024);      // 1024: timing experiment, no weight staging
             aptr[kk] += 18 * 64;
         }
 #pragma unroll
@@ -823,7 +762,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
             const int c = iw + IW * k;
 #pragma unroll
             for (int part = 0; part < PARTS; ++part) {
-                if (c < C3_B_CHUNKS && !((C3_ABM) & 2048))                                    // 2048: timing experiment, no patch staging
+                if (c < C3_B_CHUNKS)                                    // 2048: timing experiment, no patch staging
                     lds_dma16(bptr[k][part], base + A_CHUNKS * 1024 + part * C3_B_BYTES + c * 1024);
                 bptr[k][part] += bstep[k];
             }
@@ -849,7 +788,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
     constexpr int EC = 32 * MBW;
     static_assert(3 * EC * 4 <= conv3_ec_bytes<MBW>(), "ec[] must fit the bytes launch_conv3 reserves behind the ring");
     const bool own_epilogue = !UP2 && KS == 1;
-    if ((own_epilogue || fusedup) && tid < EC && !((C3_ABM) & 256)) {
+    if ((own_epilogue || fusedup) && tid < EC) {
         const int ch = 32 * mb0 + tid;
         ec[tid] = P.dcoef ? P.dcoef[(long long)n * P.Cout + ch] : 1.0f;
         ec[EC + tid] = P.bias[ch];
@@ -859,13 +798,9 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #pragma unroll
     for (int nb = 0; nb < NBW; ++nb) {
         const int y = min(ty0 + NBW * min(wave, WV - 1) + nb, P.H - 1), x = min(tx0 + j, P.W - 1);
-        nzv[nb] = (own_epilogue && P.noise && !((C3_ABM) & 256)) ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
+        nzv[nb] = (own_epilogue && P.noise) ? P.noise[n * P.noise_n_stride + (long long)y * P.W + x] * P.noise_strength : 0.0f;
     }
 
-#ifdef C3_PROFILE
-    unsigned long long prof_load = 0, prof_comp = 0, prof_vm = 0, prof_bar = 0;
-    const unsigned long long ts_start = __builtin_amdgcn_s_memtime();
-#endif
     static_assert(LW == 0 || (STAGES >= 2 && !UP2), "loader waves need a ring of at least two stages; plain 3x3 only");
     if (issues)
         for (int pre = 0; pre < STAGES - 1; ++pre)
@@ -883,20 +818,15 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
         return;
     }
     for (int g = 0; g < G; ++g) {
-        C3_STAMPK(ts0);
         if (STAGES == 1) { __syncthreads(); issue(0); }
         // K-group g has landed once at most the loads of the STAGES-2 younger K-groups are outstanding (in-order return)
         if (LW > 0) {}                  // compute waves issue no loads: the loader waves wait for them
-        else if ((C3_ABM) & 64) {}
         else if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
-        C3_STAMPK(ts0a);
-        if (!((C3_ABM) & 4)) __syncthreads();
-        C3_STAMPK(ts0b);
+        __syncthreads();
         const bool more = g + STAGES - 1 < G;
         const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
         if (LW == 0 && STAGES >= 2 && more) issue(nstage);
-        C3_STAMPK(ts1);
         const unsigned char* base = lds + stage * STAGE_BYTES;
         const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
         const unsigned char* ldsB = base + A_CHUNKS * 1024;
@@ -965,12 +895,10 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
-#if C3_FRAG_PIPE
         // Fragment reads run ONE (tap, N-block) step ahead of the MFMAs that use them (register double buffer, order pinned by
         // sched_barrier): the compiler's own schedule issues a read one or two MFMAs before its use, which leaves the matrix pipe
         // idle for most of the LDS latency some thirty times per K-group while this wave is the only one computing on its SIMD.
         auto load_a = [&](int t, Frag8 (&ah_)[MBW], Frag8 (&al_)[MBW]) {
-            if (((C3_ABM) & 8) && (g > 0 || t > 0)) return;
 #pragma unroll
             for (int m = 0; m < MBW; ++m) {
                 ah_[m].q = ldsA[((m * 9 + t) * PARTS + 0) * 64];
@@ -978,7 +906,6 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
             }
         };
         auto load_b = [&](int t, int nb, Frag8& bh_, Frag8& bl_) {
-            if (((C3_ABM) & 8) && (g > 0 || t > 0)) return;
             const int kh = t / 3, kw = t % 3;
             const int dy = UP2 ? 1 - (kh >> 1) : kh, dx = UP2 ? 1 - (kw >> 1) : kw;
             bh_.q = *reinterpret_cast<const uint4*>(ldsB + brd[nb + dy][dx]);
@@ -999,16 +926,11 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int m = 0; m < MBW; ++m) {
-#if (C3_ABM) & 2
-                acc[a][m][nb][0] += __builtin_bit_cast(float, ah[t & 1][m].u[0] ^ bh[s_ & 1].u[0]);
-                if (TERMS == 3) acc[a][m][nb][1] += __builtin_bit_cast(float, al[t & 1][m].u[0] ^ bl[s_ & 1].u[0]);
-#else
                 acc[a][m][nb] = mfma16<TERMS>(ah[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
                 if (TERMS == 3) {
                     acc[a][m][nb] = mfma16<TERMS>(ah[t & 1][m].v, bl[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
                     acc[a][m][nb] = mfma16<TERMS>(al[t & 1][m].v, bh[s_ & 1].v, acc[a][m][nb], 0, 0, 0);
                 }
-#endif
             }
             if (UP2 && nb == NBW - 1 && kw == 2 && edge_tile && wave == 0) {   // wave-uniform
                 Frag8 eh, el;
@@ -1026,69 +948,10 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-#else
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int kh = t / 3, kw = t % 3;
-            Frag8 ah[MBW], al[MBW];
-#pragma unroll
-            for (int m = 0; m < MBW; ++m) {
-                ah[m].q = ldsA[((m * 9 + t) * PARTS + 0) * 64];
-                if (TERMS == 3) al[m].q = ldsA[((m * 9 + t) * PARTS + 1) * 64];
-            }
-#pragma unroll
-            for (int nb = 0; nb < NBW; ++nb) {
-                Frag8 bh, bl;
-                const int dy = UP2 ? 1 - (kh >> 1) : kh, dx = UP2 ? 1 - (kw >> 1) : kw;
-                const int a = UP2 ? (kh & 1) * 2 + (kw & 1) : 0;
-                bh.q = *reinterpret_cast<const uint4*>(ldsB + brd[nb + dy][dx]);
-                if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brd[nb + dy][dx]);
-#pragma unroll
-                for (int m = 0; m < MBW; ++m) {
-                    acc[a][m][nb] = mfma16<TERMS>(ah[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
-                    if (TERMS == 3) {
-                        acc[a][m][nb] = mfma16<TERMS>(ah[m].v, bl.v, acc[a][m][nb], 0, 0, 0);
-                        acc[a][m][nb] = mfma16<TERMS>(al[m].v, bh.v, acc[a][m][nb], 0, 0, 0);
-                    }
-                }
-            }
-            if (UP2 && kw == 2 && edge_tile && wave == 0) {   // wave-uniform
-                Frag8 bh, bl;
-                const int dy = 1 - (kh >> 1);
-                bh.q = *reinterpret_cast<const uint4*>(ldsB + brde[dy]);
-                if (TERMS == 3) bl.q = *reinterpret_cast<const uint4*>(ldsB + C3_B_BYTES + brde[dy]);
-#pragma unroll
-                for (int m = 0; m < MBW; ++m) {
-                    acce[kh & 1][m] = mfma16<TERMS>(ah[m].v, bh.v, acce[kh & 1][m], 0, 0, 0);
-                    if (TERMS == 3) {
-                        acce[kh & 1][m] = mfma16<TERMS>(ah[m].v, bl.v, acce[kh & 1][m], 0, 0, 0);
-                        acce[kh & 1][m] = mfma16<TERMS>(al[m].v, bh.v, acce[kh & 1][m], 0, 0, 0);
-                    }
-                }
-            }
-        }
-#endif
         }
         stage = stage + 1 == STAGES ? 0 : stage + 1;
-#ifdef C3_PROFILE
-        { C3_STAMPK(ts2); prof_load += ts1 - ts0; prof_comp += ts2 - ts1; prof_vm += ts0a - ts0; prof_bar += ts0b - ts0a; }
-#endif
     }
-#ifdef C3_PROFILE
-    C3_STAMP(ts_ep0);
-#endif
 
-#if (C3_ABM) & 128      // timing experiment: no epilogue (the accumulators are only kept alive)
-    {
-#pragma unroll
-        for (int a = 0; a < NACC; ++a)
-#pragma unroll
-            for (int m = 0; m < MBW; ++m)
-#pragma unroll
-                for (int nb = 0; nb < NBW; ++nb) asm volatile("" :: "v"(acc[a][m][nb][0]), "v"(acc[a][m][nb][15]));
-        return;
-    }
-#endif
     // ---- epilogue: lane (j,h) register r holds out channel 32mb + (r&3) + 8(r>>2) + 4h of pixel (row, j) ----
     if (UP2 && edge_tile && wave == 0 && j < C3_TH && ty0 + j <= P.H) {           // edge column: T[2y + a][2W], a = 0, 1
         const int TH2 = 2 * P.H + 1, TW2 = 2 * P.W + 1, y = ty0 + j;
@@ -1276,10 +1139,8 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #pragma unroll
             for (int qq = 0; qq < 4; ++qq) {
                 float4 d = make_float4(1, 1, 1, 1), b = make_float4(0.1f, 0.2f, 0.3f, 0.4f), wq[4];
-                if (!((C3_ABM) & 256)) {
-                    d = *reinterpret_cast<const float4*>(ec + 32 * m + 8 * qq + 4 * h);
-                    b = *reinterpret_cast<const float4*>(ec + EC + 32 * m + 8 * qq + 4 * h);
-                }
+                d = *reinterpret_cast<const float4*>(ec + 32 * m + 8 * qq + 4 * h);
+                b = *reinterpret_cast<const float4*>(ec + EC + 32 * m + 8 * qq + 4 * h);
                 if (fuse_rgb) {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
@@ -1313,8 +1174,7 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
                     for (int it = 0; it < 4; ++it) {
                         const int p = 8 * it + (lane >> 3), c = lane & 7;
                         const float4 v = *reinterpret_cast<const float4*>(st_nb + p * ST_STRIDE + 4 * c);
-                        if ((C3_ABM) & 512) asm volatile("" :: "v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
-                        else if (tx0 + p < P.W) *reinterpret_cast<float4*>(P.out + o_row + (long long)p * P.Cout + 4 * c) = v;
+                        if (tx0 + p < P.W) *reinterpret_cast<float4*>(P.out + o_row + (long long)p * P.Cout + 4 * c) = v;
                     }
                 }
                 if (P.split_hi) {               // one store instruction = the 32 pixels x 16 channels of one plane of the group-major image:
@@ -1324,14 +1184,13 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
                         const float* np_ = ec + 2 * EC + 32 * m + 16 * gI + 8 * sh;
                         const float4 v0 = *reinterpret_cast<const float4*>(tp), v1 = *reinterpret_cast<const float4*>(tp + 4);
                         float4 s0 = make_float4(1, 1, 1, 1), s1 = s0;
-                        if (!((C3_ABM) & 256)) { s0 = *reinterpret_cast<const float4*>(np_); s1 = *reinterpret_cast<const float4*>(np_ + 4); }
+                        s0 = *reinterpret_cast<const float4*>(np_); s1 = *reinterpret_cast<const float4*>(np_ + 4);
                         uint4 hi4, lo4;
                         split2<TERMS>(v0.x * s0.x, v0.y * s0.y, hi4.x, lo4.x); split2<TERMS>(v0.z * s0.z, v0.w * s0.w, hi4.y, lo4.y);
                         split2<TERMS>(v1.x * s1.x, v1.y * s1.y, hi4.z, lo4.z); split2<TERMS>(v1.z * s1.z, v1.w * s1.w, hi4.w, lo4.w);
                         // uint2 units of split_index: 4 per (pixel, plane); this lane's 8 channels are units 2 sh, 2 sh + 1
                         const long long si = split_index(n, P.Cout >> 4, P.H, P.W, y, tx0 + sp, 4 * (2 * (mb0 + m) + gI) + 2 * sh);
-                        if ((C3_ABM) & 512) asm volatile("" :: "v"(hi4.x), "v"(hi4.y), "v"(hi4.z), "v"(hi4.w), "v"(lo4.x), "v"(lo4.w));
-                        else if (tx0 + sp < P.W) {
+                        if (tx0 + sp < P.W) {
                             *reinterpret_cast<uint4*>(P.split_hi + si) = hi4;
                             if (TERMS == 3) *reinterpret_cast<uint4*>(P.split_lo + si) = lo4;
                         }
@@ -1351,19 +1210,6 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
             }
         }
     }
-#if C3_PROFILE + 0 == 2
-    if (lane == 0) {
-        C3_STAMP(ts_ep1);
-        const unsigned slot = ((((unsigned)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * WV + wave) & (C3_PROF_SLOTS - 1);
-        c3_prof_w[slot][0] = ts_ep0 - ts_start; c3_prof_w[slot][1] = ts_ep1 - ts_ep0;
-    }
-#elif defined(C3_PROFILE)
-    if (lane == 0) {
-        C3_STAMP(ts_ep1);
-        atomicAdd(&c3_prof[0], prof_load); atomicAdd(&c3_prof[1], prof_comp); atomicAdd(&c3_prof[2], ts_ep1 - ts_ep0); atomicAdd(&c3_prof[3], 1ull);
-        atomicAdd(&c3_prof[4], prof_vm); atomicAdd(&c3_prof[5], prof_bar); atomicAdd(&c3_prof[6], ts_ep1 - ts_start);
-    }
-#endif
 }
 
 // Fused ToRGB, second half: add the M-block-group partial sums of every pixel in group order, then what torgb's own epilogue
@@ -1728,14 +1574,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvK P, long long n
 
 // FIR + epilogue of the up-conv: out[Y][X] = act(dcoef * sum_ab F[a]F[b] T[Y+a-1][X+b-1] + noise + bias),
 // F = [1,3,3,1]/4 per axis (setup_filter/64 * gain 4; conv2d_resample.py:127, upfirdn2d.py:169-207)
-#ifndef NFE_UPFIR_ROWS
 #define NFE_UPFIR_ROWS 4
-#endif
 constexpr int UPFIR_ROWS = NFE_UPFIR_ROWS;     // 2-row output blocks per thread: consecutive blocks share 3 of their 5 filtered rows
 
-#ifndef UPFIR_WAVES
 #define UPFIR_WAVES 2      // no register cap below what the kernel wants: at 3 waves per SIMD (168 registers) it spilled inside the row loop, and scratch traffic shares the vmcnt queue
-#endif
 // HAS_OUT / PARTS (0: no consumer image, 1: bf16 hi, 2: hi + lo) are compile-time on purpose: with the stores under run-time
 // conditions the compiler cannot count them and waits with `s_waitcnt vmcnt(0)` for the prefetched rows - i.e. for the stores it has
 // just issued as well (loads and stores retire in order on gfx9) - and the read and write streams serialise: 391 us for the SR
@@ -1777,11 +1619,7 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
             const float* __restrict__ trow = tbase + (long long)min(max(ty, 0), TH - 1) * TW * P.Cout;
 #pragma unroll
             for (int jj = 0; jj < 5; ++jj) {
-#if defined(UPFIR_ABLATE) && UPFIR_ABLATE == 1      // timing experiment: no scratch reads
-                t[jj] = make_float4((float)ty, (float)jj, (float)c4, 1.0f);
-#else
                 t[jj] = *reinterpret_cast<const float4*>(trow + toff[jj]);
-#endif
             }
         };
         auto reduce_row = [&](int ty, float4 (&t)[5], float4 (&rf)[2]) {
@@ -1842,10 +1680,6 @@ __global__ __launch_bounds__(256, UPFIR_WAVES) void upfir_kernel(ConvK P) {
                     o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
                     o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
                     const long long oi = (((long long)n * OH + Y) * OW + X) * C4 + c4;
-#if defined(UPFIR_ABLATE) && UPFIR_ABLATE == 2      // timing experiment: no stores
-                    asm volatile("" :: "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "v"(s2.x));
-                    continue;
-#endif
                     if (HAS_OUT) reinterpret_cast<float4*>(P.out)[oi] = o;
                     if (PARTS) {                            // what modsplit_kernel would make of `o` for the next layer (group-major)
                         unsigned h0, l0, h1, l1;
@@ -2200,30 +2034,16 @@ static void launch_conv(const ConvK& P, int math, dim3 grid, hipStream_t st) {
     else hipLaunchKernelGGL((conv_kernel<MODE, 3>), grid, dim3(256), 0, st, P);
 }
 
-#ifndef C3_STAGES_BF16
 #define C3_STAGES_BF16 2
 #define C3_STAGES_BF16_UP 2
 #define C3_STAGES_X3 1
 #define C3_STAGES_X3_UP 1
-#endif
-#ifndef C3_UP_FUSED_WAVES
 #define C3_UP_FUSED_WAVES 0          // 0 = the run-time form (shipped).  > 0: waves per SIMD (= workgroups per CU) of a compile-time fused variant of the up-sampling kernel in bf16 / fp16: 2 measured the same as 0 (same box, three repetitions); 3 (168 registers: no patch-fragment cache, or 19 spilled dwords) measured 0 to -4 % on the 256-channel layers and +10 % on the 32-channel one, with the cache and its spills +40 %
-#endif
-#ifndef C3_MID
 #define C3_MID 0
-#endif
-#ifndef C3_BIG
 #define C3_BIG 0          // measured slower (1 wave per SIMD, compiler-scheduled): bf16 SR 3.8 -> 4.0 ms, split-bf16 3.26 -> 3.45 ms
-#endif
-#ifndef C3_TALL_MIN_TILES
 #define C3_TALL_MIN_TILES 4          // use the 8-wave 32x16 tile from 64 rows up
-#endif
-#ifndef C3_WIDE8_DEFAULT
 #define C3_WIDE8_DEFAULT 0
-#endif
-#ifndef C3_LC_DEFAULT
 #define C3_LC_DEFAULT 0
-#endif
 
 static void launch_upfir(const ConvK& P, long long total, hipStream_t st) {
     const dim3 grid(grid1d(total, 256, 1 << 15)), block(256);
@@ -2740,23 +2560,3 @@ extern "C" int nfe_resize_bilinear(const float* in, int n, int h, int w, int c, 
     return NFE_OK;
 }
 
-#ifdef C3_PROFILE
-extern "C" int nfe_debug_c3_profile(unsigned long long* out8, int reset) {
-#if C3_PROFILE + 0 == 2
-    {   // light form: average the per-wave records written since the last reset: out8 = {0, K loop sum, epilogue sum, waves, 0, 0, life sum, 0}
-        static std::vector<unsigned long long> host(2ull * nfe::C3_PROF_SLOTS);
-        if (hipDeviceSynchronize() != hipSuccess) return -1;
-        if (hipMemcpyFromSymbol(host.data(), HIP_SYMBOL(nfe::c3_prof_w), host.size() * 8) != hipSuccess) return -1;
-        unsigned long long k = 0, e = 0, nw = 0;
-        for (unsigned i = 0; i < nfe::C3_PROF_SLOTS; ++i)
-            if (host[2 * i] | host[2 * i + 1]) { k += host[2 * i]; e += host[2 * i + 1]; ++nw; }
-        out8[0] = 0; out8[1] = k; out8[2] = e; out8[3] = nw ? nw : 1; out8[4] = 0; out8[5] = 0; out8[6] = k + e; out8[7] = 0;
-        if (reset) { std::fill(host.begin(), host.end(), 0ull); if (hipMemcpyToSymbol(HIP_SYMBOL(nfe::c3_prof_w), host.data(), host.size() * 8) != hipSuccess) return -1; }
-        return 0;
-    }
-#endif
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(nfe::c3_prof), 64) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(nfe::c3_prof), z, 64) != hipSuccess) return -1; }
-    return 0;
-}
-#endif
