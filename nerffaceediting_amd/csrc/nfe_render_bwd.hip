@@ -1183,7 +1183,7 @@ __device__ __forceinline__ void prod_issue(const ProdCtx& c, float4 (&b)[12]) {
 }
 
 // returns false when the hand-off wait was abandoned
-template <int SET, int G>
+template <int SET, int G, bool AFF>
 __device__ __forceinline__ bool prod_consume(const ProdCtx& c, const float4 (&b)[12], float4 (&acc)[8], unsigned& q, bool alive) {
     const int lane = c.lane, s8 = lane >> 3, c4 = (lane & 7) * 4;
     if constexpr (G < 8) {
@@ -1201,11 +1201,15 @@ __device__ __forceinline__ bool prod_consume(const ProdCtx& c, const float4 (&b)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float w = comp(w4, k);
-                wsum += w;
+                if (AFF) wsum += w;
                 sm = fma4(w, b[4 * p + k], sm);
             }
-            const float4 scp = *reinterpret_cast<const float4*>(c.aff + (SET * 3 + p) * 64 + c4), shp = *reinterpret_cast<const float4*>(c.aff + (SET * 3 + p) * 64 + 32 + c4);
-            fs = affine(sm, scp, wsum, shp, fs);
+            if (AFF) {
+                const float4 scp = *reinterpret_cast<const float4*>(c.aff + (SET * 3 + p) * 64 + c4), shp = *reinterpret_cast<const float4*>(c.aff + (SET * 3 + p) * 64 + 32 + c4);
+                fs = affine(sm, scp, wsum, shp, fs);
+            } else {          // no appearance statistics at all (scale 1, shift 0): f + fma(s, 1, wsum * 0) is f + s, to the bit
+                fs = make_float4(fs.x + sm.x, fs.y + sm.y, fs.z + sm.z, fs.w + sm.w);
+            }
         }
         // (formed HERE: without this the optimiser sinks the whole sum behind the hand-off wait, where acc is first read, and every tap
         // load of the set stays live until then - 2.5 KB of spills per lane)
@@ -1251,15 +1255,15 @@ template <bool DO_G, bool DO_A, int T> struct ProdStage {
     static constexpr int SET = (DO_G && DO_A) ? (T >= 9 ? 1 : 0) : (DO_A ? 1 : 0);
     static constexpr int G = T - ((DO_G && DO_A && T >= 9) ? 9 : 0);
 };
-template <bool DO_G, bool DO_A, int T>
+template <bool DO_G, bool DO_A, bool AFF, int T>
 __device__ __forceinline__ bool prod_run(const ProdCtx& c, float4 (&buf)[DEC_RING][12], float4 (&acc)[8], unsigned& q, bool alive) {
     constexpr int NST = 9 * ((DO_G ? 1 : 0) + (DO_A ? 1 : 0));
     if constexpr (T < NST) {
         if constexpr (T + DEC_RING - 1 < NST) prod_issue<ProdStage<DO_G, DO_A, T + DEC_RING - 1>::SET, ProdStage<DO_G, DO_A, T + DEC_RING - 1>::G>(c, buf[(T + DEC_RING - 1) % DEC_RING]);
         NFE_STAGE_FENCE();
-        alive = prod_consume<ProdStage<DO_G, DO_A, T>::SET, ProdStage<DO_G, DO_A, T>::G>(c, buf[T % DEC_RING], acc, q, alive);
+        alive = prod_consume<ProdStage<DO_G, DO_A, T>::SET, ProdStage<DO_G, DO_A, T>::G, AFF>(c, buf[T % DEC_RING], acc, q, alive);
         NFE_STAGE_FENCE();
-        return prod_run<DO_G, DO_A, T + 1>(c, buf, acc, q, alive);
+        return prod_run<DO_G, DO_A, AFF, T + 1>(c, buf, acc, q, alive);
     } else {
         return alive;
     }
@@ -1361,7 +1365,7 @@ __device__ __forceinline__ void dec_records_end(const BwdK& P, const DecRecords&
 // records are written (its geometry in LDS is dead then) the next item's geometry is staged, its rank atomics and its first two
 // stages are issued.  Returns false when a
 // hand-off wait was abandoned.
-template <bool DO_G, bool DO_A>
+template <bool DO_G, bool DO_A, bool AFF>
 __device__ __forceinline__ bool dec_producer(const BwdK& P, unsigned first, unsigned step, unsigned n_items, unsigned n_views, int lane,
                                              float* feat, float* cot, unsigned* flags, float* geo_lds, float* aff_lds) {
     if (first >= n_items) return true;
@@ -1389,7 +1393,7 @@ __device__ __forceinline__ bool dec_producer(const BwdK& P, unsigned first, unsi
         // (the lane index laundered per item: the unrolled stages derive some two hundred per-lane LDS and tile addresses from it, which
         // loop-invariant code motion would otherwise compute once in front of the item loop - and spill, 2 KB per lane)
         const ProdCtx ctx{P, it.n, it.m, pinned(lane), gsig, omega, feat, cot, flags, geo_lds, aff_lds};
-        alive = prod_run<DO_G, DO_A, 0>(ctx, buf, acc, q, alive);
+        alive = prod_run<DO_G, DO_A, AFF, 0>(ctx, buf, acc, q, alive);
         dec_records_end(P, R, lane, geo_lds, n_views);
         NFE_STAGE_FENCE();
         if (item + step < n_items) {
@@ -1435,9 +1439,15 @@ __global__ __launch_bounds__(128 * DEC_PAIRS) __attribute__((amdgpu_waves_per_eu
     unsigned q = 0;                      // plane sets handed over so far
     bool alive = true;
     if (producer) {
-        if (do_g && do_a) alive = dec_producer<true, true>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
-        else if (do_g) alive = dec_producer<true, false>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
-        else alive = dec_producer<false, true>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds);
+        // AFF = false: no appearance statistics on either plane set (planes edited directly: the common case of the backward) - the
+        // tap sums then skip the scale / shift arithmetic, a fifth of the producer's vector instructions
+        const bool aff_any = sgpr_nonnull(P.aff[0]) != 0 || sgpr_nonnull(P.aff[2]) != 0;
+#define NFE_DEC_PRODUCER(G_, A_) (aff_any ? dec_producer<G_, A_, true>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds) \
+                                          : dec_producer<G_, A_, false>(P, first, step, n_items, n_views, lane, feat, cot, flags, geo_lds, aff_lds))
+        if (do_g && do_a) alive = NFE_DEC_PRODUCER(true, true);
+        else if (do_g) alive = NFE_DEC_PRODUCER(true, false);
+        else alive = NFE_DEC_PRODUCER(false, true);
+#undef NFE_DEC_PRODUCER
     } else {
         const FragLds F{(unsigned)lane * 16u};
         const int jj = lane & 31, hh = lane >> 5;
