@@ -5,6 +5,7 @@
 #      config-3 shape in bf16, the FFHQ shape in fp16 and in split-bf16)
 #   2. rocprofv3 --kernel-trace --stats of the headline, twopass, full and ffhq commands
 #   3. the bench line of every workload
+#   4. tools/r05_backward_profile.sh (gpurun_out/r05_bwd/)
 # Output: gpurun_out/r05_profile/ (copy what is quoted into profiles/).
 export TMPDIR=/tmp
 OUT=gpurun_out/r05_profile
@@ -47,3 +48,5 @@ PY
 grep -h '"kernel"\|avg_ns_profiled' $OUT/r05_issue_floor*.json
 head -6 $OUT/r05_kernel_stats.csv | cut -c1-180
 tail -3 $OUT/bench.err
+# 4. the edit step's backward (kernel trace + PMC passes of tools/time_backward.py, both decoder-backward kernels) and the SR-head gradient
+bash tools/r05_backward_profile.sh
