@@ -13,7 +13,11 @@
  *   - all data pointers are DEVICE pointers to fp32 unless stated; the caller allocates every
  *     output and the workspace, the library never frees or retains caller memory.
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on that stream.
- *   - stateless and re-entrant.
+ *   - re-entrant, and stateless EXCEPT for two diagnostics that no result depends on (ABI v15): one pinned host word per process,
+ *     the sticky count of lost wave hand-offs (nfe_render_status: written by the device with system-scope atomics from any
+ *     stream of any thread, so a count cannot be attributed to a thread or stream - the per-call answer is nfe_render_call_status /
+ *     nfe_render_backward_call_status on the CALL'S OWN workspace), and a thread-local list of kernel names
+ *     (nfe_render_last_kernels).  Neither makes any call refuse to run or changes what it computes.
  *
  * The reference has no native entry point for the renderer (its renderer is ~25 ATen ops,
  * training/volumetric_rendering/renderer.py:301-363); each function below names the reference
@@ -29,13 +33,13 @@
 extern "C" {
 #endif
 
-#define NFE_ABI_VERSION 14
+#define NFE_ABI_VERSION 15
 
 #define NFE_OK 0
 #define NFE_EINVAL (-1)      /* bad argument (null pointer, size out of range, unsupported option) */
 #define NFE_ELAUNCH (-2)     /* HIP launch / runtime error */
 #define NFE_EWORKSPACE (-3)  /* workspace too small */
-#define NFE_EHANDOFF (-4)    /* an EARLIER nfe_render call lost wave hand-offs (see "lost hand-offs" at nfe_render) */
+#define NFE_EHANDOFF (-4)    /* the call this status query is about lost wave hand-offs; its outputs are NaN (see "lost hand-offs") */
 
 #define NFE_PLANE_CHANNELS 32   /* channels per plane (triplane.py:113-115) */
 #define NFE_NUM_PLANES 3
@@ -176,18 +180,29 @@ uint64_t nfe_render_sample_colors_floats(int n_views, int n_rays, int n_samples)
  * importance sampling the coarse depths / weights and the merged depths of every ray (density_noise: see above) */
 uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int depth_resolution,
                                     int depth_resolution_importance);
-/* Lost hand-offs (ABI v14).  Large launches run the wave-specialised kernel: gather waves hand feature tiles to decoder waves of
- * the same workgroup through LDS counters.  A wave that waits longer than ~50 ms for its partner gives up instead of hanging the
- * GPU (never observed; a bounded wait is the safety net).  Such a call is NOT silent garbage:
- *   - the kernel that closes every nfe_render call overwrites ALL four outputs of that call with NaN, and
- *   - it adds the number of abandoned waits to a pinned host word of the process, so that the NEXT nfe_render (any stream, any
- *     thread) launches nothing, returns NFE_EHANDOFF with the count in nfe_last_error(), and clears the word: the caller repeats
- *     its work.  No host synchronisation is involved anywhere; the reference's TORCH_CHECK convention (bias_act.cpp:39-55) has no
- *     asynchronous failures, this is the closest a stream-ordered library gets.
- * nfe_render_status() reads (clear != 0: and resets) the same word at any time, e.g. after the caller's own synchronisation
- * point: *lost_handoffs = abandoned waits, *poisoned_calls = nfe_render calls whose outputs were set to NaN.  Either may be NULL. */
+/* Lost hand-offs (ABI v15; v14 made the NEXT nfe_render of the process fail instead, which blamed a healthy call on another
+ * stream or thread, launched nothing for it, and never reported the last call of a process).  Large launches run the
+ * wave-specialised kernel: gather waves hand feature tiles to decoder waves of the same workgroup through LDS counters.  A wave
+ * that waits longer than ~50 ms for its partner gives up instead of hanging the GPU (never observed; a bounded wait is the safety
+ * net).  Such a call is NOT silent garbage, and the failure belongs to THAT call:
+ *   - the kernel that closes every nfe_render call overwrites ALL outputs the call was given with NaN: rgb, seg, depth, wsum and
+ *     the optional taps (tap_depths_all, tap_weights_coarse, tap_depths_fine, tap_sample_colors) - a backward fed with them
+ *     produces NaN gradients, not plausible ones;
+ *   - the number of abandoned waits stays in the call's workspace: nfe_render_call_status(workspace, stream, &lost) waits for
+ *     `stream`, reads it and returns NFE_EHANDOFF when it is not 0 (NFE_OK otherwise) - the caller's own synchronisation point is
+ *     where an asynchronous failure can be reported against the right call (the reference's TORCH_CHECK convention,
+ *     bias_act.cpp:39-55, has no asynchronous failures; this is the closest a stream-ordered library gets);
+ *   - the same kernel adds (count, 1 call) to the process's sticky status word with ONE 64-bit system-scope atomic, so that a
+ *     caller that never synchronises per call can still find out, without any synchronisation, that SOME call was poisoned:
+ *     nfe_render_status(&lost, &calls, clear) reads (clear != 0: and resets, one atomic exchange) it at any time.  No later call
+ *     is refused because of it.  *lost_handoffs = abandoned waits, *poisoned_calls = render / backward calls whose outputs were set
+ *     to NaN since the last clear.  Either may be NULL.  Callable without a GPU (returns zeros). */
 int nfe_render(const nfe_render_args* args, nfe_stream_t stream);
 int nfe_render_status(uint32_t* lost_handoffs, uint32_t* poisoned_calls, int clear);
+/* Per-call status: synchronises `stream`, then reads the abandoned-wait count of the LAST nfe_render call that used `workspace`
+ * (both passes of a two-pass call).  Returns NFE_OK (count 0: the outputs are valid), NFE_EHANDOFF (count > 0: every output of that
+ * call is NaN; repeat it - NFE_RENDER_WS=0 selects the fused kernel, which has no hand-off), or NFE_ELAUNCH.  *lost_handoffs optional. */
+int nfe_render_call_status(const void* workspace, nfe_stream_t stream, uint32_t* lost_handoffs);
 /* Names of the render kernels the last nfe_render call of THIS thread launched, space separated, in launch order (e.g.
  * "render_ws_kernel<4,2,SIGMA_ONLY> importance_kernel render_ws_kernel<4,2,DUAL>"); diagnostic, valid until the thread's next call. */
 const char* nfe_render_last_kernels(void);
@@ -224,8 +239,12 @@ int nfe_decoder_forward(const float* features_geo, const float* features_app, in
  * per-ray reverse recurrence (no divisions by 1 - alpha), the per-sample decoder backward (wave-specialised: gather waves hand
  * feature tiles to decoder waves through LDS counters), and a binned accumulate pass.  density_noise is not supported (absent
  * from every shipped config).
- * Lost hand-offs: the decoder-backward kernel bounds its waits like the render kernel (~100 ms; never observed).  A launch that
- * abandoned one does not pass for a result: the accumulate pass turns every gradient entry the call adds to into NaN. */
+ * Lost hand-offs: the decoder-backward kernel bounds its waits like the render kernel (~100 ms; never observed).  A call that
+ * abandoned one does not pass for a result (ABI v15): the kernel that closes the call overwrites BOTH gradient buffers entirely
+ * with NaN (every view, whichever chunk of the call lost the hand-off), adds (count, 1 call) to the sticky status word
+ * nfe_render_status reads, and leaves the count in the workspace for nfe_render_backward_call_status (same contract as
+ * nfe_render_call_status).  The direct and sorted forms (NFE_BWD_SCATTER=direct / sorted, planes beyond the bin table) and the
+ * single-wave decoder kernel have no hand-off and never report one. */
 typedef struct nfe_render_backward_args {
     uint32_t struct_size;              /* = sizeof(nfe_render_backward_args) */
     const float* planes_geo;           /* as in nfe_render_args (gather layout [Np,3,H,W,32]) */
@@ -266,6 +285,7 @@ typedef struct nfe_render_backward_args {
 
 uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples);
 int nfe_render_backward(const nfe_render_backward_args* args, nfe_stream_t stream);
+int nfe_render_backward_call_status(const void* workspace, nfe_stream_t stream, uint32_t* lost_handoffs);
 
 #ifdef __cplusplus
 }

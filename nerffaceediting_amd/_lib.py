@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # NFE_RENDER_LIB lets tools/ load an experimental build of the same ABI (kernel ablations)
 LIB_PATH = os.environ.get("NFE_RENDER_LIB") or os.path.join(_HERE, "libnfe_render.so")
 
-NFE_ABI_VERSION = 14
+NFE_ABI_VERSION = 15
 NFE_MAX_SAMPLES = 256
 NFE_DECODER_PACKED_FLOATS = 4 * 2048 + 64 + 64 + 32 + 32 + 8192
 NFE_DECODER_CROSS_FLOATS = 2048
@@ -111,9 +111,11 @@ _SIGNATURES = {
     "nfe_render_sample_colors_floats": (c_uint64, [c_int, c_int, c_int]),
     "nfe_render": (c_int, [POINTER(RenderArgs), c_void_p]),
     "nfe_render_status": (c_int, [POINTER(c_uint32), POINTER(c_uint32), c_int]),
+    "nfe_render_call_status": (c_int, [FP, c_void_p, POINTER(c_uint32)]),
     "nfe_render_last_kernels": (c_char_p, []),
     "nfe_render_backward_workspace_bytes": (c_uint64, [c_int, c_int, c_int]),
     "nfe_render_backward": (c_int, [POINTER(RenderBackwardArgs), c_void_p]),
+    "nfe_render_backward_call_status": (c_int, [FP, c_void_p, POINTER(c_uint32)]),
     # include/nfe_dense.h
     "nfe_nchw_to_nhwc": (c_int, [FP, c_int, c_int, c_int, c_int, FP, c_void_p]),
     "nfe_nhwc_to_nchw": (c_int, [FP, c_int, c_int, c_int, c_int, FP, c_void_p]),

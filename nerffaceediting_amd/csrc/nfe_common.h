@@ -15,6 +15,7 @@ int fail(int code, const char* fmt, ...);   // records the thread-local message,
 int render_eval_pass(const nfe_render_backward_args* a, const float* decoder_packed, float* rec_sig, float* rec_a, hipStream_t st);
 int render_color_dot_pass(const nfe_render_backward_args* a, float* rec_sig, float* rec_a, hipStream_t st);
 const char* last_error();
+unsigned long long* handoff_status_word();   // nfe_api.cpp: the process's sticky (poisoned calls << 32 | lost hand-offs) word, or null
 
 #define NFE_REQUIRE(cond, ...)                                   \
     do {                                                         \

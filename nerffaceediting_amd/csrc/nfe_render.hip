@@ -1244,8 +1244,8 @@ constexpr int WS_SPIN_LIMIT = 1 << 18;                      // x (s_sleep 1 + an
 // Wait until *flag has reached `need` (wrap-safe).  Returns false when the wait was abandoned: the flag's pair is then marked
 // aborted and every later wait of the pair returns at once - the launch finishes with garbage in that pair's rays and a count in
 // depth_minmax[2] instead of hanging the GPU.  The count is not silent: depth_clamp_kernel, which closes every nfe_render
-// call, turns ALL outputs of a call with a non-zero count into NaN and adds the count to the library's pinned host status word, so
-// that the next nfe_render of the process fails with NFE_EHANDOFF (nfe_render.h, "lost hand-offs").
+// call, turns ALL outputs of a call with a non-zero count into NaN, leaves the count in the call's workspace (nfe_render_call_status:
+// NFE_EHANDOFF for THAT call) and adds it to the process's sticky status word (nfe_render.h, "lost hand-offs").
 __device__ int g_ws_spin_limit = WS_SPIN_LIMIT;            // device global, read only on the slow path of a wait (NFE_WS_SPIN_LIMIT: the abort test shortens it)
 __device__ __forceinline__ bool ws_wait(unsigned* flags, int which, unsigned need) {
     int spins = 0;
@@ -1716,9 +1716,13 @@ __global__ __launch_bounds__(256) void render_combine_kernel(RenderK P, int sigm
 
 // nan_to_num(depth, inf) then clamp to the whole-tensor [min,max] of sampled depths (ray_marcher.py:93-94).
 // This kernel closes every nfe_render call, so it is also where a lost wave hand-off of render_ws_kernel becomes an error instead
-// of silent garbage: with minmax[2] != 0 every output of the call is overwritten with NaN and the count goes to the pinned host
-// status word (system-scope atomic), which the next nfe_render / nfe_render_status reads without any synchronisation.
-__global__ void depth_clamp_kernel(float* depth, float* rgb, float* seg, float* wsum, long long n, const unsigned* minmax, unsigned* host_status) {
+// of silent garbage: with minmax[2] + minmax[6] != 0 EVERY output the call was given - the four images and the optional taps - is
+// overwritten with NaN (an aborted coarse pass feeds garbage weights to importance_kernel, whose merged depths would otherwise go
+// on to nfe_render_backward as plausible constants) and (count, 1 call) goes to the process's sticky status word with one
+// system-scope 64-bit atomic.  The count itself stays in the workspace for nfe_render_call_status.
+struct ClampTaps { float* p[4]; unsigned long long n[4]; };      // tap_depths_all, tap_weights_coarse, tap_depths_fine, tap_sample_colors
+__global__ void depth_clamp_kernel(float* depth, float* rgb, float* seg, float* wsum, long long n, const unsigned* minmax, ClampTaps taps,
+                                   unsigned long long* host_status) {
     const float lo = ord2f(minmax[0]), hi = ord2f(minmax[1]);
     const unsigned lost = minmax[2] + minmax[6];       // final pass + coarse pass (whose min / max words 4, 5 are scratch)
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long long)gridDim.x * blockDim.x;
@@ -1727,10 +1731,11 @@ __global__ void depth_clamp_kernel(float* depth, float* rgb, float* seg, float* 
         for (long long i = i0; i < n; i += stride) { depth[i] = bad; wsum[i] = bad; }
         for (long long i = i0; i < n * NFE_RGB_CHANNELS; i += stride) rgb[i] = bad;
         for (long long i = i0; i < n * NFE_SEG_CHANNELS; i += stride) seg[i] = bad;
-        if (i0 == 0 && host_status) {
-            __hip_atomic_fetch_add(host_status + 0, lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_fetch_add(host_status + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
+        for (int t = 0; t < 4; ++t)
+            if (taps.p[t])
+                for (unsigned long long i = (unsigned long long)i0; i < taps.n[t]; i += (unsigned long long)stride) taps.p[t][i] = bad;
+        if (i0 == 0 && host_status)
+            __hip_atomic_fetch_add(host_status, (1ull << 32) | (unsigned long long)lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         return;
     }
     for (long long i = i0; i < n; i += stride) {
@@ -2104,19 +2109,6 @@ static void note_kernel(const char* name) {
     if (have) { g_kernels[have] = ' '; memcpy(g_kernels + have + 1, name, add + 1); } else memcpy(g_kernels, name, add + 1);
 }
 
-// Lost hand-offs (render_ws_kernel, see ws_wait): a pinned, device-visible host word per process.  depth_clamp_kernel adds a call's
-// abort count to word 0 (and 1 to word 1 = poisoned calls) with system-scope atomics; the host reads it WITHOUT synchronising at the
-// start of the next nfe_render (-> NFE_EHANDOFF, count reported and cleared) and in nfe_render_status.  Allocation failure leaves the
-// pointer null: outputs are still poisoned with NaN, only the return-code path is absent.
-static unsigned* handoff_status_word() {
-    static unsigned* word = [] {
-        void* p = nullptr;
-        if (hipHostMalloc(&p, 64, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return (unsigned*)nullptr; }
-        memset(p, 0, 64);
-        return (unsigned*)p;
-    }();
-    return word;
-}
 // Polls of a hand-off wait before it is abandoned: the device global g_ws_spin_limit.  NFE_WS_SPIN_LIMIT (read once) overrides it for
 // tests/test_handoff_abort_gpu.py; the symbol is written once per device, and only when the variable is set.
 static int apply_ws_spin_limit() {
@@ -2363,18 +2355,6 @@ extern "C" uint64_t nfe_render_workspace_bytes(int n_views, int n_rays, int D, i
 
 extern "C" const char* nfe_render_last_kernels(void) { return g_kernels; }
 
-extern "C" int nfe_render_status(uint32_t* lost_handoffs, uint32_t* poisoned_calls, int clear) {
-    unsigned* status = handoff_status_word();
-    unsigned lost = 0, calls = 0;
-    if (status) {
-        if (clear) { lost = __atomic_exchange_n(status + 0, 0u, __ATOMIC_RELAXED); calls = __atomic_exchange_n(status + 1, 0u, __ATOMIC_RELAXED); }
-        else { lost = __atomic_load_n(status + 0, __ATOMIC_RELAXED); calls = __atomic_load_n(status + 1, __ATOMIC_RELAXED); }
-    }
-    if (lost_handoffs) *lost_handoffs = lost;
-    if (poisoned_calls) *poisoned_calls = calls;
-    return NFE_OK;
-}
-
 extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     NFE_REQUIRE(a != nullptr, "nfe_render: args is null");
     NFE_REQUIRE(a->struct_size == sizeof(nfe_render_args), "nfe_render: struct_size %u != %zu (ABI mismatch)",
@@ -2408,16 +2388,6 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
                                                (unsigned long long)a->workspace_bytes, (unsigned long long)need);
     hipStream_t st = (hipStream_t)stream;
     g_kernels[0] = 0;
-    unsigned* status = handoff_status_word();
-    if (status) {       // an EARLIER call's lost hand-offs (its outputs are NaN): reported once, by the next call, without a host sync
-        const unsigned lost = __atomic_exchange_n(status + 0, 0u, __ATOMIC_RELAXED);
-        if (lost) {
-            const unsigned calls = __atomic_exchange_n(status + 1, 0u, __ATOMIC_RELAXED);
-            return fail(NFE_EHANDOFF, "nfe_render: %u earlier render call(s) of this process lost %u wave hand-offs in render_ws_kernel "
-                                      "(a producer / consumer wave gave up waiting for its partner); their outputs were set to NaN. "
-                                      "Nothing was launched by this call; repeat it (NFE_RENDER_WS=0 selects the fused kernel)", calls, lost);
-        }
-    }
     const uint64_t nr = (uint64_t)a->n_views * a->n_rays;
     char* ws = (char*)a->workspace;
     unsigned* minmax = (unsigned*)ws; ws += 256;
@@ -2505,7 +2475,13 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     }
     long long cb = ((long long)nr + 255) / 256;
     if (cb > 4096) cb = 4096;
-    hipLaunchKernelGGL(depth_clamp_kernel, dim3((unsigned)cb), dim3(256), 0, st, a->depth, a->rgb, a->seg, a->wsum, (long long)nr, minmax, status);
+    ClampTaps taps{};                   // NaN for these too when the call lost a hand-off (see depth_clamp_kernel)
+    taps.p[0] = a->tap_depths_all; taps.n[0] = nr * (uint64_t)(D + Di);
+    taps.p[1] = Di > 0 ? a->tap_weights_coarse : nullptr; taps.n[1] = nr * (uint64_t)(D - 1);
+    taps.p[2] = Di > 0 ? a->tap_depths_fine : nullptr; taps.n[2] = nr * (uint64_t)Di;
+    taps.p[3] = a->tap_sample_colors; taps.n[3] = a->tap_sample_colors ? nfe_render_sample_colors_floats(a->n_views, a->n_rays, D + Di) : 0;
+    hipLaunchKernelGGL(depth_clamp_kernel, dim3((unsigned)cb), dim3(256), 0, st, a->depth, a->rgb, a->seg, a->wsum, (long long)nr, minmax, taps,
+                       handoff_status_word());
     NFE_CHECK_LAUNCH("depth_clamp_kernel");
     return NFE_OK;
 }

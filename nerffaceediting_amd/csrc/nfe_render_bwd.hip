@@ -1815,7 +1815,22 @@ static uint64_t tiled_floats(int n_views, int n_rays, int n_samples) {
 // df rows + (key, weights) records + (bin, rank) + sorted record indices + counts and offsets
 static uint64_t binned_bytes(uint64_t slots) {
     return align256(slots * 256) + align256(slots * 3 * 8) + align256(slots * 3 * 16) + align256(slots * 3 * 8) + align256(slots * 3 * 4) +
-           2 * align256(BWD_MAX_BINS * 4) + 256;          // + the hand-off abort word
+           2 * align256(BWD_MAX_BINS * 4);
+}
+
+// Closes nfe_render_backward's binned form (the one with a hand-off): see the launch.
+struct BwdPoison { const unsigned* abort_word; unsigned long long* host_status; float* g[2]; int sets; long long view_stride; unsigned long long per_set; };
+__global__ __launch_bounds__(256) void bwd_poison_kernel(BwdPoison Z) {
+    const unsigned lost = *Z.abort_word;
+    if (lost == 0u) return;
+    const float bad = __uint_as_float(0x7fc00000u);
+    const unsigned long long i0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, stride = (unsigned long long)gridDim.x * blockDim.x;
+    for (int b = 0; b < 2; ++b)
+        if (Z.g[b])
+            for (int v = 0; v < Z.sets; ++v)
+                for (unsigned long long i = i0; i < Z.per_set; i += stride) Z.g[b][(long long)v * Z.view_stride + (long long)i] = bad;
+    if (i0 == 0 && Z.host_status)
+        __hip_atomic_fetch_add(Z.host_status, (1ull << 32) | (unsigned long long)lost, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 }  // namespace nfe
@@ -1836,7 +1851,7 @@ static int apply_dec_spin_limit() {
 }
 
 extern "C" uint64_t nfe_render_backward_workspace_bytes(int n_views, int n_rays, int n_samples) {
-    return BWD_DEC_BYTES + 4 * align256(tiled_floats(n_views, n_rays, n_samples) * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES) +
+    return 256 /* word 0: the call's hand-off abort count (nfe_render_backward_call_status) */ + BWD_DEC_BYTES + 4 * align256(tiled_floats(n_views, n_rays, n_samples) * 4) + align256((uint64_t)NFE_DECODER_PACKED_FLOATS * 4) + align256(BWD_FRAG_BYTES) +
            binned_bytes(chunk_slots(n_views, n_rays, n_samples));
 }
 
@@ -1868,6 +1883,8 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
                                                (unsigned long long)a->workspace_bytes, (unsigned long long)need);
     hipStream_t st = (hipStream_t)stream;
     char* ws = (char*)a->workspace;
+    unsigned* abort_word = (unsigned*)ws; ws += 256;       // zeroed now, whichever form runs: the per-call status reads it
+    if (hipMemsetAsync(abort_word, 0, 4, st) != hipSuccess) return fail(NFE_ELAUNCH, "nfe_render_backward: hipMemsetAsync failed");
     float* dec = (float*)ws; ws += BWD_DEC_BYTES;
     PrepK Q{};
     Q.w[0] = a->geo_w0; Q.w[1] = a->geo_b0; Q.w[2] = a->geo_w1; Q.w[3] = a->geo_b1;
@@ -1948,8 +1965,7 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
     P.perm = (unsigned*)bw; bw += align256(slots_max * 3 * 4);
     P.counts = (unsigned*)bw; bw += align256(BWD_MAX_BINS * 4);
     P.offsets = (unsigned*)bw; bw += align256(BWD_MAX_BINS * 4);
-    P.abort_word = (unsigned*)bw;
-    if (hipMemsetAsync(P.abort_word, 0, 4, st) != hipSuccess) return fail(NFE_ELAUNCH, "nfe_render_backward: hipMemsetAsync failed");
+    P.abort_word = abort_word;
     const uint64_t per_tile = 64ull * (uint64_t)a->n_samples, view_slots = (uint64_t)ray_tiles * per_tile;
     unsigned views_per_chunk = 1, tiles_per_chunk = ray_tiles;
     if (view_slots >= slots_max) tiles_per_chunk = (unsigned)(slots_max / per_tile);
@@ -1983,5 +1999,13 @@ extern "C" int nfe_render_backward(const nfe_render_backward_args* a, nfe_stream
             NFE_CHECK_LAUNCH("bwd_accumulate_kernel");
         }
     }
+    // closes the call: a lost hand-off in ANY chunk poisons BOTH gradient buffers entirely (the accumulate passes of the chunks
+    // before the aborting one wrote finite numbers) and is counted in the sticky status word; nothing to do otherwise
+    BwdPoison Z{};
+    Z.abort_word = abort_word; Z.host_status = handoff_status_word();
+    Z.g[0] = a->grad_planes_geo; Z.g[1] = a->grad_planes_app == a->grad_planes_geo ? nullptr : a->grad_planes_app;
+    Z.sets = a->grad_view_stride ? a->n_views : 1; Z.view_stride = a->grad_view_stride; Z.per_set = 96ull * (unsigned long long)a->plane_h * a->plane_w;
+    hipLaunchKernelGGL(bwd_poison_kernel, dim3(256), dim3(256), 0, st, Z);
+    NFE_CHECK_LAUNCH("bwd_poison_kernel");
     return NFE_OK;
 }

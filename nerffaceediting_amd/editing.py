@@ -4,7 +4,7 @@ matches an edited one, appearance is carried by the plane statistics).  Here eve
 `nfe_render_backward`; the optimiser itself is torch.optim on the plane tensor."""
 import torch
 
-from . import utils
+from . import ops, utils
 
 
 def segmentation_loss(image_seg, target_labels):
@@ -35,7 +35,8 @@ def optimize_planes(G, ws, cam, norm_planes, mean, var, loss_fn, steps=100, lr=0
         loss = loss_fn(out)
         loss.backward()
         opt.step()
-        losses.append(float(loss.detach()))
+        losses.append(float(loss.detach()))           # synchronises: the place to learn that this step's render or backward was poisoned
+        ops.raise_if_handoff_lost()
         if callback is not None:
             callback(step, out, losses[-1])
     return norm.detach(), mean.detach(), var.detach(), losses

@@ -50,27 +50,62 @@ def _workspace(device, nbytes):
     return ws
 
 
-def render_handoff_aborts(device=None):
-    """Diagnostic (synchronises): how many producer / consumer waits render_ws_kernel abandoned in the LAST nfe_render call issued
-    from the current stream of `device` (words 2 and 6 of the render workspace, zeroed by every call).  Must be 0: a non-zero count means a
-    wave pair lost its partner, finished with garbage in its rays instead of hanging the GPU, and the outputs are invalid."""
+def _call_ws(device):
     device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-    ws = _workspaces.get((device.index, torch.cuda.current_stream(device).cuda_stream))
+    return device, _workspaces.get((device.index, torch.cuda.current_stream(device).cuda_stream))
+
+
+def render_call_status(device=None, backward=False):
+    """The per-call error surface of a lost wave hand-off (nfe_render_call_status / nfe_render_backward_call_status, ABI v15):
+    synchronises the current stream of `device` and raises RuntimeError (NFE_EHANDOFF, -4) when the LAST ops.render (backward=True:
+    ops.render_backward) call issued from that stream abandoned a producer / consumer wait - every output of that call is NaN then.
+    Returns None otherwise.  This is the check to put at one's own synchronisation point; no later call is refused because of an
+    earlier call's failure."""
+    device, ws = _call_ws(device)
+    if ws is None:
+        return
+    lib = _lib.load()
+    fn = lib.nfe_render_backward_call_status if backward else lib.nfe_render_call_status
+    with torch.cuda.device(device):
+        _lib.check(fn(ctypes.c_void_p(ws.data_ptr()), _stream(), None), fn.__name__)
+
+
+def render_handoff_aborts(device=None, backward=False):
+    """Diagnostic (synchronises): how many producer / consumer waits the wave-specialised kernel abandoned in the LAST ops.render
+    (backward=True: ops.render_backward) call issued from the current stream of `device` - the count nfe_render_call_status reads.
+    Must be 0: a non-zero count means a wave pair lost its partner, finished with garbage instead of hanging the GPU, and every output
+    of that call was overwritten with NaN."""
+    device, ws = _call_ws(device)
     if ws is None:
         return 0
-    torch.cuda.synchronize(device)
-    words = ws[:32].view(torch.int32).cpu()
-    return int(words[2]) + int(words[6])         # final pass + coarse pass of a two-pass call
+    lib = _lib.load()
+    lost = ctypes.c_uint32(0)
+    fn = lib.nfe_render_backward_call_status if backward else lib.nfe_render_call_status
+    with torch.cuda.device(device):
+        rc = fn(ctypes.c_void_p(ws.data_ptr()), _stream(), ctypes.byref(lost))
+    if rc not in (0, -4):
+        _lib.check(rc, fn.__name__)
+    return int(lost.value)
 
 
 def render_status(clear=False):
-    """nfe_render_status (no synchronisation): (lost_handoffs, poisoned_calls) of this process since the last clear.  A render call
-    whose wave-specialised kernel abandoned a hand-off wait has NaN in all its outputs and is counted here once its closing kernel has
-    run; the next render call raises RuntimeError (NFE_EHANDOFF) by itself - this is for callers that want to look first, e.g. right
-    after their own synchronisation point."""
+    """nfe_render_status (no synchronisation): (lost_handoffs, poisoned_calls) of this PROCESS since the last clear - a sticky
+    diagnostic fed by every stream and thread.  A render or render-backward call whose wave-specialised kernel abandoned a hand-off
+    wait has NaN in all its outputs and is counted here once its closing kernel has run.  No call is refused because of it;
+    raise_if_handoff_lost() turns it into an exception at a point where the caller has synchronised anyway."""
     lost, calls = ctypes.c_uint32(0), ctypes.c_uint32(0)
     _lib.check(_lib.load().nfe_render_status(ctypes.byref(lost), ctypes.byref(calls), 1 if clear else 0), "nfe_render_status")
     return int(lost.value), int(calls.value)
+
+
+def raise_if_handoff_lost():
+    """For the caller's own synchronisation points (frames copied to the host, a loss value read): raise RuntimeError when any render
+    / backward call of this process has been poisoned since the last clear (and clear).  No synchronisation of its own."""
+    lost, calls = render_status()
+    if lost:
+        lost, calls = render_status(clear=True)
+        raise RuntimeError(f"{calls} render call(s) of this process lost {lost} wave hand-offs (NFE_EHANDOFF): their outputs are NaN; "
+                           "repeat them (NFE_RENDER_WS=0 / NFE_BWD_DECODER=single select the kernels without a hand-off)")
 
 
 def render_last_kernels():

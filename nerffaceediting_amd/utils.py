@@ -201,6 +201,8 @@ def render_video(G, fn, ws, norm_planes, denorm_planes, frames=150, fps=30, a_de
     if fn and os.path.dirname(fn):
         os.makedirs(os.path.dirname(fn), exist_ok=True)                # utils.py:75
     host = out.cpu().numpy()
+    from . import ops
+    ops.raise_if_handoff_lost()          # the copy above synchronised: a frame poisoned by a lost wave hand-off is an error here, not a black frame in the video
     if writer is None and fn is not None and str(fn).endswith(".npy"):
         np.save(fn, host)
         return out

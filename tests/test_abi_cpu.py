@@ -138,3 +138,20 @@ def test_backward_workspace_is_bounded():
     assert cap == fixed(8, 512 * 512, 192)         # more views, same chunk
     assert (1 << 23) * per_slot * 0.99 <= cap <= (1 << 23) * per_slot + (8 << 20)
     assert lib.nfe_render_backward_workspace_bytes(0, 64, 4) < (1 << 23)
+
+
+def test_status_queries_are_callable_without_a_gpu():
+    """the two diagnostics that make the library not-quite-stateless (include/nfe_render.h, conventions) answer on a
+    box without a GPU: the sticky hand-off word reads (0, 0) - with and without clear - and the thread-local kernel list is empty;
+    the per-call queries reject a null workspace with NFE_EINVAL instead of touching a device."""
+    from nerffaceediting_amd import _lib
+    lib = _lib.load()
+    for clear in (0, 1, 0):
+        lost, calls = ctypes.c_uint32(7), ctypes.c_uint32(7)
+        assert lib.nfe_render_status(ctypes.byref(lost), ctypes.byref(calls), clear) == 0
+        assert (lost.value, calls.value) == (0, 0)
+    assert lib.nfe_render_status(None, None, 0) == 0                       # both outputs are optional
+    k = lib.nfe_render_last_kernels()
+    assert k is not None and k.decode() == ""
+    for fn in (lib.nfe_render_call_status, lib.nfe_render_backward_call_status):
+        assert fn(None, None, None) == -1 and b"workspace is null" in lib.nfe_last_error()

@@ -4,11 +4,15 @@ The wave-specialised render kernel bounds its producer / consumer waits so that 
 that gives up must not become silent garbage: the reference's ops fail loudly (TORCH_CHECK, torch_utils/ops/bias_act.cpp:39-55).
 Here a child interpreter shortens the bound to ONE poll (NFE_WS_SPIN_LIMIT=1, read once per process: a consumer's first wait
 for a tile that needs a whole gather is then certain to be abandoned) and checks the three things the header promises:
-  1. every output of the affected call is NaN;
-  2. the NEXT render call raises RuntimeError (NFE_EHANDOFF) naming the count, and launches nothing;
-  3. the call after that works again (the status word was cleared) - with the bound back in force it would abort again, so the
-     child checks this through the fused kernel (too few ray blocks for the wave-specialised launch).
-Both passes of a two-pass render count (the coarse sigma-only pass has no depth min/max words but does have the abort counter)."""
+  1. every output of the affected call is NaN - the four images AND the taps it was given (merged depths, coarse weights, fine depths);
+  2. the failure belongs to THAT call (ABI v15): ops.render_call_status() - the per-call query on the call's own workspace, at the
+     caller's synchronisation point - raises RuntimeError (NFE_EHANDOFF, -4) naming the count, and the process's sticky word
+     (ops.render_status) counts (lost, 1 call) in one 64-bit word; ops.raise_if_handoff_lost() raises once and clears it;
+  3. NO LATER CALL IS REFUSED: the next render launches and is judged on its own (v14 made it launch nothing and return the error
+     of the earlier call - the wrong call, possibly another stream's or thread's).  With the one-poll bound still in force a
+     wave-specialised launch would abort again, so the child checks this through the fused kernel (too few ray blocks).
+Both passes of a two-pass render count (the coarse sigma-only pass has no depth min/max words but does have the abort counter).
+The backward's decoder kernel has the same surface: whole gradient buffers NaN, ops.render_call_status(backward=True), sticky word."""
 import os
 import subprocess
 import sys
@@ -36,23 +40,34 @@ for D, Di, want in ((16, 0, ["render_ws_kernel<4,2>"]),
                     (12, 12, ["render_ws_kernel<4,2,SIGMA_ONLY>", "importance_kernel", "render_ws_kernel<4,2>"])):
     opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
     assert ops.render_status(clear=True) is not None
-    out = ops.render(packed, packed, dec, opts, resolution=R, **cam)[:4]          # 8 192 ray blocks: wave-specialised launch
+    res = ops.render(packed, packed, dec, opts, resolution=R, taps=True, **cam)         # 8 192 ray blocks: wave-specialised launch
+    out, tap = res[:4], res[4]
     assert ops.render_last_kernels() == want, ops.render_last_kernels()
     torch.cuda.synchronize()
     assert all(bool(torch.isnan(o).all()) for o in out), "outputs of a call that lost hand-offs must be NaN, all of them"
+    assert all(bool(torch.isnan(v).all()) for k, v in tap.items() if isinstance(v, torch.Tensor)), "the taps of such a call must be NaN too"
+    assert ("weights_coarse" in tap) == (Di > 0)
     lost, calls = ops.render_status()
     assert lost > 0 and calls == 1, (lost, calls)
     assert ops.render_handoff_aborts() == lost
     try:
-        ops.render(packed, packed, dec, opts, resolution=R, **cam)
-        raise SystemExit("the call after a poisoned one must raise")
+        ops.render_call_status()
+        raise SystemExit("the per-call status of a poisoned call must raise")
     except RuntimeError as e:
         assert "(-4)" in str(e) and "lost %d wave hand-offs" % lost in str(e), str(e)
-    assert ops.render_status() == (0, 0)                                            # reported once, then cleared
-    small = ops.render(packed, packed, dec, opts, resolution=64, **cam)[:4]         # 128 ray blocks: fused kernel, no hand-off
+    assert ops.render_status() == (lost, 1)                                         # sticky: the per-call query does not clear it
+    small = ops.render(packed, packed, dec, opts, resolution=64, **cam)[:4]         # the NEXT call is not refused: 128 ray blocks, fused kernel, no hand-off
     assert not any(k.startswith("render_ws_kernel") for k in ops.render_last_kernels())
-    torch.cuda.synchronize()
-    assert all(bool(torch.isfinite(o).all()) for o in small) and ops.render_status() == (0, 0)
+    ops.render_call_status()                                                        # ... and it is healthy: no exception, finite outputs
+    assert all(bool(torch.isfinite(o).all()) for o in small) and ops.render_handoff_aborts() == 0
+    assert ops.render_status() == (lost, 1)
+    try:
+        ops.raise_if_handoff_lost()
+        raise SystemExit("raise_if_handoff_lost must raise while the sticky word is set")
+    except RuntimeError as e:
+        assert "lost %d wave hand-offs" % lost in str(e), str(e)
+    assert ops.render_status() == (0, 0)                                            # reported once, then cleared (one atomic exchange)
+    ops.raise_if_handoff_lost()
 print("HANDOFF_ABORT_OK")
 """
 
@@ -72,23 +87,31 @@ from tests.test_render_backward_gpu import _editing_size_case
 dev = torch.device("cuda:0")
 args, kw = _editing_size_case(dev)                 # its forward: 2 x 128^2 rays = 1 024 ray blocks, the fused render kernel (no hand-off)
 assert not any(k.startswith("render_ws_kernel") for k in ops.render_last_kernels())
-for need in ((True, True), (True, False), (False, True)):
+ops.render_status(clear=True)
+for k, need in enumerate(((True, True), (True, False), (False, True))):
     gg, ga = ops.render_backward(*args, need=need, **kw)
     torch.cuda.synchronize()
     for g, n in ((gg, need[0]), (ga, need[1])):
         if not n:
             continue
-        bad = torch.isnan(g)
-        assert bool(bad.any()), "gradients of a backward that lost hand-offs must be NaN"
-        assert bool(((g == 0) | bad).all()), "every entry the call touched must be NaN, none a plausible number"
-        assert int(bad.sum()) > 1000000
+        assert bool(torch.isnan(g).all()), "EVERY entry of a gradient buffer of a backward that lost hand-offs must be NaN"
+    lost = ops.render_handoff_aborts(backward=True)
+    assert lost > 0
+    try:
+        ops.render_call_status(backward=True)
+        raise SystemExit("the per-call status of a poisoned backward must raise")
+    except RuntimeError as e:
+        assert "(-4)" in str(e) and "lost %d wave hand-offs" % lost in str(e), str(e)
+    assert ops.render_status()[1] == k + 1                 # poisoned calls so far, in the sticky word
+assert ops.render_status(clear=True)[1] == 3 and ops.render_status() == (0, 0)
 print("BWD_HANDOFF_ABORT_OK")
 """
 
 
 def test_lost_handoff_in_the_backward_poisons_the_gradients():
     """bwd_decoder_kernel (producer / consumer wave pairs) under NFE_WS_SPIN_LIMIT=1: the consumer's first wait is abandoned, the
-    launch ends, and the accumulate pass writes NaN into every gradient entry it adds to (include/nfe_render.h, nfe_render_backward)."""
+    launch ends, and the kernel that closes the call overwrites both gradient buffers with NaN, whichever chunk lost the hand-off;
+    the count is in the call's workspace (nfe_render_backward_call_status -> NFE_EHANDOFF) and in the sticky word (ABI v15)."""
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, NFE_WS_SPIN_LIMIT="1", PYTHONPATH=root)
     env.pop("NFE_BWD_DECODER", None)

@@ -253,6 +253,11 @@ def test_render_full_size_vs_reference(math, dev):
     decp = ops.decoder_pack(*[_t(dec[k], dev) for k in names])
     rgb, seg, depth, wsum = ops.render(packed, packed, decp, opts, cam2world=_t(z["cam2world"], dev), intrinsics=_t(z["intrinsics"], dev),
                                        resolution=R, affines=ops.make_affine(mean, std), u_coarse=_t(u_c, dev), decoder_math=math)[:4]
+    # the launch rule (nfe_render.hip: >= 4 096 ray blocks, split-bf16 decoder -> the wave-specialised kernel; exact fp32 -> the fused
+    # one) is part of what this test pins: the headline of bench.py is THIS shape on THESE kernels, and a threshold change that moves it
+    # elsewhere must fail here, not pass silently on another kernel
+    assert ops.render_last_kernels() == (["render_ws_kernel<4,2>"] if math == "bf16x3" else ["render_kernel"]), ops.render_last_kernels()
+    assert ops.render_handoff_aborts() == 0
     idx = torch.arange(0, R * R, stride, device=dev)
     errs = {"rgb": max_abs(rgb[:, idx].cpu().numpy(), z["rgb"]), "seg": max_abs(seg[:, idx].cpu().numpy(), z["seg"]),
             "depth": max_abs(depth[:, idx].cpu().numpy(), z["depth"]), "wsum": max_abs(wsum[:, idx].cpu().numpy(), z["wsum"])}

@@ -1,4 +1,4 @@
-"""CPU, world_size 2 over gloo: view sharding + frame all-gather (the N>1 path of bench.py / SURVEY §8e)."""
+"""CPU, world_size 2 and 8 over gloo: view sharding + frame all-gather (the N>1 path of bench.py / SURVEY §8e)."""
 import os
 
 import pytest
@@ -53,12 +53,12 @@ def _chunk_worker(rank, world, port, V, chunk, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        g = sharding.ChunkedFrameGather(V, chunk, (2, 3), torch.uint8, torch.device("cpu"), max_in_flight=2)
+        g = sharding.ChunkedFrameGather(V, chunk, (2, 3), torch.int32, torch.device("cpu"), max_in_flight=2)
         order = []
         for k in range(g.rounds()):
             s, e = g.local_slice(k)
             order.append((s, e))
-            frames = torch.stack([torch.full((2, 3), i, dtype=torch.uint8) for i in range(s, e)]) if e > s else torch.zeros(0, 2, 3, dtype=torch.uint8)
+            frames = torch.stack([torch.full((2, 3), i, dtype=torch.int32) for i in range(s, e)]) if e > s else torch.zeros(0, 2, 3, dtype=torch.int32)
             g.submit(k, frames)                       # "render" of round k+1 proceeds while round k is exchanged
         out = g.finish()
         ok = out.shape == (V, 2, 3) and all(int(out[i, 1, 2]) == i for i in range(V))
@@ -83,6 +83,42 @@ def test_chunked_overlapped_gather_world2_uneven_shards(V, chunk, rounds):
     for p in procs:
         p.join(timeout=60)
     assert res == [(0, True, rounds), (1, True, rounds)]
+
+
+@pytest.mark.parametrize("V,chunk", [(512, 8), (500, 8), (5, 8), (64, 3)])
+def test_chunked_overlapped_gather_world8(V, chunk):
+    """The TARGET's rank count (BASELINE config 4: one node, 8 GPUs), on gloo: the config-4 orbit itself (512 frames in chunks of 8:
+    the staging tensor is [8 ranks, 8 frames, ...]), a frame count the ranks do not divide (500: blocks of 63 and a last block of 59,
+    ragged last rounds on every rank), FEWER FRAMES THAN RANKS (5: ranks 5-7 own nothing and still have to join every collective),
+    and a chunk that divides nothing.  Every rank must end with every frame, in view order, having rendered its own block once."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    from nerffaceediting_amd.launch import free_port
+    port = free_port()
+    world = 8
+    rounds = -(-(-(-V // world)) // chunk)
+    procs = [ctx.Process(target=_chunk_worker, args=(r, world, port, V, chunk, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True, rounds) for r in range(world)]
+
+
+def test_all_gather_frames_world8_with_empty_ranks():
+    """sharding.all_gather_frames / _async (bench.py's per-step frame exchange) at 8 ranks with 5 views: three ranks contribute nothing."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    from nerffaceediting_amd.launch import free_port
+    port = free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 8, port, 5, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [(r, True) for r in range(8)]
 
 
 def test_chunked_gather_single_process():
@@ -131,6 +167,19 @@ def test_bench_self_launches_its_ranks_on_gloo():
     line = _last_json(r.stdout)
     assert line["n_gpus"] == 2 and line["frames_ok"] is True
     assert line["distributed"] == {"backend": "gloo", "world_size": 2, "launcher": "self"}
+
+
+@pytest.mark.parametrize("frames", [512, 5])
+def test_bench_self_launches_eight_ranks_on_gloo(frames):
+    """`python bench.py --gpus 8 --workload exchange --backend gloo`: the launch + frame-exchange plumbing of the config-4 job at the
+    target's rank count - the 512-frame orbit, and 5 frames over 8 ranks (empty ranks).  No rendering, no scaling number: no 8-GPU
+    node has been available in any round."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--workload", "exchange", "--backend", "gloo",
+                        "--orbit-frames", str(frames), "--steps", "1"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _last_json(r.stdout)
+    assert line["n_gpus"] == 8 and line["frames_ok"] is True and line["config"]["frames"] == frames
+    assert line["distributed"] == {"backend": "gloo", "world_size": 8, "launcher": "self"}
 
 
 def test_bench_under_torch_distributed_run_on_gloo():
