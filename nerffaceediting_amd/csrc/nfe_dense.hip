@@ -565,7 +565,11 @@ struct Conv3K {
     float* partial;     //      raw partial sums [ksplit][N,H,W,Cout] that splitk_reduce_kernel adds in slice order (+ epilogue)
     const float* next_styles; uint2* split_hi; uint2* split_lo;     // plain 3x3, no split-K: the consuming layer's modulated bf16 image
     int f16;            // host-side only: launch the TERMS = 2 (fp16 operand) instantiation of the bf16 variant
-};                                                                  // (what modsplit_kernel would make of `out`), written by the epilogue
+                                                                    // (what modsplit_kernel would make of `out`), written by the epilogue
+    // upconv_strip_kernel (round 6): a workgroup walks `seg_blocks` 8-row blocks down a 30-column strip of the extended input grid
+    float* seam;        // [N][segs - 1][6][2W][Cout]: the three row-filtered T rows either side of every segment boundary
+    int strips, segs, seg_blocks, blocks;
+};
 
 #define C3_XCD_ALL 0
 __host__ __device__ constexpr bool c3_xcd_order(int terms) { return terms == 3 || C3_XCD_ALL; }
@@ -589,6 +593,12 @@ template <int ROWS> struct C3Tile {
 __device__ __forceinline__ void lds_dma16(const void* src, void* lds_dst) {
     const unsigned l = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds_dst;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(src) : "memory", "m0");
+}
+
+// The same with one dword per lane: 64 lanes x 4 bytes -> 256 bytes of LDS at lds_dst (the strip kernel's noise rows).
+__device__ __forceinline__ void lds_dma4(const void* src, void* lds_dst) {
+    const unsigned l = (unsigned)(unsigned long long)(__attribute__((address_space(3))) void*)lds_dst;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" ::"s"(l), "v"(src) : "memory", "m0");
 }
 
 // UP2: the stride-2 transposed convolution of the up-sampling layers as four output phases over the (H+1)x(W+1)
@@ -1207,6 +1217,419 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
                 if (h == 0 && y < P.H && x < P.W)
                     *reinterpret_cast<float4*>(P.rgb_partial + ((((long long)mbg_ * P.N + n) * P.H + y) * P.W + x) * 4) =
                         make_float4(rgb[nb][0], rgb[nb][1], rgb[nb][2], rgb[nb][3]);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused up-sampling convolution, strip form (round 6).  conv3_kernel<.., UP2> with the FIR in its epilogue tiles the extended input
+// grid with OVERLAPPING 32 x 8 tiles: the 4 x 4 FIR of an output needs the transposed-conv result T one pixel before and two after,
+// so a tile yields 30 x 6 new pixels and every staged byte, every MFMA and the 1 080-instruction tile prologue are paid 1.42 times
+// (profiles/experiments/r05_up_conv.md).  Here the vertical overlap is gone: a workgroup owns a 30-column STRIP and walks DOWN it in
+// 8-row blocks; the FIR threads keep the last three row-filtered T rows of their column in registers from one block to the next
+// (the sliding window upfir_kernel uses, across K loops), so block b emits the output rows [16 b - 2, 16 b + 14) and nothing is
+// computed twice vertically (horizontally the strips still overlap by 2 of 32 columns).  A strip is cut into `segs` segments of
+// `seg_blocks` blocks for parallelism; a segment cannot finish the three output rows across its upper boundary (their footprint
+// needs rows of both segments), so each side of a boundary leaves its three row-filtered rows in `seam` and upconv_seam_kernel
+// finishes those rows - 3 of every 16 x seg_blocks, an elementwise pass.  Same arithmetic in the same order as upfir_kernel and the
+// overlapping form: bit-identical outputs (tests/test_dense_gpu.py::test_fused_up_layer_is_bit_identical_to_scratch_form).
+//   workgroup = 4 waves, wave w owns the block's extended rows 2 w, 2 w + 1 (two N-blocks) x one M-block x four phase accumulators;
+//   K loop    = conv3_kernel's (LDS-DMA ring over 16-channel K-groups, same patch swizzle and fragment order), with a 34 x 9 patch
+//               (the transposed conv reads one row above, none below) and the K-group's chunks dealt round-robin to the waves:
+//               19 chunks (bf16 / fp16) = 5,5,5,4 - no per-slot branches, running source pointers;
+//   epilogue  = two passes of 16 channels: accumulators -> LDS slices [2][2][16][64] float4 (64 KB, over the ring), then wave
+//               (slice, lane half), lane = output column: 16 rows x (row filter: 4 LDS reads + 16 FMA, column filter: 16 FMA,
+//               demodulation / noise / bias / activation / consumer image).
+// ------------------------------------------------------------------------------------------------
+#define UPS_XCD_ORDER 1
+#ifndef UPS_ABLATE
+#define UPS_ABLATE 0                                              // timing experiments (wrong results): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads, 8 no K-loop barrier, 16 no FIR rows, 32 no output stores, 64 no vmcnt wait
+#endif
+#ifndef UPS_PRIO
+#define UPS_PRIO 0                                                // bits 0-1: s_setprio of a wave inside its K loop, bits 2-3: outside
+#endif
+#ifndef UPS_DMA_SPREAD
+#define UPS_DMA_SPREAD 0                                          // 0 (A/B): the next stage's LDS-DMA as one burst after the K-group's barrier
+#endif
+#ifndef UPS_A_AHEAD
+#define UPS_A_AHEAD 3                                             // 1 .. 3
+#endif
+#ifndef UPS_PROFILE
+#define UPS_PROFILE 0                                             // 1 (variant builds only): per-phase cycle sums of wave 0 of every workgroup -> P.partial[8]
+#endif
+#define UPS_KSTAMP(i) do { if (UPS_PROFILE == 2 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
+#define UPS_STAMP(i) do { if (UPS_PROFILE == 1 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
+constexpr int UPS_PW = 34, UPS_PH = 9, UPS_HALF_ITEMS = UPS_PW * UPS_PH, UPS_B_CHUNKS = (2 * UPS_HALF_ITEMS + 63) / 64, UPS_B_BYTES = UPS_B_CHUNKS * 1024;
+constexpr int UPS_SLICE_BYTES = 2 * 2 * 16 * 64 * 16;             // Tl[slice 2][lane half 2][T row 16][T column 64] float4
+template <int TERMS> constexpr int ups_stage_bytes() { return (9 + UPS_B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
+template <int TERMS, int STAGES> constexpr int ups_lds_bytes() {
+    return (STAGES * ups_stage_bytes<TERMS>() > UPS_SLICE_BYTES ? STAGES * ups_stage_bytes<TERMS>() : UPS_SLICE_BYTES) + 512 + 16 * 256;   // + epilogue constants + 16 noise rows
+}
+
+template <int TERMS, int STAGES>
+__global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
+    constexpr int PARTS = TERMS == 3 ? 2 : 1;
+    constexpr int A_CHUNKS = 9 * PARTS, CT = A_CHUNKS + PARTS * UPS_B_CHUNKS, SLOTS = (CT + 3) / 4;
+    constexpr int STAGE_BYTES = ups_stage_bytes<TERMS>();
+    constexpr int EC_OFFSET = STAGES * STAGE_BYTES > UPS_SLICE_BYTES ? STAGES * STAGE_BYTES : UPS_SLICE_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    int item = blockIdx.x, mb0 = blockIdx.y;
+    if (UPS_XCD_ORDER) {                                         // the M-blocks of an item back to back on one XCD: its patches are fetched into that L2 once
+        const int MBG = gridDim.y, L = blockIdx.y * gridDim.x + blockIdx.x, k_ = L >> 3;
+        item = (k_ / MBG) * 8 + (L & 7); mb0 = k_ % MBG;
+        if (item >= P.c3_tiles) return;                          // grid.x is padded to a multiple of 8
+    }
+    const int seg = item / P.strips, strip = item % P.strips, n = blockIdx.z;
+    const int by_first = seg * P.seg_blocks, by_end = min(by_first + P.seg_blocks, P.blocks);
+    const int tx0 = strip * 30 - 1;
+    const int G = P.Cin >> 4;
+    const int OH = 2 * P.H, OW = 2 * P.W;
+
+    // ---- per-lane constants of the staging slots: chunk c = wave + 4 k of the K-group's CT chunks; c < A_CHUNKS: weight chunk (tap, part),
+    // else patch chunk: LDS item 2 pp + (hh ^ bit3(pp)) = channel half hh of patch pixel pp (conv3_kernel's layout)
+    // patch slots: ((patch row * W + image column) * 16 + 8 * channel half) * 2 bytes - a multiple of 16 - with the patch row in the low
+    // four bits, or ~0 = padding lane.  A block adds its first row: no 64-bit arithmetic per slot and block.
+    unsigned s_info[SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const int c = wave + 4 * k, cb = c - A_CHUNKS, bc = cb >= 0 ? cb % UPS_B_CHUNKS : 0;
+        const int it = bc * 64 + lane, pp = it >> 1, hh = (it & 1) ^ ((pp >> 3) & 1), py = pp / UPS_PW, px = pp % UPS_PW;
+        const int x = tx0 - 1 + px;
+        s_info[k] = (cb >= 0 && c < CT && pp < UPS_HALF_ITEMS && x >= 0 && x < P.W) ? ((unsigned)((py * P.W + x) * 16 + 8 * hh) * 2u) | (unsigned)py : ~0u;
+    }
+    const unsigned char* xbase[PARTS];                            // view n, K-group 0 of the split image (uniform)
+    xbase[0] = reinterpret_cast<const unsigned char*>(P.xh + (long long)n * G * P.H * P.W * 16);
+    if (PARTS == 2) xbase[PARTS - 1] = reinterpret_cast<const unsigned char*>(P.xl + (long long)n * G * P.H * P.W * 16);
+    const unsigned char* sptr[SLOTS];                             // running source pointers, one K-group per issue()
+    bool sadv[SLOTS];                                             // patch slots: does the lane advance (false: it stays on the zero page)
+    const unsigned plane_bytes = (unsigned)P.H * (unsigned)P.W * 32u;
+    auto issue_slot = [&](int stage, int k) {                     // k: compile-time after unrolling
+        unsigned char* base = lds + stage * STAGE_BYTES;
+        const int c = wave + 4 * k;
+        if (!(UPS_ABLATE & 1) && (4 * k + 3 < CT || c < CT)) lds_dma16(sptr[k], base + c * 1024);      // only the last slot can be past the end (wave-uniform)
+        if (4 * k + 3 < A_CHUNKS) sptr[k] += 18u * 64u * 16u;                    // a weight slot in every wave
+        else if (4 * k < A_CHUNKS) sptr[k] += c < A_CHUNKS ? 18u * 64u * 16u : (sadv[k] ? plane_bytes : 0u);   // weight chunk in the first waves only (wave-uniform)
+        else sptr[k] += sadv[k] ? plane_bytes : 0u;
+    };
+    auto issue = [&](int stage) {
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) issue_slot(stage, k);
+    };
+
+    // fragment offsets inside the patch: rows 2 wave + (0..2), columns j + (0..1)
+    int brd[3][2];
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) {
+            const int pp = (2 * wave + rr) * UPS_PW + j + cc;
+            brd[rr][cc] = (2 * pp + (h ^ ((pp >> 3) & 1))) * 16;
+        }
+
+    float* ec = reinterpret_cast<float*>(lds + EC_OFFSET);       // [0] demodulation, [1] bias, [2] the consuming layer's styles
+    float* nzl = reinterpret_cast<float*>(lds + EC_OFFSET + 512);     // [16 output rows of the block][64 lanes = output columns]: raw noise
+    if (tid < 32) {
+        const int ch = 32 * mb0 + tid;
+        ec[tid] = P.dcoef ? P.dcoef[(long long)n * P.Cout + ch] : 1.0f;
+        ec[32 + tid] = P.bias[ch];
+        ec[64 + tid] = P.split_hi ? P.next_styles[(long long)n * P.Cout + ch] : 0.0f;
+    }
+
+    // ---- the FIR role of this thread: wave -> (slice s, lane half hs), lane -> output column
+    const int fs = wave >> 1, fhs = wave & 1, xs = lane;
+    const int Xl = 2 + min(xs, 59), X = 2 * tx0 + Xl;
+    const bool xok = xs < 60 && X >= 0 && X < OW;
+    const float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    float4 win[2][3];                                             // row-filtered T rows Yt - 3 .. Yt - 1 of this thread's column, per pass
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) win[p][q] = make_float4(0, 0, 0, 0);
+    float4* Tl = reinterpret_cast<float4*>(lds);
+    const long long o_row = (long long)OW * P.Cout, s_row = (long long)OW * 4;
+    const long long seam_row = (long long)OW * P.Cout;
+
+    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = UPS_PROFILE ? __builtin_readcyclecounter() : 0;
+    for (int by = by_first; by < by_end; ++by) {
+        UPS_STAMP(0);                                            // between blocks
+        const int r0 = 8 * by;                                   // first extended row of the block; patch row py <-> image row r0 - 1 + py
+        // staging pointers of this block, K-group 0
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k) {
+            const int c = wave + 4 * k;
+            if (c < A_CHUNKS) {                                   // weight chunk (t, part) <- packed[((mb0 * G + g) * 18 + t * 2 + part)]   (wave-uniform)
+                const int part = c % PARTS, t = (c / PARTS) % 9;
+                sptr[k] = reinterpret_cast<const unsigned char*>(P.packed + (((long long)mb0 * G) * 18 + t * 2 + part) * 64 + lane);
+                sadv[k] = true;
+            } else {
+                const int cb = c - A_CHUNKS, part = cb / UPS_B_CHUNKS;
+                const int y = r0 - 1 + (int)(s_info[k] & 15u);
+                const bool ok = s_info[k] != ~0u && (unsigned)y < (unsigned)P.H;
+                const long long off = (long long)(s_info[k] & ~15u) + (long long)(r0 - 1) * P.W * 32;      // (r0 - 1) may be -1: those lanes are not ok
+                sptr[k] = ok ? xbase[PARTS == 2 ? part : 0] + off : reinterpret_cast<const unsigned char*>(nfe_zero16);
+                sadv[k] = ok;
+            }
+        }
+        // the block's 16 noise rows -> LDS by LDS-DMA (wave w: rows 4 w .. 4 w + 3; lane = output column; clamped addresses: a value that is
+        // out of range belongs to an output that is not stored).  They land before the first K-group's wait.
+        if (P.noise) {
+            const int Xc = min(max(2 * tx0 + 2 + lane, 0), OW - 1);
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * wave + rr, Y = min(max(16 * by + r - 2, 0), OH - 1);
+                lds_dma4(P.noise + n * P.noise_n_stride + (long long)Y * OW + Xc, nzl + r * 64);
+            }
+        }
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.0f;
+
+        // ---- K loop
+        UPS_STAMP(1);                                            // block prologue
+        // STAGES-deep ring: the loads of K-group g + STAGES - 1 are issued while g is computed, so a load has STAGES - 1 K-groups to land.
+        // A lone workgroup on a CU spends 1 900 cycles per K-group with a ring of two (576 of them MFMA): the LDS-DMA round trip, not
+        // the matrix pipe, paces the loop (UPS_PROFILE, round 6) - and the ring fits under the epilogue's 64 KB of slices for free.
+        constexpr int MIN_LOADS = CT / 4;                        // fewest LDS-DMA instructions a wave issues per stage
+        if (UPS_PRIO) __builtin_amdgcn_s_setprio(UPS_PRIO & 3);   // the K loop's wave ahead of (1..3) the co-resident workgroup's epilogue wave on the SIMD
+#pragma unroll
+        for (int pre = 0; pre < STAGES - 1; ++pre)
+            if (pre < G) issue(pre);
+        int stage = 0;
+        for (int g = 0; g < G; ++g) {
+            if (STAGES == 1) { __syncthreads(); issue(0); }
+            UPS_KSTAMP(0);                                       // tail of the previous K-group (loop control)
+            // K-group g has landed once at most the loads of the STAGES - 2 younger K-groups are outstanding (in-order return)
+            if (UPS_ABLATE & 64) {}
+            else if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
+            UPS_KSTAMP(1);                                       // waiting for the stage's loads
+            if (!(UPS_ABLATE & 8)) __syncthreads();
+            UPS_KSTAMP(2);                                       // barrier
+            // The LDS-DMA of K-group g + STAGES - 1 is SPREAD over this K-group's MFMA steps (one instruction after every other step), not
+            // issued as a burst here: right after the barrier all eight waves of the CU push their five instructions into one texture
+            // addresser, an instruction waits ~250 cycles in that queue (178 of the launch's 550 us, UPS_ABLATE 1; nobody waits for the DATA,
+            // UPS_ABLATE 64) and a wave stuck in the queue issues no MFMA.
+            const bool more = STAGES >= 2 && g + STAGES - 1 < G;      // wave-uniform
+            const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
+            if (more && !UPS_DMA_SPREAD) issue(nstage);
+            UPS_KSTAMP(3);                                       // LDS-DMA issue
+            const unsigned char* base = lds + stage * STAGE_BYTES;
+            const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
+            const unsigned char* ldsB = base + A_CHUNKS * 1024;
+            if constexpr (TERMS != 3) {
+                // the nine taps read 2 x 2 input offsets: (2 + 1) x 2 = 6 distinct patch fragments for the wave's two rows, kept in registers
+                Frag8 Bc[3][2];
+#pragma unroll
+                for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+                    for (int dx = 0; dx < 2; ++dx) { if (!(UPS_ABLATE & 4)) Bc[rr][dx].q = *reinterpret_cast<const uint4*>(ldsB + brd[rr][dx]); else Bc[rr][dx].q = make_uint4(rr, dx, g, lane); }
+                // weight fragments UPS_A_AHEAD taps (2 MFMAs = 64 matrix cycles each) ahead of their use, through a ring of four
+                Frag8 ah[4];
+#pragma unroll
+                for (int t = 0; t < UPS_A_AHEAD; ++t) { if (!(UPS_ABLATE & 4)) ah[t].q = ldsA[t * 64]; else ah[t].q = make_uint4(t, g, lane, 1); }
+                UPS_KSTAMP(4);                                   // first fragments read (the stamp waits for them)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int kh = t / 3, kw = t % 3, dy = 1 - (kh >> 1), dx = 1 - (kw >> 1), a = (kh & 1) * 2 + (kw & 1);
+                    if (t + UPS_A_AHEAD < 9) { if (!(UPS_ABLATE & 4)) ah[(t + UPS_A_AHEAD) & 3].q = ldsA[(t + UPS_A_AHEAD) * 64]; else ah[(t + UPS_A_AHEAD) & 3].q = make_uint4(t, g, lane, 2); }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        if (!(UPS_ABLATE & 2)) acc[a][nb] = mfma16<TERMS>(ah[t & 3].v, Bc[nb + dy][dx].v, acc[a][nb], 0, 0, 0);
+                        else acc[a][nb][t] += __uint_as_float(ah[t & 3].u[nb] ^ Bc[nb + dy][dx].u[0]);
+                    }
+                    if (UPS_DMA_SPREAD && more && (t & 1) == 0 && t / 2 < SLOTS) issue_slot(nstage, t / 2);      // SLOTS = 5: after steps 0, 2, 4, 6, 8
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                // split-bf16: fragment reads one (tap, row) step ahead of the three MFMAs that use them
+                auto load_a = [&](int t, Frag8& ah_, Frag8& al_) { ah_.q = ldsA[(t * 2 + 0) * 64]; al_.q = ldsA[(t * 2 + 1) * 64]; };
+                auto load_b = [&](int t, int nb, Frag8& bh_, Frag8& bl_) {
+                    const int kh = t / 3, kw = t % 3, dy = 1 - (kh >> 1), dx = 1 - (kw >> 1);
+                    bh_.q = *reinterpret_cast<const uint4*>(ldsB + brd[nb + dy][dx]);
+                    bl_.q = *reinterpret_cast<const uint4*>(ldsB + UPS_B_BYTES + brd[nb + dy][dx]);
+                };
+                Frag8 ah[2], al[2], bh[2], bl[2];
+                load_a(0, ah[0], al[0]);
+                load_b(0, 0, bh[0], bl[0]);
+#pragma unroll
+                for (int s_ = 0; s_ < 18; ++s_) {
+                    const int t = s_ >> 1, nb = s_ & 1, kh = t / 3, kw = t % 3, a = (kh & 1) * 2 + (kw & 1);
+                    if (s_ + 1 < 18) {
+                        const int t1 = (s_ + 1) >> 1, nb1 = (s_ + 1) & 1;
+                        load_b(t1, nb1, bh[(s_ + 1) & 1], bl[(s_ + 1) & 1]);
+                        if (nb1 == 0) load_a(t1, ah[t1 & 1], al[t1 & 1]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc[a][nb] = mfma16<TERMS>(ah[t & 1].v, bh[s_ & 1].v, acc[a][nb], 0, 0, 0);
+                    acc[a][nb] = mfma16<TERMS>(ah[t & 1].v, bl[s_ & 1].v, acc[a][nb], 0, 0, 0);
+                    acc[a][nb] = mfma16<TERMS>(al[t & 1].v, bh[s_ & 1].v, acc[a][nb], 0, 0, 0);
+                    if (UPS_DMA_SPREAD && more && s_ < SLOTS) issue_slot(nstage, s_);                            // SLOTS = 10 of the 18 steps
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            UPS_KSTAMP(5);                                       // MFMA steps issued
+            stage = stage + 1 == STAGES ? 0 : stage + 1;
+        }
+        if (UPS_PRIO) __builtin_amdgcn_s_setprio((UPS_PRIO >> 2) & 3);
+        UPS_KSTAMP(6);
+        UPS_STAMP(2);                                            // K loop
+        __syncthreads();                                         // every wave is done with the last K-group's fragments: LDS is free
+        UPS_STAMP(3);                                            // barrier after the K loop
+
+        // ---- epilogue: lane (j, h) register r holds out channel 32 mb0 + (r & 3) + 8 (r >> 2) + 4 h of the pixel (row, j)
+        const bool seam_top = by == by_first && seg > 0;         // wave-uniform: the window is not valid for this block's first three rows
+        const bool seam_bottom = by + 1 == by_end && seg + 1 < P.segs;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl) {
+                const int qq = 2 * p + sl;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        Tl[((sl * 2 + h) * 16 + 2 * (2 * wave + nb) + (a >> 1)) * 64 + 2 * j + (a & 1)] =
+                            make_float4(acc[a][nb][4 * qq], acc[a][nb][4 * qq + 1], acc[a][nb][4 * qq + 2], acc[a][nb][4 * qq + 3]);
+            }
+            __syncthreads();
+            UPS_STAMP(4);                                        // slices written + barrier
+            {
+                const int qq = 2 * p + fs;
+                const float4 d = *reinterpret_cast<const float4*>(ec + 8 * qq + 4 * fhs);
+                const float4 b = *reinterpret_cast<const float4*>(ec + 32 + 8 * qq + 4 * fhs);
+                const float4 s2 = *reinterpret_cast<const float4*>(ec + 64 + 8 * qq + 4 * fhs);
+                const float4* col = Tl + ((fs * 2 + fhs) * 16) * 64 + Xl - 1;
+                // the four T pixels under a row's filter are read one row ahead of their use (alone on a CU the row loop took 570 cycles
+                // per row against ~300 of issue: every row waited for its own LDS reads), the block's noise values all at once
+                auto load_row = [&](int yl, float4 (&t)[4]) {
+                    const float4* rp = col + yl * 64;
+                    t[0] = rp[0]; t[1] = rp[1]; t[2] = rp[2]; t[3] = rp[3];
+                };
+                auto filt_row = [&](const float4 (&t)[4]) {
+                    float4 a4 = make_float4(0, 0, 0, 0);
+                    a4.x = fmaf(F[0], t[0].x, a4.x); a4.y = fmaf(F[0], t[0].y, a4.y); a4.z = fmaf(F[0], t[0].z, a4.z); a4.w = fmaf(F[0], t[0].w, a4.w);
+                    a4.x = fmaf(F[1], t[1].x, a4.x); a4.y = fmaf(F[1], t[1].y, a4.y); a4.z = fmaf(F[1], t[1].z, a4.z); a4.w = fmaf(F[1], t[1].w, a4.w);
+                    a4.x = fmaf(F[2], t[2].x, a4.x); a4.y = fmaf(F[2], t[2].y, a4.y); a4.z = fmaf(F[2], t[2].z, a4.z); a4.w = fmaf(F[2], t[2].w, a4.w);
+                    a4.x = fmaf(F[3], t[3].x, a4.x); a4.y = fmaf(F[3], t[3].y, a4.y); a4.z = fmaf(F[3], t[3].z, a4.z); a4.w = fmaf(F[3], t[3].w, a4.w);
+                    return a4;
+                };
+                float4 trow[2][4];
+                load_row(0, trow[0]);
+                float nzr[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) nzr[r] = P.noise ? nzl[r * 64 + xs] : 0.0f;
+                const int ch = 32 * mb0 + 8 * qq + 4 * fhs;
+                const int Y0 = 16 * by - 2;                      // the output row the block's T row 0 completes
+                long long oi = (((long long)n * OH + Y0) * OW + X) * P.Cout + ch - o_row;
+                long long si = split_index(n, P.Cout >> 4, OH, OW, Y0, X, 8 * mb0 + 2 * qq + fhs) - s_row;
+                float* seam = P.seam ? P.seam + ((((long long)n * (P.segs - 1) + (seg - 1)) * 6 + 3) * OW + X) * P.Cout + ch : nullptr;   // this segment's upper boundary, rows 3..5
+                float4 w0 = win[p][0], w1 = win[p][1], w2 = win[p][2];
+#pragma unroll
+                for (int r = 0; r < ((UPS_ABLATE & 16) ? 1 : 16); ++r) {
+                    oi += o_row; si += s_row;
+                    if (r + 1 < 16) load_row(r + 1, trow[(r + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const float4 w3 = filt_row(trow[r & 1]);
+                    if (r < 3 && seam_top && xok) *reinterpret_cast<float4*>(seam + r * seam_row) = w3;
+                    float4 sm = make_float4(0, 0, 0, 0);
+                    sm.x = fmaf(F[0], w0.x, sm.x); sm.y = fmaf(F[0], w0.y, sm.y); sm.z = fmaf(F[0], w0.z, sm.z); sm.w = fmaf(F[0], w0.w, sm.w);
+                    sm.x = fmaf(F[1], w1.x, sm.x); sm.y = fmaf(F[1], w1.y, sm.y); sm.z = fmaf(F[1], w1.z, sm.z); sm.w = fmaf(F[1], w1.w, sm.w);
+                    sm.x = fmaf(F[2], w2.x, sm.x); sm.y = fmaf(F[2], w2.y, sm.y); sm.z = fmaf(F[2], w2.z, sm.z); sm.w = fmaf(F[2], w2.w, sm.w);
+                    sm.x = fmaf(F[3], w3.x, sm.x); sm.y = fmaf(F[3], w3.y, sm.y); sm.z = fmaf(F[3], w3.z, sm.z); sm.w = fmaf(F[3], w3.w, sm.w);
+                    w0 = w1; w1 = w2; w2 = w3;
+                    const int Y = Y0 + r;
+                    if (!(xok && Y >= 0 && Y < OH) || (r < 3 && seam_top)) continue;
+                    const float nz = nzr[r] * P.noise_strength;
+                    float4 o;
+                    o.x = epilogue_act(sm.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+                    o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+                    o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+                    o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+                    if ((UPS_ABLATE & 32) && o.x != 123.456f) continue;
+                    if (P.out) *reinterpret_cast<float4*>(P.out + oi) = o;
+                    if (P.split_hi) {
+                        // (Round 6 also built the coalesced form - the lane's 8 bytes parked in its dead slice row, whole 32-byte pixels stored by
+                        // the workgroup after the pass: 4 x fewer texture-addresser cycles and 5 % SLOWER, one more barrier per pass and the stores
+                        // bunched where nothing else runs: profiles/experiments/r06_up_conv.md.)
+                        unsigned h0, l0, h1, l1;
+                        if (TERMS == 3) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
+                        else { split2<TERMS>(o.x * s2.x, o.y * s2.y, h0, l0); split2<TERMS>(o.z * s2.z, o.w * s2.w, h1, l1); }
+                        P.split_hi[si] = make_uint2(h0, h1);
+                    }
+                }
+                win[p][0] = w0; win[p][1] = w1; win[p][2] = w2;
+                if (seam_bottom && xok) {                         // the next segment's upper boundary, rows 0..2: T rows 16 by_end - 3 .. - 1
+                    float* sb = P.seam + ((((long long)n * (P.segs - 1) + seg) * 6) * OW + X) * P.Cout + ch;
+                    *reinterpret_cast<float4*>(sb) = w0; *reinterpret_cast<float4*>(sb + seam_row) = w1; *reinterpret_cast<float4*>(sb + 2 * seam_row) = w2;
+                }
+            }
+            UPS_STAMP(5);                                        // FIR rows
+            __syncthreads();
+            UPS_STAMP(6);                                        // barrier after the FIR
+        }
+    }
+    if (UPS_PROFILE && tid == 0) {
+        if (UPS_PROFILE == 2) prof[6] = 0;                       // everything outside the K loop landed here
+#pragma unroll
+        for (int i = 0; i < 7; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(P.partial) + i, prof[i]);
+        atomicAdd(reinterpret_cast<unsigned long long*>(P.partial) + 7, 1ull);
+    }
+}
+
+// The three output rows across every segment boundary of upconv_strip_kernel: rows 16 b0 - 2 .. 16 b0 of the boundary in front of
+// block b0, from the six row-filtered T rows 16 b0 - 3 .. 16 b0 + 2 the two segments left in `seam`; column filter and layer epilogue
+// exactly as in the strip kernel (and upfir_kernel).  One thread = (view, boundary, column, channel quad).
+template <int TERMS>
+__global__ __launch_bounds__(256) void upconv_seam_kernel(Conv3K P) {
+    const int OH = 2 * P.H, OW = 2 * P.W, C4 = P.Cout >> 2, seams = P.segs - 1;
+    const long long total = (long long)P.N * seams * OW * C4;
+    const float F[4] = {0.25f, 0.75f, 0.75f, 0.25f};
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4); long long r_ = i / C4;
+        const int X = (int)(r_ % OW); r_ /= OW;
+        const int q = (int)(r_ % seams), n = (int)(r_ / seams);
+        const float* sp = P.seam + ((((long long)n * seams + q) * 6) * OW + X) * P.Cout + 4 * c4;
+        float4 hr[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) hr[k] = *reinterpret_cast<const float4*>(sp + (long long)k * OW * P.Cout);
+        const float4 d = P.dcoef ? *reinterpret_cast<const float4*>(P.dcoef + (long long)n * P.Cout + 4 * c4) : make_float4(1, 1, 1, 1);
+        const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
+        float4 s2 = make_float4(0, 0, 0, 0);
+        if (P.split_hi) s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
+        const int Y0 = 16 * (q + 1) * P.seg_blocks - 2;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int Y = Y0 + r;
+            float4 sm = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int aa = 0; aa < 4; ++aa) {
+                sm.x = fmaf(F[aa], hr[r + aa].x, sm.x); sm.y = fmaf(F[aa], hr[r + aa].y, sm.y);
+                sm.z = fmaf(F[aa], hr[r + aa].z, sm.z); sm.w = fmaf(F[aa], hr[r + aa].w, sm.w);
+            }
+            if (Y < 0 || Y >= OH) continue;
+            const float nz = P.noise ? P.noise[n * P.noise_n_stride + (long long)Y * OW + X] * P.noise_strength : 0.0f;
+            float4 o;
+            o.x = epilogue_act(sm.x * d.x + nz + b.x, P.lrelu, P.act_gain, P.clamp);
+            o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
+            o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
+            o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
+            if (P.out) *reinterpret_cast<float4*>(P.out + (((long long)n * OH + Y) * OW + X) * P.Cout + 4 * c4) = o;
+            if (P.split_hi) {
+                unsigned h0, l0, h1, l1;
+                const long long si = split_index(n, C4 >> 2, OH, OW, Y, X, c4);
+                if (TERMS == 3) { split2<3>(o.x * s2.x, o.y * s2.y, h0, l0); split2<3>(o.z * s2.z, o.w * s2.w, h1, l1); P.split_lo[si] = make_uint2(l0, l1); }
+                else { split2<TERMS>(o.x * s2.x, o.y * s2.y, h0, l0); split2<TERMS>(o.z * s2.z, o.w * s2.w, h1, l1); }
+                P.split_hi[si] = make_uint2(h0, h1);
             }
         }
     }
@@ -2054,16 +2477,98 @@ static void launch_upfir(const ConvK& P, long long total, hipStream_t st) {
 #undef NFE_UPFIR
 }
 
-// Up-sampling layers on the conv3 fast path: FIR + layer epilogue fused into the transposed conv (overlapping 32 x 8 tiles, 1.5x the
-// K-loop work, no fp32 scratch round trip) where that pays: measured per math mode and input width (tools/r03_upfused_ab.sh) -
-// plain bf16 up to 256 input channels; split-bf16, whose K loop is MFMA-bound, only the 32-channel layer at the head's entry.
-// NFE_UP_FUSED=0 switches it off, NFE_UP_FUSED_CIN_BF16 / NFE_UP_FUSED_CIN_X3 move the thresholds (A/B knobs).
+// Up-sampling layers on the conv3 fast path: FIR + layer epilogue fused into the transposed conv (no fp32 scratch round trip) where
+// that pays, measured per math mode and input width (round 3: tools/r03_upfused_ab.sh; round 6: tools/r06_up_trace.sh).
+//   strips (upconv_strip_kernel, round 6: no vertical overlap, 2 of 32 columns horizontally): bf16 / fp16 up to 256 input channels
+//     (-12 / -17 % against the overlapping tiles on the two 256-channel layers, -2 % on the 32-channel one); split-bf16 from 64 to 256
+//     input channels (-8 / -6 % against the unfused form, whose upfir pass it removes; the overlapping tiles LOSE to the unfused form
+//     there: their 1.42 x MFMA work is what the split-bf16 K loop is bound by);
+//   overlapping 32 x 8 tiles (conv3_kernel<.., UP2> with up_fused): split-bf16 with 32 input channels, where the launch is all
+//     epilogue and the strips' longer row loop per thread measured 5 % slower; and everything above with NFE_UP_STRIP=0 (A/B).
+// NFE_UP_FUSED=0 switches fusing off, NFE_UP_FUSED_CIN_BF16 / NFE_UP_FUSED_CIN_X3 move the thresholds (A/B knobs).
+static bool up_strip_on() { static const bool on = [] { const char* e = getenv("NFE_UP_STRIP"); return !e || e[0] != '0'; }(); return on; }
 static bool up_fused(int math, int ksplit, int cin) {
     if (math == NFE_CONV_F16) math = NFE_CONV_BF16;      // fp16 operands: same sizes, variants and thresholds as bf16
     static const bool on = [] { const char* e = getenv("NFE_UP_FUSED"); return !e || e[0] != '0'; }();
-    static const int max_x3 = [] { const char* e = getenv("NFE_UP_FUSED_CIN_X3"); return e ? atoi(e) : 32; }();
+    static const int max_x3 = [] { const char* e = getenv("NFE_UP_FUSED_CIN_X3"); return e ? atoi(e) : (up_strip_on() ? 256 : 32); }();
     static const int max_bf16 = [] { const char* e = getenv("NFE_UP_FUSED_CIN_BF16"); return e ? atoi(e) : 256; }();
     return on && !ksplit && cin <= (math == NFE_CONV_BF16 ? max_bf16 : max_x3);
+}
+static bool up_strips(int math, int cin) {               // a fused layer: strips or overlapping tiles
+    if (math == NFE_CONV_F16) math = NFE_CONV_BF16;
+    return up_strip_on() && (math == NFE_CONV_BF16 || cin > 32);
+}
+
+// ---- strip form of the fused up-sampling layers (upconv_strip_kernel): geometry and launch
+// NFE_UP_STRIP=0 keeps round 5's overlapping-tile kernel (A/B); NFE_UP_STRIP_SEGS=<n> fixes the segment count.
+struct UpStripGeom { int strips, blocks, segs, seg_blocks; };
+static UpStripGeom up_strip_geometry(int n, int h, int w, int cout) {
+    UpStripGeom g;
+    g.strips = (w + 29) / 30;                                  // 60 output columns per strip
+    g.blocks = (2 * h + 17) / 16;                              // block b emits the output rows [16 b - 2, 16 b + 14)
+    static const int forced = [] { const char* e = getenv("NFE_UP_STRIP_SEGS"); return e ? atoi(e) : 0; }();
+    // Segments per strip: enough workgroups to keep two per CU busy to the end, as few boundaries as that allows.  Estimated
+    // utilisation of S segments = blocks of work / (rounds of 2 x CUs workgroups x longest segment), charged 5 output rows' worth of time per
+    // boundary (three rows leave as six fp32 row-filtered rows and come back: measured 22 us of 560 at 6 boundaries of a 512-row image).
+    const long long slots = 2LL * num_cus(), wg0 = (long long)g.strips * (cout / 32) * n;
+    int best = 1; double best_u = -1.0;
+    for (int S = 1; S <= g.blocks && S <= 32; ++S) {
+        const int L = (g.blocks + S - 1) / S, S2 = (g.blocks + L - 1) / L;
+        if (S2 != S) continue;
+        const long long wgs = wg0 * S;
+        const double u = (double)g.blocks * wg0 / ((double)((wgs + slots - 1) / slots) * L * slots) / (1.0 + 5.0 * (S - 1) / (2.0 * h));
+        if (u > best_u + 1e-9) { best_u = u; best = S; }
+    }
+    int S = forced > 0 ? (forced < g.blocks ? forced : g.blocks) : best;
+    g.seg_blocks = (g.blocks + S - 1) / S;
+    g.segs = (g.blocks + g.seg_blocks - 1) / g.seg_blocks;
+    return g;
+}
+template <int TERMS, int STAGES>
+static int launch_up_strip_t(const Conv3K& K0, hipStream_t st) {
+    Conv3K K = K0;
+    const UpStripGeom g = up_strip_geometry(K.N, K.H, K.W, K.Cout);
+    K.strips = g.strips; K.blocks = g.blocks; K.segs = g.segs; K.seg_blocks = g.seg_blocks;
+    K.c3_tiles = g.strips * g.segs;
+    K.seam = g.segs > 1 ? K.scratch : nullptr;                 // the (2H+1) x (2W+1) scratch of the unfused form is free here and far larger
+    constexpr int bytes = ups_lds_bytes<TERMS, STAGES>();
+    static LdsOptIn opt;
+    const hipError_t e = opt.apply(upconv_strip_kernel<TERMS, STAGES>, bytes);
+    if (e != hipSuccess) return fail(NFE_ELAUNCH, "upconv_strip_kernel: LDS opt-in: %s", hipGetErrorString(e));
+    const dim3 grid(UPS_XCD_ORDER ? (unsigned)((K.c3_tiles + 7) / 8 * 8) : (unsigned)K.c3_tiles, (unsigned)(K.Cout / 32), (unsigned)K.N);
+    if (UPS_PROFILE) {                                          // variant builds: phase profile of this launch on stderr
+        static unsigned long long* buf = nullptr;
+        if (!buf) (void)hipMalloc(&buf, 64);
+        (void)hipMemsetAsync(buf, 0, 64, st);
+        K.partial = reinterpret_cast<float*>(buf);
+        hipLaunchKernelGGL((upconv_strip_kernel<TERMS, STAGES>), grid, dim3(256), bytes, st, K);
+        unsigned long long h[8];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, buf, 64, hipMemcpyDeviceToHost);
+        const double wg = (double)(h[7] ? h[7] : 1), nb = (double)g.blocks * g.strips * (K.Cout / 32) * K.N;
+        if (UPS_PROFILE == 2)
+            fprintf(stderr, "UPS_KPROFILE H=%d Cin=%d N=%d segs=%d | cycles per K-group: loop %.0f vmcnt %.0f barrier %.0f dma-issue %.0f first-reads %.0f mfma-steps %.0f\n",
+                    K.H, K.Cin, K.N, g.segs, h[0] / nb / (K.Cin / 16), h[1] / nb / (K.Cin / 16), h[2] / nb / (K.Cin / 16), h[3] / nb / (K.Cin / 16), h[4] / nb / (K.Cin / 16), h[5] / nb / (K.Cin / 16));
+        else
+        fprintf(stderr, "UPS_PROFILE H=%d Cin=%d Cout=%d N=%d segs=%d wgs=%.0f | cycles per block: between %.0f prologue %.0f kloop %.0f bar %.0f put+bar %.0f fir %.0f bar %.0f | total per wg %.0f\n",
+                K.H, K.Cin, K.Cout, K.N, g.segs, wg, h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb, h[6] / nb,
+                (h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6]) / wg);
+    } else
+    hipLaunchKernelGGL((upconv_strip_kernel<TERMS, STAGES>), grid, dim3(256), bytes, st, K);
+    if (g.segs > 1) {
+        const long long total = (long long)K.N * (g.segs - 1) * 2 * K.W * (K.Cout / 4);
+        hipLaunchKernelGGL((upconv_seam_kernel<TERMS>), dim3(grid1d(total, 256, 1 << 14)), dim3(256), 0, st, K);
+    }
+    return NFE_OK;
+}
+#ifndef UPS_STAGES_BF16
+#define UPS_STAGES_BF16 3
+#endif
+#define UPS_STAGES_X3 1
+static int launch_up_strip(const Conv3K& K, bool bf16, hipStream_t st) {
+    if (!bf16) return launch_up_strip_t<3, UPS_STAGES_X3>(K, st);
+    if (K.f16) return launch_up_strip_t<2, UPS_STAGES_BF16>(K, st);
+    return launch_up_strip_t<1, UPS_STAGES_BF16>(K, st);
 }
 
 static_assert(conv3_ec_bytes<2>() == 1024 && conv3_ec_bytes<4>() == 1536, "epilogue constants: three float rows of 32 * MBW channels");
@@ -2216,7 +2721,7 @@ extern "C" int nfe_conv_describe(int mode, int math, int n, int h, int w, int ci
         snprintf(buf, (size_t)buf_len, "conv3[%s] %s ksplit=%d fuse_rgb=%d split_in_epilogue=%d%s", names[conv3_variant(mode, math, n, h, w, cout)], m, ks,
                  rgb_channels > 0 ? nfe_conv_fuses_rgb(mode, math, n, h, w, cin, cout, rgb_channels) : 0,
                  nfe_conv_splits_in_epilogue(mode, n, h, w, cin, cout),
-                 mode != NFE_CONV_3X3_UP2 ? "" : (up_fused(math, ks, cin) ? " fused FIR epilogue (overlapping tiles)" : " +upfir"));
+                 mode != NFE_CONV_3X3_UP2 ? "" : (up_fused(math, ks, cin) ? (up_strips(math, cin) ? " fused FIR epilogue (strips)" : " fused FIR epilogue (overlapping tiles)") : " +upfir"));
         return NFE_OK;
     }
     const int ks = splitk_slices(mode, math, n, h, w, cin, cout);
@@ -2322,6 +2827,10 @@ extern "C" int nfe_modulated_conv(const nfe_conv_args* a, nfe_stream_t stream) {
             // (round 2 measured, without gain: a double-buffered stage (C3_STAGES_X3_UP = 2) and the 32 x 16 tile on 8 waves: DESIGN.md 5)
             if (up_fused(math, c3ks, a->cin)) {                 // FIR and layer epilogue inside the conv kernel, overlapping tiles
                 K.up_fused = 1; K.next_styles = P.next_styles; K.split_hi = P.split_hi; K.split_lo = P.split_lo;
+                if (up_strips(math, a->cin)) {                  // round 6: strips walked top to bottom, no vertical tile overlap
+                    if (int rc = launch_up_strip(K, bf16, st)) return rc;
+                    break;
+                }
                 const unsigned tiles = (unsigned)((a->h + 5) / 6) * (unsigned)((a->w + 29) / 30);      // ROWS = 8: 6 x 30 new extended-input pixels per tile
                 if (bf16) launch_conv3<1, 1, true, C3_STAGES_BF16_UP, 4, 2, 0, C3_UP_FUSED_WAVES>(K, 0, 0, st, tiles);
                 else launch_conv3<3, 1, true, C3_STAGES_X3_UP, 4>(K, 0, 0, st, tiles);

@@ -247,7 +247,8 @@ sys.path.insert(0, sys.argv[1])
 from nerffaceediting_amd import _lib, dense_ops as D
 dev = torch.device("cuda:0")
 out = {}
-for ci, (N, H, W, cin, cout) in enumerate([(2, 40, 72, 32, 64), (1, 64, 64, 32, 96), (2, 33, 63, 16, 32), (1, 128, 128, 32, 64)]):
+for ci, (N, H, W, cin, cout) in enumerate([(2, 40, 72, 32, 64), (1, 64, 64, 32, 96), (2, 33, 63, 16, 32), (1, 128, 128, 32, 64),
+                                           (2, 24, 40, 64, 32), (1, 72, 61, 64, 64)]):      # 64 input channels: split-bf16 takes the strip kernel too
     for math in ("bf16x3", "bf16"):
         g = torch.Generator(device="cpu").manual_seed(21 + ci)
         x = torch.randn(N, H, W, cin, generator=g).to(dev)
@@ -272,10 +273,12 @@ np.savez(sys.argv[2], **out)
 
 
 def test_fused_up_layer_is_bit_identical_to_scratch_form(dev, tmp_path):
-    """the up-sampling layers whose 4x4 FIR runs inside the transposed-conv kernel (overlapping tiles) give the SAME
-    BITS as the (2H+1)^2 fp32 scratch + upfir_kernel form - fp32 output and the consumer's bf16 image, odd sizes, both math modes,
-    noise, bias, clamp.  The switch is read once per process, so each form runs in its own child process (NFE_UP_FUSED=0 / 1 with the
-    per-mode thresholds lifted)."""
+    """the up-sampling layers whose 4x4 FIR runs inside the transposed-conv kernel give the SAME BITS as the (2H+1)^2
+    fp32 scratch + upfir_kernel form - fp32 output and the consumer's bf16 image, odd sizes, both math modes, noise, bias, clamp - in
+    all three fused forms: the strip kernel (round 6: upconv_strip_kernel + upconv_seam_kernel, several segments per strip and several
+    strips per image in these shapes), the overlapping tiles where the selection rule still takes them (split-bf16, <= 32 input
+    channels), and the overlapping tiles everywhere (NFE_UP_STRIP=0).  The switches are read once per process, so each form runs in its
+    own child process (NFE_UP_FUSED=0 / 1 with the per-mode thresholds lifted)."""
     import os
     import subprocess
     import sys
@@ -283,18 +286,24 @@ def test_fused_up_layer_is_bit_identical_to_scratch_form(dev, tmp_path):
     script = tmp_path / "up_fused.py"
     script.write_text(_UP_FUSED_SCRIPT)
     res = {}
-    for tag, env in (("scratch", {"NFE_UP_FUSED": "0"}), ("fused", {"NFE_UP_FUSED": "1", "NFE_UP_FUSED_CIN_X3": "512", "NFE_UP_FUSED_CIN_BF16": "512"})):
+    lifted = {"NFE_UP_FUSED": "1", "NFE_UP_FUSED_CIN_X3": "512", "NFE_UP_FUSED_CIN_BF16": "512"}
+    for tag, env in (("scratch", {"NFE_UP_FUSED": "0"}), ("fused", lifted), ("segs3", dict(lifted, NFE_UP_STRIP_SEGS="3")), ("tiles", dict(lifted, NFE_UP_STRIP="0"))):
         f = tmp_path / f"{tag}.npz"
         subprocess.run([sys.executable, str(script), root, str(f)], check=True, env=dict(os.environ, **env), timeout=600)
         res[tag] = np.load(f)
     keys = sorted(res["scratch"].files)
-    assert keys == sorted(res["fused"].files) and len(keys) >= 20
-    for k in keys:
-        a, b = res["scratch"][k], res["fused"][k]
-        if k.startswith("how_"):
-            assert b"upfir" in a.tobytes() and b"fused FIR" in b.tobytes(), (k, a.tobytes(), b.tobytes())
-        else:
-            assert a.shape == b.shape and np.array_equal(a, b), k
+    strips = 0
+    for tag in ("fused", "segs3", "tiles"):
+        assert keys == sorted(res[tag].files) and len(keys) >= 30
+        for k in keys:
+            a, b = res["scratch"][k], res[tag][k]
+            if k.startswith("how_"):
+                assert b"upfir" in a.tobytes() and b"fused FIR" in b.tobytes(), (k, a.tobytes(), b.tobytes())
+                assert tag != "tiles" or b"overlapping tiles" in b.tobytes()
+                strips += b"(strips)" in b.tobytes()
+            else:
+                assert a.shape == b.shape and np.array_equal(a, b), (tag, k)
+    assert strips >= 2 * 8                      # every bf16 shape and the 64-channel split-bf16 shapes ran the strip kernel, in both strip runs
 
 
 @pytest.mark.parametrize("math", ["bf16x3", "bf16"])

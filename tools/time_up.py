@@ -29,13 +29,14 @@ for name, H, cin, cout in LAYERS:
     kw = dict(dcoef=dc, math=MATH)
     if os.environ.get("PIPE", "1") != "0":
         kw.update(next_styles=(torch.randn(NV, cout, generator=g) * 0.5 + 1).to(dev), want_out=False)
-    for _ in range(3):
+    ITERS = int(os.environ.get("ITERS", "10"))
+    for _ in range(max(3, ITERS // 2)):
         D.modulated_conv(x, st, packed, cout, _lib.NFE_CONV_3X3_UP2, bias, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(10):
+    for _ in range(ITERS):
         D.modulated_conv(x, st, packed, cout, _lib.NFE_CONV_3X3_UP2, bias, **kw)
     e1.record(); torch.cuda.synchronize()
-    out.append(f"{name}: {e0.elapsed_time(e1) / 10 * 1e3:7.1f} us")
+    out.append(f"{name}: {e0.elapsed_time(e1) / ITERS * 1e3:7.1f} us")
 print(f"[{MATH} x{NV}] " + " | ".join(out))
