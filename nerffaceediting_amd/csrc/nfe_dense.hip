@@ -1261,7 +1261,13 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #define UPS_KSTAMP(i) do { if (UPS_PROFILE == 2 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
 #define UPS_STAMP(i) do { if (UPS_PROFILE == 1 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
 constexpr int UPS_PW = 34, UPS_PH = 9, UPS_HALF_ITEMS = UPS_PW * UPS_PH, UPS_B_CHUNKS = (2 * UPS_HALF_ITEMS + 63) / 64, UPS_B_BYTES = UPS_B_CHUNKS * 1024;
-constexpr int UPS_SLICE_BYTES = 2 * 2 * 16 * 64 * 16;             // Tl[slice 2][lane half 2][T row 16][T column 64] float4
+// Slices Tl[slice 2][lane half 2][T row 16][UPS_XS] float4: a row holds its 32 even T columns at [0, 32) and its 32 odd ones at [40, 72).
+// The accumulators of a lane are the columns 2 j + b: with the columns in order a wave's ds_write_b128 strides 32 bytes (2-way bank
+// conflicts on every slice write: SQ_LDS_BANK_CONFLICT 1.5e7 per launch of the largest layer); split by parity the writes are contiguous,
+// and the row filter's reads (columns X - 1 .. X + 2 of consecutive lanes) stay conflict-free because the odd half starts 8 slots (half a
+// 256-byte bank row) past a multiple of 16: within each of ds_read_b128's 16-lane groups the even and the odd lanes take complementary slots.
+constexpr int UPS_XS = 72, UPS_ODD = 40;
+constexpr int UPS_SLICE_BYTES = 2 * 2 * 16 * UPS_XS * 16;
 template <int TERMS> constexpr int ups_stage_bytes() { return (9 + UPS_B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
 template <int TERMS, int STAGES> constexpr int ups_lds_bytes() {
     return (STAGES * ups_stage_bytes<TERMS>() > UPS_SLICE_BYTES ? STAGES * ups_stage_bytes<TERMS>() : UPS_SLICE_BYTES) + 512 + 16 * 256;   // + epilogue constants + 16 noise rows
@@ -1498,7 +1504,7 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        Tl[((sl * 2 + h) * 16 + 2 * (2 * wave + nb) + (a >> 1)) * 64 + 2 * j + (a & 1)] =
+                        Tl[((sl * 2 + h) * 16 + 2 * (2 * wave + nb) + (a >> 1)) * UPS_XS + j + UPS_ODD * (a & 1)] =
                             make_float4(acc[a][nb][4 * qq], acc[a][nb][4 * qq + 1], acc[a][nb][4 * qq + 2], acc[a][nb][4 * qq + 3]);
             }
             __syncthreads();
@@ -1508,12 +1514,14 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                 const float4 d = *reinterpret_cast<const float4*>(ec + 8 * qq + 4 * fhs);
                 const float4 b = *reinterpret_cast<const float4*>(ec + 32 + 8 * qq + 4 * fhs);
                 const float4 s2 = *reinterpret_cast<const float4*>(ec + 64 + 8 * qq + 4 * fhs);
-                const float4* col = Tl + ((fs * 2 + fhs) * 16) * 64 + Xl - 1;
+                // columns Xl - 1 .. Xl + 2: c0, c2 in one parity half, c1, c3 in the other
+                const int c0 = Xl - 1;
+                const float4* col02 = Tl + ((fs * 2 + fhs) * 16) * UPS_XS + (c0 >> 1) + UPS_ODD * (c0 & 1);
+                const float4* col13 = Tl + ((fs * 2 + fhs) * 16) * UPS_XS + ((c0 + 1) >> 1) + UPS_ODD * ((c0 + 1) & 1);
                 // the four T pixels under a row's filter are read one row ahead of their use (alone on a CU the row loop took 570 cycles
                 // per row against ~300 of issue: every row waited for its own LDS reads), the block's noise values all at once
                 auto load_row = [&](int yl, float4 (&t)[4]) {
-                    const float4* rp = col + yl * 64;
-                    t[0] = rp[0]; t[1] = rp[1]; t[2] = rp[2]; t[3] = rp[3];
+                    t[0] = col02[yl * UPS_XS]; t[1] = col13[yl * UPS_XS]; t[2] = col02[yl * UPS_XS + 1]; t[3] = col13[yl * UPS_XS + 1];
                 };
                 auto filt_row = [&](const float4 (&t)[4]) {
                     float4 a4 = make_float4(0, 0, 0, 0);
