@@ -68,7 +68,8 @@ typedef struct nfe_fc_group {
 int nfe_fully_connected_grouped(const nfe_fc_group* groups, int n_groups, int n, nfe_stream_t stream);
 
 /* nfe_conv_demod for several layers in one launch */
-typedef struct nfe_demod_group { const float* styles; const float* wsq; float* dcoef; int32_t cin, cout; } nfe_demod_group;
+typedef struct nfe_demod_group { const float* styles; const float* wsq; float* dcoef; int32_t cin, cout;
+                                 float* styles_norm;   /* ABI v15, optional [N,cin]: see nfe_conv_demod */ } nfe_demod_group;
 int nfe_conv_demod_grouped(const nfe_demod_group* groups, int n_groups, int n, nfe_stream_t stream);
 
 /* normalize_2nd_moment (networks_stylegan2.py:24-26): y = x * rsqrt(mean(x^2, dim=1) + 1e-8) */
@@ -85,11 +86,19 @@ int nfe_broadcast_truncate(const float* w, const float* w_avg, int n, int w_dim,
  * packed must hold nfe_conv_packed_words(cout,cin,k) 4-byte words; wsq is [Cout,Cin]. */
 uint64_t nfe_conv_packed_words(int cout, int cin, int k);
 int nfe_conv_pack(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream);
-/* the same image with fp16 operand words (hi part; the lo part is zero): for math = NFE_CONV_F16 only */
-int nfe_conv_pack_f16(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream);
+/* the same image with fp16 operand words (hi part; the lo part is zero): for math = NFE_CONV_F16 only.
+ * prenormalize != 0 (ABI v15; every DEMODULATED layer: modulated_conv2d's `x.dtype == float16 and demodulate`, networks_stylegan2.py:53-55):
+ * the weights of output channel o are multiplied by 1 / max |w[o]| before they are rounded (the reference's further 1 / sqrt(Cin k k)
+ * protects its fp16 accumulator; this library accumulates in fp32 and leaves it out: it would push small weights into fp16's subnormal
+ * range), wsq is formed from the scaled weights, and `packed` must hold nfe_conv_packed_words() + cout words (the scales are kept behind the image).  Use it together with
+ * the pre-normalised styles of nfe_conv_demod(.., styles_norm): the coefficient cancels both scales.  ToRGB (no demodulation): 0. */
+int nfe_conv_pack_f16(const float* weight, int cout, int cin, int k, int prenormalize, float* packed, float* wsq, nfe_stream_t stream);
 
-/* demodulation coefficients: dcoef[n,o] = rsqrt(sum_i styles[n,i]^2 * wsq[o,i] + 1e-8)  (:64-65) */
-int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int cout, float* dcoef, nfe_stream_t stream);
+/* demodulation coefficients: dcoef[n,o] = rsqrt(sum_i styles[n,i]^2 * wsq[o,i] + 1e-8)  (:64-65).
+ * styles_norm (ABI v15, optional [N,cin]; the fp16 operand mode): the reference's pre-normalisation of the styles (:56): styles_norm[n,:] =
+ * styles[n,:] / max_i |styles[n,i]| is written, and dcoef is formed from it (with the wsq of nfe_conv_pack_f16(prenormalize = 1)); the
+ * convolution is then given styles_norm as its `styles` (and as the producing layer's `next_styles`). */
+int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int cout, float* dcoef, float* styles_norm, nfe_stream_t stream);
 
 typedef struct nfe_conv_args {
     uint32_t struct_size;

@@ -88,7 +88,7 @@ class FcGroup(ctypes.Structure):
 
 class DemodGroup(ctypes.Structure):
     """Mirror of ``nfe_demod_group``."""
-    _fields_ = [("styles", FP), ("wsq", FP), ("dcoef", FP), ("cin", c_int32), ("cout", c_int32)]
+    _fields_ = [("styles", FP), ("wsq", FP), ("dcoef", FP), ("cin", c_int32), ("cout", c_int32), ("styles_norm", FP)]
 
 
 NFE_MAX_GROUPS = 32
@@ -128,8 +128,8 @@ _SIGNATURES = {
     "nfe_broadcast_truncate": (c_int, [FP, FP, c_int, c_int, c_int, c_float, c_int, FP, c_void_p]),
     "nfe_conv_packed_words": (c_uint64, [c_int, c_int, c_int]),
     "nfe_conv_pack": (c_int, [FP, c_int, c_int, c_int, FP, FP, c_void_p]),
-    "nfe_conv_pack_f16": (c_int, [FP, c_int, c_int, c_int, FP, FP, c_void_p]),
-    "nfe_conv_demod": (c_int, [FP, FP, c_int, c_int, c_int, FP, c_void_p]),
+    "nfe_conv_pack_f16": (c_int, [FP, c_int, c_int, c_int, c_int, FP, FP, c_void_p]),
+    "nfe_conv_demod": (c_int, [FP, FP, c_int, c_int, c_int, FP, FP, c_void_p]),
     "nfe_modulated_conv": (c_int, [POINTER(ConvArgs), c_void_p]),
     "nfe_conv_scratch_floats": (c_uint64, [c_int] * 7),
     "nfe_conv_split_floats": (c_uint64, [c_int] * 5),

@@ -21,12 +21,13 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 //   1  bf16 (one MFMA per product)                                    NFE_CONV_BF16
 //   2  fp16 (one MFMA per product, v_mfma_f32_32x32x16_f16)           NFE_CONV_F16: the operand FORMAT of the reference's fp16 layers
 //      (networks_stylegan2.py:421-423: fp16 operands, clamp +-256) - 11 significand bits against bf16's 8 at the same MFMA rate;
-//      accumulation stays fp32 and the activations between layers stay fp32 (only the MFMA operands are rounded).  NOT the reference's
-//      fp16 arithmetic in one respect: its fused modulated conv pre-normalises weights (/ max|w| / sqrt(I k k)) and styles (/ max|s|)
-//      so that no product leaves the fp16 range (networks_stylegan2.py:54-56); here the raw weights and activation x style are rounded
-//      to fp16 directly and SATURATE at +-65504 (f16_pair): an operand beyond the range (a huge style on the unclamped 4^2..16^2
-//      layers, which the reference keeps in fp32) is clipped, it never becomes inf -> NaN
-//      (tests/test_dense_gpu.py::test_fp16_operands_saturate_instead_of_overflowing).
+//      accumulation stays fp32 and the activations between layers stay fp32 (only the MFMA operands are rounded).  Round 6: the
+//      reference's pre-normalisation of a demodulated fp16 layer (networks_stylegan2.py:53-56) - weights / max|w[o]| at pack time
+//      (conv_wmax_kernel + conv_pack_kernel; the reference's further 1 / sqrt(I k k) guards its fp16 accumulation, see conv_wmax_kernel), styles / max|s| per sample in the demodulation pass (demod_wave), both cancelled
+//      in the demodulation coefficient formed from the normalised values (:64-66) - so neither the modulated activation nor any weight
+//      leaves the fp16 range whatever the style's magnitude; the saturating conversion (f16_pair, +-65504) stays as the last resort for
+//      what no normalisation bounds (an unclamped activation itself beyond 65504; ToRGB, which the reference does not normalise either)
+//      (tests/test_dense_gpu.py::test_fp16_huge_styles_are_prenormalised).
 // Everything that is "one part or two" asks TERMS == 3; TERMS 1 and 2 differ only in the conversion and the MFMA opcode.
 template <int TERMS>
 __device__ __forceinline__ f32x16 mfma16(bf16x8 a, bf16x8 b, f32x16 c, int, int, int) {
@@ -185,17 +186,39 @@ __global__ void broadcast_truncate_kernel(const float* __restrict__ w, const flo
     }
 }
 
-__global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq, int n, int cin, int cout,
-                                                    float* __restrict__ dcoef) {
-    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (wid >= (long long)n * cout) return;
+// One wave per (sample, output channel): dcoef = rsqrt(sum_i s_i^2 wsq[o][i] + 1e-8) (networks_stylegan2.py:64-65).  With `snorm` (the fp16
+// operand mode) the styles are pre-normalised as the reference does before an fp16 modulated conv (:53-56: styles / max_i |styles|, so that
+// no modulated activation leaves the fp16 range; the weights' half of it is in conv_pack_kernel): every wave of a sample finds the
+// sample's maximum again (cin <= 512: eight loads per lane), the wave of channel 0 writes the normalised row for the convolution's
+// modulation, and the coefficient is formed from the normalised values - the normalisation cancels in styles x dcoef exactly as in the
+// reference (up to its 1e-8, which now sits beside normalised magnitudes, as there).
+__device__ __forceinline__ void demod_wave(const float* __restrict__ styles, const float* __restrict__ wsq, int cin, int cout, long long wid, int lane,
+                                           float* __restrict__ dcoef, float* __restrict__ snorm) {
     const int row = (int)(wid / cout), o = (int)(wid % cout);
+    const float* sr = styles + (long long)row * cin;
+    float inv = 1.0f;
+    if (snorm) {
+        float m = 0.0f;
+        for (int i = lane; i < cin; i += 64) m = fmaxf(m, fabsf(sr[i]));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+        inv = m > 0.0f ? m : 1.0f;                          // an all-zero style row stays zero (the reference would divide by zero)
+    }
     float acc = 0.0f;
-    for (int i = lane; i < cin; i += 64) { const float s = styles[(long long)row * cin + i]; acc = fmaf(s * s, wsq[(long long)o * cin + i], acc); }
+    for (int i = lane; i < cin; i += 64) {
+        const float s = snorm ? sr[i] / inv : sr[i];
+        if (snorm && o == 0) snorm[(long long)row * cin + i] = s;
+        acc = fmaf(s * s, wsq[(long long)o * cin + i], acc);
+    }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
     if (lane == 0) dcoef[wid] = rsqrtf(acc + 1e-8f);
+}
+__global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ styles, const float* __restrict__ wsq, int n, int cin, int cout,
+                                                    float* __restrict__ dcoef, float* __restrict__ snorm) {
+    const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= (long long)n * cout) return;
+    demod_wave(styles, wsq, cin, cout, wid, threadIdx.x & 63, dcoef, snorm);
 }
 
 // All style affines / demodulation coefficients of a network in ONE launch each (they depend on ws only): a forward pass
@@ -220,21 +243,36 @@ __global__ __launch_bounds__(256) void fc_grouped_kernel(FcGroups G, int n) {
 __global__ __launch_bounds__(256) void demod_grouped_kernel(DemodGroups G, int n) {
     const nfe_demod_group g = G.g[blockIdx.y];
     const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
     if (wid >= (long long)n * g.cout) return;
-    const int row = (int)(wid / g.cout), o = (int)(wid % g.cout);
-    float acc = 0.0f;
-    for (int i = lane; i < g.cin; i += 64) { const float s = g.styles[(long long)row * g.cin + i]; acc = fmaf(s * s, g.wsq[(long long)o * g.cin + i], acc); }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-    if (lane == 0) g.dcoef[wid] = rsqrtf(acc + 1e-8f);
+    demod_wave(g.styles, g.wsq, g.cin, g.cout, wid, threadIdx.x & 63, g.dcoef, g.styles_norm);
 }
 
 // ------------------------------------------------------------------------------------------------
 // weights -> MFMA A-fragment image: [Cout/32][Cin/16][taps][part][lane 64][4 words]; word w of lane l
 // holds elements e = 2w, 2w+1 of the 8-vector: out channel 32*mb + (l&31), in channel 16g + 8(l>>5) + e.
 // ------------------------------------------------------------------------------------------------
-__global__ void conv_pack_kernel(const float* __restrict__ weight, int cout, int cin, int taps, float* __restrict__ packed, float* __restrict__ wsq, int f16) {
+// fp16 pre-normalisation of the weights (networks_stylegan2.py:55): alpha[o] = 1 / max |w[o]|, one wave per output channel.
+// The reference's factor is 1 / (max |w[o]| sqrt(Cin k k)); its sqrt(Cin k k) keeps the SUM of Cin k k products inside fp16, because its
+// convolution accumulates and returns fp16.  Here the accumulators and the activations are fp32 and only the operands must fit, so that
+// half of the factor is left out - deliberately: with it a weight below 0.4 % of its channel's maximum (512 x 9 products: 1/68) lands in
+// fp16's subnormal range, which the MFMA's operand path does not keep, and config 3's per-channel mean error against the fp32 capture
+// grew four-fold (image_raw 1.7e-5 -> 7.6e-5, depth 4.7e-6 -> 2.6e-5; -DNFE_F16_PRENORM_SQRT=1 rebuilds that form).
+__global__ __launch_bounds__(256) void conv_wmax_kernel(const float* __restrict__ weight, int cout, long long per_o, float* __restrict__ alpha) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= cout) return;
+    float m = 0.0f;
+    for (long long i = lane; i < per_o; i += 64) m = fmaxf(m, fabsf(weight[(long long)o * per_o + i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+#ifndef NFE_F16_PRENORM_SQRT
+#define NFE_F16_PRENORM_SQRT 0
+#endif
+    if (lane == 0) alpha[o] = m > 0.0f ? (NFE_F16_PRENORM_SQRT ? 1.0f / sqrtf((float)per_o) / m : 1.0f / m) : 1.0f;
+}
+// alpha (fp16 operand mode of a demodulated layer only, else null): every weight is multiplied by its output channel's alpha before it is
+// rounded to fp16, and wsq is formed from the scaled weights, so that the demodulation coefficient cancels the scale (:53-66).
+__global__ void conv_pack_kernel(const float* __restrict__ weight, int cout, int cin, int taps, float* __restrict__ packed, float* __restrict__ wsq, int f16,
+                                 const float* __restrict__ alpha) {
     const int G = (cin + 15) / 16, MB = (cout + 31) / 32;
     const long long total = (long long)MB * G * taps * 2 * 256;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
@@ -243,10 +281,11 @@ __global__ void conv_pack_kernel(const float* __restrict__ weight, int cout, int
         const int t = (int)(r % taps); r /= taps;
         const int g = (int)(r % G); const int mb = (int)(r / G);
         const int o = 32 * mb + (lane & 31), h = lane >> 5;
+        const float al = (alpha && o < cout) ? alpha[o] : 1.0f;
         unsigned bits[2];
         for (int k = 0; k < 2; ++k) {
             const int ch = 16 * g + 8 * h + 2 * word + k;
-            const float v = (o < cout && ch < cin) ? weight[((long long)o * cin + ch) * taps + t] : 0.0f;
+            const float v = (o < cout && ch < cin) ? weight[((long long)o * cin + ch) * taps + t] * al : 0.0f;
             const unsigned hi = bf16_rne(v);
             bits[k] = f16 ? (part == 0 ? (f16_pair(v, 0.0f) & 0xffffu) : 0u) : (part == 0 ? hi : bf16_rne(v - __uint_as_float(hi << 16)));
         }
@@ -254,9 +293,10 @@ __global__ void conv_pack_kernel(const float* __restrict__ weight, int cout, int
     }
     const long long nw = (long long)cout * cin;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < nw; i += (long long)gridDim.x * blockDim.x) {
-        float s = 0.0f;
-        for (int t = 0; t < taps; ++t) { const float v = weight[i * taps + t]; s = fmaf(v, v, s); }
-        wsq[i] = s;
+        const float al = alpha ? alpha[i / cin] : 1.0f;
+        float s_ = 0.0f;
+        for (int t = 0; t < taps; ++t) { const float v = weight[i * taps + t] * al; s_ = fmaf(v, v, s_); }
+        wsq[i] = s_;
     }
 }
 
@@ -2436,24 +2476,29 @@ extern "C" uint64_t nfe_conv_packed_words(int cout, int cin, int k) {
     if (cout <= 0 || cin <= 0 || cin % 4 != 0 || (k != 1 && k != 3)) return 0;
     return (uint64_t)((cout + 31) / 32) * ((cin + 15) / 16) * (k * k) * 2 * 256;
 }
-static int conv_pack_any(const float* weight, int cout, int cin, int k, float* packed, float* wsq, int f16, nfe_stream_t stream) {
+static int conv_pack_any(const float* weight, int cout, int cin, int k, float* packed, float* wsq, int f16, int prenormalize, nfe_stream_t stream) {
     NFE_REQUIRE(weight && packed && wsq, "nfe_conv_pack: null pointer");
     NFE_REQUIRE(cout > 0 && cin > 0 && cin % 4 == 0 && (k == 1 || k == 3), "nfe_conv_pack: need cin %% 4 == 0 and k in {1,3} (cout=%d cin=%d k=%d)", cout, cin, k);
+    float* alpha = nullptr;
+    if (f16 && prenormalize) {                           // the per-output-channel scales live behind the image (nfe_conv_pack_f16: + cout words)
+        alpha = packed + nfe_conv_packed_words(cout, cin, k);
+        hipLaunchKernelGGL(conv_wmax_kernel, dim3((unsigned)((cout + 3) / 4)), dim3(256), 0, (hipStream_t)stream, weight, cout, (long long)cin * k * k, alpha);
+    }
     hipLaunchKernelGGL(conv_pack_kernel, dim3(grid1d((long long)nfe_conv_packed_words(cout, cin, k), 256, 4096)), dim3(256), 0, (hipStream_t)stream,
-                       weight, cout, cin, k * k, packed, wsq, f16);
+                       weight, cout, cin, k * k, packed, wsq, f16, alpha);
     NFE_CHECK_LAUNCH("conv_pack_kernel");
     return NFE_OK;
 }
 extern "C" int nfe_conv_pack(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream) {
-    return conv_pack_any(weight, cout, cin, k, packed, wsq, 0, stream);
+    return conv_pack_any(weight, cout, cin, k, packed, wsq, 0, 0, stream);
 }
-extern "C" int nfe_conv_pack_f16(const float* weight, int cout, int cin, int k, float* packed, float* wsq, nfe_stream_t stream) {
-    return conv_pack_any(weight, cout, cin, k, packed, wsq, 1, stream);
+extern "C" int nfe_conv_pack_f16(const float* weight, int cout, int cin, int k, int prenormalize, float* packed, float* wsq, nfe_stream_t stream) {
+    return conv_pack_any(weight, cout, cin, k, packed, wsq, 1, prenormalize, stream);
 }
-extern "C" int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int cout, float* dcoef, nfe_stream_t stream) {
+extern "C" int nfe_conv_demod(const float* styles, const float* wsq, int n, int cin, int cout, float* dcoef, float* styles_norm, nfe_stream_t stream) {
     NFE_REQUIRE(styles && wsq && dcoef && n > 0 && cin > 0 && cout > 0, "nfe_conv_demod: bad arguments");
     const long long waves = (long long)n * cout;
-    hipLaunchKernelGGL(demod_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, styles, wsq, n, cin, cout, dcoef);
+    hipLaunchKernelGGL(demod_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, (hipStream_t)stream, styles, wsq, n, cin, cout, dcoef, styles_norm);
     NFE_CHECK_LAUNCH("demod_kernel");
     return NFE_OK;
 }

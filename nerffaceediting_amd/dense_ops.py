@@ -99,19 +99,23 @@ def fully_connected_grouped(groups):
     return outs
 
 
-def conv_demod_grouped(pairs):
-    """nfe_conv_demod_grouped: pairs = [(styles [N,cin], wsq [cout,cin])] -> list of dcoef [N,cout], one launch."""
+def conv_demod_grouped(pairs, prenormalize=False):
+    """nfe_conv_demod_grouped: pairs = [(styles [N,cin], wsq [cout,cin])] -> list of dcoef [N,cout], one launch.
+    prenormalize (fp16 operand mode) -> (list of dcoef, list of pre-normalised styles): see conv_demod."""
     lib = _lib.load()
     arr = (_lib.DemodGroup * len(pairs))()
     N, dev = pairs[0][0].shape[0], pairs[0][0].device
-    outs = []
+    outs, norms = [], []
     for i, (s, wsq) in enumerate(pairs):
         d = torch.empty(N, wsq.shape[0], device=dev)
         g = arr[i]
         g.styles, g.wsq, g.dcoef, g.cin, g.cout = s.data_ptr(), wsq.data_ptr(), d.data_ptr(), s.shape[1], wsq.shape[0]
+        if prenormalize:
+            norms.append(torch.empty_like(s))
+            g.styles_norm = norms[-1].data_ptr()
         outs.append(d)
     _call(dev, lambda: lib.nfe_conv_demod_grouped(arr, len(pairs), N, _stream()), "nfe_conv_demod_grouped")
-    return outs
+    return (outs, norms) if prenormalize else outs
 
 
 def normalize_2nd_moment(x, out=None, out_offset=0):
@@ -142,31 +146,40 @@ def broadcast_truncate(w, w_avg, num_ws, psi=1.0, cutoff=None):
     return ws
 
 
-def conv_pack(weight, math=None):
+def conv_pack(weight, math=None, prenormalize=False):
     """[Cout,Cin,k,k] -> (packed MFMA fragment image, wsq [Cout,Cin]).  math='fp16' packs fp16 operand words (for layers run with
-    math='fp16' only); every other mode shares the bf16 hi + lo image."""
+    math='fp16' only); every other mode shares the bf16 hi + lo image.  prenormalize (fp16, demodulated layers): the reference's
+    weight pre-normalisation (networks_stylegan2.py:55); pair it with conv_demod(.., prenormalize=True)."""
     lib = _lib.load()
     weight = _dev(weight, "weight", (None, None, None, None))
     cout, cin, k, _ = weight.shape
     words = lib.nfe_conv_packed_words(cout, cin, k)
     if words == 0:
         raise RuntimeError(f"conv_pack: unsupported weight shape {list(weight.shape)}")
-    packed = torch.empty(words, device=weight.device)
+    f16 = MATH[math] == _lib.NFE_CONV_F16
+    assert f16 or not prenormalize, "prenormalize belongs to the fp16 operand mode"
+    packed = torch.empty(words + (cout if f16 else 0), device=weight.device)
     wsq = torch.empty(cout, cin, device=weight.device)
-    fn = lib.nfe_conv_pack_f16 if MATH[math] == _lib.NFE_CONV_F16 else lib.nfe_conv_pack
-    _call(weight.device, lambda: fn(_ptr(weight), cout, cin, k, _ptr(packed), _ptr(wsq), _stream()), "nfe_conv_pack")
+    if f16:
+        _call(weight.device, lambda: lib.nfe_conv_pack_f16(_ptr(weight), cout, cin, k, int(bool(prenormalize)), _ptr(packed), _ptr(wsq), _stream()),
+              "nfe_conv_pack_f16")
+    else:
+        _call(weight.device, lambda: lib.nfe_conv_pack(_ptr(weight), cout, cin, k, _ptr(packed), _ptr(wsq), _stream()), "nfe_conv_pack")
     return packed, wsq
 
 
-def conv_demod(styles, wsq):
+def conv_demod(styles, wsq, prenormalize=False):
+    """dcoef [N,Cout].  prenormalize (fp16 operand mode): -> (dcoef, styles / max|styles| per sample), the reference's style
+    pre-normalisation (networks_stylegan2.py:56); wsq must come from conv_pack(.., 'fp16', prenormalize=True)."""
     lib = _lib.load()
     styles = _dev(styles, "styles", (None, None))
     N, cin = styles.shape
     wsq = _dev(wsq, "wsq", (None, cin))
     cout = wsq.shape[0]
     d = torch.empty(N, cout, device=styles.device)
-    _call(styles.device, lambda: lib.nfe_conv_demod(_ptr(styles), _ptr(wsq), N, cin, cout, _ptr(d), _stream()), "nfe_conv_demod")
-    return d
+    sn = torch.empty_like(styles) if prenormalize else None
+    _call(styles.device, lambda: lib.nfe_conv_demod(_ptr(styles), _ptr(wsq), N, cin, cout, _ptr(d), _ptr(sn), _stream()), "nfe_conv_demod")
+    return (d, sn) if prenormalize else d
 
 
 FAST_PATH = True      # tests flip this to compare the LDS-DMA 3x3 path with the generic kernel

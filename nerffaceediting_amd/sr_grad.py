@@ -138,7 +138,11 @@ def sr_forward_saving(sr, feat, ws, noise_mode):
     """The head's forward_nhwc (two blocks, superresolution.py:29-290) layer by layer, keeping what the backward needs.  feat [N,R,R,32] NHWC."""
     assert type(sr).__name__ in HEADS, f"the SR-head gradient is not built for {type(sr).__name__}"
     ws3 = ws[:, -1:, :].repeat(1, 3, 1).to(torch.float32)                                   # superresolution.py:280
-    st, dc = batch_styles(block_layers(sr.block0) + block_layers(sr.block1), ws3, [0, 1, 2, 0, 1, 2])
+    layers = block_layers(sr.block0) + block_layers(sr.block1)
+    st, dc = batch_styles(layers, ws3, [0, 1, 2, 0, 1, 2], sr.conv_math)
+    # fp16 operands: the forward runs on pre-normalised weights, styles and coefficients; the backward-data convolutions use the raw
+    # weights (GRAD_MATH images), so they get the raw styles and coefficients - the products styles x dcoef x weight are the same.
+    st_b, dc_b = (st, dc) if dense_ops.MATH[sr.conv_math] != _lib.NFE_CONV_F16 else batch_styles(layers, ws3, [0, 1, 2, 0, 1, 2])
     x, img = feat, feat[..., :3].contiguous()
     r = sr.input_resolution
     if _resizes(sr, feat.shape[1]):                                                           # superresolution.py:283-286
@@ -147,7 +151,7 @@ def sr_forward_saving(sr, feat, ws, noise_mode):
     saved = [(feat.shape[1], feat.shape[2])]
     for b, blk in enumerate((sr.block0, sr.block1)):
         x, img, sv = block_forward_saving(blk, x, img, st[3 * b:3 * b + 3], (dc[3 * b], dc[3 * b + 1]), noise_mode, sr.conv_math)
-        saved.append(sv)
+        saved.append(sv[:3] + (st_b[3 * b], st_b[3 * b + 1], st_b[3 * b + 2], dc_b[3 * b], dc_b[3 * b + 1]))
     return img, saved
 
 

@@ -24,7 +24,8 @@ def _pack_cached(module, weight, conv_math=None):
     key = (weight.data_ptr(), weight._version, tuple(weight.shape))
     attr = "_packed_f16" if f16 else "_packed"
     if getattr(module, attr + "_key", None) != key:
-        setattr(module, attr, dense_ops.conv_pack(weight.detach(), "fp16" if f16 else None))
+        # fp16: the reference pre-normalises the weights of its DEMODULATED layers (modulated_conv2d, :53-55); ToRGB is not demodulated
+        setattr(module, attr, dense_ops.conv_pack(weight.detach(), "fp16" if f16 else None, prenormalize=f16 and isinstance(module, SynthesisLayer)))
         _publish()
         setattr(module, attr + "_key", key)
     return getattr(module, attr)
@@ -138,6 +139,8 @@ class SynthesisLayer(torch.nn.Module):
         if styles is None:
             styles = self.affine(w)
         packed, wsq = _pack_cached(self, self.weight, conv_math)
+        if dcoef is None and _is_f16(conv_math):            # fp16 operands: pre-normalised styles (networks_stylegan2.py:56) and the coefficient formed from them
+            dcoef, styles = dense_ops.conv_demod(styles, wsq, prenormalize=True)
         if dcoef is None:
             dcoef = dense_ops.conv_demod(styles, wsq)
         noise, strength = None, 0.0
@@ -187,9 +190,15 @@ def block_layers(block):
     return ([block.conv0] if hasattr(block, "conv0") else []) + [block.conv1, block.torgb]
 
 
-def batch_styles(layers, ws, cols):
+def _is_f16(conv_math):
+    return dense_ops.MATH[conv_math] == _lib.NFE_CONV_F16
+
+
+def batch_styles(layers, ws, cols, conv_math=None):
     """Styles (and demodulation coefficients) of many layers in two launches instead of two per layer: layer i reads
-    ws[:, cols[i]] (a strided column block, no copy).  -> ([styles], [dcoef or None])."""
+    ws[:, cols[i]] (a strided column block, no copy).  -> ([styles], [dcoef or None]).  conv_math='fp16': the styles of the
+    demodulated layers come back pre-normalised (each sample's row divided by its largest magnitude) and their coefficients are
+    formed from the pre-normalised weights and styles, as modulated_conv2d does before an fp16 convolution (:53-66)."""
     groups = []
     for L, col in zip(layers, cols):
         lin = L.affine
@@ -198,7 +207,12 @@ def batch_styles(layers, ws, cols):
     styles = dense_ops.fully_connected_grouped(groups)
     dcoefs = [None] * len(layers)
     idx = [i for i, L in enumerate(layers) if isinstance(L, SynthesisLayer)]
-    if idx:
+    if idx and _is_f16(conv_math):
+        ds, sn = dense_ops.conv_demod_grouped([(styles[i], _pack_cached(layers[i], layers[i].weight, conv_math)[1]) for i in idx], prenormalize=True)
+        styles = list(styles)
+        for d, s_, i in zip(ds, sn, idx):
+            dcoefs[i], styles[i] = d, s_
+    elif idx:
         for d, i in zip(dense_ops.conv_demod_grouped([(styles[i], _pack_cached(layers[i], layers[i].weight)[1]) for i in idx]), idx):
             dcoefs[i] = d
     return styles, dcoefs
@@ -257,7 +271,7 @@ class SynthesisBlock(torch.nn.Module):
         the next block's conv0; the block then returns that layer's SplitImage in place of x."""
         assert ws.shape[1:] == (self.num_conv + self.num_torgb, self.w_dim), f"wrong ws shape {list(ws.shape)}"   # :419
         ws = ws.to(torch.float32)
-        st, dc = pre if pre is not None else batch_styles(block_layers(self), ws, range(ws.shape[1]))
+        st, dc = pre if pre is not None else batch_styles(block_layers(self), ws, range(ws.shape[1]), conv_math)
         xs_next = None
         if self.in_channels == 0:
             const = getattr(self, "_const_nhwc", None)
@@ -331,7 +345,7 @@ class SynthesisNetwork(torch.nn.Module):
             layers += bl
             cols += list(range(w_idx, w_idx + len(bl)))
             w_idx += block.num_conv
-        st, dc = batch_styles(layers, ws, cols)
+        st, dc = batch_styles(layers, ws, cols, self.conv_math)
         x = img = None
         w_idx = k = 0
         for i, (res, block) in enumerate(zip(self.block_resolutions, blocks)):

@@ -33,7 +33,7 @@ class SynthesisBlockNoUp(torch.nn.Module):
     def forward_nhwc(self, x, img, ws, noise_mode="random", conv_math=None, pre=None, **_ignored):
         assert ws.shape[1:] == (self.num_conv + self.num_torgb, self.w_dim), f"wrong ws shape {list(ws.shape)}"
         ws = ws.to(torch.float32)
-        st, dc = pre if pre is not None else batch_styles(block_layers(self), ws, range(3))
+        st, dc = pre if pre is not None else batch_styles(block_layers(self), ws, range(3), conv_math)
         x = self.conv0.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[0], dcoef=dc[0])
         x = self.conv1.forward_nhwc(x, None, noise_mode=noise_mode, conv_math=conv_math, styles=st[1], dcoef=dc[1])
         y = self.torgb.forward_nhwc(x, None, conv_math=conv_math, styles=st[2])
@@ -63,7 +63,7 @@ class _TwoBlockSR(torch.nn.Module):
             x = dense_ops.resize_bilinear(x, r, r, self.sr_antialias)
             rgb = dense_ops.resize_bilinear(rgb, r, r, self.sr_antialias)
         ws = ws.to(torch.float32)
-        st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2])   # all six in one launch
+        st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2], self.conv_math)   # all six in one launch
         chain = hasattr(self.block0, "chains_to") and self.block0.chains_to(self.block1, ws.shape[0], self.conv_math)
         x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]),
                                           next_styles=st[3] if chain else None)
@@ -149,7 +149,7 @@ class SuperresolutionHybrid8XDC(torch.nn.Module):
             x = dense_ops.resize_bilinear(x, r, r, self.sr_antialias)                     # :283-286
             rgb = dense_ops.resize_bilinear(rgb, r, r, self.sr_antialias)
         ws = ws.to(torch.float32)
-        st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2])   # all six in one launch
+        st, dc = batch_styles(block_layers(self.block0) + block_layers(self.block1), ws, [0, 1, 2, 0, 1, 2], self.conv_math)   # all six in one launch
         chain = hasattr(self.block0, "chains_to") and self.block0.chains_to(self.block1, ws.shape[0], self.conv_math)
         x, rgb = self.block0.forward_nhwc(x, rgb, ws, noise_mode=noise_mode, conv_math=self.conv_math, pre=(st[:3], dc[:3]),
                                           next_styles=st[3] if chain else None)

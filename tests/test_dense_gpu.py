@@ -329,25 +329,40 @@ def test_torgb_fast_paths_match_generic(shape, math, dev):
     assert float((fast - slow).abs().max()) <= 1e-5 * float(slow.abs().max())
 
 
-def test_fp16_operands_saturate_instead_of_overflowing(dev):
-    """`conv_math='fp16'` rounds raw weights and activation x style to fp16 (the reference pre-normalises both to stay in
-    range, networks_stylegan2.py:54-56).  An operand beyond +-65504 must saturate, not become inf: a layer whose styles push the
-    modulated input to 1e6 still returns finite values, and where nothing saturates the outputs are what they were."""
+def test_fp16_huge_styles_are_prenormalised(dev):
+    """`conv_math='fp16'` gives a demodulated layer the reference's pre-normalisation (modulated_conv2d,
+    networks_stylegan2.py:53-66): weights / max|w[o]| at pack time (the operand-range half of the reference's factor; its 1 / sqrt(I k k)
+    guards an fp16 accumulator this library does not have), styles / max|s| per sample in the demodulation pass, the coefficient formed
+    from the normalised values so that both cancel.  Round 5 rounded `activation x style` straight to fp16 and
+    SATURATED at +-65504: a style of 1e6 gave finite but WRONG values.  Now a layer whose styles are scaled by 1, 1e3 and 1e6 - and a
+    weight tensor scaled by 1e4, which would overflow fp16 on its own - returns the fp32-grade (split-bf16, raw styles) result within the
+    fp16 operand bound, the same bound in every case: nothing saturates.  The pre-normalised pieces are checked against their
+    definitions too."""
     from nerffaceediting_amd import _lib, dense_ops as D
     g = torch.Generator(device="cpu").manual_seed(77)
     N, H, cin, cout = 2, 32, 64, 64
     x = torch.randn(N, H, H, cin, generator=g).to(dev)
-    w = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
+    w0 = torch.randn(cout, cin, 3, 3, generator=g).to(dev)
     bias = torch.zeros(cout, device=dev)
-    packed, wsq = D.conv_pack(w, math="fp16")
-    for scale, finite_only in ((1.0, False), (1e6, True)):
-        st = ((torch.randn(N, cin, generator=g) * 0.5 + 1.0) * scale).to(dev)
-        dc = D.conv_demod(st, wsq)
-        y = D.modulated_conv(x, st, packed, cout, _lib.NFE_CONV_3X3, bias, dcoef=dc, math="fp16")
-        assert bool(torch.isfinite(y).all()), scale
-        if not finite_only:
-            ref = D.modulated_conv(x, st, D.conv_pack(w)[0], cout, _lib.NFE_CONV_3X3, bias, dcoef=dc, math="bf16x3")
-            assert float((y - ref).abs().max()) <= 4e-3 * float(ref.abs().max())
+    for mode in (_lib.NFE_CONV_3X3, _lib.NFE_CONV_3X3_UP2):
+        for wscale, sscale in ((1.0, 1.0), (1.0, 1e3), (1.0, 1e6), (1e4, 1.0), (1e4, 1e6)):
+            w = w0 * wscale
+            packed, wsq = D.conv_pack(w, math="fp16", prenormalize=True)
+            st = ((torch.randn(N, cin, generator=g) * 0.5 + 1.0) * sscale).to(dev)
+            dc, sn = D.conv_demod(st, wsq, prenormalize=True)
+            # definitions (networks_stylegan2.py:55-56, 64-65)
+            alpha = 1.0 / w.abs().amax(dim=(1, 2, 3), keepdim=True)
+            assert float((sn - st / st.abs().amax(dim=1, keepdim=True)).abs().max()) <= 1e-6
+            assert float((wsq - (w * alpha).square().sum(dim=(2, 3))).abs().max()) <= 1e-6 * float(wsq.abs().max())
+            want_dc = ((sn[:, None, :] ** 2 * wsq[None]).sum(-1) + 1e-8).rsqrt()
+            assert float(((dc - want_dc) / want_dc).abs().max()) <= 1e-5
+            assert float(sn.abs().max()) == 1.0
+            y = D.modulated_conv(x, sn, packed, cout, mode, bias, dcoef=dc, math="fp16")
+            rp, rwsq = D.conv_pack(w)
+            ref = D.modulated_conv(x, st, rp, cout, mode, bias, dcoef=D.conv_demod(st, rwsq), math="bf16x3")
+            assert bool(torch.isfinite(y).all()), (wscale, sscale)
+            err = float((y - ref).abs().max()) / float(ref.abs().max())
+            assert err <= 4e-3, (mode, wscale, sscale, err)
 
 
 _TORGB_SCRIPT = r"""
