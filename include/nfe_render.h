@@ -167,9 +167,15 @@ typedef struct nfe_render_args {
                                           of that launch = (p[2]-p[0]) / (p[3]-p[1]) x 100 MHz.  Measurement only; NULL = off */
     float* tap_sample_colors;          /* ABI v11, optional, nfe_render_sample_colors_floats() floats, opaque: what the decoders
                                           returned for every sample of the final march (32 colour features, 15 segmentation
-                                          logits, sigma).  Handed to nfe_render_backward as `sample_colors` it replaces that call's
-                                          re-evaluation pass (gather + both decoder heads for every sample) by one pass over these
-                                          values.  Only with the split-bf16 decoder, no density_noise, no decoder_cross. */
+                                          logits, sigma - with its density noise, if any).  Handed to nfe_render_backward as
+                                          `sample_colors` it replaces that call's re-evaluation pass (gather + both decoder heads for
+                                          every sample) by one pass over these values.  Only with the split-bf16 decoder; since ABI v15
+                                          also with density_noise (the backward of a noisy render NEEDS them: it has no draws of its
+                                          own) and with decoder_cross. */
+    const float* density_noise_values; /* ABI v15, optional [N,M,D+Di]: the standard normals themselves instead of the Philox draws, indexed by
+                                          draw - coarse sample k at k, the fine sample of ascending rank r at D + r (the reference draws
+                                          randn_like per run_model call, renderer.py:285-286: this is the parity hook, like u_coarse /
+                                          u_fine for the jitter).  Used only when density_noise > 0. */
 } nfe_render_args;
 
 /* floats of nfe_render_args.tap_sample_colors / nfe_render_backward_args.sample_colors for these sizes (S = D + Di) */

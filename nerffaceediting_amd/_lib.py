@@ -38,7 +38,7 @@ class RenderArgs(ctypes.Structure):
         ("channels_first", c_int32),
         ("tap_weights_coarse", FP), ("tap_depths_fine", FP), ("tap_depths_all", FP),
         ("workspace", FP), ("workspace_bytes", c_uint64), ("density_noise", c_float), ("decoder_cross", FP),
-        ("clock_probe", FP), ("tap_sample_colors", FP),
+        ("clock_probe", FP), ("tap_sample_colors", FP), ("density_noise_values", FP),
     ]
 
 

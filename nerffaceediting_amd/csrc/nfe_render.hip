@@ -42,6 +42,7 @@ struct RenderK {
     unsigned* depth_minmax;        // ordered-uint {min, max}, and [2] = wave pairs of render_ws_kernel that abandoned a hand-off wait
     float density_noise;           // std of the Gaussian added to sigma (renderer.py:285-286), NOISE variants only
     const int* src_buf;            // DEPTH_BUFFER + NOISE: [N*M, S] which draw each merged sample is (k, or D + fine rank)
+    const float* noise_buf; int noise_stride;      // optional: the normals themselves, [N*M, noise_stride] indexed by draw (nfe_render_args.density_noise_values)
     const float* dec_cross;        // CROSS variants: packed cross fragments (nfe_decoder_pack_cross)
     // EVAL variants (first pass of nfe_render_backward): per sample sigma and a = <2 g_rgb, rgb> + <g_seg, seg> instead of a march
     const float* ev_g_rgb; const float* ev_g_seg; int ev_channels_first; float* ev_sig; float* ev_a;
@@ -1086,7 +1087,8 @@ __global__ __launch_bounds__(256, 2) void render_kernel(RenderK P) {
 
             if (NOISE) {
                 const unsigned draw = (P.depth_mode == DEPTH_BUFFER && P.src_buf) ? (unsigned)P.src_buf[ray * S + k] : (unsigned)k;
-                og[0] = fmaf(P.density_noise, sample_gaussian(seed, (unsigned)ray, draw), og[0]);
+                const float nv = P.noise_buf ? P.noise_buf[(long long)ray * P.noise_stride + draw] : sample_gaussian(seed, (unsigned)ray, draw);
+                og[0] = fmaf(P.density_noise, nv, og[0]);
             }
             if (STORE) {      // keep what the decoders returned (nfe_render_args.tap_sample_colors): lane = ray of the block, 128-byte rows
                 float* cb = P.tap_colors + (((long long)rb * S + k) * 48) * 32 + j;
@@ -2091,7 +2093,9 @@ static void launch_render_math(const RenderK& P, int math, dim3 grid, hipStream_
         if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_FP32>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
     } else {
-        if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+        if (noise && P.tap_colors && !SIGMA_ONLY)          // density_noise with kept colours (round 6): the stored sigma carries its noise, the backward needs no draw
+            hipLaunchKernelGGL((render_kernel<DUAL, false, NFE_MATH_BF16X3, true, false, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
+        else if (noise) hipLaunchKernelGGL((render_kernel<DUAL, SIGMA_ONLY, NFE_MATH_BF16X3, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else if (P.tap_colors && !SIGMA_ONLY)
             hipLaunchKernelGGL((render_kernel<DUAL, false, NFE_MATH_BF16X3, false, false, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES, st, P);
         else if (P.H == P.W)               // shared axis geometry + the in-bounds gather path (round 4: pays with two plane sets too)
@@ -2173,11 +2177,14 @@ static int launch_render(const RenderK& P, bool dual, bool sigma_only, int math,
     dim3 grid((unsigned)blocks);
     if (P.dec_cross) {       // validated by nfe_render: one plane set, split-bf16 decoder, no density_noise; the coarse pass of a
                              // two-pass render runs the full decoder too (sigma needs the appearance head's hidden layer)
-        static LdsOptIn opt;
-        const hipError_t e = opt.apply(render_kernel<false, false, NFE_MATH_BF16X3, false, true>, RENDER_LDS_BYTES_CROSS);
+        static LdsOptIn opt, opt_store;
+        const hipError_t e = P.tap_colors ? opt_store.apply(render_kernel<false, false, NFE_MATH_BF16X3, false, true, false, false, false, true>, RENDER_LDS_BYTES_CROSS)
+                                          : opt.apply(render_kernel<false, false, NFE_MATH_BF16X3, false, true>, RENDER_LDS_BYTES_CROSS);
         if (e != hipSuccess) return fail(NFE_ELAUNCH, "render_kernel<CROSS>: LDS opt-in: %s", hipGetErrorString(e));
-        hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, true>), grid, dim3(256), RENDER_LDS_BYTES_CROSS, st, P);
-        note_kernel("render_kernel<CROSS>");
+        if (P.tap_colors)     // kept colours for the plane-gradient backward of SegmentationOSGDecoder (round 6)
+            hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, true, false, false, false, true>), grid, dim3(256), RENDER_LDS_BYTES_CROSS, st, P);
+        else hipLaunchKernelGGL((render_kernel<false, false, NFE_MATH_BF16X3, false, true>), grid, dim3(256), RENDER_LDS_BYTES_CROSS, st, P);
+        note_kernel(P.tap_colors ? "render_kernel<CROSS,STORE>" : "render_kernel<CROSS>");
         NFE_CHECK_LAUNCH("render_kernel");
         return NFE_OK;
     }
@@ -2408,6 +2415,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     P.rgb = a->rgb; P.seg = a->seg; P.depth = a->depth; P.wsum = a->wsum; P.channels_first = a->channels_first;
     P.seed = a->seed; P.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device);
     P.density_noise = a->density_noise;
+    P.noise_buf = a->density_noise > 0.0f ? a->density_noise_values : nullptr; P.noise_stride = D + Di;
     P.dec_cross = a->decoder_cross;
     P.clock_probe = reinterpret_cast<unsigned long long*>(a->clock_probe);
     P.partials = a->decoder_cross ? nullptr : partials;
@@ -2423,8 +2431,7 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
     NFE_CHECK_LAUNCH("minmax_init_kernel");
 
     if (a->tap_sample_colors)
-        NFE_REQUIRE(math == NFE_MATH_BF16X3 && a->density_noise == 0.0f && !a->decoder_cross,
-                    "nfe_render: tap_sample_colors needs NFE_MATH_BF16X3, density_noise == 0 and no decoder_cross");
+        NFE_REQUIRE(math == NFE_MATH_BF16X3, "nfe_render: tap_sample_colors needs NFE_MATH_BF16X3");
     if (Di == 0) {
         P.S = D; P.depth_mode = mode; P.u = a->u_coarse; P.depth_minmax = minmax;
         P.out_depths = a->tap_depths_all;

@@ -251,9 +251,11 @@ def decoder_forward(features_geo, features_app, decoder_packed, decoder_math=Non
 def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dirs=None, cam2world=None,
            intrinsics=None, resolution=0, affines=None, u_coarse=None, u_fine=None, seed=0,
            channels_first=False, taps=False, ray_limits=None, decoder_math=None, decoder_cross=None, clock_probe=None,
-           sample_colors=False):
+           sample_colors=False, noise_values=None):
     """nfe_render.  planes_* are packed [Np,3,H,W,32] (Np == N or 1); affines = 4x [N,96] or None.
     clock_probe: optional int64 device tensor [4] the final render launch stamps (nfe_render_args.clock_probe).
+    noise_values: optional [N,M,D+Di] standard normals for options['density_noise'] instead of the Philox draws (parity hook:
+    coarse sample k at k, the fine sample of ascending rank r at D + r; nfe_render_args.density_noise_values).
 
     Returns (rgb, seg, depth, wsum[, taps]) with rgb [N,M,32] (or [N,32,M] if channels_first),
     seg [N,M,15], depth [N,M,1], wsum [N,M,1] — the tuple DisentangledImportanceRenderer.forward
@@ -295,6 +297,10 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
         decoder_cross = _dev(decoder_cross, "decoder_cross", (_lib.NFE_DECODER_CROSS_FLOATS,))
         a.decoder_cross = decoder_cross.data_ptr()
         keep.append(decoder_cross)
+    if noise_values is not None:
+        noise_values = _dev(noise_values, "noise_values", (N, M, D + Di))
+        a.density_noise_values = noise_values.data_ptr()
+        keep.append(noise_values)
     if clock_probe is not None:
         assert clock_probe.is_cuda and clock_probe.dtype == torch.int64 and clock_probe.numel() >= 4
         a.clock_probe = clock_probe.data_ptr()
@@ -346,8 +352,7 @@ def render(planes_geo, planes_app, decoder_packed, options, *, origins=None, dir
         if sample_colors:
             # the decoders' outputs for every sample of the final march (192 bytes per sample, opaque): render_backward(...,
             # sample_colors=) then skips its re-evaluation pass.  Split-bf16 decoder without density noise / cross decoder only.
-            assert a.decoder_math == _lib.NFE_MATH_BF16X3 and a.density_noise == 0 and decoder_cross is None, \
-                "sample_colors needs the split-bf16 decoder, no density_noise and no cross decoder"
+            assert a.decoder_math == _lib.NFE_MATH_BF16X3, "sample_colors needs the split-bf16 decoder"
             tap["sample_colors"] = torch.empty(lib.nfe_render_sample_colors_floats(N, M, D + Di), device=dev)
             a.tap_sample_colors = tap["sample_colors"].data_ptr()
             # the buffer's ray order follows the launch's ray-block shape (8x4 pixel tiles when resolution % 8 == 0 and resolution^2 ==
@@ -374,8 +379,9 @@ def render_backward(planes_geo, planes_app, decoder_heads, lr_mul, options, dept
     be None.  Returns (grad_planes_geo, grad_planes_app) in gather layout [Np,3,H,W,32] (None where `need` is False; the
     same tensor twice when planes_app is planes_geo)."""
     lib = _lib.load()
-    if float(options.get("density_noise", 0) or 0) > 0:
-        raise RuntimeError("render_backward: density_noise > 0 is not supported")
+    if float(options.get("density_noise", 0) or 0) > 0 and sample_colors is None:
+        raise RuntimeError("render_backward: with density_noise > 0 the backward needs the forward's kept per-sample outputs (render(..., taps=True, "
+                           "sample_colors=True) -> sample_colors=): it has no noise draws of its own to re-evaluate the samples with")
     planes_geo = _dev(planes_geo, "planes_geo", (None, 3, None, None, 32))
     same = planes_app is planes_geo or planes_app.data_ptr() == planes_geo.data_ptr()
     planes_app = planes_geo if same else _dev(planes_app, "planes_app", tuple(planes_geo.shape))

@@ -127,6 +127,18 @@ class SegmentationOSGDecoder(torch.nn.Module):
         gw[1:], gb[1:], gb[:1] = sw2, sb2, nb2[:1]
         return [sw0, sb0, gw, gb, nw0, nb0, nw2[1:].contiguous(), nb2[1:].contiguous()]
 
+    def backward_heads(self):
+        """The two parameter sets whose two-head backward passes add up to this decoder's plane gradient (renderer.py,
+        _RenderWithPlaneGrad.backward): `net` as both heads (sigma row + rgb rows), and `seg_net` as the geometry head (sigma row
+        zero) beside a null appearance head."""
+        nw0, nb0, nw2, nb2, sw0, sb0, sw2, sb2 = (p.detach() for p in self._params())
+        ga = torch.zeros(16, 64, device=nw2.device); gab = torch.zeros(16, device=nw2.device)
+        ga[:1], gab[:1] = nw2[:1], nb2[:1]
+        gb = torch.zeros(16, 64, device=nw2.device); gbb = torch.zeros(16, device=nw2.device)
+        gb[1:], gbb[1:] = sw2, sb2
+        return ([nw0, nb0, ga, gab, nw0, nb0, nw2[1:].contiguous(), nb2[1:].contiguous()],
+                [sw0, sb0, gb, gbb, nw0, nb0, torch.zeros_like(nw2[1:]).contiguous(), torch.zeros_like(nb2[1:]).contiguous()])
+
     def cross(self):
         x = torch.zeros(16, 64, device=self.net[2].weight.device)
         x[:1] = self.net[2].weight.detach()[:1]

@@ -33,19 +33,29 @@ class _RenderWithPlaneGrad(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, norm_planes, denorm_planes, renderer, decoder, ray_origins, ray_directions, options, jitter, seed, limits):
-        if _cross(decoder) is not None:
-            raise RuntimeError("plane gradients are not built for SegmentationOSGDecoder (disable_alignment)")
+        cross = _cross(decoder)
+        noise = float(options.get("density_noise", 0) or 0)
+        bf16x3 = renderer.decoder_math in (None, "bf16x3")
+        if (cross is not None or noise) and not bf16x3:
+            raise RuntimeError("plane gradients with SegmentationOSGDecoder or density_noise need the split-bf16 decoder (decoder_math=None): "
+                               "their backward runs on the per-sample outputs the forward keeps")
         same = norm_planes is denorm_planes
-        pg, pa = renderer._pack_pair(norm_planes.detach(), norm_planes.detach() if same else denorm_planes.detach())
-        # with the split-bf16 decoder and no density noise the forward keeps the decoders' per-sample outputs (192 B per sample) and
-        # the backward skips its re-evaluation pass (nfe_render_args.tap_sample_colors, ABI v11)
-        colors = renderer.decoder_math in (None, "bf16x3") and not float(options.get("density_noise", 0) or 0) and renderer.keep_sample_colors
+        if cross is not None:       # SegmentationOSGDecoder reads the denorm features only (triplane.py:209-230): one plane set, one gradient
+            pa = renderer._packed(denorm_planes.detach())
+            pg, same = pa, True
+        else:
+            pg, pa = renderer._pack_pair(norm_planes.detach(), norm_planes.detach() if same else denorm_planes.detach())
+        # with the split-bf16 decoder the forward keeps the decoders' per-sample outputs (192 B per sample) and the backward skips its
+        # re-evaluation pass (nfe_render_args.tap_sample_colors, ABI v11).  With density_noise the kept sigma carries its noise, and
+        # the backward - which has no draws of its own - NEEDS them; so does the two-pass backward of the cross decoder (round 6).
+        colors = bf16x3 and (renderer.keep_sample_colors or noise > 0 or cross is not None)
         out = ops.render(pg, pa, decoder.packed(), options, origins=ray_origins, dirs=ray_directions, u_coarse=jitter[0],
-                         u_fine=jitter[1], seed=seed, ray_limits=limits, taps=True, decoder_math=renderer.decoder_math, sample_colors=colors)
+                         u_fine=jitter[1], seed=seed, ray_limits=limits, taps=True, decoder_math=renderer.decoder_math, sample_colors=colors,
+                         decoder_cross=cross, noise_values=options.get("density_noise_values"))
         ctx.save_for_backward(pg, pa, ray_origins, ray_directions, out[4]["depths_all"])
         ctx.sample_colors = out[4].get("sample_colors")
         ctx.sample_colors_resolution = out[4].get("sample_colors_resolution")
-        ctx.decoder, ctx.options, ctx.same = decoder, dict(options), same
+        ctx.decoder, ctx.options, ctx.same, ctx.cross = decoder, dict(options), same, cross is not None
         ctx.shape = tuple(norm_planes.shape)
         if renderer.keep_taps:
             renderer.last_taps = out[4]
@@ -55,11 +65,23 @@ class _RenderWithPlaneGrad(torch.autograd.Function):
     def backward(ctx, g_rgb, g_seg, g_depth, g_wsum):
         pg, pa, o, d, depths_all = ctx.saved_tensors
         need = (ctx.needs_input_grad[0], ctx.needs_input_grad[1])
-        gg, ga = ops.render_backward(pg, pg if ctx.same else pa, ctx.decoder.heads(), ctx.decoder.lr_mul, ctx.options, depths_all,
-                                     (g_rgb, g_seg, g_depth, g_wsum), origins=o, dirs=d,
-                                     need=(need[0] or (ctx.same and need[1]), need[1] and not ctx.same), sample_colors=ctx.sample_colors,
-                                     sample_colors_resolution=ctx.sample_colors_resolution)
         unpack = lambda g: None if g is None else g.permute(0, 1, 4, 2, 3).reshape(ctx.shape)   # gather layout -> [N,3,32,H,W]
+        kw = dict(origins=o, dirs=d, sample_colors=ctx.sample_colors, sample_colors_resolution=ctx.sample_colors_resolution)
+        cots = (g_rgb, g_seg, g_depth, g_wsum)
+        if ctx.cross:
+            # SegmentationOSGDecoder (round 6): the vector-Jacobian product is linear in the per-sample cotangents, which come from the
+            # KEPT outputs of the true decoder; so it is the sum of two passes of the two-head backward over the same plane set - `net`
+            # as both heads (sigma row + rgb rows, as OSGDecoder is run) and `seg_net` as the geometry head with a null appearance head.
+            # norm_planes get no gradient: the reference's decoder never reads the norm features (triplane.py:209-230).
+            if not need[1]:
+                return (None,) * 10
+            total = None
+            for heads in ctx.decoder.backward_heads():
+                gg, _ = ops.render_backward(pa, pa, heads, ctx.decoder.lr_mul, ctx.options, depths_all, cots, need=(True, True), **kw)
+                total = gg if total is None else total + gg
+            return (None, unpack(total)) + (None,) * 8
+        gg, ga = ops.render_backward(pg, pg if ctx.same else pa, ctx.decoder.heads(), ctx.decoder.lr_mul, ctx.options, depths_all,
+                                     cots, need=(need[0] or (ctx.same and need[1]), need[1] and not ctx.same), **kw)
         if ctx.same:        # one tensor fed both inputs: its whole gradient goes to whichever slot autograd asked for first
             g = unpack(gg)
             return (g if need[0] else None, g if (need[1] and not need[0]) else None) + (None,) * 8
@@ -151,9 +173,11 @@ class DisentangledImportanceRenderer(torch.nn.Module):
             return _RenderWithPlaneGrad.apply(norm_planes, denorm_planes, self, decoder, ray_origins.detach(), ray_directions.detach(),
                                               rendering_options, (u_c, u_f), self._seed(), limits)
         pg, pa = self._pack_pair(norm_planes, denorm_planes)
+        if _cross(decoder) is not None:       # SegmentationOSGDecoder: both nets read the denorm features (triplane.py:209-230)
+            pg = pa
         out = ops.render(pg, pa, decoder.packed(), rendering_options, origins=ray_origins, dirs=ray_directions,
                          u_coarse=u_c, u_fine=u_f, seed=self._seed(), ray_limits=limits, taps=self.keep_taps,
-                         decoder_math=self.decoder_math, decoder_cross=_cross(decoder))
+                         decoder_math=self.decoder_math, decoder_cross=_cross(decoder), noise_values=rendering_options.get("density_noise_values"))
         if self.keep_taps:
             self.last_taps = out[4]
         return out[0], out[1], out[2], out[3]

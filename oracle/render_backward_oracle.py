@@ -64,16 +64,25 @@ def _fc(dec, name, lr_mul):
     return w * (lr_mul / np.sqrt(w.shape[1])), dec[name + ".bias"].astype(F64) * lr_mul
 
 
-def render_backward(norm_planes, denorm_planes, dec, origins, dirs, depths_all, options, g_rgb, g_seg, g_depth, g_wsum):
+def render_backward(norm_planes, denorm_planes, dec, origins, dirs, depths_all, options, g_rgb, g_seg, g_depth, g_wsum, sigma_offset=None):
     """norm_planes / denorm_planes [N,3,32,H,W]; origins, dirs [N,M,3]; depths_all [N,M,S] (the sorted depths the
     forward marched); cotangents g_rgb [N,M,32], g_seg [N,M,15], g_depth [N,M,1], g_wsum [N,M,1].
+    sigma_offset [N,M,S] (round 6): what renderer.py:285-286 added to sigma (randn_like * density_noise), per MERGED sample - a constant
+    of the backward, it only moves the point where the march's softplus is differentiated.
+    `dec` with the keys of SegmentationOSGDecoder (net.*, seg_net.*; triplane.py:192-230): sigma and rgb from `net`, seg from `seg_net`,
+    both on the DENORM features - the norm planes get a zero gradient.
     Returns (grad_norm_planes, grad_denorm_planes), both [N,3,32,H,W] float64."""
     N, _, C, H, W = norm_planes.shape
     M, S = depths_all.shape[1], depths_all.shape[2]
     lr = float(options.get("decoder_lr_mul", 1))
     wb = bool(options.get("white_back", False))
-    gw0, gb0 = _fc(dec, "geo_net.0", lr); gw1, gb1 = _fc(dec, "geo_net.2", lr)
-    aw0, ab0 = _fc(dec, "app_net.0", lr); aw1, ab1 = _fc(dec, "app_net.2", lr)
+    segosg = "net.0.weight" in dec
+    if segosg:
+        nw0, nb0 = _fc(dec, "net.0", lr); nw1, nb1 = _fc(dec, "net.2", lr)
+        sw0, sb0 = _fc(dec, "seg_net.0", lr); sw1, sb1 = _fc(dec, "seg_net.2", lr)
+    else:
+        gw0, gb0 = _fc(dec, "geo_net.0", lr); gw1, gb1 = _fc(dec, "geo_net.2", lr)
+        aw0, ab0 = _fc(dec, "app_net.0", lr); aw1, ab1 = _fc(dec, "app_net.2", lr)
     scale = 2.0 / float(options["box_warp"])
     grads = [np.zeros((N, 3, H * W, C), F64), np.zeros((N, 3, H * W, C), F64)]
     for n in range(N):
@@ -90,11 +99,19 @@ def render_backward(norm_planes, denorm_planes, dec, origins, dirs, depths_all, 
                     f += flat[idx[k]] * wgt[k][:, None]
             feats.append(f / 3.0)                                                  # mean over planes, triplane.py:251-252
         fn, fd = feats
-        pre_g = fn @ gw0.T + gb0; out_g = _softplus(pre_g) @ gw1.T + gb1          # sigma = ch 0, seg = ch 1..15
-        pre_a = fd @ aw0.T + ab0; y = _softplus(pre_a) @ aw1.T + ab1
-        sg = _sigmoid(y)
+        if segosg:
+            pre_n = fd @ nw0.T + nb0; out_n = _softplus(pre_n) @ nw1.T + nb1          # sigma = ch 0, rgb = ch 1..32
+            pre_s = fd @ sw0.T + sb0; out_s = _softplus(pre_s) @ sw1.T + sb1          # seg
+            sg = _sigmoid(out_n[:, 1:])
+            sigma = out_n[:, 0].reshape(M, S); seg = out_s.reshape(M, S, 15)
+        else:
+            pre_g = fn @ gw0.T + gb0; out_g = _softplus(pre_g) @ gw1.T + gb1          # sigma = ch 0, seg = ch 1..15
+            pre_a = fd @ aw0.T + ab0; y = _softplus(pre_a) @ aw1.T + ab1
+            sg = _sigmoid(y)
+            sigma = out_g[:, 0].reshape(M, S); seg = out_g[:, 1:].reshape(M, S, 15)
         rgb = (sg * 1.002 - 0.001).reshape(M, S, 32)
-        sigma = out_g[:, 0].reshape(M, S); seg = out_g[:, 1:].reshape(M, S, 15)
+        if sigma_offset is not None:
+            sigma = sigma + sigma_offset[n].astype(F64).reshape(M, S)
         # ---- forward march (ray_marcher.py:68-101) ----------------------------------------------------------------
         delta = t[:, 1:] - t[:, :-1]
         smid = 0.5 * (sigma[:, :-1] + sigma[:, 1:]) - 1.0
@@ -128,10 +145,16 @@ def render_backward(norm_planes, denorm_planes, dec, origins, dirs, depths_all, 
         gsig = np.zeros((M, S)); gsig[:, :-1] += 0.5 * gsm; gsig[:, 1:] += 0.5 * gsm
         omega = np.zeros((M, S)); omega[:, :-1] += 0.5 * w; omega[:, 1:] += 0.5 * w
         # ---- decoder backward ---------------------------------------------------------------------------------------
-        dout_g = np.concatenate([gsig.reshape(-1, 1), (omega[:, :, None] * Gs[:, None, :]).reshape(-1, 15)], 1)
-        dfn = ((dout_g @ gw1) * _softplus_grad(pre_g)) @ gw0
+        dseg = (omega[:, :, None] * Gs[:, None, :]).reshape(-1, 15)
         dy = (omega[:, :, None] * Gr[:, None, :]).reshape(-1, 32) * 1.002 * sg * (1.0 - sg)
-        dfd = ((dy @ aw1) * _softplus_grad(pre_a)) @ aw0
+        if segosg:
+            dout_n = np.concatenate([gsig.reshape(-1, 1), dy], 1)
+            dfd = ((dout_n @ nw1) * _softplus_grad(pre_n)) @ nw0 + ((dseg @ sw1) * _softplus_grad(pre_s)) @ sw0
+            dfn = np.zeros_like(dfd)
+        else:
+            dout_g = np.concatenate([gsig.reshape(-1, 1), dseg], 1)
+            dfn = ((dout_g @ gw1) * _softplus_grad(pre_g)) @ gw0
+            dfd = ((dy @ aw1) * _softplus_grad(pre_a)) @ aw0
         # ---- scatter (grid_sample backward wrt input) ----------------------------------------------------------------
         for gi, df in enumerate((dfn, dfd)):
             for p in range(3):
