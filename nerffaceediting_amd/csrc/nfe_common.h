@@ -62,6 +62,20 @@ struct LdsOptIn {          // one per kernel instantiation (function-local stati
     }
 };
 
+struct LdsOptInMax {       // the same for a kernel whose LDS size depends on the call: the largest size each device has been given
+    std::atomic<int> have[MAX_DEVICES];
+    template <typename K> hipError_t apply(K kernel, int bytes) {
+        const int dev = current_device();
+        if (dev < MAX_DEVICES && have[dev].load(std::memory_order_acquire) >= bytes) return hipSuccess;
+        const hipError_t e = allow_lds(kernel, bytes);
+        if (e == hipSuccess && dev < MAX_DEVICES) {
+            int cur = have[dev].load(std::memory_order_relaxed);
+            while (cur < bytes && !have[dev].compare_exchange_weak(cur, bytes, std::memory_order_release)) {}
+        }
+        return e;
+    }
+};
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

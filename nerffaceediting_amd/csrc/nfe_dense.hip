@@ -1338,14 +1338,14 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
     // ---- per-lane constants of the staging slots: chunk c = wave + 4 k of the K-group's CT chunks; c < A_CHUNKS: weight chunk (tap, part),
     // else patch chunk: LDS item 2 pp + (hh ^ bit3(pp)) = channel half hh of patch pixel pp (conv3_kernel's layout)
     // patch slots: ((patch row * W + image column) * 16 + 8 * channel half) * 2 bytes - a multiple of 16 - with the patch row in the low
-    // four bits, or ~0 = padding lane.  A block adds its first row: no 64-bit arithmetic per slot and block.
+    // four bits, or bit 31 alone = padding lane.  A block adds its first row: no 64-bit arithmetic per slot and block.
     unsigned s_info[SLOTS];
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const int c = wave + 4 * k, cb = c - A_CHUNKS, bc = cb >= 0 ? cb % UPS_B_CHUNKS : 0;
         const int it = bc * 64 + lane, pp = it >> 1, hh = (it & 1) ^ ((pp >> 3) & 1), py = pp / UPS_PW, px = pp % UPS_PW;
         const int x = tx0 - 1 + px;
-        s_info[k] = (cb >= 0 && c < CT && pp < UPS_HALF_ITEMS && x >= 0 && x < P.W) ? ((unsigned)((py * P.W + x) * 16 + 8 * hh) * 2u) | (unsigned)py : ~0u;
+        s_info[k] = (cb >= 0 && c < CT && pp < UPS_HALF_ITEMS && x >= 0 && x < P.W) ? ((unsigned)((py * P.W + x) * 16 + 8 * hh) * 2u) | (unsigned)py : 0x80000000u;
     }
     const unsigned char* xbase[PARTS];                            // view n, K-group 0 of the split image (uniform)
     xbase[0] = reinterpret_cast<const unsigned char*>(P.xh + (long long)n * G * P.H * P.W * 16);
@@ -1413,9 +1413,12 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                 sadv[k] = true;
             } else {
                 const int cb = c - A_CHUNKS, part = cb / UPS_B_CHUNKS;
-                const int y = r0 - 1 + (int)(s_info[k] & 15u);
-                const bool ok = s_info[k] != ~0u && (unsigned)y < (unsigned)P.H;
-                const long long off = (long long)(s_info[k] & ~15u) + (long long)(r0 - 1) * P.W * 32;      // (r0 - 1) may be -1: those lanes are not ok
+                // ONE compare decides the lane (tools/lint_lane_masks.py, S1: no select on a scalar-combined lane mask - written as two
+                // conditions the compiler hoists the padding test out of the block loop as a lane mask and ANDs it with the row test on
+                // the scalar unit): a padding lane's bit 31 becomes a row far below the image by arithmetic.
+                const int y = r0 - 1 + (int)(s_info[k] & 15u) + (((int)s_info[k] >> 31) & 0x40000000);
+                const bool ok = (unsigned)y < (unsigned)P.H;
+                const long long off = (long long)(s_info[k] & 0x7ffffff0u) + (long long)(r0 - 1) * P.W * 32;      // (r0 - 1) may be -1: those lanes are not ok
                 sptr[k] = ok ? xbase[PARTS == 2 ? part : 0] + off : reinterpret_cast<const unsigned char*>(nfe_zero16);
                 sadv[k] = ok;
             }
@@ -1998,10 +2001,12 @@ static void launch_torgb_t(const ConvK& P, hipStream_t st) {
     static const bool coalesced_on = [] { const char* e = getenv("NFE_TORGB_COALESCED"); return !e || e[0] != '0'; }();
     const int cbytes = bytes + TC_WAVES * tc_wave_floats(P.Cin) * 4;
     if (coalesced_on && P.W % 32 == 0 && P.Cout == 32 * MB && P.Cin % 16 == 0 && (P.Cin & 3) == 0 && cbytes <= 160 * 1024 && !(P.skip && ((P.H | P.W) & 1))) {
-        static int callowed = 0;
-        if (cbytes > callowed) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(torgb_coalesced_kernel<TERMS, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, cbytes);
-            callowed = cbytes;
+        static LdsOptInMax copt;                      // per device (a function-static int was per process and unsynchronised)
+        if (copt.apply(torgb_coalesced_kernel<TERMS, MB>, cbytes) != hipSuccess) {      // no opt-in on this device: the per-lane form needs none beyond `bytes`
+            (void)hipGetLastError();
+            const long long blocks = ((long long)P.N * ((P.H * P.W + 31) / 32) + 3) / 4;
+            hipLaunchKernelGGL((torgb_kernel<TERMS, MB>), dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), bytes, st, P);
+            return;
         }
         const long long cblocks = ((long long)P.N * (P.H * P.W / 32) + TC_WAVES - 1) / TC_WAVES;
         const long long cap = (long long)num_cus() * (cbytes <= 80 * 1024 ? 2 : 1);
@@ -2638,10 +2643,8 @@ static void launch_conv3_t(const Conv3K& K, int mode_h, int mode_w, hipStream_t 
     constexpr int ROWS = NBW * WV;
     constexpr int ring = STAGES * conv3_stage_bytes<TERMS, MBW, ROWS>(), fused_t = UP2 ? conv3_fused_t_bytes(ROWS) : 0;
     constexpr int bytes = (ring > fused_t ? ring : fused_t) + conv3_ec_bytes<MBW>();  // ring (or the fused FIR's tile) + the epilogue constants
-    static bool once = [] {
-        return hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW, FU>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-    }();
-    (void)once;
+    static LdsOptIn opt;                              // per device; a failed opt-in shows as the launch's own error (NFE_CHECK_LAUNCH at the call site)
+    if (opt.apply(conv3_kernel<TERMS, MBW, UP2, STAGES, WV, NBW, LW, FU>, bytes) != hipSuccess) (void)hipGetLastError();
     const unsigned tiles = tiles_override ? tiles_override : ((mode_h + ROWS - 1) / ROWS) * ((mode_w + C3_TW - 1) / C3_TW);
     Conv3K K2 = K; K2.c3_tiles = (int)tiles;
     dim3 grid(c3_xcd_order(TERMS) ? (tiles + 7) / 8 * 8 : tiles, K.Cout / (32 * MBW), K.N * (K.ksplit > 1 ? K.ksplit : 1));

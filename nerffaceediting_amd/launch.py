@@ -9,6 +9,7 @@ are children, the parent waits for them, forwards rank 0's standard output and r
 waiting in it).  No torch import here: this must stay safe to call before anything initialises HIP.
 """
 import os
+import re
 import signal
 import socket
 import subprocess
@@ -71,7 +72,7 @@ def _address_in_use(exc):
         if getattr(e, "errno", None) == errno.EADDRINUSE:
             return True
         text = str(e).lower()
-        if "address already in use" in text or "eaddrinuse" in text or "errno: 98" in text or "error code: 98" in text:
+        if "address already in use" in text or "eaddrinuse" in text or re.search(r"\b(errno|error code):\s*98\b", text):     # anchored: not "errno: 980"
             return True
         e = e.__cause__ or e.__context__
     return False
@@ -142,10 +143,25 @@ def _run_ranks(script, argv, nprocs, base, procs, stop_all, deadline, timeout, s
     def pump():
         for line in procs[0].stdout:
             captured.append(line)
+            if len(captured) > 200000:          # a chatty rank must not grow the buffer without bound: keep the newest half
+                del captured[:100000]
     t = threading.Thread(target=pump, daemon=True)
     t.start()
     rc = 0
     live = set(range(nprocs))
+    try:
+        return _watch_ranks(procs, live, rc, stop_all, deadline, timeout, t, captured, stdout)
+    except BaseException:
+        # interrupted (SIGTERM / Ctrl-C become KeyboardInterrupt in spawn_ranks): what rank 0 has printed so far is still the caller's -
+        # partial results must not vanish with the buffer
+        t.join(1)
+        for line in captured:
+            stdout.write(line)
+        stdout.flush()
+        raise
+
+
+def _watch_ranks(procs, live, rc, stop_all, deadline, timeout, t, captured, stdout):
     while live:
         for r in sorted(live):
             code = procs[r].poll()
