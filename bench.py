@@ -46,9 +46,9 @@ HBM_PEAK_GBS = rl.HBM_PEAK_GBS               # MI355X_MICROARCH.md: 8 TB/s spec
 # Per-launch hardware counters of every kernel a roofline block names: rocprofv3 --pmc passes of THESE commands on the shipped build
 # (tools/pmc.sh -> tools/pmc_summary.py -> issue_floor.json, committed under profiles/; PMC cannot be collected inside the timed
 # process).  All roofline arithmetic lives in bench_roofline.py: one formula per number, the same for every workload.
-PMC = {"render": "r05_issue_floor.json", "render_fp32": "r05_issue_floor_fp32.json",
-       "twopass_final": "r05_issue_floor_twopass_final.json", "twopass_sigma": "r05_issue_floor_twopass_sigma.json",
-       "twopass_importance": "r05_issue_floor_twopass_importance.json"}                 # tools/r05_profile.sh
+PMC = {"render": "r06_issue_floor.json", "render_fp32": "r06_issue_floor_fp32.json",
+       "twopass_final": "r06_issue_floor_twopass_final.json", "twopass_sigma": "r06_issue_floor_twopass_sigma.json",
+       "twopass_importance": "r06_issue_floor_twopass_importance.json"}                 # tools/r06_profile.sh
 # split-bf16 decoder: 3 MFMAs per product, and the geometry head's second layer runs a 32-row M block for 16 rows (8 192 padded of the
 # 7 168 algorithmic MACs per sample): matrix work issued per algorithmic flop
 DECODER_MFMA_WORK = 3.0 * 8192.0 / 7168.0
@@ -62,7 +62,7 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
     import json
     import os
     rec = None
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_backward_counters.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r06_backward_counters.json")
     if os.path.exists(path):
         rec = json.load(open(path))
     ach = rec["hbm_bytes_per_launch"] / rec["avg_ns_profiled"] if rec else None            # GB/s
@@ -77,7 +77,7 @@ def backward_roofline(bwd_ms, samples, logical_gbs):
             "kernel_ms": rec["avg_ns_profiled"] * 1e-6 if rec else None, "backward_ms": bwd_ms,
             "hbm_bytes_per_sample_model": 1240, "hbm_model_gbs": samples * 1240 / (bwd_ms * 1e-3) / 1e9,
             "logical_gather_scatter_gbs": logical_gbs,
-            "note": "achieved / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r05_backward_counters.json "
+            "note": "achieved / traffic / kernel_ms: the accumulate pass of one 4-view launch from profiles/r06_backward_counters.json "
                     "(FETCH_SIZE corrected as the guide prescribes + WRITE_SIZE; duration = rocprofv3 kernel trace of the both-sets mode, which "
                     "agrees with the duration under the counters to a few per cent), not re-measured by this run; peak = the 8 TB/s HBM figure (a "
                     "read-only stream reaches 6.3 TB/s on this machine, tools/microbench/read_bw.hip, so the kernel is at 0.87 of what reads "
@@ -365,7 +365,7 @@ def extra_workload(args, torch, dist, dev, rank, world):
 
 # matrix-pipe busy fraction of the conv kernel variants = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) over all launches of a
 # `tools/time_full.py` run under rocprofv3 --pmc, written by tools/dense_pmc_table.py into the committed JSON next to the raw summary
-DENSE_PMC_FILE = "r05_dense_kernels.json"
+DENSE_PMC_FILE = "r06_dense_kernels.json"
 
 
 def dense_kernel_pmc(conv_math):

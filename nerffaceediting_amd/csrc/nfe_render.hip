@@ -1432,6 +1432,8 @@ __global__ __launch_bounds__(NP * 128, WPS) void render_ws_kernel(RenderK P) {
     unsigned step = 0;                       // samples handed over so far by this pair (both roles count alike)
     bool alive = true;
 
+    // (round 6: s_setprio 1..3 on the producer wave of a pair: 14.52 M cycles per launch against 14.48 M, inside the noise; on the consumer
+    // wave: 15.25 M, 5 % slower - profiles/experiments/r06_render_prio.md.  No priorities are set.)
     // per-role register census (round 4, compile-only builds of one role each): consumer 152 VGPRs, producer 169-203
     if (producer) {
         const unsigned long long seed = P.seed_dev ? *P.seed_dev : P.seed;

@@ -88,7 +88,7 @@ def test_algorithmic_block():
     rays = bench.VIEWS_PER_GPU * bench.R * bench.R
     assert abs(a["flops_per_launch"] / rays * 1000 / 1e9 - 0.9175) < 1e-3            # 64 x 14 336 flop per ray = 0.9175 GFLOP per kray (+ bilinear)
     assert a["gather_bytes_per_launch"] == rays * 98500
-    assert abs(a["frac_of_mfma_peak"] / blk["fractions"]["matrix_pipe"] - 1.0) < 0.12   # peak 2.5 PF is quoted at 2.4 GHz; the run held less
+    assert abs(a["frac_of_mfma_peak"] / blk["fractions"]["matrix_pipe"] - 1.0) < 0.16   # peak 2.5 PF is quoted at 2.4 GHz; the runs held 2.05 (round 6's box under the counter passes) to 2.35
     assert abs(a["frac_of_l1_aggregate"] / blk["fractions"]["l1_request"] - 1.0) < 0.05
     assert a["frac_of_hbm_logical"] > 1.0 and blk["fractions"]["hbm"] < 0.02            # logical bytes are not a physical rate
     assert 0.8 < a["frac_of_fp32_matrix_peak"] < 1.2
@@ -120,9 +120,9 @@ def test_census_file_is_consistent():
 
 def test_backward_block_reads_the_committed_counters():
     """--workload editstep: the HBM roofline of the accumulate pass and, beside it, the counter-measured busy fractions of the longest
-    kernel (the wave-specialised decoder-backward kernel), all from profiles/r05_backward_counters.json (tools/r05_backward_profile.sh)."""
+    kernel (the wave-specialised decoder-backward kernel), all from profiles/r06_backward_counters.json (tools/r06_backward_profile.sh)."""
     import bench
-    c = _counters("r05_backward_counters.json")
+    c = _counters("r06_backward_counters.json")
     r = bench.backward_roofline(3.5, c["samples_per_launch"], 1000.0)
     assert r["bound"] == "hbm" and abs(r["achieved"] - c["hbm_bytes_per_launch"] / c["avg_ns_profiled"]) < 1e-9 and 0.5 < r["frac"] < 0.9
     assert r["traffic"] == c["hbm_bytes_per_launch"] and 1.0 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.4

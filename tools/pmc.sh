@@ -1,4 +1,5 @@
 #!/bin/bash
+# (round 6: every pass runs under `timeout` - a pass whose counter set rocprofv3 rejects can abort inside the tool and hang until the box limit)
 # PMC counter passes for the render kernel (run on the GPU box via gpurun; counters only, no traces
 # beyond --kernel-trace).  Usage: tools/pmc.sh <outdir-under-gpurun_out> [bench args...]
 set -u
@@ -9,7 +10,7 @@ export TMPDIR=/tmp
 mkdir -p $OUT
 pass() {
   name=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $PROG $ARGS > $OUT/$name.log 2>&1
+  timeout ${PMC_TIMEOUT:-240} rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 $PROG $ARGS > $OUT/$name.log 2>&1
   echo "pass $name rc=$?"
 }
 pass sq1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES
