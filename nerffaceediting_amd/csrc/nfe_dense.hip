@@ -609,6 +609,7 @@ struct Conv3K {
     // upconv_strip_kernel (round 6): a workgroup walks `seg_blocks` 8-row blocks down a 30-column strip of the extended input grid
     float* seam;        // [N][segs - 1][6][2W][Cout]: the three row-filtered T rows either side of every segment boundary
     int strips, segs, seg_blocks, blocks;
+    int tyl;            // T rows a block adds (16: two image rows per wave, 8: one)
 };
 
 #define C3_XCD_ALL 0
@@ -1300,25 +1301,46 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 #endif
 #define UPS_KSTAMP(i) do { if (UPS_PROFILE == 2 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
 #define UPS_STAMP(i) do { if (UPS_PROFILE == 1 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
-constexpr int UPS_PW = 34, UPS_PH = 9, UPS_HALF_ITEMS = UPS_PW * UPS_PH, UPS_B_CHUNKS = (2 * UPS_HALF_ITEMS + 63) / 64, UPS_B_BYTES = UPS_B_CHUNKS * 1024;
+// NBW = image rows per wave: 2 (32 x 8 blocks, two workgroups per CU) or 1 (32 x 4 blocks: 64 accumulator registers per wave instead of
+// 128, three workgroups per CU - the occupancy experiment of profiles/experiments/r06_up_conv.md, section 5).
+constexpr int UPS_PW = 34;
+template <int NBW> struct UpsGeo {
+    static constexpr int ROWS = 4 * NBW, PH = ROWS + 1, TYL = 2 * ROWS;      // extended rows per block, patch rows, T rows per block
+    static constexpr int HALF_ITEMS = UPS_PW * PH, B_CHUNKS = (2 * HALF_ITEMS + 63) / 64, B_BYTES = B_CHUNKS * 1024;
+};
 // Slices Tl[slice 2][lane half 2][T row 16][UPS_XS] float4: a row holds its 32 even T columns at [0, 32) and its 32 odd ones at [40, 72).
 // The accumulators of a lane are the columns 2 j + b: with the columns in order a wave's ds_write_b128 strides 32 bytes (2-way bank
 // conflicts on every slice write: SQ_LDS_BANK_CONFLICT 1.5e7 per launch of the largest layer); split by parity the writes are contiguous,
 // and the row filter's reads (columns X - 1 .. X + 2 of consecutive lanes) stay conflict-free because the odd half starts 8 slots (half a
 // 256-byte bank row) past a multiple of 16: within each of ds_read_b128's 16-lane groups the even and the odd lanes take complementary slots.
 constexpr int UPS_XS = 72, UPS_ODD = 40;
-constexpr int UPS_SLICE_BYTES = 2 * 2 * 16 * UPS_XS * 16;
-template <int TERMS> constexpr int ups_stage_bytes() { return (9 + UPS_B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
-template <int TERMS, int STAGES> constexpr int ups_lds_bytes() {
-    return (STAGES * ups_stage_bytes<TERMS>() > UPS_SLICE_BYTES ? STAGES * ups_stage_bytes<TERMS>() : UPS_SLICE_BYTES) + 512 + 16 * 256;   // + epilogue constants + 16 noise rows
+template <int NBW> constexpr int ups_slice_bytes() { return 2 * 2 * UpsGeo<NBW>::TYL * UPS_XS * 16; }
+// KG = 16-channel K-groups per ring stage (1 or 2): one barrier, one wait and one round of first fragment reads per KG x 18 MFMAs of a wave.
+// The one-row-per-wave experiment (NBW = 1: three workgroups per CU, 9 MFMAs per wave and K-group) took as long per K-group as two rows
+// do - the K loop pays ~1 400 cycles per K-GROUP that are not MFMA (profiles/experiments/r06_up_conv.md) - so the stage is widened
+// instead: two stages of 38 KiB; the block's noise rows then live in the ring's tail beyond the slices and are fetched after the K loop.
+template <int TERMS, int NBW, int KG> constexpr int ups_stage_bytes() { return KG * (9 + UpsGeo<NBW>::B_CHUNKS) * (TERMS == 3 ? 2 : 1) * 1024; }
+template <int TERMS, int STAGES, int NBW, int KG> constexpr bool ups_noise_late() {
+    return STAGES * ups_stage_bytes<TERMS, NBW, KG>() >= ups_slice_bytes<NBW>() + UpsGeo<NBW>::TYL * 256;
+}
+template <int TERMS, int STAGES, int NBW, int KG> constexpr int ups_lds_bytes() {
+    return (STAGES * ups_stage_bytes<TERMS, NBW, KG>() > ups_slice_bytes<NBW>() ? STAGES * ups_stage_bytes<TERMS, NBW, KG>() : ups_slice_bytes<NBW>()) + 512 +
+           (ups_noise_late<TERMS, STAGES, NBW, KG>() ? 0 : UpsGeo<NBW>::TYL * 256);   // + epilogue constants (+ the block's noise rows)
 }
 
-template <int TERMS, int STAGES>
-__global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
+template <int TERMS, int STAGES, int NBW = 2, int KG = 1>
+__global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Conv3K P) {
     constexpr int PARTS = TERMS == 3 ? 2 : 1;
-    constexpr int A_CHUNKS = 9 * PARTS, CT = A_CHUNKS + PARTS * UPS_B_CHUNKS, SLOTS = (CT + 3) / 4;
-    constexpr int STAGE_BYTES = ups_stage_bytes<TERMS>();
+    constexpr int ROWS = UpsGeo<NBW>::ROWS, TYL = UpsGeo<NBW>::TYL, UPS_HALF_ITEMS = UpsGeo<NBW>::HALF_ITEMS, UPS_B_CHUNKS = UpsGeo<NBW>::B_CHUNKS,
+                  UPS_B_BYTES = UpsGeo<NBW>::B_BYTES, UPS_SLICE_BYTES = ups_slice_bytes<NBW>();
+    // chunks of one K-group, dealt round-robin to the four waves: chunk c = wave + 4 k of K-group `sub` of the stage sits at LDS chunk sub * CT1 + c.
+    // The KG K-groups of a stage share the slots' geometry and pointers: K-group sub is fetched at pointer + sub x (one K-group's stride).
+    constexpr int A_CHUNKS = 9 * PARTS, CT1 = A_CHUNKS + PARTS * UPS_B_CHUNKS, CT = CT1, SLOTS = (CT + 3) / 4;
+    constexpr int STAGE_BYTES = ups_stage_bytes<TERMS, NBW, KG>();
+    constexpr bool NOISE_LATE = ups_noise_late<TERMS, STAGES, NBW, KG>();
+    static_assert(KG == 1 || (KG == 2 && TERMS != 3), "two K-groups per stage: single-part operands only");
     constexpr int EC_OFFSET = STAGES * STAGE_BYTES > UPS_SLICE_BYTES ? STAGES * STAGE_BYTES : UPS_SLICE_BYTES;
+    static_assert(NBW == 1 || NBW == 2, "one or two image rows per wave");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, j = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1355,29 +1377,43 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
     const unsigned plane_bytes = (unsigned)P.H * (unsigned)P.W * 32u;
     auto issue_slot = [&](int stage, int k) {                     // k: compile-time after unrolling
         unsigned char* base = lds + stage * STAGE_BYTES;
-        const int c = wave + 4 * k;
-        if (!(UPS_ABLATE & 1) && (4 * k + 3 < CT || c < CT)) lds_dma16(sptr[k], base + c * 1024);      // only the last slot can be past the end (wave-uniform)
-        if (4 * k + 3 < A_CHUNKS) sptr[k] += 18u * 64u * 16u;                    // a weight slot in every wave
-        else if (4 * k < A_CHUNKS) sptr[k] += c < A_CHUNKS ? 18u * 64u * 16u : (sadv[k] ? plane_bytes : 0u);   // weight chunk in the first waves only (wave-uniform)
-        else sptr[k] += sadv[k] ? plane_bytes : 0u;
+        const int c = wave + 4 * k;                               // weight chunk if c < A_CHUNKS (wave-uniform)
+        constexpr unsigned A_GROUP = 18u * 64u * 16u;             // bytes between the K-groups of the weight image
+        const bool all_w = 4 * k + 3 < A_CHUNKS, all_p = 4 * k >= A_CHUNKS;      // compile time: the slot is a weight / a patch chunk in every wave
+#pragma unroll
+        for (int sub = 0; sub < KG; ++sub) {
+            const unsigned char* src = sptr[k];
+            if (sub) {
+                if (all_w) src += A_GROUP;
+                else if (all_p) src += sadv[k] ? plane_bytes : 0u;
+                else if (c < A_CHUNKS) src += A_GROUP;
+                else src += sadv[k] ? plane_bytes : 0u;
+            }
+            if (!(UPS_ABLATE & 1) && (4 * k + 3 < CT || c < CT)) lds_dma16(src, base + (sub * CT1 + c) * 1024);      // only the last slot can be past the end (wave-uniform)
+        }
+        if (all_w) sptr[k] += KG * A_GROUP;
+        else if (all_p) sptr[k] += sadv[k] ? KG * plane_bytes : 0u;
+        else if (c < A_CHUNKS) sptr[k] += KG * A_GROUP;           // mixed slot: wave-uniform branch
+        else sptr[k] += sadv[k] ? KG * plane_bytes : 0u;
     };
     auto issue = [&](int stage) {
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) issue_slot(stage, k);
     };
 
-    // fragment offsets inside the patch: rows 2 wave + (0..2), columns j + (0..1)
-    int brd[3][2];
+    // fragment offsets inside the patch: rows NBW wave + (0..NBW), columns j + (0..1)
+    int brd[NBW + 1][2];
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr)
+    for (int rr = 0; rr < NBW + 1; ++rr)
 #pragma unroll
         for (int cc = 0; cc < 2; ++cc) {
-            const int pp = (2 * wave + rr) * UPS_PW + j + cc;
+            const int pp = (NBW * wave + rr) * UPS_PW + j + cc;
             brd[rr][cc] = (2 * pp + (h ^ ((pp >> 3) & 1))) * 16;
         }
 
     float* ec = reinterpret_cast<float*>(lds + EC_OFFSET);       // [0] demodulation, [1] bias, [2] the consuming layer's styles
-    float* nzl = reinterpret_cast<float*>(lds + EC_OFFSET + 512);     // [16 output rows of the block][64 lanes = output columns]: raw noise
+    // [TYL output rows of the block][64 lanes = output columns]: raw noise - behind the constants, or (NOISE_LATE) in the ring's tail beyond the slices
+    float* nzl = reinterpret_cast<float*>(NOISE_LATE ? lds + UPS_SLICE_BYTES : lds + EC_OFFSET + 512);
     if (tid < 32) {
         const int ch = 32 * mb0 + tid;
         ec[tid] = P.dcoef ? P.dcoef[(long long)n * P.Cout + ch] : 1.0f;
@@ -1402,7 +1438,7 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
     unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = UPS_PROFILE ? __builtin_readcyclecounter() : 0;
     for (int by = by_first; by < by_end; ++by) {
         UPS_STAMP(0);                                            // between blocks
-        const int r0 = 8 * by;                                   // first extended row of the block; patch row py <-> image row r0 - 1 + py
+        const int r0 = ROWS * by;                                // first extended row of the block; patch row py <-> image row r0 - 1 + py
         // staging pointers of this block, K-group 0
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k) {
@@ -1423,22 +1459,24 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                 sadv[k] = ok;
             }
         }
-        // the block's 16 noise rows -> LDS by LDS-DMA (wave w: rows 4 w .. 4 w + 3; lane = output column; clamped addresses: a value that is
+        // the block's TYL noise rows -> LDS by LDS-DMA (wave w: rows (TYL / 4) w ..; lane = output column; clamped addresses: a value that is
         // out of range belongs to an output that is not stored).  They land before the first K-group's wait.
-        if (P.noise) {
+        auto fetch_noise = [&]() {
+            if (!P.noise) return;
             const int Xc = min(max(2 * tx0 + 2 + lane, 0), OW - 1);
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = 4 * wave + rr, Y = min(max(16 * by + r - 2, 0), OH - 1);
+            for (int rr = 0; rr < TYL / 4; ++rr) {
+                const int r = (TYL / 4) * wave + rr, Y = min(max(TYL * by + r - 2, 0), OH - 1);
                 lds_dma4(P.noise + n * P.noise_n_stride + (long long)Y * OW + Xc, nzl + r * 64);
             }
-        }
+        };
+        if (!NOISE_LATE) fetch_noise();
 
-        f32x16 acc[4][2];
+        f32x16 acc[4][NBW];
 #pragma unroll
         for (int a = 0; a < 4; ++a)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.0f;
 
@@ -1447,18 +1485,19 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
         // STAGES-deep ring: the loads of K-group g + STAGES - 1 are issued while g is computed, so a load has STAGES - 1 K-groups to land.
         // A lone workgroup on a CU spends 1 900 cycles per K-group with a ring of two (576 of them MFMA): the LDS-DMA round trip, not
         // the matrix pipe, paces the loop (UPS_PROFILE, round 6) - and the ring fits under the epilogue's 64 KB of slices for free.
-        constexpr int MIN_LOADS = CT / 4;                        // fewest LDS-DMA instructions a wave issues per stage
+        constexpr int MIN_LOADS = KG * (CT / 4);                 // fewest LDS-DMA instructions a wave issues per stage
+        const int GS = G / KG;                                   // stages of this block's K loop (the launch checks G % KG == 0)
         if (UPS_PRIO) __builtin_amdgcn_s_setprio(UPS_PRIO & 3);   // the K loop's wave ahead of (1..3) the co-resident workgroup's epilogue wave on the SIMD
 #pragma unroll
         for (int pre = 0; pre < STAGES - 1; ++pre)
-            if (pre < G) issue(pre);
+            if (pre < GS) issue(pre);
         int stage = 0;
-        for (int g = 0; g < G; ++g) {
+        for (int g = 0; g < GS; ++g) {
             if (STAGES == 1) { __syncthreads(); issue(0); }
             UPS_KSTAMP(0);                                       // tail of the previous K-group (loop control)
             // K-group g has landed once at most the loads of the STAGES - 2 younger K-groups are outstanding (in-order return)
             if (UPS_ABLATE & 64) {}
-            else if (STAGES <= 2 || g + STAGES - 2 >= G) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (STAGES <= 2 || g + STAGES - 2 >= GS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
             UPS_KSTAMP(1);                                       // waiting for the stage's loads
             if (!(UPS_ABLATE & 8)) __syncthreads();
@@ -1467,18 +1506,20 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
             // issued as a burst here: right after the barrier all eight waves of the CU push their five instructions into one texture
             // addresser, an instruction waits ~250 cycles in that queue (178 of the launch's 550 us, UPS_ABLATE 1; nobody waits for the DATA,
             // UPS_ABLATE 64) and a wave stuck in the queue issues no MFMA.
-            const bool more = STAGES >= 2 && g + STAGES - 1 < G;      // wave-uniform
+            const bool more = STAGES >= 2 && g + STAGES - 1 < GS;     // wave-uniform
             const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
             if (more && !UPS_DMA_SPREAD) issue(nstage);
             UPS_KSTAMP(3);                                       // LDS-DMA issue
-            const unsigned char* base = lds + stage * STAGE_BYTES;
+#pragma unroll
+            for (int sub = 0; sub < KG; ++sub) {
+            const unsigned char* base = lds + stage * STAGE_BYTES + sub * (CT1 * 1024);
             const uint4* ldsA = reinterpret_cast<const uint4*>(base) + lane;
             const unsigned char* ldsB = base + A_CHUNKS * 1024;
             if constexpr (TERMS != 3) {
                 // the nine taps read 2 x 2 input offsets: (2 + 1) x 2 = 6 distinct patch fragments for the wave's two rows, kept in registers
-                Frag8 Bc[3][2];
+                Frag8 Bc[NBW + 1][2];
 #pragma unroll
-                for (int rr = 0; rr < 3; ++rr)
+                for (int rr = 0; rr < NBW + 1; ++rr)
 #pragma unroll
                     for (int dx = 0; dx < 2; ++dx) { if (!(UPS_ABLATE & 4)) Bc[rr][dx].q = *reinterpret_cast<const uint4*>(ldsB + brd[rr][dx]); else Bc[rr][dx].q = make_uint4(rr, dx, g, lane); }
                 // weight fragments UPS_A_AHEAD taps (2 MFMAs = 64 matrix cycles each) ahead of their use, through a ring of four
@@ -1492,7 +1533,7 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                     if (t + UPS_A_AHEAD < 9) { if (!(UPS_ABLATE & 4)) ah[(t + UPS_A_AHEAD) & 3].q = ldsA[(t + UPS_A_AHEAD) * 64]; else ah[(t + UPS_A_AHEAD) & 3].q = make_uint4(t, g, lane, 2); }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
+                    for (int nb = 0; nb < NBW; ++nb) {
                         if (!(UPS_ABLATE & 2)) acc[a][nb] = mfma16<TERMS>(ah[t & 3].v, Bc[nb + dy][dx].v, acc[a][nb], 0, 0, 0);
                         else acc[a][nb][t] += __uint_as_float(ah[t & 3].u[nb] ^ Bc[nb + dy][dx].u[0]);
                     }
@@ -1511,10 +1552,10 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                 load_a(0, ah[0], al[0]);
                 load_b(0, 0, bh[0], bl[0]);
 #pragma unroll
-                for (int s_ = 0; s_ < 18; ++s_) {
-                    const int t = s_ >> 1, nb = s_ & 1, kh = t / 3, kw = t % 3, a = (kh & 1) * 2 + (kw & 1);
-                    if (s_ + 1 < 18) {
-                        const int t1 = (s_ + 1) >> 1, nb1 = (s_ + 1) & 1;
+                for (int s_ = 0; s_ < 9 * NBW; ++s_) {
+                    const int t = s_ / NBW, nb = s_ % NBW, kh = t / 3, kw = t % 3, a = (kh & 1) * 2 + (kw & 1);
+                    if (s_ + 1 < 9 * NBW) {
+                        const int t1 = (s_ + 1) / NBW, nb1 = (s_ + 1) % NBW;
                         load_b(t1, nb1, bh[(s_ + 1) & 1], bl[(s_ + 1) & 1]);
                         if (nb1 == 0) load_a(t1, ah[t1 & 1], al[t1 & 1]);
                     }
@@ -1526,6 +1567,7 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            }
             UPS_KSTAMP(5);                                       // MFMA steps issued
             stage = stage + 1 == STAGES ? 0 : stage + 1;
         }
@@ -1533,6 +1575,7 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
         UPS_KSTAMP(6);
         UPS_STAMP(2);                                            // K loop
         __syncthreads();                                         // every wave is done with the last K-group's fragments: LDS is free
+        if (NOISE_LATE) fetch_noise();                           // into the ring's tail; they land under the first pass's slice writes
         UPS_STAMP(3);                                            // barrier after the K loop
 
         // ---- epilogue: lane (j, h) register r holds out channel 32 mb0 + (r & 3) + 8 (r >> 2) + 4 h of the pixel (row, j)
@@ -1544,12 +1587,13 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
             for (int sl = 0; sl < 2; ++sl) {
                 const int qq = 2 * p + sl;
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NBW; ++nb)
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
-                        Tl[((sl * 2 + h) * 16 + 2 * (2 * wave + nb) + (a >> 1)) * UPS_XS + j + UPS_ODD * (a & 1)] =
+                        Tl[((sl * 2 + h) * TYL + 2 * (NBW * wave + nb) + (a >> 1)) * UPS_XS + j + UPS_ODD * (a & 1)] =
                             make_float4(acc[a][nb][4 * qq], acc[a][nb][4 * qq + 1], acc[a][nb][4 * qq + 2], acc[a][nb][4 * qq + 3]);
             }
+            if (NOISE_LATE && p == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             UPS_STAMP(4);                                        // slices written + barrier
             {
@@ -1559,8 +1603,8 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                 const float4 s2 = *reinterpret_cast<const float4*>(ec + 64 + 8 * qq + 4 * fhs);
                 // columns Xl - 1 .. Xl + 2: c0, c2 in one parity half, c1, c3 in the other
                 const int c0 = Xl - 1;
-                const float4* col02 = Tl + ((fs * 2 + fhs) * 16) * UPS_XS + (c0 >> 1) + UPS_ODD * (c0 & 1);
-                const float4* col13 = Tl + ((fs * 2 + fhs) * 16) * UPS_XS + ((c0 + 1) >> 1) + UPS_ODD * ((c0 + 1) & 1);
+                const float4* col02 = Tl + ((fs * 2 + fhs) * TYL) * UPS_XS + (c0 >> 1) + UPS_ODD * (c0 & 1);
+                const float4* col13 = Tl + ((fs * 2 + fhs) * TYL) * UPS_XS + ((c0 + 1) >> 1) + UPS_ODD * ((c0 + 1) & 1);
                 // the four T pixels under a row's filter are read one row ahead of their use (alone on a CU the row loop took 570 cycles
                 // per row against ~300 of issue: every row waited for its own LDS reads), the block's noise values all at once
                 auto load_row = [&](int yl, float4 (&t)[4]) {
@@ -1576,19 +1620,19 @@ __global__ __launch_bounds__(256, 2) void upconv_strip_kernel(Conv3K P) {
                 };
                 float4 trow[2][4];
                 load_row(0, trow[0]);
-                float nzr[16];
+                float nzr[TYL];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) nzr[r] = P.noise ? nzl[r * 64 + xs] : 0.0f;
+                for (int r = 0; r < TYL; ++r) nzr[r] = P.noise ? nzl[r * 64 + xs] : 0.0f;
                 const int ch = 32 * mb0 + 8 * qq + 4 * fhs;
-                const int Y0 = 16 * by - 2;                      // the output row the block's T row 0 completes
+                const int Y0 = TYL * by - 2;                     // the output row the block's T row 0 completes
                 long long oi = (((long long)n * OH + Y0) * OW + X) * P.Cout + ch - o_row;
                 long long si = split_index(n, P.Cout >> 4, OH, OW, Y0, X, 8 * mb0 + 2 * qq + fhs) - s_row;
                 float* seam = P.seam ? P.seam + ((((long long)n * (P.segs - 1) + (seg - 1)) * 6 + 3) * OW + X) * P.Cout + ch : nullptr;   // this segment's upper boundary, rows 3..5
                 float4 w0 = win[p][0], w1 = win[p][1], w2 = win[p][2];
 #pragma unroll
-                for (int r = 0; r < ((UPS_ABLATE & 16) ? 1 : 16); ++r) {
+                for (int r = 0; r < ((UPS_ABLATE & 16) ? 1 : TYL); ++r) {
                     oi += o_row; si += s_row;
-                    if (r + 1 < 16) load_row(r + 1, trow[(r + 1) & 1]);
+                    if (r + 1 < TYL) load_row(r + 1, trow[(r + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
                     const float4 w3 = filt_row(trow[r & 1]);
                     if (r < 3 && seam_top && xok) *reinterpret_cast<float4*>(seam + r * seam_row) = w3;
@@ -1657,7 +1701,7 @@ __global__ __launch_bounds__(256) void upconv_seam_kernel(Conv3K P) {
         const float4 b = *reinterpret_cast<const float4*>(P.bias + 4 * c4);
         float4 s2 = make_float4(0, 0, 0, 0);
         if (P.split_hi) s2 = *reinterpret_cast<const float4*>(P.next_styles + (long long)n * P.Cout + 4 * c4);
-        const int Y0 = 16 * (q + 1) * P.seg_blocks - 2;
+        const int Y0 = P.tyl * (q + 1) * P.seg_blocks - 2;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int Y = Y0 + r;
@@ -2560,17 +2604,17 @@ static bool up_strips(int math, int cin) {               // a fused layer: strip
 // ---- strip form of the fused up-sampling layers (upconv_strip_kernel): geometry and launch
 // NFE_UP_STRIP=0 keeps round 5's overlapping-tile kernel (A/B); NFE_UP_STRIP_SEGS=<n> fixes the segment count.
 struct UpStripGeom { int strips, blocks, segs, seg_blocks; };
-static UpStripGeom up_strip_geometry(int n, int h, int w, int cout) {
+static UpStripGeom up_strip_geometry(int n, int h, int w, int cout, int tyl, int wgs_per_cu) {
     UpStripGeom g;
     g.strips = (w + 29) / 30;                                  // 60 output columns per strip
-    g.blocks = (2 * h + 17) / 16;                              // block b emits the output rows [16 b - 2, 16 b + 14)
+    g.blocks = (2 * h + 1 + tyl) / tyl;                        // block b emits the output rows [tyl b - 2, tyl b + tyl - 2)
     static const int forced = [] { const char* e = getenv("NFE_UP_STRIP_SEGS"); return e ? atoi(e) : 0; }();
-    // Segments per strip: enough workgroups to keep two per CU busy to the end, as few boundaries as that allows.  Estimated
-    // utilisation of S segments = blocks of work / (rounds of 2 x CUs workgroups x longest segment), charged 5 output rows' worth of time per
+    // Segments per strip: enough workgroups to keep every workgroup slot of the chip busy to the end, as few boundaries as that allows.  Estimated
+    // utilisation of S segments = blocks of work / (rounds of slots x longest segment), charged 5 output rows' worth of time per
     // boundary (three rows leave as six fp32 row-filtered rows and come back: measured 22 us of 560 at 6 boundaries of a 512-row image).
-    const long long slots = 2LL * num_cus(), wg0 = (long long)g.strips * (cout / 32) * n;
+    const long long slots = (long long)wgs_per_cu * num_cus(), wg0 = (long long)g.strips * (cout / 32) * n;
     int best = 1; double best_u = -1.0;
-    for (int S = 1; S <= g.blocks && S <= 32; ++S) {
+    for (int S = 1; S <= g.blocks && S <= 64; ++S) {
         const int L = (g.blocks + S - 1) / S, S2 = (g.blocks + L - 1) / L;
         if (S2 != S) continue;
         const long long wgs = wg0 * S;
@@ -2582,16 +2626,17 @@ static UpStripGeom up_strip_geometry(int n, int h, int w, int cout) {
     g.segs = (g.blocks + g.seg_blocks - 1) / g.seg_blocks;
     return g;
 }
-template <int TERMS, int STAGES>
+template <int TERMS, int STAGES, int NBW, int KG = 1>
 static int launch_up_strip_t(const Conv3K& K0, hipStream_t st) {
     Conv3K K = K0;
-    const UpStripGeom g = up_strip_geometry(K.N, K.H, K.W, K.Cout);
+    K.tyl = UpsGeo<NBW>::TYL;
+    const UpStripGeom g = up_strip_geometry(K.N, K.H, K.W, K.Cout, K.tyl, NBW == 1 ? 3 : 2);
     K.strips = g.strips; K.blocks = g.blocks; K.segs = g.segs; K.seg_blocks = g.seg_blocks;
     K.c3_tiles = g.strips * g.segs;
     K.seam = g.segs > 1 ? K.scratch : nullptr;                 // the (2H+1) x (2W+1) scratch of the unfused form is free here and far larger
-    constexpr int bytes = ups_lds_bytes<TERMS, STAGES>();
+    constexpr int bytes = ups_lds_bytes<TERMS, STAGES, NBW, KG>();
     static LdsOptIn opt;
-    const hipError_t e = opt.apply(upconv_strip_kernel<TERMS, STAGES>, bytes);
+    const hipError_t e = opt.apply(upconv_strip_kernel<TERMS, STAGES, NBW, KG>, bytes);
     if (e != hipSuccess) return fail(NFE_ELAUNCH, "upconv_strip_kernel: LDS opt-in: %s", hipGetErrorString(e));
     const dim3 grid(UPS_XCD_ORDER ? (unsigned)((K.c3_tiles + 7) / 8 * 8) : (unsigned)K.c3_tiles, (unsigned)(K.Cout / 32), (unsigned)K.N);
     if (UPS_PROFILE) {                                          // variant builds: phase profile of this launch on stderr
@@ -2599,7 +2644,7 @@ static int launch_up_strip_t(const Conv3K& K0, hipStream_t st) {
         if (!buf) (void)hipMalloc(&buf, 64);
         (void)hipMemsetAsync(buf, 0, 64, st);
         K.partial = reinterpret_cast<float*>(buf);
-        hipLaunchKernelGGL((upconv_strip_kernel<TERMS, STAGES>), grid, dim3(256), bytes, st, K);
+        hipLaunchKernelGGL((upconv_strip_kernel<TERMS, STAGES, NBW, KG>), grid, dim3(256), bytes, st, K);
         unsigned long long h[8];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, buf, 64, hipMemcpyDeviceToHost);
@@ -2608,11 +2653,11 @@ static int launch_up_strip_t(const Conv3K& K0, hipStream_t st) {
             fprintf(stderr, "UPS_KPROFILE H=%d Cin=%d N=%d segs=%d | cycles per K-group: loop %.0f vmcnt %.0f barrier %.0f dma-issue %.0f first-reads %.0f mfma-steps %.0f\n",
                     K.H, K.Cin, K.N, g.segs, h[0] / nb / (K.Cin / 16), h[1] / nb / (K.Cin / 16), h[2] / nb / (K.Cin / 16), h[3] / nb / (K.Cin / 16), h[4] / nb / (K.Cin / 16), h[5] / nb / (K.Cin / 16));
         else
-        fprintf(stderr, "UPS_PROFILE H=%d Cin=%d Cout=%d N=%d segs=%d wgs=%.0f | cycles per block: between %.0f prologue %.0f kloop %.0f bar %.0f put+bar %.0f fir %.0f bar %.0f | total per wg %.0f\n",
-                K.H, K.Cin, K.Cout, K.N, g.segs, wg, h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb, h[6] / nb,
+        fprintf(stderr, "UPS_PROFILE H=%d Cin=%d Cout=%d N=%d rows/wave=%d segs=%d wgs=%.0f | cycles per block: between %.0f prologue %.0f kloop %.0f bar %.0f put+bar %.0f fir %.0f bar %.0f | total per wg %.0f\n",
+                K.H, K.Cin, K.Cout, K.N, NBW, g.segs, wg, h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb, h[6] / nb,
                 (h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6]) / wg);
     } else
-    hipLaunchKernelGGL((upconv_strip_kernel<TERMS, STAGES>), grid, dim3(256), bytes, st, K);
+    hipLaunchKernelGGL((upconv_strip_kernel<TERMS, STAGES, NBW, KG>), grid, dim3(256), bytes, st, K);
     if (g.segs > 1) {
         const long long total = (long long)K.N * (g.segs - 1) * 2 * K.W * (K.Cout / 4);
         hipLaunchKernelGGL((upconv_seam_kernel<TERMS>), dim3(grid1d(total, 256, 1 << 14)), dim3(256), 0, st, K);
@@ -2623,10 +2668,17 @@ static int launch_up_strip_t(const Conv3K& K0, hipStream_t st) {
 #define UPS_STAGES_BF16 3
 #endif
 #define UPS_STAGES_X3 1
+// NFE_UP_STRIP_ROWS=1 (A/B, read once): one image row per wave - 32 x 4 blocks, three workgroups per CU
 static int launch_up_strip(const Conv3K& K, bool bf16, hipStream_t st) {
-    if (!bf16) return launch_up_strip_t<3, UPS_STAGES_X3>(K, st);
-    if (K.f16) return launch_up_strip_t<2, UPS_STAGES_BF16>(K, st);
-    return launch_up_strip_t<1, UPS_STAGES_BF16>(K, st);
+    static const int rows1 = [] { const char* e = getenv("NFE_UP_STRIP_ROWS"); return e && e[0] == '1'; }();
+    // NFE_UP_STRIP_K32=1 (A/B): two K-groups per stage, ring of two - measured neutral on the 256-channel layers (523 vs 528 us) and 5 % slower
+    // on the 32-channel one (a single stage: nothing to prefetch), so the ring of three single K-groups stays the default
+    static const bool k32 = [] { const char* e = getenv("NFE_UP_STRIP_K32"); return e && e[0] == '1'; }();
+    if (!bf16) return launch_up_strip_t<3, UPS_STAGES_X3, 2>(K, st);
+    if (rows1) return K.f16 ? launch_up_strip_t<2, UPS_STAGES_BF16, 1>(K, st) : launch_up_strip_t<1, UPS_STAGES_BF16, 1>(K, st);
+    if (k32 && K.Cin % 32 == 0) return K.f16 ? launch_up_strip_t<2, 2, 2, 2>(K, st) : launch_up_strip_t<1, 2, 2, 2>(K, st);
+    if (K.f16) return launch_up_strip_t<2, UPS_STAGES_BF16, 2>(K, st);
+    return launch_up_strip_t<1, UPS_STAGES_BF16, 2>(K, st);
 }
 
 static_assert(conv3_ec_bytes<2>() == 1024 && conv3_ec_bytes<4>() == 1536, "epilogue constants: three float rows of 32 * MBW channels");
