@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void demod_grouped_kernel(DemodGroups G, int n
 // convolution accumulates and returns fp16.  Here the accumulators and the activations are fp32 and only the operands must fit, so that
 // half of the factor is left out - deliberately: with it a weight below 0.4 % of its channel's maximum (512 x 9 products: 1/68) lands in
 // fp16's subnormal range, which the MFMA's operand path does not keep, and config 3's per-channel mean error against the fp32 capture
-// grew four-fold (image_raw 1.7e-5 -> 7.6e-5, depth 4.7e-6 -> 2.6e-5; -DNFE_F16_PRENORM_SQRT=1 rebuilds that form).
+// grew four-fold (image_raw 1.7e-5 -> 7.6e-5, depth 4.7e-6 -> 2.6e-5; commit 74f5a14 has the switch that rebuilds that form).
 __global__ __launch_bounds__(256) void conv_wmax_kernel(const float* __restrict__ weight, int cout, long long per_o, float* __restrict__ alpha) {
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (o >= cout) return;
@@ -264,10 +264,7 @@ __global__ __launch_bounds__(256) void conv_wmax_kernel(const float* __restrict_
     for (long long i = lane; i < per_o; i += 64) m = fmaxf(m, fabsf(weight[(long long)o * per_o + i]));
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
-#ifndef NFE_F16_PRENORM_SQRT
-#define NFE_F16_PRENORM_SQRT 0
-#endif
-    if (lane == 0) alpha[o] = m > 0.0f ? (NFE_F16_PRENORM_SQRT ? 1.0f / sqrtf((float)per_o) / m : 1.0f / m) : 1.0f;
+    if (lane == 0) alpha[o] = m > 0.0f ? 1.0f / m : 1.0f;
 }
 // alpha (fp16 operand mode of a demodulated layer only, else null): every weight is multiplied by its output channel's alpha before it is
 // rounded to fp16, and wsq is formed from the scaled weights, so that the demodulation coefficient cancels the scale (:53-66).
@@ -1284,23 +1281,9 @@ __global__ __launch_bounds__(64 * (WV + LW), FU ? FU : LW ? (WV + LW) / 4 : ((NB
 //               demodulation / noise / bias / activation / consumer image).
 // ------------------------------------------------------------------------------------------------
 #define UPS_XCD_ORDER 1
-#ifndef UPS_ABLATE
-#define UPS_ABLATE 0                                              // timing experiments (wrong results): 1 no LDS-DMA, 2 no MFMA, 4 no fragment reads, 8 no K-loop barrier, 16 no FIR rows, 32 no output stores, 64 no vmcnt wait
-#endif
-#ifndef UPS_PRIO
-#define UPS_PRIO 0                                                // bits 0-1: s_setprio of a wave inside its K loop, bits 2-3: outside
-#endif
-#ifndef UPS_DMA_SPREAD
-#define UPS_DMA_SPREAD 0                                          // 0 (A/B): the next stage's LDS-DMA as one burst after the K-group's barrier
-#endif
-#ifndef UPS_A_AHEAD
-#define UPS_A_AHEAD 3                                             // 1 .. 3
-#endif
-#ifndef UPS_PROFILE
-#define UPS_PROFILE 0                                             // 1 (variant builds only): per-phase cycle sums of wave 0 of every workgroup -> P.partial[8]
-#endif
-#define UPS_KSTAMP(i) do { if (UPS_PROFILE == 2 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
-#define UPS_STAMP(i) do { if (UPS_PROFILE == 1 && tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); prof[i] += t_ - tprev; tprev = t_; } } while (0)
+// (The experiment switches of round 6 - UPS_ABLATE timing builds, UPS_PROFILE phase stamps, UPS_PRIO, UPS_DMA_SPREAD, the read-ahead depth -
+// left this file at the end of the round; commit 74f5a14 has them, profiles/experiments/r06_up_conv.md what they measured.)
+constexpr int UPS_A_AHEAD = 3;                                    // weight fragments read this many taps ahead of their MFMAs (1 measured equal)
 // NBW = image rows per wave: 2 (32 x 8 blocks, two workgroups per CU) or 1 (32 x 4 blocks: 64 accumulator registers per wave instead of
 // 128, three workgroups per CU - the occupancy experiment of profiles/experiments/r06_up_conv.md, section 5).
 constexpr int UPS_PW = 34;
@@ -1389,7 +1372,7 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
                 else if (c < A_CHUNKS) src += A_GROUP;
                 else src += sadv[k] ? plane_bytes : 0u;
             }
-            if (!(UPS_ABLATE & 1) && (4 * k + 3 < CT || c < CT)) lds_dma16(src, base + (sub * CT1 + c) * 1024);      // only the last slot can be past the end (wave-uniform)
+            if (4 * k + 3 < CT || c < CT) lds_dma16(src, base + (sub * CT1 + c) * 1024);      // only the last slot can be past the end (wave-uniform)
         }
         if (all_w) sptr[k] += KG * A_GROUP;
         else if (all_p) sptr[k] += sadv[k] ? KG * plane_bytes : 0u;
@@ -1435,9 +1418,7 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
     const long long o_row = (long long)OW * P.Cout, s_row = (long long)OW * 4;
     const long long seam_row = (long long)OW * P.Cout;
 
-    unsigned long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = UPS_PROFILE ? __builtin_readcyclecounter() : 0;
     for (int by = by_first; by < by_end; ++by) {
-        UPS_STAMP(0);                                            // between blocks
         const int r0 = ROWS * by;                                // first extended row of the block; patch row py <-> image row r0 - 1 + py
         // staging pointers of this block, K-group 0
 #pragma unroll
@@ -1481,35 +1462,26 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
                 for (int r = 0; r < 16; ++r) acc[a][nb][r] = 0.0f;
 
         // ---- K loop
-        UPS_STAMP(1);                                            // block prologue
         // STAGES-deep ring: the loads of K-group g + STAGES - 1 are issued while g is computed, so a load has STAGES - 1 K-groups to land.
         // A lone workgroup on a CU spends 1 900 cycles per K-group with a ring of two (576 of them MFMA): the LDS-DMA round trip, not
         // the matrix pipe, paces the loop (UPS_PROFILE, round 6) - and the ring fits under the epilogue's 64 KB of slices for free.
         constexpr int MIN_LOADS = KG * (CT / 4);                 // fewest LDS-DMA instructions a wave issues per stage
         const int GS = G / KG;                                   // stages of this block's K loop (the launch checks G % KG == 0)
-        if (UPS_PRIO) __builtin_amdgcn_s_setprio(UPS_PRIO & 3);   // the K loop's wave ahead of (1..3) the co-resident workgroup's epilogue wave on the SIMD
 #pragma unroll
         for (int pre = 0; pre < STAGES - 1; ++pre)
             if (pre < GS) issue(pre);
         int stage = 0;
         for (int g = 0; g < GS; ++g) {
             if (STAGES == 1) { __syncthreads(); issue(0); }
-            UPS_KSTAMP(0);                                       // tail of the previous K-group (loop control)
             // K-group g has landed once at most the loads of the STAGES - 2 younger K-groups are outstanding (in-order return)
-            if (UPS_ABLATE & 64) {}
-            else if (STAGES <= 2 || g + STAGES - 2 >= GS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (STAGES <= 2 || g + STAGES - 2 >= GS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * MIN_LOADS) : "memory");
-            UPS_KSTAMP(1);                                       // waiting for the stage's loads
-            if (!(UPS_ABLATE & 8)) __syncthreads();
-            UPS_KSTAMP(2);                                       // barrier
-            // The LDS-DMA of K-group g + STAGES - 1 is SPREAD over this K-group's MFMA steps (one instruction after every other step), not
-            // issued as a burst here: right after the barrier all eight waves of the CU push their five instructions into one texture
-            // addresser, an instruction waits ~250 cycles in that queue (178 of the launch's 550 us, UPS_ABLATE 1; nobody waits for the DATA,
-            // UPS_ABLATE 64) and a wave stuck in the queue issues no MFMA.
+            __syncthreads();
+            // The LDS-DMA of K-group g + STAGES - 1 goes out as one burst here.  (Spread over the MFMA steps - one instruction after every
+            // other step - it measured the same: an instruction costs its ~65 cycles of issue wherever it sits; r06_up_conv.md.)
             const bool more = STAGES >= 2 && g + STAGES - 1 < GS;     // wave-uniform
             const int nstage = stage == 0 ? STAGES - 1 : stage - 1;
-            if (more && !UPS_DMA_SPREAD) issue(nstage);
-            UPS_KSTAMP(3);                                       // LDS-DMA issue
+            if (more) issue(nstage);
 #pragma unroll
             for (int sub = 0; sub < KG; ++sub) {
             const unsigned char* base = lds + stage * STAGE_BYTES + sub * (CT1 * 1024);
@@ -1521,23 +1493,18 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
 #pragma unroll
                 for (int rr = 0; rr < NBW + 1; ++rr)
 #pragma unroll
-                    for (int dx = 0; dx < 2; ++dx) { if (!(UPS_ABLATE & 4)) Bc[rr][dx].q = *reinterpret_cast<const uint4*>(ldsB + brd[rr][dx]); else Bc[rr][dx].q = make_uint4(rr, dx, g, lane); }
+                    for (int dx = 0; dx < 2; ++dx) Bc[rr][dx].q = *reinterpret_cast<const uint4*>(ldsB + brd[rr][dx]);
                 // weight fragments UPS_A_AHEAD taps (2 MFMAs = 64 matrix cycles each) ahead of their use, through a ring of four
                 Frag8 ah[4];
 #pragma unroll
-                for (int t = 0; t < UPS_A_AHEAD; ++t) { if (!(UPS_ABLATE & 4)) ah[t].q = ldsA[t * 64]; else ah[t].q = make_uint4(t, g, lane, 1); }
-                UPS_KSTAMP(4);                                   // first fragments read (the stamp waits for them)
+                for (int t = 0; t < UPS_A_AHEAD; ++t) ah[t].q = ldsA[t * 64];
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int kh = t / 3, kw = t % 3, dy = 1 - (kh >> 1), dx = 1 - (kw >> 1), a = (kh & 1) * 2 + (kw & 1);
-                    if (t + UPS_A_AHEAD < 9) { if (!(UPS_ABLATE & 4)) ah[(t + UPS_A_AHEAD) & 3].q = ldsA[(t + UPS_A_AHEAD) * 64]; else ah[(t + UPS_A_AHEAD) & 3].q = make_uint4(t, g, lane, 2); }
+                    if (t + UPS_A_AHEAD < 9) ah[(t + UPS_A_AHEAD) & 3].q = ldsA[(t + UPS_A_AHEAD) * 64];
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int nb = 0; nb < NBW; ++nb) {
-                        if (!(UPS_ABLATE & 2)) acc[a][nb] = mfma16<TERMS>(ah[t & 3].v, Bc[nb + dy][dx].v, acc[a][nb], 0, 0, 0);
-                        else acc[a][nb][t] += __uint_as_float(ah[t & 3].u[nb] ^ Bc[nb + dy][dx].u[0]);
-                    }
-                    if (UPS_DMA_SPREAD && more && (t & 1) == 0 && t / 2 < SLOTS) issue_slot(nstage, t / 2);      // SLOTS = 5: after steps 0, 2, 4, 6, 8
+                    for (int nb = 0; nb < NBW; ++nb) acc[a][nb] = mfma16<TERMS>(ah[t & 3].v, Bc[nb + dy][dx].v, acc[a][nb], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             } else {
@@ -1563,20 +1530,14 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
                     acc[a][nb] = mfma16<TERMS>(ah[t & 1].v, bh[s_ & 1].v, acc[a][nb], 0, 0, 0);
                     acc[a][nb] = mfma16<TERMS>(ah[t & 1].v, bl[s_ & 1].v, acc[a][nb], 0, 0, 0);
                     acc[a][nb] = mfma16<TERMS>(al[t & 1].v, bh[s_ & 1].v, acc[a][nb], 0, 0, 0);
-                    if (UPS_DMA_SPREAD && more && s_ < SLOTS) issue_slot(nstage, s_);                            // SLOTS = 10 of the 18 steps
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             }
-            UPS_KSTAMP(5);                                       // MFMA steps issued
             stage = stage + 1 == STAGES ? 0 : stage + 1;
         }
-        if (UPS_PRIO) __builtin_amdgcn_s_setprio((UPS_PRIO >> 2) & 3);
-        UPS_KSTAMP(6);
-        UPS_STAMP(2);                                            // K loop
         __syncthreads();                                         // every wave is done with the last K-group's fragments: LDS is free
         if (NOISE_LATE) fetch_noise();                           // into the ring's tail; they land under the first pass's slice writes
-        UPS_STAMP(3);                                            // barrier after the K loop
 
         // ---- epilogue: lane (j, h) register r holds out channel 32 mb0 + (r & 3) + 8 (r >> 2) + 4 h of the pixel (row, j)
         const bool seam_top = by == by_first && seg > 0;         // wave-uniform: the window is not valid for this block's first three rows
@@ -1595,7 +1556,6 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
             }
             if (NOISE_LATE && p == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            UPS_STAMP(4);                                        // slices written + barrier
             {
                 const int qq = 2 * p + fs;
                 const float4 d = *reinterpret_cast<const float4*>(ec + 8 * qq + 4 * fhs);
@@ -1630,7 +1590,7 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
                 float* seam = P.seam ? P.seam + ((((long long)n * (P.segs - 1) + (seg - 1)) * 6 + 3) * OW + X) * P.Cout + ch : nullptr;   // this segment's upper boundary, rows 3..5
                 float4 w0 = win[p][0], w1 = win[p][1], w2 = win[p][2];
 #pragma unroll
-                for (int r = 0; r < ((UPS_ABLATE & 16) ? 1 : TYL); ++r) {
+                for (int r = 0; r < TYL; ++r) {
                     oi += o_row; si += s_row;
                     if (r + 1 < TYL) load_row(r + 1, trow[(r + 1) & 1]);
                     __builtin_amdgcn_sched_barrier(0);
@@ -1650,7 +1610,6 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
                     o.y = epilogue_act(sm.y * d.y + nz + b.y, P.lrelu, P.act_gain, P.clamp);
                     o.z = epilogue_act(sm.z * d.z + nz + b.z, P.lrelu, P.act_gain, P.clamp);
                     o.w = epilogue_act(sm.w * d.w + nz + b.w, P.lrelu, P.act_gain, P.clamp);
-                    if ((UPS_ABLATE & 32) && o.x != 123.456f) continue;
                     if (P.out) *reinterpret_cast<float4*>(P.out + oi) = o;
                     if (P.split_hi) {
                         // (Round 6 also built the coalesced form - the lane's 8 bytes parked in its dead slice row, whole 32-byte pixels stored by
@@ -1668,16 +1627,8 @@ __global__ __launch_bounds__(256, NBW == 1 ? 3 : 2) void upconv_strip_kernel(Con
                     *reinterpret_cast<float4*>(sb) = w0; *reinterpret_cast<float4*>(sb + seam_row) = w1; *reinterpret_cast<float4*>(sb + 2 * seam_row) = w2;
                 }
             }
-            UPS_STAMP(5);                                        // FIR rows
             __syncthreads();
-            UPS_STAMP(6);                                        // barrier after the FIR
         }
-    }
-    if (UPS_PROFILE && tid == 0) {
-        if (UPS_PROFILE == 2) prof[6] = 0;                       // everything outside the K loop landed here
-#pragma unroll
-        for (int i = 0; i < 7; ++i) atomicAdd(reinterpret_cast<unsigned long long*>(P.partial) + i, prof[i]);
-        atomicAdd(reinterpret_cast<unsigned long long*>(P.partial) + 7, 1ull);
     }
 }
 
@@ -2639,24 +2590,6 @@ static int launch_up_strip_t(const Conv3K& K0, hipStream_t st) {
     const hipError_t e = opt.apply(upconv_strip_kernel<TERMS, STAGES, NBW, KG>, bytes);
     if (e != hipSuccess) return fail(NFE_ELAUNCH, "upconv_strip_kernel: LDS opt-in: %s", hipGetErrorString(e));
     const dim3 grid(UPS_XCD_ORDER ? (unsigned)((K.c3_tiles + 7) / 8 * 8) : (unsigned)K.c3_tiles, (unsigned)(K.Cout / 32), (unsigned)K.N);
-    if (UPS_PROFILE) {                                          // variant builds: phase profile of this launch on stderr
-        static unsigned long long* buf = nullptr;
-        if (!buf) (void)hipMalloc(&buf, 64);
-        (void)hipMemsetAsync(buf, 0, 64, st);
-        K.partial = reinterpret_cast<float*>(buf);
-        hipLaunchKernelGGL((upconv_strip_kernel<TERMS, STAGES, NBW, KG>), grid, dim3(256), bytes, st, K);
-        unsigned long long h[8];
-        (void)hipStreamSynchronize(st);
-        (void)hipMemcpy(h, buf, 64, hipMemcpyDeviceToHost);
-        const double wg = (double)(h[7] ? h[7] : 1), nb = (double)g.blocks * g.strips * (K.Cout / 32) * K.N;
-        if (UPS_PROFILE == 2)
-            fprintf(stderr, "UPS_KPROFILE H=%d Cin=%d N=%d segs=%d | cycles per K-group: loop %.0f vmcnt %.0f barrier %.0f dma-issue %.0f first-reads %.0f mfma-steps %.0f\n",
-                    K.H, K.Cin, K.N, g.segs, h[0] / nb / (K.Cin / 16), h[1] / nb / (K.Cin / 16), h[2] / nb / (K.Cin / 16), h[3] / nb / (K.Cin / 16), h[4] / nb / (K.Cin / 16), h[5] / nb / (K.Cin / 16));
-        else
-        fprintf(stderr, "UPS_PROFILE H=%d Cin=%d Cout=%d N=%d rows/wave=%d segs=%d wgs=%.0f | cycles per block: between %.0f prologue %.0f kloop %.0f bar %.0f put+bar %.0f fir %.0f bar %.0f | total per wg %.0f\n",
-                K.H, K.Cin, K.Cout, K.N, NBW, g.segs, wg, h[0] / nb, h[1] / nb, h[2] / nb, h[3] / nb, h[4] / nb, h[5] / nb, h[6] / nb,
-                (h[0] + h[1] + h[2] + h[3] + h[4] + h[5] + h[6]) / wg);
-    } else
     hipLaunchKernelGGL((upconv_strip_kernel<TERMS, STAGES, NBW, KG>), grid, dim3(256), bytes, st, K);
     if (g.segs > 1) {
         const long long total = (long long)K.N * (g.segs - 1) * 2 * K.W * (K.Cout / 4);
@@ -2664,10 +2597,7 @@ static int launch_up_strip_t(const Conv3K& K0, hipStream_t st) {
     }
     return NFE_OK;
 }
-#ifndef UPS_STAGES_BF16
-#define UPS_STAGES_BF16 3
-#endif
-#define UPS_STAGES_X3 1
+constexpr int UPS_STAGES_BF16 = 3, UPS_STAGES_X3 = 1;       // ring depth per operand mode (bf16 / fp16: 2 measured 6 % slower)
 // NFE_UP_STRIP_ROWS=1 (A/B, read once): one image row per wave - 32 x 4 blocks, three workgroups per CU
 static int launch_up_strip(const Conv3K& K, bool bf16, hipStream_t st) {
     static const int rows1 = [] { const char* e = getenv("NFE_UP_STRIP_ROWS"); return e && e[0] == '1'; }();
