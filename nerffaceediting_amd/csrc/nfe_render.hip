@@ -1788,8 +1788,12 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {
 
 // Ascending bitonic sort of 64 * R order-preserving depth keys held R per lane (element i = lane + 64 r), round 4.  Only the sorted
 // depths leave the kernel, so the keys carry no index and ties need no order.  Stage (k, j): element i keeps the smaller of (itself,
-// element i ^ j) iff ((i & k) == 0) == ((i & j) == 0).  j >= 64 pairs two registers of one lane; j < 64 is a lane exchange
-// (ds_bpermute through __shfl_xor; the LDS crossbar, no VALU issue slot for the data movement).
+// element i ^ j) iff bits k and j of i are equal.  j >= 64 pairs two registers of one lane; j < 64 is a lane exchange (ds_bpermute
+// through __shfl_xor; the LDS crossbar, no VALU issue slot for the data movement) followed by ONE v_med3_u32 (round 6): the median of
+// (own, partner, 0) is the smaller of two unsigned keys, the median of (own, partner, ~0) the larger, so the stage's choice is a third
+// operand - the sign-extended bit j of lane ^ (lane >> (log2 k - log2 j)), one v_bfe_i32 per stage on a loop-invariant register -
+// instead of a min, a max and a select per key (943 -> ~640 vector instructions per ray at 96 + 96 together with count_leading()).
+__device__ __forceinline__ unsigned med3_u32(unsigned a, unsigned b, unsigned c) { return max(min(a, b), min(max(a, b), c)); }
 template <int R>
 __device__ __forceinline__ void bitonic_sort_keys(unsigned (&v)[R], int lane) {
 #pragma unroll
@@ -1807,16 +1811,35 @@ __device__ __forceinline__ void bitonic_sort_keys(unsigned (&v)[R], int lane) {
                     }
                 }
             } else {
+                const int lj = __builtin_ctz((unsigned)j);
+                // 0 where the element keeps the minimum, ~0 where it keeps the maximum; for k >= 64 bit k of i is a bit of r
+                const int x = k < 64 ? lane ^ (lane >> (__builtin_ctz((unsigned)k) - lj)) : lane;
+                const unsigned up = (unsigned)((x << (31 - lj)) >> 31);
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
                     const unsigned o = (unsigned)__shfl_xor((int)v[r], j);
-                    const int i = lane + 64 * r;
-                    const bool keep_min = ((i & k) == 0) == ((i & j) == 0);
-                    v[r] = keep_min ? min(v[r], o) : max(v[r], o);
+                    const bool flip = k >= 64 && ((64 * r) & k) != 0;              // compile-time
+                    v[r] = med3_u32(v[r], o, flip ? ~up : up);
                 }
             }
         }
     }
+}
+
+// Number of leading entries of the ascending array a[0 .. 64 R) that are <= v (UPPER: searchsorted right = True) or < v.  The arrays'
+// tails beyond their live entries hold +inf (written once per wave), so the search needs no bounds: log2(64 R) fixed steps - a read, a
+// compare and a conditional add each - and one more for an array that is live to its last entry; the divergent `while (lo < hi)` loops
+// of rounds 1-5 spent nine instructions per step on the same result.
+template <int R, bool UPPER>
+__device__ __forceinline__ int count_leading(const float* __restrict__ a, float v) {
+    int pos = 0;
+#pragma unroll
+    for (int step = 32 * R; step >= 1; step >>= 1) {
+        const float x = a[pos + step - 1];
+        pos += (UPPER ? x <= v : x < v) ? step : 0;
+    }
+    const float x = a[pos];
+    return pos + ((UPPER ? x <= v : x < v) ? 1 : 0);
 }
 
 // R = number of 64-sample chunks that hold D and Di (1, 2 or 4: <= 64, <= 128, <= 256 samples); WITH_SRC: the draw index of every
@@ -1827,18 +1850,29 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int D = P.D, Di = P.Di;
     const int DiP = (Di + 2) & ~1;                       // key pairs are read two at a time; at least one +inf key pads the list
-    int stride = ((3 * D + 3) & ~3) + 2 * DiP + Di;      // per-wave LDS floats (same formula at the launch)
-    stride = (stride + 3) & ~3;                          // keep every wave's block 16-byte aligned
-    float* tc = lds + wave * stride;                     // [D] coarse depths
-    float* wq = tc + D;                                  // [D] weights, then smoothed weights
-    float* cdf = wq + D;                                 // [D] cdf knots (D-2 used)
-    uint2* keys = reinterpret_cast<uint2*>(tc + ((3 * D + 3) & ~3));     // [DiP] (draw index, order-preserving depth bits), 16-byte aligned
-    float* tf = reinterpret_cast<float*>(keys + DiP);    // [Di] fine depths, ascending
+    constexpr int CAP = 64 * R;                          // capacity of the searched arrays (count_leading)
+    const int stride = 4 * CAP + 2 * DiP;                // per-wave LDS floats (same formula at the launch); a multiple of 4
+    float* tc = lds + wave * stride;                     // [CAP] coarse depths, +inf beyond D
+    float* wq = tc + CAP;                                // [CAP] weights, then smoothed weights
+    float* cdf = wq + CAP;                               // [CAP] cdf knots (D-2 used), +inf beyond
+    uint2* keys = reinterpret_cast<uint2*>(cdf + CAP);   // [DiP] (draw index, order-preserving depth bits), 16-byte aligned
+    float* tf = reinterpret_cast<float*>(keys + DiP);    // [CAP] fine depths, ascending, +inf beyond Di
     const int B = D - 3;                                 // number of pdf bins (weights[:,1:-1])
+    for (int i = D + lane; i < CAP; i += 64) tc[i] = INFINITY;             // the tails stay: every ray rewrites the live entries only
+    for (int i = D - 2 + lane; i < CAP; i += 64) cdf[i] = INFINITY;
+    for (int i = Di + lane; i < CAP; i += 64) tf[i] = INFINITY;
 
     for (long long ray = (long long)blockIdx.x * 4 + wave; ray < P.n_rays_total; ray += (long long)gridDim.x * 4) {
-        for (int i = lane; i < D; i += 64) tc[i] = P.t_coarse[ray * D + i];
-        for (int i = lane; i < D - 1; i += 64) wq[i] = P.w_coarse[ray * (D - 1) + i];
+        {   // D <= 64 R: R guarded loads per array (a loop over a run-time D was unrolled eight-fold by the compiler, each copy with its own 64-bit address)
+            const float* __restrict__ tsrc = P.t_coarse + ray * D;
+            const float* __restrict__ wsrc = P.w_coarse + ray * (D - 1);
+#pragma unroll
+            for (int c = 0; c < R; ++c) {
+                const int i = c * 64 + lane;
+                if (i < D) tc[i] = tsrc[i];
+                if (i < D - 1) wq[i] = wsrc[i];
+            }
+        }
         wave_lds_fence();
         // smoothed weights a_i, i=0..D-2 (max_pool1d(k2,s1,p1) then avg_pool1d(k2,s1), +0.01): :205-207
         // only a[1..D-3] are used; q_i = a_{i+1} + 1e-5, i = 0..B-1 (:210, :228)
@@ -1898,8 +1932,7 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
                 u = u01(bits);
             }
             // searchsorted(cdf[0..B], u, right=True): number of knots <= u
-            int lo = 0, hi = B + 1;
-            while (lo < hi) { int mid = (lo + hi) >> 1; if (cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+            const int lo = min(count_leading<R, true>(cdf, u), B + 1);
             const int below = max(lo - 1, 0), above = min(lo, B);
             const float cb = cdf[below], ca = cdf[above];
             const float bb = 0.5f * (tc[below] + tc[below + 1]);     // z_vals_mid (:209)
@@ -1955,19 +1988,28 @@ __global__ __launch_bounds__(256) void importance_kernel(ImportanceK P) {
         }
         wave_lds_fence();
         float* out = P.t_all + ray * (D + Di);
-        for (int e = lane; e < Di; e += 64) {            // fine: #coarse <= v (upper bound)
-            const float v = tf[e];
-            int lo = 0, hi = D;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (tc[mid] <= v) lo = mid + 1; else hi = mid; }
-            out[e + lo] = v;
-            if (P.src_all) P.src_all[ray * (D + Di) + e + lo] = D + e;
+        // fine: #coarse <= v (upper bound); coarse: #fine < v (lower bound).  Every lane searches (entries beyond D / Di are the +inf
+        // tails: their counts are clamped and never stored), so the 2 R searches are straight-line code the scheduler can interleave
+        float vf[R], vc[R];
+        int pf[R], pc[R];
+#pragma unroll
+        for (int c = 0; c < R; ++c) { vf[c] = tf[c * 64 + lane]; vc[c] = tc[c * 64 + lane]; }
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            pf[c] = min(count_leading<R, true>(tc, vf[c]), D);
+            pc[c] = min(count_leading<R, false>(tf, vc[c]), Di);
         }
-        for (int e = lane; e < D; e += 64) {             // coarse: #fine < v (lower bound)
-            const float v = tc[e];
-            int lo = 0, hi = Di;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (tf[mid] < v) lo = mid + 1; else hi = mid; }
-            out[e + lo] = v;
-            if (P.src_all) P.src_all[ray * (D + Di) + e + lo] = e;
+#pragma unroll
+        for (int c = 0; c < R; ++c) {
+            const int e = c * 64 + lane;
+            if (e < Di) {
+                out[e + pf[c]] = vf[c];
+                if (P.src_all) P.src_all[ray * (D + Di) + e + pf[c]] = D + e;
+            }
+            if (e < D) {
+                out[e + pc[c]] = vc[c];
+                if (P.src_all) P.src_all[ray * (D + Di) + e + pc[c]] = e;
+            }
         }
         wave_lds_fence();
     }
@@ -2459,7 +2501,8 @@ extern "C" int nfe_render(const nfe_render_args* a, nfe_stream_t stream) {
         ImportanceK I{};
         I.t_coarse = t_c; I.w_coarse = w_c; I.u_fine = a->u_fine; I.seed = a->seed; I.seed_dev = reinterpret_cast<const unsigned long long*>(a->seed_device); I.n_rays_total = (long long)nr;
         I.D = D; I.Di = Di; I.t_all = t_all; I.src_all = src_all; I.tap_fine = a->tap_depths_fine;
-        const int lds_bytes = 4 * ((((3 * D + 3) & ~3) + 2 * ((Di + 2) & ~1) + Di + 3) & ~3) * 4;      // four waves, importance_kernel's layout
+        const int cap = (D > Di ? D : Di) <= 64 ? 64 : ((D > Di ? D : Di) <= 128 ? 128 : 256);
+        const int lds_bytes = 4 * (4 * cap + 2 * ((Di + 2) & ~1)) * 4;      // four waves, importance_kernel's layout (CAP = 64 R)
         long long blocks = ((long long)nr + 3) / 4;
         if (blocks > (long long)num_cus() * 8) blocks = (long long)num_cus() * 8;
         {
