@@ -1987,11 +1987,8 @@ static void launch_torgb(const ConvK& P, hipStream_t st) {
 template <int TERMS, int MB>
 static void launch_torgb_t(const ConvK& P, hipStream_t st) {
     const int bytes = MB * (P.Cin / 16) * (TERMS == 3 ? 2 : 1) * 1024;
-    static int allowed = 0;
-    if (bytes > allowed) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(torgb_kernel<TERMS, MB>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-        allowed = bytes;
-    }
+    static LdsOptInMax topt;                          // per device; a refused opt-in surfaces as the launch error the caller checks (NFE_ELAUNCH)
+    if (topt.apply(torgb_kernel<TERMS, MB>, bytes) != hipSuccess) (void)hipGetLastError();
     // coalesced form (see torgb_coalesced_kernel): whole 32-pixel row segments, whole 32-channel output slices, LDS for eight waves
     static const bool coalesced_on = [] { const char* e = getenv("NFE_TORGB_COALESCED"); return !e || e[0] != '0'; }();
     const int cbytes = bytes + TC_WAVES * tc_wave_floats(P.Cin) * 4;

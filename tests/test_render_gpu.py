@@ -212,6 +212,49 @@ def test_larger_render_vs_oracle(math, dev):
         assert e <= TOL, (k, e)
 
 
+@pytest.mark.parametrize("D,Di", [(8, 2), (5, 64), (48, 48), (64, 64), (33, 65), (96, 96), (128, 128), (129, 40), (40, 200), (256, 256)])
+def test_importance_kernel_every_chunk_count(D, Di, dev):
+    """importance_kernel in its three instantiations (<= 64, <= 128, <= 256 samples per list: one, two, four keys per lane in the sorting
+    network, search arrays of 64 / 128 / 256 entries with +inf tails), at sizes that fill an array to its last entry (64 + 64, 128 + 128,
+    256 + 256: the searches' extra step) and at ragged ones.  The kernel's inputs are the call's own taps - the coarse weights the first
+    pass wrote - so the check isolates sample_importance / sample_pdf / unify_samples (renderer.py:194-253, 288-300) from the decoders'
+    arithmetic: fine depths against the oracle's inverse CDF on the same weights and draws; the merged list must be the sorted union,
+    bit for bit, of the coarse depths and the kernel's own fine depths."""
+    from nerffaceediting_amd import ops
+    import torch
+    rng = np.random.RandomState(D * 1000 + Di)
+    N, R, H = 1, 12, 32
+    M = R * R
+    planes = ops.plane_pack(_t(rng.randn(N, 96, H, H).astype(np.float32), dev))
+    dec = orc.random_decoder(7, bias_scale=0.3)
+    dec["geo_net.2.bias"][0] += np.float32(2.0)                      # enough density for peaked weights
+    c2w = orc.lookat_pose(np.pi / 2 + 0.2, np.pi / 2 - 0.1, [0, 0, 0.2], 2.7).reshape(1, 4, 4)
+    K = orc.fov_to_intrinsics(18.837)[None]
+    opts = dict(depth_resolution=D, depth_resolution_importance=Di, ray_start=2.25, ray_end=3.3, box_warp=1.0)
+    u_c = rng.rand(N, M, D).astype(np.float32)
+    u_f = rng.rand(N * M, Di).astype(np.float32)
+    out = ops.render(planes, planes, _dec(dec, dev), opts, cam2world=_t(c2w, dev), intrinsics=_t(K, dev), resolution=R,
+                     u_coarse=_t(u_c, dev), u_fine=_t(u_f, dev), taps=True)
+    assert ops.render_last_kernels()[1] == "importance_kernel"
+    taps = {k: v.cpu().numpy() for k, v in out[4].items() if isinstance(v, torch.Tensor)}
+    t_all, w_c, t_f = taps["depths_all"], taps["weights_coarse"], taps["depths_fine"]
+    assert t_all.shape == (N, M, D + Di) and t_f.shape == (N, M, Di) and np.isfinite(t_all).all()
+    t_c = orc.sample_stratified(N, M, 2.25, 3.3, D, u_c)
+    want_f = orc.sample_importance(t_c.reshape(N, M, D, 1), w_c.reshape(N, M, D - 1, 1), Di, u_f).reshape(N, M, Di)
+    # a draw within rounding of a cdf knot may pick the neighbouring bin: the inverse CDF is continuous there, the depth moves by ulps
+    assert max_abs(t_f, want_f) <= 2e-5, max_abs(t_f, want_f)
+    assert (np.diff(t_all, axis=-1) >= 0).all()
+    # the merged list = sorted union of (coarse depths, the kernel's fine depths); the coarse depths are the kernel's own fp32 values,
+    # recovered as the entries of the merged list that are not fine depths
+    for m in range(0, M, 7):
+        merged = t_all[0, m]
+        fine_sorted = np.sort(t_f[0, m])
+        rest = list(merged)
+        for v in fine_sorted:
+            rest.remove(v)                                            # every fine depth is in the merged list, bit for bit
+        assert len(rest) == D and max_abs(np.asarray(rest, np.float32), t_c[0, m]) <= 2e-6
+
+
 def test_errors_raise(dev):
     from nerffaceediting_amd import ops
     import torch
