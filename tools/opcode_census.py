@@ -3,6 +3,7 @@
 
     python3 tools/opcode_census.py nerffaceediting_amd/csrc/build/nfe_render.hip.s <mangled-kernel-substring> [--json out.json]
                                    [--anchor global_load_dwordx4]      (the producer loop of a wave-specialised kernel)
+                                   [--loops [--pick <first instruction>]]  list every loop that holds anchors / census of one of them
 
 Finer than isa_census.py's issue classes: what the vector instructions outside the transcendental / packed / MFMA classes ARE
 (moves, selects, byte permutes, bit operations, conversions, compares, min / max, plain fp32 arithmetic, lane reads).
@@ -59,6 +60,20 @@ def main():
                 inside = sum(1 for a in mf if tgt <= a <= k)
                 if 2 * inside >= len(mf) and (best is None or (k - tgt) < (best[1] - best[0])):
                     best = (tgt, k)
+    if "--loops" in sys.argv or best is None:          # several loops share the anchors (template variants inlined side by side): list them
+        loops = []
+        for k, it in enumerate(insts):
+            if it[0].startswith(("s_cbranch", "s_branch")):
+                tgt = labels.get(it[1].strip())
+                if tgt is not None and tgt < k:
+                    loops.append((sum(1 for a in mf if tgt <= a <= k), k - tgt + 1, tgt, k))
+        loops = [lp for lp in loops if lp[0]]
+        for n_anchor, size, tgt, k in sorted(loops, key=lambda t: t[2]):
+            print("loop at instructions %6d..%6d: %5d instructions, %4d anchors" % (tgt, k, size, n_anchor))
+        pick = int(sys.argv[sys.argv.index("--pick") + 1]) if "--pick" in sys.argv else None
+        if pick is None:
+            return
+        best = next((tgt, k) for n_anchor, size, tgt, k in loops if tgt == pick)
     body = insts[best[0]:best[1] + 1]
     ops = Counter(mn for mn, _ in body)
     groups = Counter()
