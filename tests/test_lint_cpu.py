@@ -151,3 +151,17 @@ def test_no_hazardous_packed_fp32_operand_form_in_the_built_kernels():
                          capture_output=True, text=True, timeout=600)
     assert raw.returncode == 0
     assert sum(1 for l in raw.stdout.split("\n") if f.hazardous(l)) >= 1
+
+
+def test_api_file_refuses_to_compile_outside_the_makefile():
+    """Every link of libnfe_render.so needs nfe_api.cpp, and nfe_api.cpp needs the define only csrc/Makefile passes (after its assembly
+    pass over the kernels): a library assembled from plain `hipcc -c` objects - which would carry the packed-fp32 hazard - cannot be
+    built by accident.  Host-only syntax check, with and without the define."""
+    csrc = os.path.join(ROOT, "nerffaceediting_amd", "csrc")
+    base = ["/opt/rocm/bin/hipcc", "-std=c++17", "--offload-arch=gfx950", "-I" + os.path.join(ROOT, "include"), "-I" + csrc, "-x", "hip",
+            "--cuda-host-only", "-fsyntax-only", os.path.join(csrc, "nfe_api.cpp")]
+    bad = subprocess.run(base, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "NFE_BUILT_BY_MAKEFILE" in bad.stderr, bad.stderr[-1500:]
+    good = subprocess.run(base + ["-DNFE_BUILT_BY_MAKEFILE=1"], capture_output=True, text=True, timeout=600)
+    assert good.returncode == 0, good.stderr[-1500:]
+    assert "-DNFE_BUILT_BY_MAKEFILE=1" in open(os.path.join(csrc, "Makefile")).read()
