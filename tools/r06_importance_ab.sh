@@ -1,3 +1,5 @@
+# Round 6: parity tests + same-box A/B of importance_kernel: build/variants/base.so = the library before commit c11be5a (build it with
+# tools/build_variant.sh from `git show c11be5a~1:nerffaceediting_amd/csrc/nfe_render.hip`), against the shipped one; tools/cfg5_order.py merged.
 export TMPDIR=/tmp
 OUT=gpurun_out/r06_late
 mkdir -p $OUT

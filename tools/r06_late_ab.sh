@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6, late A/Bs on ONE box (kernel traces only):
-#   1. decoder-backward kernel: build/variants/base.so (round 5's heads) against the shipped library (e^p shared between the appearance
+#   1. decoder-backward kernel: build/variants/base.so (the library BEFORE the experiment, built with tools/build_variant.sh; not in the tree) against the shipped library (e^p shared between the appearance
 #      head's softplus and its derivative), three interleaved repetitions of tools/time_backward.py 4 128 48 48 256
 #   2. config 5, sample order: tools/cfg5_order.py merged | ideal
 export TMPDIR=/tmp

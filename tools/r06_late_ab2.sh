@@ -1,3 +1,7 @@
+# Round 6: quarter-of-the-taps timing build against the shipped library (config 5 kernels, config 2 headline) and the PMC passes of the
+# ideal-order launch.  build/variants/tapq.so is NOT in the tree: it was built with tools/build_variant.sh from a working copy whose
+# NFE_WSI_ISSUE macro (nfe_render.hip) loads tap K = 0 only and fills the other taps' registers from the weight (wrong results, timing only);
+# profiles/experiments/r06_render_floor.md section 2 has the numbers.
 export TMPDIR=/tmp
 OUT=gpurun_out/r06_late
 mkdir -p $OUT
